@@ -1,0 +1,159 @@
+"""The CPU oracle (oracle/tic_oracle.c) against fixtures produced by the unmodified reference
+(tests/golden/gen/make_goldens.py).  CPU-only; this is what pins the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import rand_frame
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def test_dct_bit_patterns(oracle, golden):
+    """utils.py:32-37 / scipy.fftpack.dct: float64 results bit-identical."""
+    d = golden("dct_blocks")
+    for blk, want in zip(d["blocks"], d["dct2_bits"]):
+        assert np.array_equal(oracle.block_dct(blk).view(np.uint64), want)
+    vec = d["vec_bits"].view(np.float64)
+    for v, want in zip(vec, d["dct1_bits"]):
+        assert np.array_equal(oracle.dct8(v).view(np.uint64), want)
+
+
+def test_idct_bit_patterns(oracle, golden):
+    """utils.py:40-45 / scipy.fftpack.idct."""
+    d = golden("dct_blocks")
+    vec = d["vec_bits"].view(np.float64)
+    for v, want in zip(vec, d["idct1_bits"]):
+        assert np.array_equal(oracle.idct8(v).view(np.uint64), want)
+    for c, want in zip(d["icoef"], d["idct2_bits"]):
+        assert np.array_equal(oracle.block_idct(c.astype(np.float64)).view(np.uint64), want)
+
+
+def test_huffman_table_digest(oracle, manifest):
+    """constants.py:53-242 == canonical Annex-K tables built by the oracle."""
+    lines = sorted(l for l in oracle.dump_tables().split("\n") if l)
+    assert len(lines) == manifest["huffman_table_digest"]["lines"] == 174
+    assert sha(("\n".join(lines) + "\n").encode()) == manifest["huffman_table_digest"]["sha256"]
+
+
+def test_small_shapes_coefficients_and_streams(oracle, golden):
+    """Ragged/tiny shapes (reflect padding), constants, patterns: dc/ac int-exact, stream byte-exact."""
+    d = golden("transform_small")
+    for key in d["names"]:
+        img = d[key + "_img"]
+        q = int(str(key).rsplit("_q", 1)[1])
+        dc, ac = oracle.encode(img, q)
+        assert np.array_equal(dc, d[key + "_dc"]), key
+        assert np.array_equal(ac, d[key + "_ac"]), key
+        want = d[key + "_bs"].tobytes()
+        if want:
+            assert oracle.compress(img, q) == want, key
+        else:  # reference raised KeyError: |coefficient| has no Huffman code
+            with pytest.raises(oracle.OracleError):
+                oracle.compress(img, q)
+
+
+def test_quality_sweep(oracle, golden):
+    d = golden("quality_sweep")
+    img = d["img"]
+    for q in d["qualities"]:
+        q = int(q)
+        dc, ac = oracle.encode(img, q)
+        assert np.array_equal(dc, d[f"q{q}_dc"]), q
+        assert np.array_equal(ac, d[f"q{q}_ac"]), q
+        want = d[f"q{q}_bs"].tobytes()
+        if want:
+            assert oracle.compress(img, q) == want, q
+        else:
+            with pytest.raises(oracle.OracleError):
+                oracle.compress(img, q)
+
+
+def test_tie_blocks(oracle, golden):
+    """Blocks whose DC sits on an exact .5 tie at q=50: rounding direction follows pocketfft's last ulp."""
+    d = golden("tie_blocks")
+    dc, ac = oracle.encode(d["img"], 50)
+    assert np.array_equal(dc, d["dc"])
+    assert np.array_equal(ac, d["ac"])
+    assert oracle.compress(d["img"], 50) == d["bs"].tobytes()
+
+
+def test_lenna(oracle, golden, manifest):
+    d = golden("lenna")
+    img = d["img"]
+    assert sha(img.tobytes()) == manifest["lenna_pixels_sha256"]
+    dc, ac = oracle.encode(img, 50)
+    assert np.array_equal(dc, d["q50_dc"])
+    assert np.array_equal(ac, d["q50_ac"].astype(np.int32))
+    for q in (10, 50, 90):
+        bs = oracle.compress(img, q)
+        assert len(bs) == manifest[f"lenna_q{q}"]["bytes"]
+        assert sha(bs) == manifest[f"lenna_q{q}"]["sha256"]
+        assert bs == d[f"q{q}_bs"].tobytes()
+    assert manifest["lenna_q50"]["bytes"] == 20765  # CR 12.62
+
+
+def test_rle_known_answers(oracle, manifest):
+    """huffman.py:12-33"""
+    for name, ka in manifest["rle_known_answers"].items():
+        got = oracle.rle_block(np.array(ka["seq"], dtype=np.int32))
+        assert [list(t) for t in got] == ka["rle"], name
+
+
+def test_decompress_small(oracle, golden):
+    """codec.py:167-189 + 46-70: decoded pixels identical (exact IDCT order + truncating uint8 cast)."""
+    d = golden("decode_small")
+    s = golden("transform_small")
+    for key in d["names"]:
+        got = oracle.decompress(s[key + "_bs"].tobytes())
+        assert np.array_equal(got, d[key]), key
+    sw = golden("quality_sweep")
+    for q in sw["qualities"]:
+        bs = sw[f"q{int(q)}_bs"].tobytes()
+        if bs:
+            assert np.array_equal(oracle.decompress(bs), d[f"sweep_q{int(q)}"]), q
+    t = golden("tie_blocks")
+    assert np.array_equal(oracle.decompress(t["bs"].tobytes()), d["tie"])
+
+
+def test_decompress_lenna(oracle, golden, manifest):
+    d = golden("lenna")
+    for q in (10, 50, 90):
+        got = oracle.decompress(d[f"q{q}_bs"].tobytes())
+        assert np.array_equal(got, d[f"q{q}_dec"])
+        assert sha(got.tobytes()) == manifest[f"lenna_q{q}"]["decoded_sha256"]
+
+
+@pytest.mark.parametrize("h,w", [(512, 512), (1080, 1920)])
+def test_seeded_frames_stream_digest(oracle, manifest, h, w):
+    m = manifest[f"rand1234_{h}x{w}_q50"]
+    img = rand_frame(1234, h, w)
+    dc, ac = oracle.encode(img, 50)
+    assert sha(dc.astype("<i4").tobytes()) == m["dc_i4_sha256"]
+    assert sha(ac.astype("<i4").tobytes()) == m["ac_i4_sha256"]
+    bs = oracle.compress(img, 50)
+    assert len(bs) == m["bytes"] and sha(bs) == m["sha256"]
+
+
+@pytest.mark.parametrize("q", [10, 50, 90])
+def test_4096_coefficient_digest(oracle, manifest, q):
+    """BASELINE config 2 (4096x4096, seed 1234): coefficient digests of the reference's encode()."""
+    m = manifest[f"rand1234_4096x4096_q{q}"]
+    dc, ac = oracle.encode(rand_frame(1234, 4096, 4096), q)
+    assert sha(dc.astype("<i4").tobytes()) == m["dc_i4_sha256"]
+    assert sha(ac.astype("<i4").tobytes()) == m["ac_i4_sha256"]
+
+
+def test_error_behaviour(oracle, manifest):
+    """utils.py:50 / codec.py:103-108: valid quality domain is 1..99."""
+    e = manifest["error_behaviour"]
+    assert not e["quality_0"]["ok"] and not e["quality_100"]["ok"]
+    img = rand_frame(3, 8, 8)
+    for q in (0, 100, -5):
+        with pytest.raises(oracle.OracleError):
+            oracle.compress(img, q)
+    assert e["empty_0x8"]["bytes"] == 16
+    assert oracle.compress(np.zeros((0, 8), np.uint8), 50).hex() == e["empty_0x8"]["hex"]
