@@ -1,0 +1,135 @@
+/*
+ * tinyimgcodec_hip.h - C-ABI of the MI355X-native tinyimgcodec hot path (libtinyimgcodec_hip.so).
+ *
+ * The reference (clysto/tinyimgcodec) has no FFI of its own: its boundary is the Python function API
+ * tinyimgcodec/__init__.py:1-5 -> codec.py (encode/decode/compress/decompress).  Each entry point below names
+ * the reference function (file:line under /root/reference) whose work it replaces.  Conventions: plain pointers
+ * and sizes, caller-owned buffers, int return codes (0 = ok, negative = error, message via tic_last_error),
+ * no exceptions across the ABI, no torch types.  A tic_ctx owns one HIP device + one stream; use one context per
+ * host thread (calls on the same context must not overlap).  All device work is issued on the context's own
+ * stream.  There is NO CPU fallback for the transform stage: without a usable gfx950 device tic_create fails.
+ *
+ * Coefficient layout produced by the device stage ("zz16"): int16 [N][64], N = ceil(h/8)*ceil(w/8) blocks in
+ * raster order, each block's 64 quantised coefficients in zig-zag scan order (constants.py:23-34); element 0 is
+ * the quantised DC *before* DPCM (the DPCM of codec.py:34-35 is applied by the entropy stage / tic_encode).
+ */
+#ifndef TINYIMGCODEC_HIP_H
+#define TINYIMGCODEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIC_OK 0
+#define TIC_E_ARG -1      /* bad argument (null pointer, negative size, ...) */
+#define TIC_E_QUALITY -2  /* quality outside 1..99 (reference: ZeroDivisionError / KeyError / struct.error) */
+#define TIC_E_RANGE -3    /* a coefficient has no Huffman code (reference: KeyError in encode_huffman) */
+#define TIC_E_SPACE -4    /* output buffer too small */
+#define TIC_E_STREAM -5   /* malformed / unsupported stream */
+#define TIC_E_HIP -6      /* HIP runtime error (see tic_last_error) */
+#define TIC_E_NODEVICE -7 /* no gfx950 device / extension unusable */
+
+/* kernel variants of the transform stage (all bit-identical in output) */
+#define TIC_KERNEL_AUTO 0
+#define TIC_KERNEL_EXACT 1  /* every coefficient in pocketfft float64 operation order */
+#define TIC_KERNEL_HYBRID 2 /* fp32 AAN fast path + guard band + exact rational coefficients + exact fallback */
+
+typedef struct tic_ctx tic_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------------------- */
+const char *tic_version(void);
+int tic_device_count(void);
+/* Create a context on HIP device `device`.  NULL on failure (tic_last_error(NULL) explains). */
+tic_ctx *tic_create(int device);
+void tic_destroy(tic_ctx *ctx);
+/* Last error message of the context (or of the failed tic_create when ctx == NULL).  Never NULL. */
+const char *tic_last_error(const tic_ctx *ctx);
+/* Device name / arch string of the context's device, e.g. "gfx950:sramecc+:xnack-". */
+const char *tic_device_arch(const tic_ctx *ctx);
+
+/* ---- sizes ------------------------------------------------------------------------------------------ */
+/* Number of 8x8 blocks of an h x w image after pad_image (utils.py:56-61); 0 when h == 0 or w == 0. */
+size_t tic_num_blocks(int h, int w);
+/* Upper bound of the compressed size in bytes (16-byte header + worst-case Huffman payload). */
+size_t tic_compress_bound(int h, int w);
+
+/* ---- transform stage: replaces encode() codec.py:26-43 (pad_image utils.py:56-61, level shift codec.py:29,
+ *      block_slice utils.py:13-20, block_dct utils.py:32-37, block_quantize utils.py:48-53, zig-zag
+ *      codec.py:32-33).  Runs on the GPU. ---------------------------------------------------------------- */
+
+/* Host-buffer convenience form: H2D copy, kernel, D2H copy, synchronous.  image: uint8, row stride in bytes.
+ * coeffs_zz: int16[N*64] (layout above). */
+int tic_dctq(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality,
+             int16_t *coeffs_zz);
+
+/* Same stage, reference output convention: dc int32[N] with DPCM applied (codec.py:34-35), ac int32[N*63]. */
+int tic_encode(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, int32_t *dc,
+               int32_t *ac);
+
+/* Device-resident form (what bench.py times): d_image / d_coeffs are device pointers from tic_dev_alloc.
+ * Asynchronous on the context's stream; `variant` is one of TIC_KERNEL_*. */
+int tic_dev_alloc(tic_ctx *ctx, size_t bytes, void **dptr);
+int tic_dev_free(tic_ctx *ctx, void *dptr);
+int tic_host_alloc_pinned(tic_ctx *ctx, size_t bytes, void **hptr);
+int tic_host_free_pinned(tic_ctx *ctx, void *hptr);
+int tic_memcpy_h2d(tic_ctx *ctx, void *dst, const void *src, size_t bytes);
+int tic_memcpy_d2h(tic_ctx *ctx, void *dst, const void *src, size_t bytes);
+int tic_memset_dev(tic_ctx *ctx, void *dst, int value, size_t bytes);
+int tic_sync(tic_ctx *ctx);
+int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
+                 void *d_coeffs_zz, int variant);
+/* Times `iters` back-to-back launches of the transform kernel with HIP events recorded on the context's stream
+ * (the stream the kernel is launched on).  *ms_total = elapsed milliseconds for all `iters` launches. */
+int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
+                       void *d_coeffs_zz, int variant, int iters, float *ms_total);
+/* Number of blocks that left the fast path (guard band tripped) in the most recent HYBRID launch that was
+ * synchronised; diagnostic only. */
+int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count);
+
+/* ---- entropy stage (host): replaces the per-block loops of compress() codec.py:133-164:
+ *      DC DPCM codec.py:34-35, encode_run_length huffman.py:12-33, encode_huffman huffman.py:41-63,
+ *      BitBuffer bitbuffer.py:5-72, make_header codec.py:102-114. -------------------------------------------- */
+int tic_entropy_encode(const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap,
+                       size_t *out_len);
+
+/* ---- whole codec ------------------------------------------------------------------------------------- */
+/* compress() codec.py:133 with auto_generate_huffman_table=False: GPU transform + host entropy stage. */
+int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, uint8_t *out,
+                 size_t cap, size_t *out_len);
+
+/* Batch of n independent frames of identical geometry (BASELINE config 3): pinned staging buffers, two HIP
+ * streams (H2D copy of frame i+1 overlaps the kernel of frame i and the D2H of frame i-1), host entropy coding
+ * on `threads` worker threads.  images[i] / outs[i] are host pointers; out_lens[i] receives each size. */
+int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
+                       int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads);
+
+/* Same batch, transform stage only (what the metric counts): per-frame coefficients land in coeffs[i]
+ * (int16[N*64], host).  If coeffs == NULL the coefficients stay on the device and are discarded. */
+int tic_dctq_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
+                   int quality, int16_t *const *coeffs);
+
+/* parse_header() codec.py:117-130 */
+int tic_parse_header(const uint8_t *data, size_t len, int *h, int *w, int *quality, uint32_t *flag);
+
+/* decode() codec.py:46-70 from coefficients: coeffs_zz int16[N*64] zig-zag with the DC already integrated
+ * (np.cumsum, codec.py:53); GPU dequantise (utils.py:52) + inverse DCT in scipy's operation order
+ * (utils.py:40-45) + clip + truncating uint8 cast + crop.  out: uint8[h*w], cap >= h*w. */
+int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap);
+
+/* decompress() codec.py:167-189 + decode() codec.py:46-70 for default-table streams: host Huffman/RLE decode
+ * (huffman.py:36-38,66-98), GPU dequantise + inverse DCT (utils.py:40-45,52) + clip + truncating uint8 cast.
+ * out: uint8[h*w]. */
+int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap);
+
+/* ---- diagnostics (not part of the drop-in surface) ------------------------------------------------------------- */
+/* Runs the in-register 8x8 byte transpose used by the kernels (DPP + v_perm) and a shuffle-based formulation of
+ * the same permutation on `nthreads` x 8 bytes (nthreads multiple of 256); the two outputs must be identical. */
+int tic_selftest_transpose(tic_ctx *ctx, const void *host_in, void *host_dpp, void *host_ref, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYIMGCODEC_HIP_H */

@@ -1,0 +1,286 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle and the reference goldens.
+
+Bar: bit-exact (integer coefficients, byte streams, decoded pixels).  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import rand_frame
+
+import tinyimgcodec_amd as T
+from tinyimgcodec_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = T.Context(0)
+    assert c.arch.startswith("gfx950"), c.arch
+    yield c
+    c.close()
+
+
+class DevFrame:
+    """Device-resident frame + coefficient buffer driven through the tic_*_dev entry points."""
+
+    def __init__(self, ctx, img, pitch=None):
+        self.ctx, self.L = ctx, N.load()
+        self.h, self.w = img.shape
+        self.pitch = pitch if pitch is not None else (self.w + 255) // 256 * 256
+        host = np.zeros((max(self.h, 1), self.pitch), dtype=np.uint8)
+        host[: self.h, : self.w] = img
+        self.n = self.L.tic_num_blocks(self.h, self.w)
+        self.d_img, self.d_out = C.c_void_p(), C.c_void_p()
+        ctx.check(self.L.tic_dev_alloc(ctx.handle, host.size, C.byref(self.d_img)))
+        ctx.check(self.L.tic_dev_alloc(ctx.handle, max(self.n, 1) * 128, C.byref(self.d_out)))
+        ctx.check(self.L.tic_memcpy_h2d(ctx.handle, self.d_img, host.ctypes.data, host.size))
+
+    def run(self, quality, variant):
+        ctx, L = self.ctx, self.L
+        ctx.check(L.tic_memset_dev(ctx.handle, self.d_out, 0x5A, max(self.n, 1) * 128))
+        ctx.check(L.tic_dctq_dev(ctx.handle, self.d_img, self.h, self.w, self.pitch, quality, self.d_out, variant))
+        zz = np.empty((self.n, 64), dtype=np.int16)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, zz.ctypes.data, self.d_out, self.n * 128))
+        return zz
+
+    def fallbacks(self):
+        c = C.c_ulonglong()
+        self.ctx.check(self.L.tic_last_fallback_blocks(self.ctx.handle, C.byref(c)))
+        return c.value
+
+    def free(self):
+        self.L.tic_dev_free(self.ctx.handle, self.d_img)
+        self.L.tic_dev_free(self.ctx.handle, self.d_out)
+
+
+def zz_to_dc_ac(zz):
+    dc = zz[:, 0].astype(np.int32)
+    dc[1:] = np.diff(zz[:, 0].astype(np.int32))
+    return dc, zz[:, 1:].astype(np.int32)
+
+
+def test_dpp_byte_transpose_selftest(ctx):
+    """The in-register DPP/v_perm 8x8 byte transpose equals the shuffle formulation and a numpy transpose."""
+    n = 4096
+    data = np.random.default_rng(5).integers(0, 256, (n, 8), dtype=np.uint8)
+    a = np.zeros_like(data)
+    b = np.zeros_like(data)
+    ctx.check(N.load().tic_selftest_transpose(ctx.handle, data.ctypes.data, a.ctypes.data, b.ctypes.data, n))
+    want = data.reshape(n // 8, 8, 8).transpose(0, 2, 1).reshape(n, 8)
+    assert np.array_equal(b, want), "shuffle formulation wrong"
+    assert np.array_equal(a, want), "DPP formulation wrong"
+
+
+@pytest.mark.parametrize("variant", [N.KERNEL_EXACT, N.KERNEL_HYBRID])
+def test_small_and_ragged_shapes_vs_goldens(ctx, golden, variant):
+    """Reference goldens incl. reflect padding (1x1 ... 15x17), constants, patterns: coefficients int-exact."""
+    d = golden("transform_small")
+    for key in d["names"]:
+        img = d[key + "_img"]
+        q = int(str(key).rsplit("_q", 1)[1])
+        f = DevFrame(ctx, img)
+        dc, ac = zz_to_dc_ac(f.run(q, variant))
+        f.free()
+        assert np.array_equal(dc, d[key + "_dc"]), key
+        assert np.array_equal(ac, d[key + "_ac"]), key
+
+
+@pytest.mark.parametrize("variant", [N.KERNEL_EXACT, N.KERNEL_HYBRID])
+def test_quality_sweep_vs_goldens(ctx, golden, variant):
+    d = golden("quality_sweep")
+    f = DevFrame(ctx, d["img"])
+    for q in d["qualities"]:
+        q = int(q)
+        dc, ac = zz_to_dc_ac(f.run(q, variant))
+        assert np.array_equal(dc, d[f"q{q}_dc"]), q
+        assert np.array_equal(ac, d[f"q{q}_ac"]), q
+    f.free()
+
+
+@pytest.mark.parametrize("variant", [N.KERNEL_EXACT, N.KERNEL_HYBRID])
+def test_tie_blocks(ctx, golden, variant):
+    """DC exactly on .5 ties at q=50: rounding must follow pocketfft's last-ulp error."""
+    d = golden("tie_blocks")
+    f = DevFrame(ctx, d["img"])
+    dc, ac = zz_to_dc_ac(f.run(50, variant))
+    f.free()
+    assert np.array_equal(dc, d["dc"])
+    assert np.array_equal(ac, d["ac"])
+
+
+def test_random_ragged_shapes_vs_oracle(ctx, oracle):
+    """Seeded random shapes (odd sizes, unaligned pitches) at random qualities: HIP == oracle, both variants."""
+    rng = np.random.default_rng(77)
+    for it in range(40):
+        h, w = int(rng.integers(1, 200)), int(rng.integers(1, 300))
+        q = int(rng.integers(1, 100))
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        want = oracle.encode_zz16(img, q)
+        pitch = None if it % 3 else w + int(rng.integers(0, 5))  # every third case: unaligned rows (byte-load path)
+        f = DevFrame(ctx, img, pitch)
+        for variant in (N.KERNEL_EXACT, N.KERNEL_HYBRID):
+            got = f.run(q, variant)
+            assert np.array_equal(got, want), (h, w, q, variant, pitch)
+        f.free()
+
+
+def test_extreme_content_vs_oracle(ctx, oracle):
+    """Saturated / adversarial content (largest intermediates of the float32 fast path) stays exact."""
+    rng = np.random.default_rng(3)
+    imgs = [
+        rng.choice(np.array([0, 255], dtype=np.uint8), (256, 256)),
+        np.tile(np.array([[0, 255], [255, 0]], dtype=np.uint8), (64, 64)),
+        np.repeat(np.repeat(rng.choice(np.array([0, 255], dtype=np.uint8), (32, 32)), 4, 0), 4, 1),
+    ]
+    for img in imgs:
+        f = DevFrame(ctx, img)
+        for q in (5, 50, 90, 99):
+            want = oracle.encode_zz16(img, q)
+            for variant in (N.KERNEL_EXACT, N.KERNEL_HYBRID):
+                assert np.array_equal(f.run(q, variant), want), (q, variant)
+        f.free()
+
+
+def test_lenna_streams_byte_exact(ctx, golden, manifest):
+    """BASELINE config 1 input: compress() bytes identical to the reference at q=10/50/90 (20,765 B at q=50)."""
+    d = golden("lenna")
+    for q in (10, 50, 90):
+        bs = T.compress(d["img"], q, ctx=ctx)
+        assert len(bs) == manifest[f"lenna_q{q}"]["bytes"]
+        assert bs == d[f"q{q}_bs"].tobytes()
+    info = T.encode(d["img"], 50, ctx=ctx)
+    assert np.array_equal(info["dc"], d["q50_dc"]) and np.array_equal(info["ac"], d["q50_ac"].astype(np.int32))
+    assert (info["height"], info["width"], info["quality"]) == (512, 512, 50)
+
+
+def test_input_dtypes_and_layouts(ctx, golden):
+    """Any numeric dtype / F-order / strided input gives the same bytes; the input is not modified."""
+    d = golden("lenna")
+    img = d["img"][:64, :72]
+    want = T.compress(img, 50, ctx=ctx)
+    for variant in (img.astype(np.int16), img.astype(np.float32), np.asfortranarray(img), img.astype(np.int64)):
+        assert T.compress(variant, 50, ctx=ctx) == want
+    big = np.zeros((128, 144), np.uint8)
+    big[::2, ::2] = img
+    view = big[::2, ::2]
+    keep = view.copy()
+    assert T.compress(view, 50, ctx=ctx) == want
+    assert np.array_equal(view, keep)
+
+
+@pytest.mark.parametrize("h,w", [(512, 512), (1080, 1920)])
+def test_seeded_frames_stream_digest(ctx, manifest, h, w):
+    m = manifest[f"rand1234_{h}x{w}_q50"]
+    img = rand_frame(1234, h, w)
+    info = T.encode(img, 50, ctx=ctx)
+    assert sha(info["dc"].astype("<i4").tobytes()) == m["dc_i4_sha256"]
+    assert sha(info["ac"].astype("<i4").tobytes()) == m["ac_i4_sha256"]
+    bs = T.compress(img, 50, ctx=ctx)
+    assert len(bs) == m["bytes"] and sha(bs) == m["sha256"]
+
+
+@pytest.mark.parametrize("q", [10, 50, 90])
+def test_config2_4096_coefficient_digest(ctx, manifest, q):
+    """BASELINE config 2: 4096x4096 seed 1234 - digests of the reference's own encode() output; both kernels."""
+    m = manifest[f"rand1234_4096x4096_q{q}"]
+    img = rand_frame(1234, 4096, 4096)
+    f = DevFrame(ctx, img)
+    zz_h = f.run(q, N.KERNEL_HYBRID)
+    fb = f.fallbacks()
+    zz_e = f.run(q, N.KERNEL_EXACT)
+    f.free()
+    assert np.array_equal(zz_h, zz_e)
+    dc, ac = zz_to_dc_ac(zz_h)
+    assert sha(dc.astype("<i4").tobytes()) == m["dc_i4_sha256"]
+    assert sha(ac.astype("<i4").tobytes()) == m["ac_i4_sha256"]
+    assert 0 < fb < 0.08 * 262144, fb  # guard band trips on a small fraction of blocks only
+
+
+@pytest.mark.parametrize("q", [10, 50, 90])
+def test_config5_16384_coefficient_digest(ctx, manifest, q):
+    """BASELINE config 5: 16384x16384 at q=10/50/90 - digest vs the reference; hybrid == exact kernel."""
+    m = manifest[f"rand1234_16384x16384_q{q}"]
+    img = rand_frame(1234, 16384, 16384)
+    f = DevFrame(ctx, img)
+    zz = f.run(q, N.KERNEL_HYBRID)
+    del img
+    dc, ac = zz_to_dc_ac(zz)
+    assert sha(dc.astype("<i4").tobytes()) == m["dc_i4_sha256"]
+    del dc
+    assert sha(ac.astype("<i4").tobytes()) == m["ac_i4_sha256"]
+    del ac
+    h_hybrid = sha(zz.tobytes())
+    del zz
+    assert sha(f.run(q, N.KERNEL_EXACT).tobytes()) == h_hybrid
+    f.free()
+
+
+def test_decompress_goldens(ctx, golden, manifest):
+    """decompress(): decoded pixels identical to the reference's (exact IDCT order, truncating cast)."""
+    d = golden("decode_small")
+    s = golden("transform_small")
+    for key in d["names"]:
+        got = T.decompress(s[key + "_bs"].tobytes(), ctx=ctx)
+        assert np.array_equal(got, d[key]), key
+    sw = golden("quality_sweep")
+    for q in sw["qualities"]:
+        bs = sw[f"q{int(q)}_bs"].tobytes()
+        if bs:
+            assert np.array_equal(T.decompress(bs, ctx=ctx), d[f"sweep_q{int(q)}"]), q
+    L = golden("lenna")
+    for q in (10, 50, 90):
+        got = T.decompress(L[f"q{q}_bs"].tobytes(), ctx=ctx)
+        assert np.array_equal(got, L[f"q{q}_dec"])
+
+
+def test_decode_dict_roundtrip(ctx, golden):
+    """decode(encode(x)) through the reference's dict convention == decompress(compress(x))."""
+    img = golden("lenna")["img"][:120, :200]
+    info = T.encode(img, 75, ctx=ctx)
+    info["scaled_dct"] = False
+    a = T.decode(info, ctx=ctx)
+    b = T.decompress(T.compress(img, 75, ctx=ctx), ctx=ctx)
+    assert np.array_equal(a, b) and a.shape == img.shape
+    err = a.astype(np.int32) - img.astype(np.int32)
+    assert np.sqrt((err**2).mean()) < 6.0
+
+
+def test_batch_pipeline_matches_single_frame(ctx, manifest):
+    """BASELINE config 3 shape (1080p, seeds 1234+i): the stream-overlapped batch == per-frame compress()."""
+    frames = [rand_frame(1234 + i, 1080, 1920) for i in range(6)]
+    out = T.compress_batch(frames, 50, threads=4, ctx=ctx)
+    assert sha(out[0]) == manifest["rand1234_1080x1920_q50"]["sha256"]
+    for i in (1, 5):
+        assert out[i] == T.compress(frames[i], 50, ctx=ctx)
+    # transform-only batch: coefficient digests of the reference for frames 0..3
+    L = N.load()
+    n = 4
+    zz = [np.empty((32400, 64), np.int16) for _ in range(n)]
+    inp = (C.c_void_p * n)(*[f.ctypes.data for f in frames[:n]])
+    outp = (C.c_void_p * n)(*[z.ctypes.data for z in zz])
+    ctx.check(L.tic_dctq_batch(ctx.handle, inp, n, 1080, 1920, 1920, 50, outp))
+    for i in range(n):
+        dc, ac = zz_to_dc_ac(zz[i])
+        m = manifest[f"rand{1234 + i}_1080x1920_q50_coeffs"]
+        assert sha(dc.astype("<i4").tobytes()) == m["dc_i4_sha256"]
+        assert sha(ac.astype("<i4").tobytes()) == m["ac_i4_sha256"]
+
+
+def test_error_paths(ctx):
+    L = N.load()
+    img = rand_frame(1, 16, 16)
+    zz = np.zeros((4, 64), np.int16)
+    assert L.tic_dctq(ctx.handle, img.ctypes.data, 16, 16, 16, 0, zz.ctypes.data) == N.TIC_E_QUALITY
+    assert L.tic_dctq(ctx.handle, img.ctypes.data, 16, 16, 16, 100, zz.ctypes.data) == N.TIC_E_QUALITY
+    assert L.tic_dctq(ctx.handle, img.ctypes.data, 16, 16, 8, 50, zz.ctypes.data) == N.TIC_E_ARG
+    assert b"stride" in L.tic_last_error(ctx.handle)
+    assert T.compress(np.zeros((0, 8), np.uint8), 50, ctx=ctx).hex() == "00000000080000003200000000000000"
+    with pytest.raises(KeyError):  # |AC| >= 1024: no Huffman code, as the reference
+        T.compress(np.tile(np.array([[0, 255], [255, 0]], dtype=np.uint8), (8, 8)), 99, ctx=ctx)

@@ -1,0 +1,140 @@
+"""CPU-side tests of the product's host logic and of the C-ABI surface (no GPU compute)."""
+import ctypes
+import hashlib
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rand_frame
+
+import tinyimgcodec_amd as T
+from tinyimgcodec_amd import _native as N
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """Every function declared in include/*.h must be exported by the shared library and bound in _native."""
+    hdr = open(os.path.join(ROOT, "include", "tinyimgcodec_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tic_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(N.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    L = N.load()
+    assert b"gfx950" in L.tic_version()
+    assert L.tic_num_blocks(1080, 1920) == 32400 and L.tic_num_blocks(9, 9) == 4 and L.tic_num_blocks(0, 8) == 0
+    assert L.tic_compress_bound(0, 8) >= 16
+
+
+def test_no_silent_cpu_fallback():
+    """Without a device the codec must fail loudly, never compute on the CPU."""
+    if N.load().tic_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(T.NativeUnavailable):
+        T.compress(np.zeros((8, 8), np.uint8))
+    with pytest.raises(T.NativeUnavailable):
+        T.encode(np.zeros((8, 8), np.uint8))
+
+
+def test_product_does_not_import_oracle():
+    """The product package must not reference oracle/ (checked textually over its sources)."""
+    pkg = os.path.join(ROOT, "tinyimgcodec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "tic_oracle" not in txt and "libtic_oracle" not in txt, f
+
+
+def test_entropy_stage_matches_reference_streams(oracle, golden, manifest):
+    """Host entropy stage (tic_entropy_encode) fed with oracle coefficients == reference compress() bytes."""
+    d = golden("lenna")
+    for q in (10, 50, 90):
+        bs = T.entropy_encode(oracle.encode_zz16(d["img"], q), 512, 512, q)
+        assert bs == d[f"q{q}_bs"].tobytes()
+    s = golden("transform_small")
+    for key in s["names"]:
+        img = s[key + "_img"]
+        q = int(str(key).rsplit("_q", 1)[1])
+        want = s[key + "_bs"].tobytes()
+        zz = oracle.encode_zz16(img, q)
+        if want:
+            assert T.entropy_encode(zz, img.shape[0], img.shape[1], q) == want, key
+        else:
+            with pytest.raises(KeyError):
+                T.entropy_encode(zz, img.shape[0], img.shape[1], q)
+    sw = golden("quality_sweep")
+    for q in sw["qualities"]:
+        q = int(q)
+        want = sw[f"q{q}_bs"].tobytes()
+        zz = oracle.encode_zz16(sw["img"], q)
+        if want:
+            assert T.entropy_encode(zz, 64, 96, q) == want, q
+    img = rand_frame(1234, 1080, 1920)
+    bs = T.entropy_encode(oracle.encode_zz16(img, 50), 1080, 1920, 50)
+    assert sha(bs) == manifest["rand1234_1080x1920_q50"]["sha256"]
+
+
+def test_entropy_rle_known_answers(manifest):
+    """huffman.py:12-33 known answers through the product's bit stream (decoded with the table digests' codes)."""
+    ka = manifest["rle_known_answers"]
+    # {62: -3} -> 3 x ZRL, (14,-3), EOB ; stream = header + DC(0)="00" + 3x"11111111001" + code(14,2)+"00" + "1010"
+    zz = np.zeros((1, 64), np.int16)
+    zz[0, 63] = -3
+    bs = T.entropy_encode(zz, 8, 8, 50)
+    bits = "".join(f"{b:08b}" for b in bs[16:])
+    assert ka["last_only"]["rle"] == [[15, 0]] * 3 + [[14, -3], [0, 0]]
+    assert bits.startswith("00" + "11111111001" * 3 + "1111111111101100" + "00" + "1010")
+    # all-zero block -> DC "00" + EOB "1010", zero padded
+    bs = T.entropy_encode(np.zeros((1, 64), np.int16), 8, 8, 50)
+    assert bs[16:] == bytes([0b00101000])
+
+
+def test_header_layout_and_parse():
+    bs = T.entropy_encode(np.zeros((0, 64), np.int16), 0, 8, 50)
+    assert bs == struct.pack("<IIII", 0, 8, 50, 0)
+    hdr = T.parse_header(struct.pack("<IIII", 512, 300, 77, 0) + b"\x00")
+    assert hdr == {"height": 512, "width": 300, "quality": 77, "flag": 0}
+    with pytest.raises(struct.error):
+        T.parse_header(b"\x00" * 5)
+
+
+def test_quality_argument_errors_mirror_reference(manifest):
+    """Exception types for invalid quality follow the reference (recorded in manifest['error_behaviour'])."""
+    e = manifest["error_behaviour"]
+    img = rand_frame(3, 8, 8)
+    assert e["quality_0"]["exc"] == "ZeroDivisionError"
+    with pytest.raises(ZeroDivisionError):
+        T.compress(img, 0)
+    assert e["quality_100"]["exc"] == "KeyError"
+    with pytest.raises(KeyError):
+        T.compress(img, 100)
+    assert e["quality_float"]["exc"] == "error" and e["quality_negative"]["exc"] == "error"
+    with pytest.raises(struct.error):
+        T.compress(img, 50.0)
+    with pytest.raises(struct.error):
+        T.compress(img, -5)
+    assert e["ndim_3"]["exc"] == "ValueError" and e["ndim_1"]["exc"] == "ValueError"
+    with pytest.raises(ValueError):
+        T.compress(np.zeros((8, 8, 3), np.uint8))
+    with pytest.raises(ValueError):
+        T.compress(np.zeros((8,), np.uint8))
+    with pytest.raises(NotImplementedError):
+        T.compress(img, 50, auto_generate_huffman_table=True)
+
+
+def test_entropy_errors():
+    zz = np.zeros((1, 64), np.int16)
+    zz[0, 5] = 1024  # size 11 has no AC code
+    with pytest.raises(KeyError):
+        T.entropy_encode(zz, 8, 8, 50)
+    zz[0, 5] = 1023
+    assert len(T.entropy_encode(zz, 8, 8, 50)) > 16

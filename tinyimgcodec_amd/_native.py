@@ -1,0 +1,151 @@
+"""ctypes binding of libtinyimgcodec_hip.so (C-ABI declared in include/tinyimgcodec_hip.h).
+
+The library is the product: there is no Python/CPU fallback for the transform stage.  If the shared object is
+missing or no gfx950 device can be opened, every codec entry point raises NativeUnavailable loudly.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtinyimgcodec_hip.so")
+
+TIC_OK = 0
+TIC_E_ARG, TIC_E_QUALITY, TIC_E_RANGE, TIC_E_SPACE, TIC_E_STREAM, TIC_E_HIP, TIC_E_NODEVICE = -1, -2, -3, -4, -5, -6, -7
+KERNEL_AUTO, KERNEL_EXACT, KERNEL_HYBRID = 0, 1, 2
+
+
+class NativeUnavailable(RuntimeError):
+    """The HIP extension (or a gfx950 device) is not usable; the codec cannot run."""
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tinyimgcodec_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_u8p, _i16p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_int32)
+_ctxp = C.c_void_p
+
+# name -> (restype, argtypes): exactly the symbols include/tinyimgcodec_hip.h declares
+SIGNATURES = {
+    "tic_version": (C.c_char_p, []),
+    "tic_device_count": (C.c_int, []),
+    "tic_create": (_ctxp, [C.c_int]),
+    "tic_destroy": (None, [_ctxp]),
+    "tic_last_error": (C.c_char_p, [_ctxp]),
+    "tic_device_arch": (C.c_char_p, [_ctxp]),
+    "tic_num_blocks": (C.c_size_t, [C.c_int, C.c_int]),
+    "tic_compress_bound": (C.c_size_t, [C.c_int, C.c_int]),
+    "tic_dctq": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p]),
+    "tic_encode": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "tic_dev_alloc": (C.c_int, [_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tic_dev_free": (C.c_int, [_ctxp, C.c_void_p]),
+    "tic_host_alloc_pinned": (C.c_int, [_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tic_host_free_pinned": (C.c_int, [_ctxp, C.c_void_p]),
+    "tic_memcpy_h2d": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tic_memcpy_d2h": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tic_memset_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_size_t]),
+    "tic_sync": (C.c_int, [_ctxp]),
+    "tic_dctq_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_int]),
+    "tic_dctq_dev_timed": (
+        C.c_int,
+        [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
+    ),
+    "tic_last_fallback_blocks": (C.c_int, [_ctxp, C.POINTER(C.c_ulonglong)]),
+    "tic_entropy_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "tic_compress": (
+        C.c_int,
+        [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)],
+    ),
+    "tic_compress_batch": (
+        C.c_int,
+        [_ctxp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.POINTER(C.c_void_p),
+         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int],
+    ),
+    "tic_dctq_batch": (
+        C.c_int,
+        [_ctxp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.POINTER(C.c_void_p)],
+    ),
+    "tic_parse_header": (
+        C.c_int,
+        [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)],
+    ),
+    "tic_idctq": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "tic_decompress": (C.c_int, [_ctxp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "tic_selftest_transpose": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the shared library (no device is touched).  Raises NativeUnavailable if it cannot be loaded."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeUnavailable(
+                    "%s not found: build it with `make -C tinyimgcodec_amd/csrc` (or __graft_entry__.build()); "
+                    "tinyimgcodec_amd has no CPU fallback" % LIB_PATH
+                )
+            try:
+                L = C.CDLL(LIB_PATH)
+            except OSError as e:  # missing ROCm runtime etc.
+                raise NativeUnavailable("cannot load %s: %s" % (LIB_PATH, e)) from e
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+class Context:
+    """One HIP device + stream (tic_ctx).  Not thread-safe: use one per host thread."""
+
+    def __init__(self, device=None):
+        L = load()
+        if device is None:
+            device = int(os.environ.get("TINYIMGCODEC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self._L = L
+        self._h = L.tic_create(int(device))
+        if not self._h:
+            msg = L.tic_last_error(None).decode()
+            raise NativeUnavailable("tic_create(%d) failed: %s" % (device, msg))
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def arch(self):
+        return self._L.tic_device_arch(self._h).decode()
+
+    def check(self, rc):
+        if rc != TIC_OK:
+            raise NativeError(rc, self._L.tic_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.tic_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx

@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's Python API (tinyimgcodec/codec.py) on top of the C-ABI.
+
+Same names, argument meaning and error behaviour as the reference so that it is a drop-in:
+
+    compress(image, quality=50, auto_generate_huffman_table=False) -> bytes      codec.py:133-164
+    decompress(data) -> np.ndarray[uint8]                                        codec.py:167-189
+    encode(image, quality=50) -> {"height","width","quality","dc","ac"}          codec.py:26-43
+    decode(data) -> np.ndarray[uint8]                                            codec.py:46-70
+
+The transform stage (pad, level shift, DCT, quantise, zig-zag) runs in hand-written gfx950 kernels; the entropy
+stage runs in C on the host.  There is no Python or CPU fallback: without the HIP library and an MI355X these
+functions raise tinyimgcodec_amd.NativeUnavailable.
+
+Documented differences from the reference (all outside its working domain):
+  * pixel values must lie in 0..255 (the device path is 8-bit; the reference would transform any integers);
+  * auto_generate_huffman_table=True raises NotImplementedError (that path is broken in the reference:
+    the table flag is written big-endian and read little-endian, codec.py:111/119);
+  * quality > 100 raises ValueError (the reference produces streams with negative divisors);
+  * streams carrying the custom-table or scaled_dct flag are rejected by decompress().
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import _native as N
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else N.default_context()
+
+
+def _check_quality(quality, packed_first):
+    """Reproduces the exception types of the reference for an invalid quality.
+
+    The reference evaluates `5000 / quality` inside encode() and only later packs the header, so the order of
+    checks depends on the entry point: encode() never packs."""
+    if isinstance(quality, (bool, np.bool_)):
+        quality = int(quality)
+    if not isinstance(quality, (int, np.integer)):
+        if isinstance(quality, (float, np.floating)) and not packed_first:
+            if quality == 0:
+                raise ZeroDivisionError("float division by zero")
+            struct.pack("I", quality)  # raises struct.error: required argument is not an integer
+        raise TypeError("quality must be an int")
+    quality = int(quality)
+    if quality == 0:
+        raise ZeroDivisionError("division by zero")  # utils.py:50
+    if quality < 0:
+        struct.pack("I", quality)  # struct.error, codec.py:103-108
+    if quality == 100:
+        raise KeyError((0, 0))  # factor 0 -> inf/NaN coefficients -> no Huffman code (huffman.py:62)
+    if quality > 100:
+        raise ValueError("quality must be in 1..99")
+    return quality
+
+
+def _as_u8_image(image):
+    image = np.asarray(image)
+    height, width = image.shape  # ValueError for non 2-D input, as codec.py:27
+    a = image.astype(np.int32)  # codec.py:29 (truncation of floats, as the reference)
+    if a.size and (a.min() < 0 or a.max() > 255):
+        raise ValueError("pixel values must lie in 0..255 (the MI355X path is 8-bit)")
+    return np.ascontiguousarray(a.astype(np.uint8)), int(height), int(width)
+
+
+def dctq(image, quality=50, ctx=None):
+    """Transform stage in the device layout: int16 [N, 64], zig-zag order, DC not differenced."""
+    img, h, w = _as_u8_image(image)
+    quality = _check_quality(quality, packed_first=True)
+    ctx = _ctx(ctx)
+    n = N.load().tic_num_blocks(h, w)
+    zz = np.zeros((n, 64), dtype=np.int16)
+    if n:
+        ctx.check(N.load().tic_dctq(ctx.handle, img.ctypes.data, h, w, img.strides[0], quality, zz.ctypes.data))
+    return zz
+
+
+def encode(image, quality=50, ctx=None):
+    img, h, w = _as_u8_image(image)
+    q = _check_quality(quality, packed_first=True)
+    ctx = _ctx(ctx)
+    n = N.load().tic_num_blocks(h, w)
+    dc = np.zeros(n, dtype=np.int32)
+    ac = np.zeros((n, 63), dtype=np.int32)
+    if n:
+        ctx.check(N.load().tic_encode(ctx.handle, img.ctypes.data, h, w, img.strides[0], q, dc.ctypes.data, ac.ctypes.data))
+    return {"height": h, "width": w, "quality": quality, "dc": dc, "ac": ac}
+
+
+def compress(image, quality=50, auto_generate_huffman_table=False, ctx=None):
+    img, h, w = _as_u8_image(image)
+    q = _check_quality(quality, packed_first=False)
+    if auto_generate_huffman_table:
+        raise NotImplementedError("auto_generate_huffman_table=True is not supported (broken in the reference)")
+    ctx = _ctx(ctx)
+    L = N.load()
+    cap = L.tic_compress_bound(h, w)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = L.tic_compress(ctx.handle, img.ctypes.data, h, w, img.strides[0] if img.size else max(w, 1), q, out.ctypes.data, cap, C.byref(n))
+    if rc == N.TIC_E_RANGE:
+        raise KeyError("coefficient magnitude has no Huffman code")  # as the reference's dict lookup
+    ctx.check(rc)
+    return out[: n.value].tobytes()
+
+
+def compress_batch(images, quality=50, threads=8, ctx=None):
+    """Batch of equally sized frames through the stream-overlapped pipeline -> list of bytes."""
+    q = _check_quality(quality, packed_first=False)
+    frames = [_as_u8_image(im) for im in images]
+    if not frames:
+        return []
+    ctx = _ctx(ctx)
+    h, w = frames[0][1], frames[0][2]
+    if any((f[1], f[2]) != (h, w) for f in frames):
+        raise ValueError("all frames of a batch must have the same shape")
+    L = N.load()
+    n = len(frames)
+    cap = L.tic_compress_bound(h, w)
+    outs = [np.empty(cap, dtype=np.uint8) for _ in range(n)]
+    inp = (C.c_void_p * n)(*[f[0].ctypes.data for f in frames])
+    outp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    caps = (C.c_size_t * n)(*([cap] * n))
+    lens = (C.c_size_t * n)()
+    rc = L.tic_compress_batch(ctx.handle, inp, n, h, w, max(w, 1), q, outp, caps, lens, int(threads))
+    if rc == N.TIC_E_RANGE:
+        raise KeyError("coefficient magnitude has no Huffman code")
+    ctx.check(rc)
+    return [outs[i][: lens[i]].tobytes() for i in range(n)]
+
+
+def entropy_encode(coeffs_zz, height, width, quality):
+    """Host entropy stage alone (no GPU needed): int16 [N,64] zig-zag coefficients -> stream bytes."""
+    L = N.load()
+    zz = np.ascontiguousarray(coeffs_zz, dtype=np.int16)
+    cap = L.tic_compress_bound(height, width)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = L.tic_entropy_encode(zz.ctypes.data, int(height), int(width), int(quality), out.ctypes.data, cap, C.byref(n))
+    if rc == N.TIC_E_RANGE:
+        raise KeyError("coefficient magnitude has no Huffman code")
+    if rc != N.TIC_OK:
+        raise N.NativeError(rc, "tic_entropy_encode failed")
+    return out[: n.value].tobytes()
+
+
+def parse_header(data):
+    L = N.load()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    h, w, q, flag = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
+    rc = L.tic_parse_header(buf.ctypes.data, buf.size, C.byref(h), C.byref(w), C.byref(q), C.byref(flag))
+    if rc != N.TIC_OK:
+        raise struct.error("unpack requires a buffer of 16 bytes")  # codec.py:119
+    return {"height": h.value, "width": w.value, "quality": q.value, "flag": flag.value}
+
+
+def decompress(data, ctx=None):
+    ctx = _ctx(ctx)
+    hdr = parse_header(data)
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.zeros((hdr["height"], hdr["width"]), dtype=np.uint8)
+    ctx.check(N.load().tic_decompress(ctx.handle, buf.ctypes.data, buf.size, out.ctypes.data, out.size))
+    return out
+
+
+def decode(data, ctx=None):
+    """decode() of the reference: dict with height, width, quality, scaled_dct, dc (DPCM'd), ac."""
+    ctx = _ctx(ctx)
+    height, width, quality = data["height"], data["width"], data["quality"]
+    if data["scaled_dct"]:
+        raise NotImplementedError("scaled_dct (C encoder) streams are not supported")
+    dc = np.cumsum(np.asarray(data["dc"], dtype=np.int64))  # codec.py:53
+    ac = np.asarray(data["ac"])
+    n = N.load().tic_num_blocks(int(height), int(width))
+    if dc.shape[0] != n or ac.shape != (n, 63):
+        raise ValueError("dc/ac shapes do not match the image geometry")
+    if n and (np.abs(dc).max() > 32767 or np.abs(ac).max(initial=0) > 32767):
+        raise ValueError("coefficients exceed the int16 device layout")
+    zz = np.empty((n, 64), dtype=np.int16)
+    zz[:, 0] = dc
+    zz[:, 1:] = ac
+    out = np.zeros((int(height), int(width)), dtype=np.uint8)
+    q = _check_quality(quality, packed_first=True)
+    if n:
+        ctx.check(N.load().tic_idctq(ctx.handle, zz.ctypes.data, int(height), int(width), q, out.ctypes.data, out.size))
+    return out

@@ -1,0 +1,566 @@
+// tic_api.hip - the C-ABI of libtinyimgcodec_hip.so (include/tinyimgcodec_hip.h): context, device buffers,
+// launches of the transform kernels on the context's own HIP stream, the stream-overlapped batch pipeline, and
+// the glue to the host entropy stage.  No CPU fallback exists for the transform stage.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tinyimgcodec_hip.h"
+#include "tic_entropy.h"
+#include "tic_kernels.h"
+#include "tic_math.h"
+
+using namespace tic;
+
+struct tic_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;     // all single-frame work
+    hipStream_t bstream[2] = {nullptr, nullptr}; // batch pipeline streams
+    DctqConsts *d_consts = nullptr;   // [100], index = quality
+    unsigned long long *d_fallback = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // scratch for the host-buffer entry points
+    void *d_img = nullptr;
+    size_t d_img_cap = 0;
+    void *d_coef = nullptr;
+    size_t d_coef_cap = 0;
+    std::vector<int16_t> h_coef;
+    std::string err;
+    char arch[128] = {0};
+};
+
+static thread_local std::string g_create_err;
+
+static int set_err(tic_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                                    \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return set_err(ctx, TIC_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,  \
+                           __LINE__);                                                                        \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" {
+
+const char *tic_version(void) { return "tinyimgcodec_amd 0.1.0 (gfx950)"; }
+
+int tic_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *tic_last_error(const tic_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+const char *tic_device_arch(const tic_ctx *ctx) { return ctx ? ctx->arch : ""; }
+
+size_t tic_num_blocks(int h, int w) { return num_blocks(h, w); }
+size_t tic_compress_bound(int h, int w) { return compress_bound(h, w); }
+
+void tic_destroy(tic_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->bstream)
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->d_img) (void)hipFree(ctx->d_img);
+    if (ctx->d_coef) (void)hipFree(ctx->d_coef);
+    if (ctx->d_consts) (void)hipFree(ctx->d_consts);
+    if (ctx->d_fallback) (void)hipFree(ctx->d_fallback);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static int create_impl(tic_ctx *ctx, int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_err(nullptr, TIC_E_NODEVICE, "no HIP device available (%s): the transform stage has no CPU fallback",
+                       e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return set_err(nullptr, TIC_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return set_err(nullptr, TIC_E_HIP, "cannot open device %d: %s", device, hipGetErrorString(e));
+    snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(nullptr, TIC_E_NODEVICE, "device %d is %s; this library contains gfx950 (MI355X) code only", device,
+                       prop.gcnArchName);
+#define CK(call)                                                                                          \
+    if ((e = (call)) != hipSuccess)                                                                       \
+        return set_err(nullptr, TIC_E_HIP, "%s failed: %s", #call, hipGetErrorString(e));
+    CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&ctx->bstream[0], hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&ctx->bstream[1], hipStreamNonBlocking));
+    CK(hipEventCreate(&ctx->ev0));
+    CK(hipEventCreate(&ctx->ev1));
+    std::vector<DctqConsts> all(100);
+    memset(all.data(), 0, all.size() * sizeof(DctqConsts));
+    for (int q = 1; q <= 99; q++) build_consts(q, &all[q]);
+    CK(hipMalloc((void **)&ctx->d_consts, all.size() * sizeof(DctqConsts)));
+    CK(hipMemcpy(ctx->d_consts, all.data(), all.size() * sizeof(DctqConsts), hipMemcpyHostToDevice));
+    CK(hipMalloc((void **)&ctx->d_fallback, sizeof(unsigned long long)));
+    CK(hipMemset(ctx->d_fallback, 0, sizeof(unsigned long long)));
+#undef CK
+    return TIC_OK;
+}
+
+tic_ctx *tic_create(int device) {
+    tic_ctx *ctx = new tic_ctx();
+    if (create_impl(ctx, device) != TIC_OK) {
+        if (ctx->device >= 0) tic_destroy(ctx); else delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+// ---- device memory helpers ---------------------------------------------------------------------------
+int tic_dev_alloc(tic_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return TIC_OK;
+}
+int tic_dev_free(tic_ctx *ctx, void *dptr) {
+    if (!ctx) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipFree(dptr));
+    return TIC_OK;
+}
+int tic_host_alloc_pinned(tic_ctx *ctx, size_t bytes, void **hptr) {
+    if (!ctx || !hptr) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return TIC_OK;
+}
+int tic_host_free_pinned(tic_ctx *ctx, void *hptr) {
+    if (!ctx) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostFree(hptr));
+    return TIC_OK;
+}
+int tic_memcpy_h2d(tic_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TIC_OK;
+}
+int tic_memcpy_d2h(tic_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TIC_OK;
+}
+int tic_memset_dev(tic_ctx *ctx, void *dst, int value, size_t bytes) {
+    if (!ctx) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return TIC_OK;
+}
+int tic_sync(tic_ctx *ctx) {
+    if (!ctx) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TIC_OK;
+}
+
+// ---- transform stage -----------------------------------------------------------------------------------
+static int check_geometry(tic_ctx *ctx, int h, int w, ptrdiff_t stride, int quality) {
+    if (!ctx) return TIC_E_ARG;
+    if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size %dx%d", h, w);
+    if (quality < 1 || quality > 99)
+        return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99 (the reference fails for 0, 100 and negatives)",
+                       quality);
+    if (h > 0 && w > 0 && stride < (ptrdiff_t)w) return set_err(ctx, TIC_E_ARG, "row stride %td < width %d", stride, w);
+    return TIC_OK;
+}
+
+static DctqArgs make_args(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t stride, int quality, void *d_out) {
+    DctqArgs a;
+    a.img = (const uint8_t *)d_image;
+    a.h = h;
+    a.w = w;
+    a.stride = (long)stride;
+    a.bw = (w + 7) / 8;
+    a.tiles_x = (a.bw + 7) / 8;
+    a.ntiles = (h > 0 && w > 0) ? ((h + 7) / 8) * a.tiles_x : 0;
+    a.aligned8 = ((((uintptr_t)d_image) | (uintptr_t)stride) & 7) == 0;
+    a.consts = ctx->d_consts + quality;
+    a.out = (int16_t *)d_out;
+    a.fallback_count = ctx->d_fallback;
+    return a;
+}
+
+int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
+                 int variant) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (h == 0 || w == 0) return TIC_OK;
+    if (!d_image || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "null device pointer");
+    if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
+        return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
+    HIPCHK(ctx, launch_dctq(a, variant == TIC_KERNEL_EXACT ? 1 : 2, ctx->stream));
+    return TIC_OK;
+}
+
+int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
+                       void *d_coeffs_zz, int variant, int iters, float *ms_total) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (!ms_total || iters < 1 || !d_image || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
+    const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; i++) HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return TIC_OK;
+}
+
+int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count) {
+    if (!ctx || !count) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(count, ctx->d_fallback, sizeof *count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_fallback, 0, sizeof *count, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TIC_OK;
+}
+
+static int ensure_scratch(tic_ctx *ctx, size_t img_bytes, size_t coef_bytes) {
+    if (img_bytes > ctx->d_img_cap) {
+        if (ctx->d_img) HIPCHK(ctx, hipFree(ctx->d_img));
+        ctx->d_img = nullptr;
+        ctx->d_img_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_img, img_bytes));
+        ctx->d_img_cap = img_bytes;
+    }
+    if (coef_bytes > ctx->d_coef_cap) {
+        if (ctx->d_coef) HIPCHK(ctx, hipFree(ctx->d_coef));
+        ctx->d_coef = nullptr;
+        ctx->d_coef_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_coef, coef_bytes));
+        ctx->d_coef_cap = coef_bytes;
+    }
+    return TIC_OK;
+}
+
+int tic_dctq(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, int16_t *coeffs_zz) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    const size_t n = num_blocks(h, w);
+    if (n == 0) return TIC_OK;
+    if (!image || !coeffs_zz) return set_err(ctx, TIC_E_ARG, "null host pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t pitch = align_up((size_t)w, 256);
+    rc = ensure_scratch(ctx, pitch * (size_t)h, n * 128);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_img, pitch, image, (size_t)row_stride, (size_t)w, (size_t)h,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    DctqArgs a = make_args(ctx, ctx->d_img, h, w, (ptrdiff_t)pitch, quality, ctx->d_coef);
+    HIPCHK(ctx, launch_dctq(a, 2, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(coeffs_zz, ctx->d_coef, n * 128, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TIC_OK;
+}
+
+int tic_encode(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, int32_t *dc,
+               int32_t *ac) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    const size_t n = num_blocks(h, w);
+    if (n == 0) return TIC_OK;
+    if (!dc || !ac) return set_err(ctx, TIC_E_ARG, "null output pointer");
+    ctx->h_coef.resize(n * 64);
+    rc = tic_dctq(ctx, image, h, w, row_stride, quality, ctx->h_coef.data());
+    if (rc) return rc;
+    int prev = 0;
+    for (size_t b = 0; b < n; b++) { // codec.py:34-36
+        const int16_t *c = ctx->h_coef.data() + b * 64;
+        dc[b] = b ? c[0] - prev : c[0];
+        prev = c[0];
+        for (int k = 1; k < 64; k++) ac[b * 63 + (k - 1)] = c[k];
+    }
+    return TIC_OK;
+}
+
+// ---- entropy stage / whole codec -------------------------------------------------------------------------
+int tic_entropy_encode(const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap, size_t *out_len) {
+    return entropy_encode(coeffs_zz, h, w, quality, out, cap, out_len);
+}
+
+int tic_parse_header(const uint8_t *data, size_t len, int *h, int *w, int *quality, uint32_t *flag) {
+    return parse_header(data, len, h, w, quality, flag);
+}
+
+int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, uint8_t *out,
+                 size_t cap, size_t *out_len) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (!out || !out_len) return set_err(ctx, TIC_E_ARG, "null output pointer");
+    const size_t n = num_blocks(h, w);
+    ctx->h_coef.resize(n * 64 + 64);
+    rc = tic_dctq(ctx, image, h, w, row_stride, quality, ctx->h_coef.data());
+    if (rc) return rc;
+    rc = entropy_encode(ctx->h_coef.data(), h, w, quality, out, cap, out_len);
+    if (rc == TIC_E_RANGE) set_err(ctx, rc, "coefficient without a Huffman code (reference raises KeyError)");
+    if (rc == TIC_E_SPACE) set_err(ctx, rc, "output buffer too small (%zu bytes)", cap);
+    return rc;
+}
+
+// ---- batch pipeline (BASELINE config 3) -------------------------------------------------------------------
+namespace {
+struct Slot {
+    uint8_t *pin_in = nullptr;
+    int16_t *pin_out = nullptr;
+    void *d_img = nullptr;
+    void *d_coef = nullptr;
+    hipEvent_t done = nullptr;
+    int frame = -1;      // frame whose results are in flight / being consumed
+    bool busy = false;   // owned by GPU or by a consumer
+};
+} // namespace
+
+static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
+                      int16_t *const *coeffs, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads,
+                      bool want_entropy) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !images)) return set_err(ctx, TIC_E_ARG, "bad batch arguments");
+    if (want_entropy && n > 0 && (!outs || !caps || !out_lens)) return set_err(ctx, TIC_E_ARG, "null output arrays");
+    if (n == 0) return TIC_OK;
+    const size_t nblk = num_blocks(h, w);
+    if (nblk == 0) {
+        for (int i = 0; i < n && want_entropy; i++) {
+            int r = entropy_encode(nullptr, h, w, quality, outs[i], caps[i], &out_lens[i]);
+            if (r) return r;
+        }
+        return TIC_OK;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool need_d2h = want_entropy || coeffs != nullptr;
+    const size_t pitch = align_up((size_t)w, 256);
+    const size_t img_bytes = pitch * (size_t)h, coef_bytes = nblk * 128;
+    const int S = 4;
+    std::vector<Slot> slots(S);
+    int result = TIC_OK;
+    auto cleanup = [&]() {
+        for (auto &s : slots) {
+            if (s.pin_in) (void)hipHostFree(s.pin_in);
+            if (s.pin_out) (void)hipHostFree(s.pin_out);
+            if (s.d_img) (void)hipFree(s.d_img);
+            if (s.d_coef) (void)hipFree(s.d_coef);
+            if (s.done) (void)hipEventDestroy(s.done);
+        }
+    };
+    for (auto &s : slots) {
+        hipError_t e;
+        if ((e = hipHostMalloc((void **)&s.pin_in, img_bytes, hipHostMallocDefault)) != hipSuccess ||
+            (need_d2h && (e = hipHostMalloc((void **)&s.pin_out, coef_bytes, hipHostMallocDefault)) != hipSuccess) ||
+            (e = hipMalloc(&s.d_img, img_bytes)) != hipSuccess || (e = hipMalloc(&s.d_coef, coef_bytes)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) {
+            cleanup();
+            return set_err(ctx, TIC_E_HIP, "batch buffer allocation failed: %s", hipGetErrorString(e));
+        }
+    }
+
+    std::mutex mu;
+    std::condition_variable cv_job, cv_free;
+    std::deque<int> jobs; // slot indices ready for a consumer (GPU work enqueued)
+    bool closing = false;
+    std::atomic<int> first_err{TIC_OK};
+
+    auto consumer = [&]() {
+        (void)hipSetDevice(ctx->device);
+        for (;;) {
+            int si;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return !jobs.empty() || closing; });
+                if (jobs.empty()) return;
+                si = jobs.front();
+                jobs.pop_front();
+            }
+            Slot &s = slots[si];
+            hipError_t e = hipEventSynchronize(s.done);
+            int r = TIC_OK;
+            if (e != hipSuccess) r = TIC_E_HIP;
+            if (r == TIC_OK && want_entropy)
+                r = entropy_encode(s.pin_out, h, w, quality, outs[s.frame], caps[s.frame], &out_lens[s.frame]);
+            if (r == TIC_OK && coeffs && coeffs[s.frame]) memcpy(coeffs[s.frame], s.pin_out, coef_bytes);
+            if (r != TIC_OK) {
+                int exp = TIC_OK;
+                first_err.compare_exchange_strong(exp, r);
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                s.busy = false;
+            }
+            cv_free.notify_all();
+        }
+    };
+    int nthreads = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++) pool.emplace_back(consumer);
+
+    for (int i = 0; i < n && result == TIC_OK; i++) {
+        const int si = i % S;
+        Slot &s = slots[si];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_free.wait(lk, [&] { return !s.busy; });
+            s.busy = true;
+            s.frame = i;
+        }
+        hipStream_t st = ctx->bstream[i & 1];
+        // stage the frame into pinned memory (row-pitched), then H2D, kernel, D2H on one of the two streams:
+        // the copy of frame i+1 overlaps the kernel of frame i and the read-back of frame i-1.
+        const uint8_t *src = images[i];
+        for (int y = 0; y < h; y++) memcpy(s.pin_in + (size_t)y * pitch, src + (ptrdiff_t)y * row_stride, (size_t)w);
+        hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
+            a.fallback_count = nullptr;
+            e = launch_dctq(a, 2, st);
+        }
+        if (e == hipSuccess && need_d2h) e = hipMemcpyAsync(s.pin_out, s.d_coef, coef_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(s.done, st);
+        if (e != hipSuccess) {
+            result = set_err(ctx, TIC_E_HIP, "batch enqueue failed at frame %d: %s", i, hipGetErrorString(e));
+            std::lock_guard<std::mutex> lk(mu);
+            s.busy = false;
+            break;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            jobs.push_back(si);
+        }
+        cv_job.notify_one();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        closing = true;
+    }
+    cv_job.notify_all();
+    for (auto &t : pool) t.join();
+    (void)hipStreamSynchronize(ctx->bstream[0]);
+    (void)hipStreamSynchronize(ctx->bstream[1]);
+    cleanup();
+    if (result == TIC_OK && first_err.load() != TIC_OK)
+        result = set_err(ctx, first_err.load(), "batch consumer failed with code %d", first_err.load());
+    return result;
+}
+
+int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
+                       uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads) {
+    return batch_impl(ctx, images, n, h, w, row_stride, quality, nullptr, outs, caps, out_lens, threads, true);
+}
+
+int tic_dctq_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
+                   int16_t *const *coeffs) {
+    return batch_impl(ctx, images, n, h, w, row_stride, quality, coeffs, nullptr, nullptr, nullptr, 2, false);
+}
+
+// ---- decode ---------------------------------------------------------------------------------------------
+int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap) {
+    if (!ctx) return TIC_E_ARG;
+    if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size");
+    if (quality < 1 || quality > 99) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
+    const size_t n = num_blocks(h, w);
+    if (n == 0) return TIC_OK;
+    if (!coeffs_zz) return set_err(ctx, TIC_E_ARG, "null coefficient pointer");
+    if (!out || (size_t)h * (size_t)w > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t pitch = align_up((size_t)w, 256);
+    int rc = ensure_scratch(ctx, pitch * (size_t)h, n * 128);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_coef, coeffs_zz, n * 128, hipMemcpyHostToDevice, ctx->stream));
+    IdctArgs a;
+    a.coeffs = (const int16_t *)ctx->d_coef;
+    a.out = (uint8_t *)ctx->d_img;
+    a.h = h;
+    a.w = w;
+    a.stride = (long)pitch;
+    a.bw = (w + 7) / 8;
+    a.tiles_x = (a.bw + 7) / 8;
+    a.ntiles = ((h + 7) / 8) * a.tiles_x;
+    a.aligned8 = 1;
+    a.consts = ctx->d_consts + quality;
+    HIPCHK(ctx, launch_idct(a, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(out, (size_t)w, ctx->d_img, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TIC_OK;
+}
+
+int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
+    if (!ctx) return TIC_E_ARG;
+    int h, w, quality;
+    uint32_t flag;
+    if (parse_header(data, len, &h, &w, &quality, &flag) != TIC_OK)
+        return set_err(ctx, TIC_E_STREAM, "stream shorter than the 16-byte header");
+    if (flag & (1u << 31)) return set_err(ctx, TIC_E_STREAM, "streams with an embedded Huffman table are not supported");
+    if (flag & (1u << 30)) return set_err(ctx, TIC_E_STREAM, "scaled_dct (C encoder) streams are not supported");
+    if (h < 0 || w < 0) return set_err(ctx, TIC_E_STREAM, "bad geometry in header");
+    if (quality < 1 || quality > 99) return set_err(ctx, TIC_E_QUALITY, "quality %d in header outside 1..99", quality);
+    const size_t n = num_blocks(h, w);
+    if (n == 0) return TIC_OK;
+    if (!out || (size_t)h * (size_t)w > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+    std::vector<int16_t> zz(n * 64);
+    entropy_decode(data, len, h, w, zz.data());
+    return tic_idctq(ctx, zz.data(), h, w, quality, out, cap);
+}
+
+// ---- self test hook (used by tests/ only; not part of the drop-in surface) --------------------------------
+int tic_selftest_transpose(tic_ctx *ctx, const void *host_in, void *host_dpp, void *host_ref, int nthreads) {
+    if (!ctx || nthreads <= 0 || nthreads % 256) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *d_in, *d_a, *d_b;
+    size_t bytes = (size_t)nthreads * 8;
+    HIPCHK(ctx, hipMalloc(&d_in, bytes));
+    HIPCHK(ctx, hipMalloc(&d_a, bytes));
+    HIPCHK(ctx, hipMalloc(&d_b, bytes));
+    HIPCHK(ctx, hipMemcpy(d_in, host_in, bytes, hipMemcpyHostToDevice));
+    HIPCHK(ctx, launch_selftest_transpose(d_in, d_a, d_b, nthreads, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(host_dpp, d_a, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(host_ref, d_b, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_a);
+    (void)hipFree(d_b);
+    return TIC_OK;
+}
+
+} // extern "C"

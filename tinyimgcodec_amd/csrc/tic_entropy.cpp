@@ -1,0 +1,296 @@
+// tic_entropy.cpp - host entropy stage of the codec (product code; independent of oracle/).
+//
+// Replaces the per-block Python loops of compress() (codec.py:133-164 of the reference): DC DPCM
+// (codec.py:34-35), run-length coding (huffman.py:12-33), Huffman symbol emission (huffman.py:41-63) into an
+// MSB-first bit stream that is zero-padded to a byte (bitbuffer.py:17-18), after the 16-byte header of
+// make_header (codec.py:102-114).  And, for decompress() (codec.py:167-189): the header parse, the bit-serial
+// Huffman decode (huffman.py:66-98) and run-length expansion (huffman.py:36-38), with the reference's
+// "swallow any per-block exception" behaviour.
+//
+// Input is the device stage's layout: int16 [N][64], zig-zag order, element 0 = quantised DC before DPCM.
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/tinyimgcodec_hip.h"
+#include "tic_entropy.h"
+#include "tic_tables.h"
+
+namespace tic {
+
+namespace {
+
+struct EncTables {
+    uint32_t dc_code[16];
+    uint8_t dc_len[16];
+    uint32_t ac_code[256];
+    uint8_t ac_len[256];
+    // decode: for each code length 1..16 the first code value, count and index into the symbol list
+    struct Dec {
+        uint16_t first[17];
+        uint16_t count[17];
+        uint16_t base[17];
+        uint8_t sym[256];
+    } dcd, acd;
+    EncTables() {
+        build(kDcBits, kDcVals, dc_code, dc_len, 16, dcd);
+        build(kAcBits, kAcVals, ac_code, ac_len, 256, acd);
+    }
+    static void build(const uint8_t bits[16], const uint8_t *vals, uint32_t *code_out, uint8_t *len_out, int nsym,
+                      Dec &d) {
+        for (int i = 0; i < nsym; i++) {
+            code_out[i] = 0;
+            len_out[i] = 0;
+        }
+        unsigned code = 0;
+        int k = 0;
+        for (int l = 1; l <= 16; l++) {
+            d.first[l] = (uint16_t)code;
+            d.count[l] = bits[l - 1];
+            d.base[l] = (uint16_t)k;
+            for (int i = 0; i < bits[l - 1]; i++) {
+                code_out[vals[k]] = code;
+                len_out[vals[k]] = (uint8_t)l;
+                d.sym[k] = vals[k];
+                code++;
+                k++;
+            }
+            code <<= 1;
+        }
+    }
+};
+
+const EncTables &tables() {
+    static const EncTables t;
+    return t;
+}
+
+// MSB-first bit writer with a 64-bit accumulator.
+struct BitWriter {
+    uint8_t *p, *end;
+    uint64_t acc = 0;
+    int nacc = 0;
+    bool overflow = false;
+    BitWriter(uint8_t *b, uint8_t *e) : p(b), end(e) {}
+    inline void put(uint32_t v, int n) { // n <= 32
+        acc = (acc << n) | v;
+        nacc += n;
+        if (nacc >= 32) flush32();
+    }
+    inline void flush32() {
+        while (nacc >= 8) {
+            if (p >= end) {
+                overflow = true;
+                nacc = 0;
+                return;
+            }
+            *p++ = (uint8_t)(acc >> (nacc - 8));
+            nacc -= 8;
+        }
+    }
+    inline void finish() {
+        flush32();
+        if (nacc > 0) {
+            if (p >= end) {
+                overflow = true;
+                return;
+            }
+            *p++ = (uint8_t)((acc << (8 - nacc)) & 0xff); // zero padding
+            nacc = 0;
+        }
+    }
+};
+
+inline int bit_length(uint32_t a) { return a ? 32 - __builtin_clz(a) : 0; } // utils.py:9-10
+
+} // namespace
+
+size_t num_blocks(int h, int w) {
+    if (h <= 0 || w <= 0) return 0;
+    return (size_t)((h + 7) / 8) * (size_t)((w + 7) / 8);
+}
+
+size_t compress_bound(int h, int w) {
+    // per block: DC 9+11 bits, 63 x (16+10) AC bits, EOB 4 bits = 1662 bits < 208 bytes
+    return 16 + num_blocks(h, w) * 208 + 8;
+}
+
+void write_header(uint8_t *out, int h, int w, int quality) {
+    uint32_t v[3] = {(uint32_t)h, (uint32_t)w, (uint32_t)quality};
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 4; k++) out[i * 4 + k] = (uint8_t)(v[i] >> (8 * k)); // struct.pack("III") little-endian
+    memset(out + 12, 0, 4);                                                         // flag 0: default tables
+}
+
+int entropy_encode(const int16_t *zz, int h, int w, int quality, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!out || !out_len || (!zz && num_blocks(h, w))) return TIC_E_ARG;
+    if (h < 0 || w < 0) return TIC_E_ARG;
+    if (quality < 1 || quality > 99) return TIC_E_QUALITY;
+    if (cap < 16) return TIC_E_SPACE;
+    const EncTables &T = tables();
+    write_header(out, h, w, quality);
+    BitWriter bw(out + 16, out + cap);
+    const size_t n = num_blocks(h, w);
+    int prev_dc = 0;
+    for (size_t b = 0; b < n; b++) {
+        const int16_t *c = zz + b * 64;
+        // DC: difference to the previous block in raster order, first block raw (codec.py:34-35)
+        int dc = c[0];
+        int diff = b ? dc - prev_dc : dc;
+        prev_dc = dc;
+        {
+            uint32_t a = (uint32_t)(diff < 0 ? -diff : diff);
+            int size = bit_length(a);
+            if (size > 11) return TIC_E_RANGE;
+            bw.put(T.dc_code[size], T.dc_len[size]);
+            if (size) bw.put((diff < 0 ? ~a : a) & ((1u << size) - 1u), size);
+        }
+        // AC: (run,size) symbols; ZRL per 16 zeros; EOB always (huffman.py:12-33)
+        int last = 63;
+        while (last > 0 && c[last] == 0) last--;
+        int run = 0;
+        for (int k = 1; k <= last; k++) {
+            int v = c[k];
+            if (v == 0) {
+                run++;
+                continue;
+            }
+            while (run >= 16) {
+                bw.put(T.ac_code[0xF0], T.ac_len[0xF0]);
+                run -= 16;
+            }
+            uint32_t a = (uint32_t)(v < 0 ? -v : v);
+            int size = bit_length(a);
+            if (size > 10) return TIC_E_RANGE;
+            int sym = (run << 4) | size;
+            bw.put(T.ac_code[sym], T.ac_len[sym]);
+            bw.put((v < 0 ? ~a : a) & ((1u << size) - 1u), size);
+            run = 0;
+        }
+        bw.put(T.ac_code[0], T.ac_len[0]); // EOB
+        if (bw.overflow) return TIC_E_SPACE;
+    }
+    bw.finish();
+    if (bw.overflow) return TIC_E_SPACE;
+    *out_len = (size_t)(bw.p - out);
+    return TIC_OK;
+}
+
+int parse_header(const uint8_t *data, size_t len, int *h, int *w, int *quality, uint32_t *flag) {
+    if (!data || len < 16) return TIC_E_STREAM;
+    uint32_t v[4];
+    for (int i = 0; i < 4; i++)
+        v[i] = (uint32_t)data[4 * i] | ((uint32_t)data[4 * i + 1] << 8) | ((uint32_t)data[4 * i + 2] << 16) |
+               ((uint32_t)data[4 * i + 3] << 24);
+    if (h) *h = (int)v[0];
+    if (w) *w = (int)v[1];
+    if (quality) *quality = (int)v[2];
+    if (flag) *flag = v[3];
+    return TIC_OK;
+}
+
+namespace {
+
+struct BitReader {
+    const uint8_t *p;
+    size_t nbits, pos;
+    // A read past the end returns no bit but still advances (bitarray slicing semantics, bitbuffer.py:20-23).
+    inline bool bit(int &b) {
+        bool ok = pos < nbits;
+        if (ok) b = (p[pos >> 3] >> (7 - (pos & 7))) & 1;
+        pos++;
+        return ok;
+    }
+};
+
+// huffman.py:66-74: grow the prefix bit by bit; fail (ValueError) after 17 reads.
+inline bool read_code(BitReader &r, const EncTables::Dec &d, int &sym) {
+    unsigned code = 0;
+    int len = 0;
+    for (int i = 0; i <= 16; i++) {
+        if (len > 0 && d.count[len] && code >= d.first[len] && code < (unsigned)d.first[len] + d.count[len]) {
+            sym = d.sym[d.base[len] + (code - d.first[len])];
+            return true;
+        }
+        if (i == 16) break;
+        int b;
+        if (r.bit(b)) {
+            code = (code << 1) | (unsigned)b;
+            len++;
+        }
+    }
+    r.pos++;
+    return false;
+}
+
+// bitbuffer.py:55-65
+inline bool read_int(BitReader &r, int size, int &out) {
+    if (size == 0) {
+        out = 0;
+        return true;
+    }
+    uint32_t v = 0;
+    int first = -1, got = 0;
+    for (int i = 0; i < size; i++) {
+        int b;
+        if (r.bit(b)) {
+            if (first < 0) first = b;
+            v = (v << 1) | (uint32_t)b;
+            got++;
+        }
+    }
+    if (!got) return false;
+    if (first == 0)
+        out = -(int)((~v) & ((1u << got) - 1u));
+    else
+        out = (int)v;
+    return true;
+}
+
+inline int16_t sat16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+} // namespace
+
+int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
+    const EncTables &T = tables();
+    const size_t n = num_blocks(h, w);
+    memset(zz, 0, n * 64 * sizeof(int16_t));
+    BitReader r{data, len * 8, 128};
+    int running_dc = 0; // np.cumsum(dc), codec.py:53
+    for (size_t b = 0; b < n; b++) {
+        int16_t *c = zz + b * 64;
+        int sym, v;
+        bool have_dc = read_code(r, T.dcd, sym) && read_int(r, sym, v);
+        if (have_dc) running_dc += v;
+        c[0] = sat16(running_dc);
+        if (!have_dc) continue; // exception before the AC loop: block stays zero (codec.py:185-186)
+        int16_t tmp[1100];
+        int m = 0;
+        bool ok = true;
+        for (;;) {
+            if (!read_code(r, T.acd, sym)) {
+                ok = false;
+                break;
+            }
+            int run = sym >> 4, size = sym & 15;
+            if (!read_int(r, size, v)) {
+                ok = false;
+                break;
+            }
+            if (m + run + 1 > 1090) {
+                ok = false;
+                break;
+            }
+            for (int z = 0; z < run; z++) tmp[m++] = 0;
+            tmp[m++] = sat16(v);
+            if (sym == 0) break;
+        }
+        if (!ok) continue;
+        m -= 1; // decode_run_length drops the element produced by EOB (huffman.py:36-38)
+        if (m > 63) continue;
+        memcpy(c + 1, tmp, (size_t)m * sizeof(int16_t));
+    }
+    return TIC_OK;
+}
+
+} // namespace tic

@@ -1,0 +1,37 @@
+// tic_kernels.h - launch interface between the C-ABI layer (tic_api.hip) and the kernels (tic_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tic_math.h"
+
+namespace tic {
+
+struct DctqArgs {
+    const uint8_t *img;  // device, uint8 [h][stride]
+    int h, w;
+    long stride;         // bytes between rows
+    int bw;              // blocks per row  = ceil(w/8)
+    int tiles_x;         // 8-block strips per block row = ceil(bw/8)
+    int ntiles;          // bh * tiles_x
+    int aligned8;        // img and stride are multiples of 8 -> 8-byte row loads
+    const DctqConsts *consts; // device
+    int16_t *out;        // device, int16 [N][64] zig-zag
+    unsigned long long *fallback_count; // device counter of blocks redone on the exact path (may be null)
+};
+
+struct IdctArgs {
+    const int16_t *coeffs; // device, int16 [N][64] zig-zag, DC integrated
+    uint8_t *out;          // device, uint8 [h][stride]
+    int h, w;
+    long stride;
+    int bw, tiles_x, ntiles;
+    int aligned8;
+    const DctqConsts *consts;
+};
+
+hipError_t launch_dctq(const DctqArgs &a, int variant, hipStream_t stream);
+hipError_t launch_idct(const IdctArgs &a, hipStream_t stream);
+hipError_t launch_selftest_transpose(const void *in, void *out_dpp, void *out_ref, int nthreads, hipStream_t stream);
+
+} // namespace tic

@@ -1,0 +1,176 @@
+// tic_math.h - per-lane arithmetic of the transform stage, usable from device code (hipcc) and from host
+// code (g++; used by the host-side constant builder and by tests that emulate a block on the CPU).
+//
+// Compile every translation unit that includes this with -ffp-contract=off: the exact path below requires each
+// + - * to be a single IEEE-754 operation in scipy/pocketfft's order, and the fast path
+// names its fused multiply-adds explicitly.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "tic_tables.h"
+
+#if defined(__HIPCC__)
+#define TIC_HD __host__ __device__ __forceinline__
+#else
+#define TIC_HD inline
+#endif
+
+namespace tic {
+
+// ---------------------------------------------------------------------------------------------------------
+// Exact path: scipy.fftpack.dct(x, norm="ortho") for N=8 in pocketfft's operation order
+// (T_dcst23 type 2 -> radb2(ido=4) -> radb4(ido=1) -> scale -> twiddle post-pass).  Replaces the arithmetic of
+// block_dct, utils.py:32-37.  In place on eight named values.
+// ---------------------------------------------------------------------------------------------------------
+TIC_HD void dct8_exact(double &c0, double &c1, double &c2, double &c3, double &c4, double &c5, double &c6,
+                       double &c7) {
+#pragma clang fp contract(off)
+    // pre-processing
+    c0 = c0 * 2.0;
+    c7 = c7 * 2.0;
+    double t;
+    t = c2; c2 = t - c1; c1 = t + c1;
+    t = c4; c4 = t - c3; c3 = t + c3;
+    t = c6; c6 = t - c5; c5 = t + c5;
+    // radb2
+    double h0 = c0 + c7, h4 = c0 - c7;
+    double h3 = 2.0 * c3, h7 = -2.0 * c4;
+    double h1 = c1 + c5, tr2 = c1 - c5;
+    double ti2 = c2 + c6, h2 = c2 - c6;
+    double pa = kWR * ti2, pb = kWI * tr2;
+    double h6 = pa + pb;
+    double pc = kWR * tr2, pd = kWI * ti2;
+    double h5 = pc - pd;
+    // radb4, k = 0
+    double a2 = h0 + h3, a1 = h0 - h3, a3 = 2.0 * h1, a4 = 2.0 * h2;
+    double o0 = a2 + a3, o4 = a2 - a3, o6 = a1 + a4, o2 = a1 - a4;
+    // radb4, k = 1
+    double b2 = h4 + h7, b1 = h4 - h7, b3 = 2.0 * h5, b4 = 2.0 * h6;
+    double o1 = b2 + b3, o5 = b2 - b3, o7 = b1 + b4, o3 = b1 - b4;
+    // normalisation 1/sqrt(2N) = 0.25
+    c0 = o0 * 0.25; c1 = o1 * 0.25; c2 = o2 * 0.25; c3 = o3 * 0.25;
+    c4 = o4 * 0.25; c5 = o5 * 0.25; c6 = o6 * 0.25; c7 = o7 * 0.25;
+    // post-processing (k, kc) = (1,7), (2,6), (3,5)
+    double p1, p2, p3, p4, t1, t2;
+    p1 = kTW0 * c7; p2 = kTW6 * c1; t1 = p1 + p2; p3 = kTW0 * c1; p4 = kTW6 * c7; t2 = p3 - p4;
+    c1 = 0.5 * (t1 + t2); c7 = 0.5 * (t1 - t2);
+    p1 = kTW1 * c6; p2 = kTW5 * c2; t1 = p1 + p2; p3 = kTW1 * c2; p4 = kTW5 * c6; t2 = p3 - p4;
+    c2 = 0.5 * (t1 + t2); c6 = 0.5 * (t1 - t2);
+    p1 = kTW2 * c5; p2 = kTW4 * c3; t1 = p1 + p2; p3 = kTW2 * c3; p4 = kTW4 * c5; t2 = p3 - p4;
+    c3 = 0.5 * (t1 + t2); c5 = 0.5 * (t1 - t2);
+    c4 = c4 * kTW3;
+    c0 = c0 * kSq2h;
+}
+
+// scipy.fftpack.idct(x, norm="ortho") (DCT-III), pocketfft order: T_dcst23 type 3 -> radf4(ido=1) -> radf2(ido=4).
+// Replaces the arithmetic of block_idct, utils.py:40-45.
+TIC_HD void idct8_exact(double &c0, double &c1, double &c2, double &c3, double &c4, double &c5, double &c6,
+                        double &c7) {
+#pragma clang fp contract(off)
+    c0 = c0 * kSqrt2;
+    double t1, t2, p1, p2, p3, p4;
+    t1 = c1 + c7; t2 = c1 - c7; p1 = kTW0 * t2; p2 = kTW6 * t1; p3 = kTW0 * t1; p4 = kTW6 * t2;
+    c1 = p1 + p2; c7 = p3 - p4;
+    t1 = c2 + c6; t2 = c2 - c6; p1 = kTW1 * t2; p2 = kTW5 * t1; p3 = kTW1 * t1; p4 = kTW5 * t2;
+    c2 = p1 + p2; c6 = p3 - p4;
+    t1 = c3 + c5; t2 = c3 - c5; p1 = kTW2 * t2; p2 = kTW4 * t1; p3 = kTW2 * t1; p4 = kTW4 * t2;
+    c3 = p1 + p2; c5 = p3 - p4;
+    c4 = c4 * (2.0 * kTW3);
+    // radf4 (k = 0 -> a0..a3 from c0,c2,c4,c6 ; k = 1 -> a4..a7 from c1,c3,c5,c7)
+    double tr1 = c6 + c2, a2 = c6 - c2, tr2 = c0 + c4, a1 = c0 - c4;
+    double a0 = tr2 + tr1, a3 = tr2 - tr1;
+    double ur1 = c7 + c3, a6 = c7 - c3, ur2 = c1 + c5, a5 = c1 - c5;
+    double a4 = ur2 + ur1, a7 = ur2 - ur1;
+    // radf2
+    double r0 = a0 + a4, r7 = a0 - a4, r4 = -a7, r3 = a3;
+    double m1 = kWR * a5, m2 = kWI * a6, q2 = m1 + m2;
+    double m3 = kWR * a6, m4 = kWI * a5, qi = m3 - m4;
+    double r1 = a1 + q2, r5 = a1 - q2, r2 = qi + a2, r6 = qi - a2;
+    c0 = r0 * 0.25; c1 = r1 * 0.25; c2 = r2 * 0.25; c3 = r3 * 0.25;
+    c4 = r4 * 0.25; c5 = r5 * 0.25; c6 = r6 * 0.25; c7 = r7 * 0.25;
+    double t;
+    t = c1; c1 = t - c2; c2 = t + c2;
+    t = c3; c3 = t - c4; c4 = t + c4;
+    t = c5; c5 = t - c6; c6 = t + c6;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path: Arai-Agui-Nakajima scaled 8-point DCT in float32 (5 multiplies, FMAs named explicitly).
+// Output k is the orthonormal DCT-II coefficient times aan[k]*sqrt(8), aan[0] = 1, aan[k] = sqrt(2)*cos(k*pi/16);
+// the scale is folded into the quantiser multiplier.  o0 and o4 are plain sums/differences of the inputs, hence
+// exact integers when the inputs are (needed by the exact sub-path for coefficients (0,0),(0,4),(4,0),(4,4)).
+// ---------------------------------------------------------------------------------------------------------
+TIC_HD void dct8_aan(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6, float &d7) {
+#pragma clang fp contract(off)
+    const float c707 = 0.70710678118654752440f, c382 = 0.38268343236508977173f;
+    const float c541 = 0.54119610014619698440f, c1306 = 1.30656296487637652786f;
+    float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    float t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    d0 = t10 + t11;
+    d4 = t10 - t11;
+    float s = t12 + t13;
+    d2 = fmaf(s, c707, t13);
+    d6 = fmaf(s, -c707, t13);
+    float u10 = t4 + t5, u11 = t5 + t6, u12 = t6 + t7;
+    float z5 = (u10 - u12) * c382;
+    float z2 = fmaf(u10, c541, z5);
+    float z4 = fmaf(u12, c1306, z5);
+    float z11 = fmaf(u11, c707, t7);
+    float z13 = fmaf(u11, -c707, t7);
+    d5 = z13 + z2;
+    d3 = z13 - z2;
+    d1 = z11 + z4;
+    d7 = z11 - z4;
+}
+
+// Guard band of the fast path, in coefficient (X) units: |X_fast - X_reference| stays below this for any uint8
+// block (worst case found by search 3.7e-4; analysis in DESIGN.md) plus the rounding of the quantiser multiply.
+static constexpr double kGuardX = 1.0e-3;
+
+// Quality-dependent constants consumed by the kernels (one instance per quality, resident in HBM; 1728 bytes).
+struct DctqConsts {
+    double div[64];    // natural order u*8+v: (Q*factor)/100 as the reference computes it (utils.py:50-53)
+    double rdiv[64];   // fl(1/div)
+    float mul[64];     // fast path: 1 / (aan[u]*aan[v]*8*div)
+    float thr[64];     // fast path accepts rint(t) when |t - rint(t)| <= thr (= 0.5 - guard/div); <0 never used
+    uint16_t zzofs[64]; // byte offset of natural index i inside the block's zig-zag ordered int16[64]
+    uint8_t zznat[64];  // natural index u*8+v of scan position k (= kZigzag)
+};
+
+// utils.py:50-53 divisor recipe.  Returns false when quality is outside 1..99.
+inline bool build_consts(int quality, DctqConsts *c) {
+#pragma clang fp contract(off)
+    if (quality < 1 || quality > 99) return false;
+    for (int i = 0; i < 64; i++) {
+        if (quality < 50) {
+            double factor = 5000.0 / (double)quality;
+            double p = (double)kQTable[i] * factor;
+            c->div[i] = p / 100.0;
+        } else {
+            int factor = 200 - 2 * quality;
+            c->div[i] = (double)(kQTable[i] * factor) / 100.0;
+        }
+        c->rdiv[i] = 1.0 / c->div[i];
+    }
+    double aan[8];
+    aan[0] = 1.0;
+    for (int k = 1; k < 8; k++) aan[k] = sqrt(2.0) * cos(k * 3.14159265358979323846 / 16.0);
+    for (int u = 0; u < 8; u++)
+        for (int v = 0; v < 8; v++) {
+            int i = u * 8 + v;
+            c->mul[i] = (float)(1.0 / (aan[u] * aan[v] * 8.0 * c->div[i]));
+            double g = kGuardX / c->div[i];
+            c->thr[i] = (float)(0.5 - g);
+            bool rational = (u == 0 || u == 4) && (v == 0 || v == 4);
+            if (rational) c->thr[i] = 1.0f; // computed on the exact sub-path; never trips
+        }
+    for (int k = 0; k < 64; k++) {
+        c->zzofs[kZigzag[k]] = (uint16_t)(2 * k);
+        c->zznat[k] = kZigzag[k];
+    }
+    return true;
+}
+
+} // namespace tic

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Runs a list of GPU steps on the gpurun box, each under its own timeout; stops at the first step that is killed
+# by its timeout (never starts another GPU step after a hang).  Usage: tools/gpu_run.sh step1 step2 ...
+# Steps: microbench | tests | tests_fast | smoke | bench | bench_exact | prof | pmc | bench16k
+set -o pipefail
+cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+run() { # name timeout cmd...
+  local name=$1 t=$2; shift 2
+  echo "=== $name ($(date +%T))"
+  timeout -k 10 "$t" "$@" > "gpurun_out/$name.txt" 2>&1
+  local rc=$?
+  echo "=== $name exit $rc"; tail -n 25 "gpurun_out/$name.txt"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name timed out: stopping"; exit 99; fi
+  return 0
+}
+for step in "$@"; do
+  case $step in
+    microbench) run microbench 240 ./tools/bin/microbench ;;
+    tests)      run pytest_gpu 900 python -m pytest tests -m gpu -x -q ;;
+    tests_fast) run pytest_gpu_fast 600 python -m pytest tests -m gpu -x -q -k "not 16384" ;;
+    tests_all)  run pytest_gpu_all 900 python -m pytest tests -m gpu -q ;;
+    smoke)      run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench)      run bench 300 python bench.py ;;
+    bench_exact) run bench_exact 300 python bench.py --variant exact --no-cpu-baseline ;;
+    bench16k)   run bench16k 300 python bench.py --height 16384 --width 16384 --steps 20 --warmup 3 --no-cpu-baseline ;;
+    sweep)      run sweep 600 python tools/sweep.py ;;
+    prof)       rm -rf gpurun_out/prof; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --no-cpu-baseline ;;
+    pmc_rd)     rm -rf gpurun_out/pmc_rd; run pmc_rd 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_rd -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline ;;
+    pmc_wr)     rm -rf gpurun_out/pmc_wr; run pmc_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_wr -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
+exit 0
