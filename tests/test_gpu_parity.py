@@ -282,5 +282,16 @@ def test_error_paths(ctx):
     assert L.tic_dctq(ctx.handle, img.ctypes.data, 16, 16, 8, 50, zz.ctypes.data) == N.TIC_E_ARG
     assert b"stride" in L.tic_last_error(ctx.handle)
     assert T.compress(np.zeros((0, 8), np.uint8), 50, ctx=ctx).hex() == "00000000080000003200000000000000"
-    with pytest.raises(KeyError):  # |AC| >= 1024: no Huffman code, as the reference
-        T.compress(np.tile(np.array([[0, 255], [255, 0]], dtype=np.uint8), (8, 8)), 99, ctx=ctx)
+
+
+def test_coefficient_without_huffman_code_raises_keyerror(ctx, golden):
+    """|AC| >= 1024 has no Huffman code: the reference raises KeyError (goldens with an empty stream)."""
+    d = golden("transform_small")
+    hit = 0
+    for key in d["names"]:
+        if d[key + "_bs"].size == 0:
+            q = int(str(key).rsplit("_q", 1)[1])
+            with pytest.raises(KeyError):
+                T.compress(d[key + "_img"], q, ctx=ctx)
+            hit += 1
+    assert hit >= 1

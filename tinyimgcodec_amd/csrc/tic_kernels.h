@@ -18,6 +18,9 @@ struct DctqArgs {
     const DctqConsts *consts; // device
     int16_t *out;        // device, int16 [N][64] zig-zag
     unsigned long long *fallback_count; // device counter of blocks redone on the exact path (may be null)
+    // persistent-wave schedule of the hybrid kernel: wave g handles strips g, g + nwaves, g + 2*nwaves, ...
+    int nwaves;          // waves in the grid
+    int step_ty, step_tx; // nwaves / tiles_x and nwaves % tiles_x (strip coordinates advance without a division)
 };
 
 struct IdctArgs {
@@ -30,7 +33,7 @@ struct IdctArgs {
     const DctqConsts *consts;
 };
 
-hipError_t launch_dctq(const DctqArgs &a, int variant, hipStream_t stream);
+hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream);
 hipError_t launch_idct(const IdctArgs &a, hipStream_t stream);
 hipError_t launch_selftest_transpose(const void *in, void *out_dpp, void *out_ref, int nthreads, hipStream_t stream);
 

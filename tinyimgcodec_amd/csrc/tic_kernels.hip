@@ -94,9 +94,9 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 }
 
 constexpr int kWavesPerWG = 4;
-constexpr int kLdsStrideDw = 72;    // dwords per block in the transpose buffer (64 + 8 pad: conflict-free ds_write_b32)
+constexpr int kLdsStrideDw = 68;    // dwords per block in the transpose buffer (64 + 4 pad; bank analysis in DESIGN.md)
 constexpr int kZzStrideB = 144;     // bytes per block in the zig-zag staging buffer (128 + 16 pad)
-constexpr int kLdsWaveBytes = 8 * kLdsStrideDw * 4; // 2304 B per wave (>= 8*144)
+constexpr int kLdsWaveBytes = 8 * kLdsStrideDw * 4; // 2176 B per wave (>= 8*144)
 
 struct Strip {
     int by, bx;   // block coordinates of this lane's block
@@ -217,108 +217,249 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Kernel 2: hybrid path.
+// Kernel 2: hybrid path (the production kernel).
+//
+// Persistent waves: wave g of the grid owns strips g, g + nwaves, ... (strip = 8 horizontally adjacent blocks).
+// Main loop, per strip (lean: ~64 VGPRs, 8 waves per SIMD):
+//   load   : lane 8*r + b reads the 8 bytes of pixel row r of block b -> every 8 lanes read 64 contiguous bytes;
+//            two strips are kept in flight in registers (prefetch depth 2).
+//   pass 1 : float32 AAN along the pixel row held by the lane (no cross-lane traffic); the level shift is folded
+//            into output 0 (row sum - 1024, an exact integer).
+//   xpose  : 8x8 dword transpose per block through wave-private LDS; lane 8*b + v then holds column v.
+//   pass 2 : float32 AAN down that column; quantise by t = Z*mul with the magic-number rounding trick, twice
+//            (t+g and t-g): the two roundings differ exactly when a .5 tie lies inside the guard band.
+//   store  : int16 results scattered to zig-zag order in LDS, read back 16 B per lane, 1 KiB contiguous per wave.
+//   trips  : a strip in which any lane tripped its guard band is recorded (8 bytes) in a wave-private LDS list.
+// After the loop the wave revisits its recorded strips: blocks whose only trips are exact ties of the four
+// rational coefficients (~2 % of blocks) get those four values from the exact float64 sub-path; blocks with any
+// other trip (~0.3 % at q=50) are redone entirely on the exact path.  Keeping this out of the loop keeps the loop's
+// register footprint small.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWavesPerWG * 64) void dctq_hybrid_kernel(DctqArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerWG][kLdsWaveBytes / 4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = lane >> 3, i = lane & 7;
-    uint32_t *lds = lds_all[wave];
-    const int tile = blockIdx.x * kWavesPerWG + wave;
-    const DctqConsts *__restrict__ C = a.consts;
-    Strip s = make_strip(tile, a.ntiles, a.tiles_x, a.bw, b);
+constexpr int kTStrideDw = kLdsStrideDw;          // the post-pass reuses exact_block(), which assumes this stride
+constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
+constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
+constexpr int kMaxStripsPerWave = 64;             // capacity of the per-wave trip list (launcher sizes the grid for it)
 
-    uint32_t lo, hi;
-    load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
+__device__ __forceinline__ void quant_guarded(float z, float mul, float g, uint32_t &bits, uint32_t &diff) {
+    // s1/s2 = round-half-even(z*mul +- g) as integers biased by kMagic; equal unless a tie is within the guard
+    float s1 = fmaf(z, mul, g) + kMagic;
+    float s2 = fmaf(z, mul, -g) + kMagic;
+    bits = __float_as_uint(s1);
+    diff = bits ^ __float_as_uint(s2);
+}
 
-    // per-lane constants for frequency row u = i (L2-resident, 80 bytes per lane)
-    const float4 m0 = *reinterpret_cast<const float4 *>(C->mul + i * 8);
-    const float4 m1 = *reinterpret_cast<const float4 *>(C->mul + i * 8 + 4);
-    const float4 h0 = *reinterpret_cast<const float4 *>(C->thr + i * 8);
-    const float4 h1 = *reinterpret_cast<const float4 *>(C->thr + i * 8 + 4);
-    const uint4 zzv = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
-
-    transpose8x8_bytes(lo, hi, i); // lane i now holds pixel column i
-
-    // ---- column pass (axis -2), float32 AAN on raw 0..255 pixels; level shift folded into output 0 ------
-    float d0 = (float)(lo & 0xffu), d1 = (float)((lo >> 8) & 0xffu), d2 = (float)((lo >> 16) & 0xffu),
-          d3 = (float)(lo >> 24);
-    float d4 = (float)(hi & 0xffu), d5 = (float)((hi >> 8) & 0xffu), d6 = (float)((hi >> 16) & 0xffu),
-          d7 = (float)(hi >> 24);
-    dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
-    d0 -= 1024.0f; // sum of 8 pixels minus 8*128: exact integer
-
-    uint32_t y[8] = {__float_as_uint(d0), __float_as_uint(d1), __float_as_uint(d2), __float_as_uint(d3),
-                     __float_as_uint(d4), __float_as_uint(d5), __float_as_uint(d6), __float_as_uint(d7)};
-    transpose8x8_dwords(lds, b, i, y); // lane i now holds frequency row u = i: Y[u][0..7]
-    float e0 = __uint_as_float(y[0]), e1 = __uint_as_float(y[1]), e2 = __uint_as_float(y[2]),
-          e3 = __uint_as_float(y[3]), e4 = __uint_as_float(y[4]), e5 = __uint_as_float(y[5]),
-          e6 = __uint_as_float(y[6]), e7 = __uint_as_float(y[7]);
-
-    // ---- rational coefficients (u,v) in {0,4}x{0,4}: exact float64 sub-path on lanes u = 0 and u = 4 ------
-    // For integer pixels the column pass outputs 0 and 4 are (integer sum) * constant, one rounding each, and
-    // the row pass outputs 0 and 4 need only 8 additions in pocketfft's order (consequence 2).
-    int q0x = 0, q4x = 0;
-    if ((i & 3) == 0) {
+// Rational coefficients (u,v) in {0,4}x{0,4} of the lane's block on their exact float64 sub-path (SURVEY
+// Appendix A, consequence 2): for integer pixels the column pass outputs 0 and 4 are (integer sum) * constant,
+// one rounding each, and the row pass outputs 0 and 4 need 8 additions in pocketfft's order.
+// col: the lane's pixel column (lane 8*b + c).  Lanes c = 0 and c = 4 return the two quantised values of
+// frequency row u = c: r0 = (u,0), r4 = (u,4).
+__device__ __forceinline__ void special_block(uint32_t colLo, uint32_t colHi, uint32_t *ldsT, int b, int i,
+                                              const DctqConsts *__restrict__ C, int &r0i, int &r4i) {
 #pragma clang fp contract(off)
-        const double K = (i == 0) ? (kSq2h * 0.5) : (kTW3 * 0.5);
-        double y0 = (double)e0 * K, y1 = (double)e1 * K, y2 = (double)e2 * K, y3 = (double)e3 * K;
-        double y4 = (double)e4 * K, y5 = (double)e5 * K, y6 = (double)e6 * K, y7 = (double)e7 * K;
-        double p07 = y0 + y7, p34 = y3 + y4, p12 = y1 + y2, p56 = y5 + y6;
+    int x0 = colLo & 0xff, x1 = (colLo >> 8) & 0xff, x2 = (colLo >> 16) & 0xff, x3 = colLo >> 24;
+    int x4 = colHi & 0xff, x5 = (colHi >> 8) & 0xff, x6 = (colHi >> 16) & 0xff, x7 = colHi >> 24;
+    int ea = x0 + x7 + x3 + x4, eb = x1 + x2 + x5 + x6;
+    double y0 = (double)(ea + eb - 1024) * (kSq2h * 0.5);
+    double y4 = (double)(ea - eb) * (kTW3 * 0.5);
+    double *dl = reinterpret_cast<double *>(ldsT) + b * 16;
+    dl[i] = y0;
+    dl[8 + i] = y4;
+    wave_lds_fence();
+    r0i = 0;
+    r4i = 0;
+    if ((i & 3) == 0) { // lane i = 0 finishes frequency row u = 0, lane i = 4 row u = 4
+        const double *yr = dl + (i ? 8 : 0);
+        double a0 = yr[0], a1 = yr[1], a2 = yr[2], a3 = yr[3], a4 = yr[4], a5 = yr[5], a6 = yr[6], a7 = yr[7];
+        double p07 = a0 + a7, p34 = a3 + a4, p12 = a1 + a2, p56 = a5 + a6;
         double A = p07 + p34, B = p12 + p56;
         double E0 = A + B, E4 = A - B;
         double X0 = E0 * (kSq2h * 0.5), X4 = E4 * (kTW3 * 0.5);
-        const double dv0 = C->div[i * 8], dv4 = C->div[i * 8 + 4];
-        const double rd0 = C->rdiv[i * 8], rd4 = C->rdiv[i * 8 + 4];
-        double t0 = X0 * rd0, t4 = X4 * rd4;
+        double t0 = X0 * C->rdiv[i * 8], t4 = X4 * C->rdiv[i * 8 + 4];
         double r0 = rint(t0), r4 = rint(t4);
         // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
-        if (fabs(fabs(t0 - r0) - 0.5) < 1e-9) r0 = rint(X0 / dv0);
-        if (fabs(fabs(t4 - r4) - 0.5) < 1e-9) r4 = rint(X4 / dv4);
-        q0x = (int)r0;
-        q4x = (int)r4;
+        if (fabs(fabs(t0 - r0) - 0.5) < 1e-9) r0 = rint(X0 / C->div[i * 8]);
+        if (fabs(fabs(t4 - r4) - 0.5) < 1e-9) r4 = rint(X4 / C->div[i * 8 + 4]);
+        r0i = (int)r0;
+        r4i = (int)r4;
     }
+    wave_lds_fence();
+}
 
-    // ---- row pass (axis -1), float32 AAN, quantise with guard band ----------------------------------------
-    dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
-    int q[8];
-    bool trip = false;
+struct TripRec {
+    int tile;
+    uint32_t masks; // bits 0-7: blocks to redo entirely, bits 8-15: blocks needing the rational coefficients only
+};
+
+__device__ __forceinline__ uint32_t byte_any(unsigned long long m) { // bit k = (byte k of m != 0)
+    m |= m >> 4;
+    m |= m >> 2;
+    m |= m >> 1;
+    m &= 0x0101010101010101ull;
+    return (uint32_t)((m * 0x0102040810204080ull) >> 56);
+}
+
+__global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
+    __shared__ TripRec list_all[kWavesPerWG][kMaxStripsPerWave];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *ldsT = ldsT_all[wave];
+    char *ldsZ = reinterpret_cast<char *>(ldsZ_all[wave]);
+    TripRec *list = list_all[wave];
+    const DctqConsts *__restrict__ C = a.consts;
+
+    const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
+    const int b = lane >> 3, i = lane & 7;   // compute phase: column / frequency v = i of block b
+    int nrec = 0;                            // wave-uniform
+
     {
-        float t, r;
-        t = e0 * m0.x; r = rintf(t); trip |= fabsf(t - r) > h0.x; q[0] = (int)r;
-        t = e1 * m0.y; r = rintf(t); trip |= fabsf(t - r) > h0.y; q[1] = (int)r;
-        t = e2 * m0.z; r = rintf(t); trip |= fabsf(t - r) > h0.z; q[2] = (int)r;
-        t = e3 * m0.w; r = rintf(t); trip |= fabsf(t - r) > h0.w; q[3] = (int)r;
-        t = e4 * m1.x; r = rintf(t); trip |= fabsf(t - r) > h1.x; q[4] = (int)r;
-        t = e5 * m1.y; r = rintf(t); trip |= fabsf(t - r) > h1.y; q[5] = (int)r;
-        t = e6 * m1.z; r = rintf(t); trip |= fabsf(t - r) > h1.z; q[6] = (int)r;
-        t = e7 * m1.w; r = rintf(t); trip |= fabsf(t - r) > h1.w; q[7] = (int)r;
-    }
-    if ((i & 3) == 0) {
-        q[0] = q0x;
-        q[4] = q4x;
+        // per-lane constants for horizontal frequency v = i (L2-resident; loaded once per wave)
+        const float4 m0 = *reinterpret_cast<const float4 *>(C->mulT + i * 8);
+        const float4 m1 = *reinterpret_cast<const float4 *>(C->mulT + i * 8 + 4);
+        const float4 g0 = *reinterpret_cast<const float4 *>(C->guardT + i * 8);
+        const float4 g1 = *reinterpret_cast<const float4 *>(C->guardT + i * 8 + 4);
+        const uint4 zzv = *reinterpret_cast<const uint4 *>(C->zzofsT + i * 8);
+        char *zzblk = ldsZ + b * kZzStrideB;
+        int16_t *zp0 = reinterpret_cast<int16_t *>(zzblk + (zzv.x & 0xffff)), *zp1 = reinterpret_cast<int16_t *>(zzblk + (zzv.x >> 16));
+        int16_t *zp2 = reinterpret_cast<int16_t *>(zzblk + (zzv.y & 0xffff)), *zp3 = reinterpret_cast<int16_t *>(zzblk + (zzv.y >> 16));
+        int16_t *zp4 = reinterpret_cast<int16_t *>(zzblk + (zzv.z & 0xffff)), *zp5 = reinterpret_cast<int16_t *>(zzblk + (zzv.z >> 16));
+        int16_t *zp6 = reinterpret_cast<int16_t *>(zzblk + (zzv.w & 0xffff)), *zp7 = reinterpret_cast<int16_t *>(zzblk + (zzv.w >> 16));
+        uint32_t *tw = ldsT + lb * kTStrideDw + lr;                                          // transpose write: [block][v*8 + row]
+        const uint4 *tr = reinterpret_cast<const uint4 *>(ldsT + b * kTStrideDw + i * 8);    // read: the 8 rows of column v
+        const uint4 *zr = reinterpret_cast<const uint4 *>(zzblk + i * 16);
+        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // simple strips: lane offset from the strip base
+        const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
+
+        // strip schedule (all scalar); three strips in flight: current (0), next (1), next-next (2)
+        int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + wave);
+        int ty0 = t0 / a.tiles_x, tx0 = t0 - ty0 * a.tiles_x;
+        int t1 = t0 + a.nwaves, ty1 = ty0 + a.step_ty, tx1 = tx0 + a.step_tx;
+        if (tx1 >= a.tiles_x) { tx1 -= a.tiles_x; ty1 += 1; }
+
+        auto load_strip = [&](int t, int ty, int tx, uint32_t &plo, uint32_t &phi) {
+            plo = 0;
+            phi = 0;
+            if (t >= a.ntiles) return;
+            const bool simple = a.aligned8 && (tx * 64 + 64 <= a.w) && (ty * 8 + 8 <= a.h); // wave-uniform
+            if (simple) {
+                const uint8_t *base = a.img + (long)ty * 8 * a.stride + tx * 64;
+                const uint2 v = *reinterpret_cast<const uint2 *>(base + ld_off);
+                plo = v.x;
+                phi = v.y;
+            } else {
+                Strip sl;
+                sl.by = ty; sl.bx = tx * 8 + lb; sl.valid = sl.bx < a.bw; sl.oblk = 0;
+                load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, sl, lr, plo, phi);
+            }
+        };
+        uint32_t lo0, hi0, lo1, hi1;
+        load_strip(t0, ty0, tx0, lo0, hi0);
+        load_strip(t1, ty1, tx1, lo1, hi1);
+
+        while (t0 < a.ntiles) {
+            int t2 = t1 + a.nwaves, ty2 = ty1 + a.step_ty, tx2 = tx1 + a.step_tx;
+            if (tx2 >= a.tiles_x) { tx2 -= a.tiles_x; ty2 += 1; }
+            uint32_t lo2, hi2;
+            load_strip(t2, ty2, tx2, lo2, hi2);
+
+            // ---- pass 1: along the pixel row (the fast path is free to choose the pass order) ------------------
+            float d0 = (float)(lo0 & 0xffu), d1 = (float)((lo0 >> 8) & 0xffu), d2 = (float)((lo0 >> 16) & 0xffu),
+                  d3 = (float)(lo0 >> 24);
+            float d4 = (float)(hi0 & 0xffu), d5 = (float)((hi0 >> 8) & 0xffu), d6 = (float)((hi0 >> 16) & 0xffu),
+                  d7 = (float)(hi0 >> 24);
+            dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
+            d0 -= 1024.0f;
+            tw[0 * 8] = __float_as_uint(d0); tw[1 * 8] = __float_as_uint(d1); tw[2 * 8] = __float_as_uint(d2);
+            tw[3 * 8] = __float_as_uint(d3); tw[4 * 8] = __float_as_uint(d4); tw[5 * 8] = __float_as_uint(d5);
+            tw[6 * 8] = __float_as_uint(d6); tw[7 * 8] = __float_as_uint(d7);
+            wave_lds_fence();
+            const uint4 ra = tr[0], rb = tr[1];
+            wave_lds_fence();
+            float e0 = __uint_as_float(ra.x), e1 = __uint_as_float(ra.y), e2 = __uint_as_float(ra.z),
+                  e3 = __uint_as_float(ra.w), e4 = __uint_as_float(rb.x), e5 = __uint_as_float(rb.y),
+                  e6 = __uint_as_float(rb.z), e7 = __uint_as_float(rb.w);
+            // ---- pass 2: down the column of horizontal frequency v = i ------------------------------------------
+            dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
+            uint32_t q0, q1, q2, q3, q4, q5, q6, q7, x0, x1, x2, x3, x4, x5, x6, x7;
+            quant_guarded(e0, m0.x, g0.x, q0, x0);
+            quant_guarded(e1, m0.y, g0.y, q1, x1);
+            quant_guarded(e2, m0.z, g0.z, q2, x2);
+            quant_guarded(e3, m0.w, g0.w, q3, x3);
+            quant_guarded(e4, m1.x, g1.x, q4, x4);
+            quant_guarded(e5, m1.y, g1.y, q5, x5);
+            quant_guarded(e6, m1.z, g1.z, q6, x6);
+            quant_guarded(e7, m1.w, g1.w, q7, x7);
+            *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
+            *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
+
+            // ---- guard band bookkeeping (v in {0,4} lanes hold the rational coefficients at u = 0 and u = 4) --------
+            const bool valid = (tx0 * 8 + b) < a.bw;
+            const uint32_t x04 = x0 | x4, xg = x1 | x2 | x3 | x5 | x6 | x7;
+            const bool rational_lane = (i & 3) == 0;
+            const bool tripG = valid && ((xg != 0u) || (!rational_lane && x04 != 0u));
+            const bool tripS = valid && rational_lane && (x04 != 0u);
+            const unsigned long long mG = __ballot(tripG), mS = __ballot(tripS);
+            if ((mG | mS) != 0ull) { // wave-uniform, rare: remember the strip for the post-pass
+                const uint32_t gm = byte_any(mG), sm = byte_any(mS) & ~gm;
+                if (lane == 0) {
+                    list[nrec].tile = t0;
+                    list[nrec].masks = gm | (sm << 8);
+                }
+                nrec++;
+            }
+            // ---- zig-zag ordered blocks -> global: 16 B per lane, 1 KiB contiguous per wave ---------------------------
+            wave_lds_fence();
+            const uint4 val = *zr;
+            wave_lds_fence();
+            if (valid) {
+                char *obase = reinterpret_cast<char *>(a.out) + ((size_t)ty0 * a.bw + (size_t)tx0 * 8) * 128;
+                *reinterpret_cast<uint4 *>(obase + st_off) = val;
+            }
+            t0 = t1; ty0 = ty1; tx0 = tx1; lo0 = lo1; hi0 = hi1;
+            t1 = t2; ty1 = ty2; tx1 = tx2; lo1 = lo2; hi1 = hi2;
+        }
     }
 
-    // ---- guard tripped somewhere in the wave: redo those blocks on the exact path ---------------------------
-    const unsigned long long tripmask = __ballot(trip && s.valid);
-    if (tripmask != 0ull) { // wave-uniform
-        int qe[8];
-        exact_block(lo, hi, lds, b, i, C, qe);
-        const bool mine = ((tripmask >> (b * 8)) & 0xffull) != 0ull;
-        if (mine) {
+    // ---- post-pass over the recorded strips (wave-uniform loop; usually a handful of iterations) -------------------
+    if (nrec == 0) return;
+    __builtin_amdgcn_s_waitcnt(0); // the patches below must land after this wave's own fast-path stores
+    wave_lds_fence();
+    unsigned long long redone = 0;
+    for (int e = 0; e < nrec; e++) {
+        const int tile = __builtin_amdgcn_readfirstlane(list[e].tile);
+        const uint32_t masks = __builtin_amdgcn_readfirstlane(list[e].masks);
+        Strip s = make_strip(tile, a.ntiles, a.tiles_x, a.bw, b);
+        uint32_t lo, hi;
+        load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi); // lane 8*b + i: row i of block b
+        transpose8x8_bytes(lo, hi, i);                                         // -> pixel column i
+        const bool blkG = (masks >> b) & 1u, blkS = (masks >> (8 + b)) & 1u;
+        if (masks & 0xffu) {
+            int qe[8];
+            exact_block(lo, hi, ldsT, b, i, C, qe); // lane i holds frequency row u = i
+            const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
+            const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+            char *zzblk = ldsZ + b * kZzStrideB;
 #pragma unroll
-            for (int v = 0; v < 8; v++) q[v] = qe[v];
+            for (int v = 0; v < 8; v++)
+                *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
+            wave_lds_fence();
+            const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
+            wave_lds_fence();
+            if (blkG && s.valid) *reinterpret_cast<uint4 *>(a.out + s.oblk * 64 + i * 8) = val;
+            redone += __builtin_popcount(masks & 0xffu);
         }
-        if (a.fallback_count != nullptr && lane == 0) {
-            unsigned long long m = tripmask, n = 0;
-            for (int k = 0; k < 8; k++) n += ((m >> (8 * k)) & 0xffull) ? 1ull : 0ull;
-            atomicAdd(a.fallback_count, n);
+        if (masks & 0xff00u) {
+            int r0, r4;
+            special_block(lo, hi, ldsT, b, i, C, r0, r4);
+            if (blkS && s.valid && (i & 3) == 0) {
+                int16_t *ob = a.out + s.oblk * 64;
+                ob[C->zzofs[i * 8] >> 1] = (int16_t)r0;
+                ob[C->zzofs[i * 8 + 4] >> 1] = (int16_t)r4;
+            }
         }
     }
-
-    uint16_t zz[8] = {(uint16_t)zzv.x, (uint16_t)(zzv.x >> 16), (uint16_t)zzv.y, (uint16_t)(zzv.y >> 16),
-                      (uint16_t)zzv.z, (uint16_t)(zzv.z >> 16), (uint16_t)zzv.w, (uint16_t)(zzv.w >> 16)};
-    store_zigzag(lds, b, i, zz, q, a.out, s);
+    if (a.fallback_count != nullptr && lane == 0 && redone) atomicAdd(a.fallback_count, redone);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -409,14 +550,25 @@ __global__ void selftest_transpose_kernel(const uint2 *in, uint2 *out_dpp, uint2
 
 // ---- launchers ---------------------------------------------------------------------------------------------
 static inline int grid_for(int ntiles) { return (ntiles + kWavesPerWG - 1) / kWavesPerWG; }
+constexpr int kPersistentWGs = 256 * 8; // 256 CUs x 8 workgroups of 4 waves = every wave slot of the chip
 
-hipError_t launch_dctq(const DctqArgs &a, int variant, hipStream_t stream) {
+hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (a.ntiles <= 0) return hipSuccess;
-    dim3 grid(grid_for(a.ntiles)), block(kWavesPerWG * 64);
-    if (variant == 1)
-        hipLaunchKernelGGL(dctq_exact_kernel, grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL(dctq_hybrid_kernel, grid, block, 0, stream, a);
+    dim3 block(kWavesPerWG * 64);
+    if (variant == 1) {
+        a.nwaves = 0;
+        hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles)), block, 0, stream, a);
+    } else {
+        // persistent waves: at most kPersistentWGs workgroups, each wave loops over its strips
+        int wgs = grid_for(a.ntiles);
+        if (wgs > kPersistentWGs) wgs = kPersistentWGs;
+        const int min_wgs = (a.ntiles + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
+        if (wgs < min_wgs) wgs = min_wgs; // the per-wave trip list holds kMaxStripsPerWave entries
+        a.nwaves = wgs * kWavesPerWG;
+        a.step_ty = a.nwaves / a.tiles_x;
+        a.step_tx = a.nwaves % a.tiles_x;
+        hipLaunchKernelGGL(dctq_hybrid_kernel, dim3(wgs), block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 

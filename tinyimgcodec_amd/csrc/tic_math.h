@@ -126,17 +126,22 @@ TIC_HD void dct8_aan(float &d0, float &d1, float &d2, float &d3, float &d4, floa
 }
 
 // Guard band of the fast path, in coefficient (X) units: |X_fast - X_reference| stays below this for any uint8
-// block (worst case found by search 3.7e-4; analysis in DESIGN.md) plus the rounding of the quantiser multiply.
+// block (worst case found by search 3.7e-4, rigorous bound ~8e-4) plus the rounding of the quantiser
+// multiply (<= 1024 * 2^-23 = 1.2e-4).
 static constexpr double kGuardX = 1.0e-3;
+// Adding 1.5*2^23 to a float |t| < 2^22 rounds it to an integer (half-even) whose two's complement sits in the
+// low mantissa bits: the quantiser needs no v_rndne / v_cvt.
+static constexpr float kMagic = 12582912.0f;
 
-// Quality-dependent constants consumed by the kernels (one instance per quality, resident in HBM; 1728 bytes).
+// Quality-dependent constants consumed by the kernels (one instance per quality, resident in HBM).
 struct DctqConsts {
-    double div[64];    // natural order u*8+v: (Q*factor)/100 as the reference computes it (utils.py:50-53)
-    double rdiv[64];   // fl(1/div)
-    float mul[64];     // fast path: 1 / (aan[u]*aan[v]*8*div)
-    float thr[64];     // fast path accepts rint(t) when |t - rint(t)| <= thr (= 0.5 - guard/div); <0 never used
-    uint16_t zzofs[64]; // byte offset of natural index i inside the block's zig-zag ordered int16[64]
-    uint8_t zznat[64];  // natural index u*8+v of scan position k (= kZigzag)
+    double div[64];      // natural order u*8+v: (Q*factor)/100 as the reference computes it (utils.py:50-53)
+    double rdiv[64];     // fl(1/div)
+    float mulT[64];      // fast path, index v*8+u: 1 / (aan[u]*aan[v]*8*div[u][v])
+    float guardT[64];    // fast path, index v*8+u: guard band in quantised units = kGuardX / div[u][v]
+    uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
+    uint16_t zzofsT[64]; // index v*8+u: same offsets, transposed (lane v holds u = 0..7)
+    uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
 };
 
 // utils.py:50-53 divisor recipe.  Returns false when quality is outside 1..99.
@@ -159,16 +164,15 @@ inline bool build_consts(int quality, DctqConsts *c) {
     for (int k = 1; k < 8; k++) aan[k] = sqrt(2.0) * cos(k * 3.14159265358979323846 / 16.0);
     for (int u = 0; u < 8; u++)
         for (int v = 0; v < 8; v++) {
-            int i = u * 8 + v;
-            c->mul[i] = (float)(1.0 / (aan[u] * aan[v] * 8.0 * c->div[i]));
-            double g = kGuardX / c->div[i];
-            c->thr[i] = (float)(0.5 - g);
-            bool rational = (u == 0 || u == 4) && (v == 0 || v == 4);
-            if (rational) c->thr[i] = 1.0f; // computed on the exact sub-path; never trips
+            int i = u * 8 + v, t = v * 8 + u;
+            c->mulT[t] = (float)(1.0 / (aan[u] * aan[v] * 8.0 * c->div[i]));
+            c->guardT[t] = (float)(kGuardX / c->div[i]);
         }
     for (int k = 0; k < 64; k++) {
-        c->zzofs[kZigzag[k]] = (uint16_t)(2 * k);
-        c->zznat[k] = kZigzag[k];
+        int nat = kZigzag[k], u = nat >> 3, v = nat & 7;
+        c->zzofs[nat] = (uint16_t)(2 * k);
+        c->zzofsT[v * 8 + u] = (uint16_t)(2 * k);
+        c->zznat[k] = (uint8_t)nat;
     }
     return true;
 }
