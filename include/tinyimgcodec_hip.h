@@ -85,8 +85,10 @@ int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_
  * (the stream the kernel is launched on).  *ms_total = elapsed milliseconds for all `iters` launches. */
 int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
                        void *d_coeffs_zz, int variant, int iters, float *ms_total);
-/* Number of blocks that left the fast path (guard band tripped) in the most recent HYBRID launch that was
- * synchronised; diagnostic only. */
+/* Diagnostics: with stats enabled the HYBRID kernel counts (with a global atomic, which costs time - keep it off
+ * when measuring) the blocks it had to redo on the exact path; tic_last_fallback_blocks returns the count
+ * accumulated since the previous call and resets it. */
+int tic_set_stats(tic_ctx *ctx, int enable);
 int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count);
 
 /* ---- entropy stage (host): replaces the per-block loops of compress() codec.py:133-164:

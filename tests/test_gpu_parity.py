@@ -192,8 +192,11 @@ def test_config2_4096_coefficient_digest(ctx, manifest, q):
     m = manifest[f"rand1234_4096x4096_q{q}"]
     img = rand_frame(1234, 4096, 4096)
     f = DevFrame(ctx, img)
+    N.load().tic_set_stats(ctx.handle, 1)
+    f.fallbacks()
     zz_h = f.run(q, N.KERNEL_HYBRID)
     fb = f.fallbacks()
+    N.load().tic_set_stats(ctx.handle, 0)
     zz_e = f.run(q, N.KERNEL_EXACT)
     f.free()
     assert np.array_equal(zz_h, zz_e)

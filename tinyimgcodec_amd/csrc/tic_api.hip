@@ -27,6 +27,7 @@ struct tic_ctx {
     hipStream_t bstream[2] = {nullptr, nullptr}; // batch pipeline streams
     DctqConsts *d_consts = nullptr;   // [100], index = quality
     unsigned long long *d_fallback = nullptr;
+    bool stats = false; // count guard-band fallbacks with a global atomic (diagnostic; serialises at ~12 ns per wave)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the host-buffer entry points
     void *d_img = nullptr;
@@ -216,7 +217,7 @@ static DctqArgs make_args(tic_ctx *ctx, const void *d_image, int h, int w, ptrdi
     a.aligned8 = ((((uintptr_t)d_image) | (uintptr_t)stride) & 7) == 0;
     a.consts = ctx->d_consts + quality;
     a.out = (int16_t *)d_out;
-    a.fallback_count = ctx->d_fallback;
+    a.fallback_count = ctx->stats ? ctx->d_fallback : nullptr;
     return a;
 }
 
@@ -241,12 +242,18 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
     if (!ms_total || iters < 1 || !d_image || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
-    const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
+    const int v = variant == TIC_KERNEL_EXACT ? 1 : (variant >= 10 ? variant : 2); // >= 10: timing-only ablation builds
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++) HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return TIC_OK;
+}
+
+int tic_set_stats(tic_ctx *ctx, int enable) {
+    if (!ctx) return TIC_E_ARG;
+    ctx->stats = enable != 0;
     return TIC_OK;
 }
 

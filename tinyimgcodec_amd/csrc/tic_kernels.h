@@ -20,7 +20,11 @@ struct DctqArgs {
     unsigned long long *fallback_count; // device counter of blocks redone on the exact path (may be null)
     // persistent-wave schedule of the hybrid kernel: wave g handles strips g, g + nwaves, g + 2*nwaves, ...
     int nwaves;          // waves in the grid
-    int step_ty, step_tx; // nwaves / tiles_x and nwaves % tiles_x (strip coordinates advance without a division)
+    int step_ty, step_tx; // nwaves / fast_tx and nwaves % fast_tx (strip coordinates advance without a division)
+    // the hybrid kernel covers the rectangle of complete, 8-byte aligned strips [0,fast_ty) x [0,fast_tx);
+    // the exact kernel (rem_mode = 1) covers the rest: right-hand partial strips and the bottom partial block row
+    int fast_ty, fast_tx;
+    int rem_mode;
 };
 
 struct IdctArgs {

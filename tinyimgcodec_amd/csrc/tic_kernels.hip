@@ -203,8 +203,22 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = lane >> 3, i = lane & 7;
     uint32_t *lds = lds_all[wave];
-    const int tile = blockIdx.x * kWavesPerWG + wave;
-    Strip s = make_strip(tile, a.ntiles, a.tiles_x, a.bw, b);
+    int tile = blockIdx.x * kWavesPerWG + wave;
+    int ntiles = a.ntiles;
+    if (a.rem_mode) { // enumerate only the strips outside the hybrid kernel's rectangle
+        const int bh = a.ntiles / a.tiles_x, rw = a.tiles_x - a.fast_tx;
+        const int n_right = bh * rw, n_bottom = (bh - a.fast_ty) * a.fast_tx;
+        ntiles = 0;
+        if (tile < n_right) {
+            tile = (tile / rw) * a.tiles_x + a.fast_tx + tile % rw;
+            ntiles = a.ntiles;
+        } else if (tile < n_right + n_bottom) {
+            const int k = tile - n_right;
+            tile = (a.fast_ty + k / a.fast_tx) * a.tiles_x + k % a.fast_tx;
+            ntiles = a.ntiles;
+        }
+    }
+    Strip s = make_strip(tile, ntiles, a.tiles_x, a.bw, b);
     uint32_t lo, hi;
     load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
     transpose8x8_bytes(lo, hi, i);
@@ -238,14 +252,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 constexpr int kTStrideDw = kLdsStrideDw;          // the post-pass reuses exact_block(), which assumes this stride
 constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
 constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
-constexpr int kMaxStripsPerWave = 64;             // capacity of the per-wave trip list (launcher sizes the grid for it)
+constexpr int kMaxStripsPerWave = 32;             // strips per wave are capped so that the trip list cannot overflow
+constexpr int kListEntries = 8 * kMaxStripsPerWave; // one entry per block in the worst case (1 KiB per wave)
 
-__device__ __forceinline__ void quant_guarded(float z, float mul, float g, uint32_t &bits, uint32_t &diff) {
-    // s1/s2 = round-half-even(z*mul +- g) as integers biased by kMagic; equal unless a tie is within the guard
-    float s1 = fmaf(z, mul, g) + kMagic;
-    float s2 = fmaf(z, mul, -g) + kMagic;
-    bits = __float_as_uint(s1);
-    diff = bits ^ __float_as_uint(s2);
+// Quantiser of the fast path.  t = z*mul; adding kMagic rounds t to an integer (half-even) whose two's complement
+// sits in the low mantissa bits (no v_rndne / v_cvt); d = t - rint(t) feeds the guard-band test.
+__device__ __forceinline__ void quant_magic(float z, float mul, uint32_t &bits, float &d) {
+    const float t = z * mul;
+    const float s = t + kMagic;
+    bits = __float_as_uint(s);
+    d = t - (s - kMagic);
 }
 
 // Rational coefficients (u,v) in {0,4}x{0,4} of the lane's block on their exact float64 sub-path (SURVEY
@@ -285,11 +301,8 @@ __device__ __forceinline__ void special_block(uint32_t colLo, uint32_t colHi, ui
     wave_lds_fence();
 }
 
-struct TripRec {
-    int tile;
-    uint32_t masks; // bits 0-7: blocks to redo entirely, bits 8-15: blocks needing the rational coefficients only
-};
-
+// Trip list entry: raster index of a block that left the fast path.  Blocks needing only their rational
+// coefficients fill the list from the front, blocks to redo entirely fill it from the back.
 __device__ __forceinline__ uint32_t byte_any(unsigned long long m) { // bit k = (byte k of m != 0)
     m |= m >> 4;
     m |= m >> 2;
@@ -298,27 +311,28 @@ __device__ __forceinline__ uint32_t byte_any(unsigned long long m) { // bit k = 
     return (uint32_t)((m * 0x0102040810204080ull) >> 56);
 }
 
+template <int ABL>
 __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
-    __shared__ TripRec list_all[kWavesPerWG][kMaxStripsPerWave];
+    __shared__ uint32_t list_all[kWavesPerWG][kListEntries];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *ldsT = ldsT_all[wave];
     char *ldsZ = reinterpret_cast<char *>(ldsZ_all[wave]);
-    TripRec *list = list_all[wave];
+    uint32_t *list = list_all[wave];
     const DctqConsts *__restrict__ C = a.consts;
 
     const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
     const int b = lane >> 3, i = lane & 7;   // compute phase: column / frequency v = i of block b
-    int nrec = 0;                            // wave-uniform
+    int nS = 0, nG = 0;                      // wave-uniform list fill counts
+    const int nfast = a.fast_ty * a.fast_tx; // strips handled here: complete, 8-byte aligned, no padding
 
     {
         // per-lane constants for horizontal frequency v = i (L2-resident; loaded once per wave)
         const float4 m0 = *reinterpret_cast<const float4 *>(C->mulT + i * 8);
         const float4 m1 = *reinterpret_cast<const float4 *>(C->mulT + i * 8 + 4);
-        const float4 g0 = *reinterpret_cast<const float4 *>(C->guardT + i * 8);
-        const float4 g1 = *reinterpret_cast<const float4 *>(C->guardT + i * 8 + 4);
+        const float2 thr = *reinterpret_cast<const float2 *>(C->thrT + i * 2);
         const uint4 zzv = *reinterpret_cast<const uint4 *>(C->zzofsT + i * 8);
         char *zzblk = ldsZ + b * kZzStrideB;
         int16_t *zp0 = reinterpret_cast<int16_t *>(zzblk + (zzv.x & 0xffff)), *zp1 = reinterpret_cast<int16_t *>(zzblk + (zzv.x >> 16));
@@ -326,140 +340,158 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
         int16_t *zp4 = reinterpret_cast<int16_t *>(zzblk + (zzv.z & 0xffff)), *zp5 = reinterpret_cast<int16_t *>(zzblk + (zzv.z >> 16));
         int16_t *zp6 = reinterpret_cast<int16_t *>(zzblk + (zzv.w & 0xffff)), *zp7 = reinterpret_cast<int16_t *>(zzblk + (zzv.w >> 16));
         uint32_t *tw = ldsT + lb * kTStrideDw + lr;                                          // transpose write: [block][v*8 + row]
-        const uint4 *tr = reinterpret_cast<const uint4 *>(ldsT + b * kTStrideDw + i * 8);    // read: the 8 rows of column v
-        const uint4 *zr = reinterpret_cast<const uint4 *>(zzblk + i * 16);
-        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // simple strips: lane offset from the strip base
+        const uint4 *tr = reinterpret_cast<const uint4 *>(
+            __builtin_assume_aligned(ldsT + b * kTStrideDw + i * 8, 16));                    // read: the 8 rows of column v
+        const uint4 *zr = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(zzblk + i * 16, 16));
+        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
         const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
+        const long row8 = 8 * a.stride;
 
-        // strip schedule (all scalar); three strips in flight: current (0), next (1), next-next (2)
+        // strip schedule (all scalar); three strips in flight: current (0), next (1), next-next (2).
+        // Loads past the end of the schedule are clamped to the last strip (no branch around a load, so the
+        // compiler can keep two loads in flight across the loop back-edge with counted vmcnt waits).
         int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + wave);
-        int ty0 = t0 / a.tiles_x, tx0 = t0 - ty0 * a.tiles_x;
+        int ty0 = t0 / a.fast_tx, tx0 = t0 - ty0 * a.fast_tx;
         int t1 = t0 + a.nwaves, ty1 = ty0 + a.step_ty, tx1 = tx0 + a.step_tx;
-        if (tx1 >= a.tiles_x) { tx1 -= a.tiles_x; ty1 += 1; }
-
-        auto load_strip = [&](int t, int ty, int tx, uint32_t &plo, uint32_t &phi) {
-            plo = 0;
-            phi = 0;
-            if (t >= a.ntiles) return;
-            const bool simple = a.aligned8 && (tx * 64 + 64 <= a.w) && (ty * 8 + 8 <= a.h); // wave-uniform
-            if (simple) {
-                const uint8_t *base = a.img + (long)ty * 8 * a.stride + tx * 64;
-                const uint2 v = *reinterpret_cast<const uint2 *>(base + ld_off);
-                plo = v.x;
-                phi = v.y;
-            } else {
-                Strip sl;
-                sl.by = ty; sl.bx = tx * 8 + lb; sl.valid = sl.bx < a.bw; sl.oblk = 0;
-                load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, sl, lr, plo, phi);
-            }
+        if (tx1 >= a.fast_tx) { tx1 -= a.fast_tx; ty1 += 1; }
+        auto load_strip = [&](int t, int ty, int tx) -> uint2 {
+            const bool in = t < nfast;
+            const int cy = in ? ty : a.fast_ty - 1, cx = in ? tx : a.fast_tx - 1;
+            const uint8_t *base = a.img + cy * row8 + cx * 64;
+            return *reinterpret_cast<const uint2 *>(base + ld_off);
         };
-        uint32_t lo0, hi0, lo1, hi1;
-        load_strip(t0, ty0, tx0, lo0, hi0);
-        load_strip(t1, ty1, tx1, lo1, hi1);
+        uint2 p0 = load_strip(t0, ty0, tx0);
+        uint2 p1 = load_strip(t1, ty1, tx1);
 
-        while (t0 < a.ntiles) {
+        while (t0 < nfast) {
             int t2 = t1 + a.nwaves, ty2 = ty1 + a.step_ty, tx2 = tx1 + a.step_tx;
-            if (tx2 >= a.tiles_x) { tx2 -= a.tiles_x; ty2 += 1; }
-            uint32_t lo2, hi2;
-            load_strip(t2, ty2, tx2, lo2, hi2);
+            if (tx2 >= a.fast_tx) { tx2 -= a.fast_tx; ty2 += 1; }
+            const uint2 p2 = load_strip(t2, ty2, tx2);
 
             // ---- pass 1: along the pixel row (the fast path is free to choose the pass order) ------------------
+            const uint32_t lo0 = p0.x, hi0 = p0.y;
             float d0 = (float)(lo0 & 0xffu), d1 = (float)((lo0 >> 8) & 0xffu), d2 = (float)((lo0 >> 16) & 0xffu),
                   d3 = (float)(lo0 >> 24);
             float d4 = (float)(hi0 & 0xffu), d5 = (float)((hi0 >> 8) & 0xffu), d6 = (float)((hi0 >> 16) & 0xffu),
                   d7 = (float)(hi0 >> 24);
-            dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
+            if (ABL != 1) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
             d0 -= 1024.0f;
-            tw[0 * 8] = __float_as_uint(d0); tw[1 * 8] = __float_as_uint(d1); tw[2 * 8] = __float_as_uint(d2);
-            tw[3 * 8] = __float_as_uint(d3); tw[4 * 8] = __float_as_uint(d4); tw[5 * 8] = __float_as_uint(d5);
-            tw[6 * 8] = __float_as_uint(d6); tw[7 * 8] = __float_as_uint(d7);
-            wave_lds_fence();
-            const uint4 ra = tr[0], rb = tr[1];
-            wave_lds_fence();
-            float e0 = __uint_as_float(ra.x), e1 = __uint_as_float(ra.y), e2 = __uint_as_float(ra.z),
-                  e3 = __uint_as_float(ra.w), e4 = __uint_as_float(rb.x), e5 = __uint_as_float(rb.y),
-                  e6 = __uint_as_float(rb.z), e7 = __uint_as_float(rb.w);
+            float e0 = d0, e1 = d1, e2 = d2, e3 = d3, e4 = d4, e5 = d5, e6 = d6, e7 = d7;
+            if (ABL != 2) {
+                tw[0 * 8] = __float_as_uint(d0); tw[1 * 8] = __float_as_uint(d1); tw[2 * 8] = __float_as_uint(d2);
+                tw[3 * 8] = __float_as_uint(d3); tw[4 * 8] = __float_as_uint(d4); tw[5 * 8] = __float_as_uint(d5);
+                tw[6 * 8] = __float_as_uint(d6); tw[7 * 8] = __float_as_uint(d7);
+                wave_lds_fence();
+                const uint4 ra = tr[0], rb = tr[1];
+                wave_lds_fence();
+                e0 = __uint_as_float(ra.x); e1 = __uint_as_float(ra.y); e2 = __uint_as_float(ra.z);
+                e3 = __uint_as_float(ra.w); e4 = __uint_as_float(rb.x); e5 = __uint_as_float(rb.y);
+                e6 = __uint_as_float(rb.z); e7 = __uint_as_float(rb.w);
+            }
             // ---- pass 2: down the column of horizontal frequency v = i ------------------------------------------
-            dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
-            uint32_t q0, q1, q2, q3, q4, q5, q6, q7, x0, x1, x2, x3, x4, x5, x6, x7;
-            quant_guarded(e0, m0.x, g0.x, q0, x0);
-            quant_guarded(e1, m0.y, g0.y, q1, x1);
-            quant_guarded(e2, m0.z, g0.z, q2, x2);
-            quant_guarded(e3, m0.w, g0.w, q3, x3);
-            quant_guarded(e4, m1.x, g1.x, q4, x4);
-            quant_guarded(e5, m1.y, g1.y, q5, x5);
-            quant_guarded(e6, m1.z, g1.z, q6, x6);
-            quant_guarded(e7, m1.w, g1.w, q7, x7);
-            *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
-            *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
-
-            // ---- guard band bookkeeping (v in {0,4} lanes hold the rational coefficients at u = 0 and u = 4) --------
-            const bool valid = (tx0 * 8 + b) < a.bw;
-            const uint32_t x04 = x0 | x4, xg = x1 | x2 | x3 | x5 | x6 | x7;
-            const bool rational_lane = (i & 3) == 0;
-            const bool tripG = valid && ((xg != 0u) || (!rational_lane && x04 != 0u));
-            const bool tripS = valid && rational_lane && (x04 != 0u);
-            const unsigned long long mG = __ballot(tripG), mS = __ballot(tripS);
-            if ((mG | mS) != 0ull) { // wave-uniform, rare: remember the strip for the post-pass
+            uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
+            unsigned long long cA = 0, cB = 0; // lanes whose guard band tripped (A: u in 1,2,3,5,6,7; B: u in 0,4)
+            if (ABL != 1) {
+                dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
+                float r0, r1, r2, r3, r4, r5, r6, r7;
+                quant_magic(e0, m0.x, q0, r0);
+                quant_magic(e1, m0.y, q1, r1);
+                quant_magic(e2, m0.z, q2, r2);
+                quant_magic(e3, m0.w, q3, r3);
+                quant_magic(e4, m1.x, q4, r4);
+                quant_magic(e5, m1.y, q5, r5);
+                quant_magic(e6, m1.z, q6, r6);
+                quant_magic(e7, m1.w, q7, r7);
+                const float mA = fmaxf(fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fmaxf(fabsf(r3), fabsf(r5))),
+                                       fmaxf(fabsf(r6), fabsf(r7)));
+                const float mB = fmaxf(fabsf(r0), fabsf(r4));
+                cA = __ballot(mA > thr.x);
+                cB = __ballot(mB > thr.y);
+            } else {
+                q0 = __float_as_uint(e0); q1 = __float_as_uint(e1); q2 = __float_as_uint(e2); q3 = __float_as_uint(e3);
+                q4 = __float_as_uint(e4); q5 = __float_as_uint(e5); q6 = __float_as_uint(e6); q7 = __float_as_uint(e7);
+            }
+            uint4 val;
+            if (ABL != 2) {
+                *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
+                *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
+            } else {
+                val = make_uint4((q0 & 0xffff) | (q1 << 16), (q2 & 0xffff) | (q3 << 16), (q4 & 0xffff) | (q5 << 16), (q6 & 0xffff) | (q7 << 16));
+            }
+            // ---- guard band bookkeeping, all scalar: lanes v in {0,4} hold the rational coefficients at u in {0,4} ------
+            const unsigned long long kRat = 0x1111111111111111ull;
+            const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
+            if ((mG | mS) != 0ull) { // rare: remember the tripped blocks for the post-pass
                 const uint32_t gm = byte_any(mG), sm = byte_any(mS) & ~gm;
-                if (lane == 0) {
-                    list[nrec].tile = t0;
-                    list[nrec].masks = gm | (sm << 8);
-                }
-                nrec++;
+                const uint32_t blk = (uint32_t)(ty0 * a.bw + tx0 * 8 + b);
+                const uint32_t below = (1u << b) - 1u;
+                if (i == 0 && ((sm >> b) & 1u)) list[nS + __builtin_popcount(sm & below)] = blk;
+                if (i == 0 && ((gm >> b) & 1u)) list[kListEntries - 1 - nG - __builtin_popcount(gm & below)] = blk;
+                nS += __builtin_popcount(sm);
+                nG += __builtin_popcount(gm);
             }
             // ---- zig-zag ordered blocks -> global: 16 B per lane, 1 KiB contiguous per wave ---------------------------
-            wave_lds_fence();
-            const uint4 val = *zr;
-            wave_lds_fence();
-            if (valid) {
-                char *obase = reinterpret_cast<char *>(a.out) + ((size_t)ty0 * a.bw + (size_t)tx0 * 8) * 128;
-                *reinterpret_cast<uint4 *>(obase + st_off) = val;
+            if (ABL != 2) {
+                wave_lds_fence();
+                val = *zr;
+                wave_lds_fence();
             }
-            t0 = t1; ty0 = ty1; tx0 = tx1; lo0 = lo1; hi0 = hi1;
-            t1 = t2; ty1 = ty2; tx1 = tx2; lo1 = lo2; hi1 = hi2;
+            char *obase = reinterpret_cast<char *>(a.out) + ((size_t)ty0 * a.bw + (size_t)tx0 * 8) * 128;
+            *reinterpret_cast<uint4 *>(obase + st_off) = val;
+
+            t0 = t1; ty0 = ty1; tx0 = tx1; p0 = p1;
+            t1 = t2; ty1 = ty2; tx1 = tx2; p1 = p2;
         }
     }
 
-    // ---- post-pass over the recorded strips (wave-uniform loop; usually a handful of iterations) -------------------
-    if (nrec == 0) return;
+    // ---- post-pass over the recorded blocks: 8 blocks per wave pass, one per group of 8 lanes ------------------------
+    if ((nS | nG) == 0 || ABL == 3) return;
     __builtin_amdgcn_s_waitcnt(0); // the patches below must land after this wave's own fast-path stores
     wave_lds_fence();
-    unsigned long long redone = 0;
-    for (int e = 0; e < nrec; e++) {
-        const int tile = __builtin_amdgcn_readfirstlane(list[e].tile);
-        const uint32_t masks = __builtin_amdgcn_readfirstlane(list[e].masks);
-        Strip s = make_strip(tile, a.ntiles, a.tiles_x, a.bw, b);
+    char *zzblk = ldsZ + b * kZzStrideB;
+    for (int base = 0; base < nS; base += 8) { // rational coefficients only (exact ties, ~2 % of blocks)
+        const bool have = base + b < nS;
+        const uint32_t blk = list[have ? base + b : 0];
+        Strip s;
+        s.by = (int)(blk / (uint32_t)a.bw);
+        s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
+        s.valid = true;
+        s.oblk = blk;
         uint32_t lo, hi;
-        load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi); // lane 8*b + i: row i of block b
+        load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi); // lane 8*b + i: row i of its block
         transpose8x8_bytes(lo, hi, i);                                         // -> pixel column i
-        const bool blkG = (masks >> b) & 1u, blkS = (masks >> (8 + b)) & 1u;
-        if (masks & 0xffu) {
-            int qe[8];
-            exact_block(lo, hi, ldsT, b, i, C, qe); // lane i holds frequency row u = i
-            const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
-            const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
-            char *zzblk = ldsZ + b * kZzStrideB;
-#pragma unroll
-            for (int v = 0; v < 8; v++)
-                *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
-            wave_lds_fence();
-            const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
-            wave_lds_fence();
-            if (blkG && s.valid) *reinterpret_cast<uint4 *>(a.out + s.oblk * 64 + i * 8) = val;
-            redone += __builtin_popcount(masks & 0xffu);
-        }
-        if (masks & 0xff00u) {
-            int r0, r4;
-            special_block(lo, hi, ldsT, b, i, C, r0, r4);
-            if (blkS && s.valid && (i & 3) == 0) {
-                int16_t *ob = a.out + s.oblk * 64;
-                ob[C->zzofs[i * 8] >> 1] = (int16_t)r0;
-                ob[C->zzofs[i * 8 + 4] >> 1] = (int16_t)r4;
-            }
+        int r0, r4;
+        special_block(lo, hi, ldsT, b, i, C, r0, r4);
+        if (have && (i & 3) == 0) {
+            int16_t *ob = a.out + (size_t)blk * 64;
+            ob[C->zzofs[i * 8] >> 1] = (int16_t)r0;
+            ob[C->zzofs[i * 8 + 4] >> 1] = (int16_t)r4;
         }
     }
-    if (a.fallback_count != nullptr && lane == 0 && redone) atomicAdd(a.fallback_count, redone);
+    for (int base = 0; base < nG; base += 8) { // whole blocks on the exact path (~0.3 % of blocks at q=50)
+        const bool have = base + b < nG;
+        const uint32_t blk = list[kListEntries - 1 - (have ? base + b : 0)];
+        Strip s;
+        s.by = (int)(blk / (uint32_t)a.bw);
+        s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
+        s.valid = true;
+        s.oblk = blk;
+        uint32_t lo, hi;
+        load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
+        transpose8x8_bytes(lo, hi, i);
+        int qe[8];
+        exact_block(lo, hi, ldsT, b, i, C, qe); // lane i holds frequency row u = i
+        const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
+        const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+#pragma unroll
+        for (int v = 0; v < 8; v++)
+            *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
+        wave_lds_fence();
+        const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
+        wave_lds_fence();
+        if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
+    }
+    if (a.fallback_count != nullptr && lane == 0 && nG) atomicAdd(a.fallback_count, (unsigned long long)nG);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -555,19 +587,42 @@ constexpr int kPersistentWGs = 256 * 8; // 256 CUs x 8 workgroups of 4 waves = e
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (a.ntiles <= 0) return hipSuccess;
     dim3 block(kWavesPerWG * 64);
+    a.nwaves = a.step_ty = a.step_tx = 0;
+    a.fast_ty = a.fast_tx = 0;
+    a.rem_mode = 0;
     if (variant == 1) {
-        a.nwaves = 0;
         hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles)), block, 0, stream, a);
-    } else {
+        return hipGetLastError();
+    }
+    // hybrid kernel: rectangle of complete 64x8 strips with 8-byte aligned rows; the exact kernel takes the rest
+    const int bh = a.ntiles / a.tiles_x;
+    a.fast_tx = a.aligned8 ? a.w / 64 : 0;
+    a.fast_ty = a.h / 8;
+    const int nfast = a.fast_tx * a.fast_ty;
+    if (nfast > 0) {
         // persistent waves: at most kPersistentWGs workgroups, each wave loops over its strips
-        int wgs = grid_for(a.ntiles);
+        int wgs = grid_for(nfast);
         if (wgs > kPersistentWGs) wgs = kPersistentWGs;
-        const int min_wgs = (a.ntiles + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
+        const int min_wgs = (nfast + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
         if (wgs < min_wgs) wgs = min_wgs; // the per-wave trip list holds kMaxStripsPerWave entries
         a.nwaves = wgs * kWavesPerWG;
-        a.step_ty = a.nwaves / a.tiles_x;
-        a.step_tx = a.nwaves % a.tiles_x;
-        hipLaunchKernelGGL(dctq_hybrid_kernel, dim3(wgs), block, 0, stream, a);
+        a.step_ty = a.nwaves / a.fast_tx;
+        a.step_tx = a.nwaves % a.fast_tx;
+        if (variant == 10)
+            hipLaunchKernelGGL(dctq_hybrid_kernel<1>, dim3(wgs), block, 0, stream, a);
+        else if (variant == 11)
+            hipLaunchKernelGGL(dctq_hybrid_kernel<2>, dim3(wgs), block, 0, stream, a);
+        else if (variant == 12)
+            hipLaunchKernelGGL(dctq_hybrid_kernel<3>, dim3(wgs), block, 0, stream, a);
+        else
+            hipLaunchKernelGGL(dctq_hybrid_kernel<0>, dim3(wgs), block, 0, stream, a);
+    } else {
+        a.fast_tx = a.fast_ty = 0;
+    }
+    const int nrem = bh * (a.tiles_x - a.fast_tx) + (bh - a.fast_ty) * a.fast_tx;
+    if (nrem > 0) {
+        a.rem_mode = 1;
+        hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(nrem)), block, 0, stream, a);
     }
     return hipGetLastError();
 }

@@ -138,7 +138,8 @@ struct DctqConsts {
     double div[64];      // natural order u*8+v: (Q*factor)/100 as the reference computes it (utils.py:50-53)
     double rdiv[64];     // fl(1/div)
     float mulT[64];      // fast path, index v*8+u: 1 / (aan[u]*aan[v]*8*div[u][v])
-    float guardT[64];    // fast path, index v*8+u: guard band in quantised units = kGuardX / div[u][v]
+    float thrT[16];      // fast path, per column v: [2v] = accept threshold for u in {1,2,3,5,6,7}, [2v+1] = for u in {0,4}
+                         // (0.5 - largest guard band kGuardX/div[u][v] of the group; accept when |t - rint(t)| <= thr)
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
     uint16_t zzofsT[64]; // index v*8+u: same offsets, transposed (lane v holds u = 0..7)
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
@@ -166,8 +167,19 @@ inline bool build_consts(int quality, DctqConsts *c) {
         for (int v = 0; v < 8; v++) {
             int i = u * 8 + v, t = v * 8 + u;
             c->mulT[t] = (float)(1.0 / (aan[u] * aan[v] * 8.0 * c->div[i]));
-            c->guardT[t] = (float)(kGuardX / c->div[i]);
         }
+    for (int v = 0; v < 8; v++) {
+        double ga = 0.0, gb = 0.0;
+        for (int u = 0; u < 8; u++) {
+            double g = kGuardX / c->div[u * 8 + v];
+            if (u == 0 || u == 4)
+                gb = g > gb ? g : gb;
+            else
+                ga = g > ga ? g : ga;
+        }
+        c->thrT[2 * v] = (float)(0.5 - ga);
+        c->thrT[2 * v + 1] = (float)(0.5 - gb);
+    }
     for (int k = 0; k < 64; k++) {
         int nat = kZigzag[k], u = nat >> 3, v = nat & 7;
         c->zzofs[nat] = (uint16_t)(2 * k);
