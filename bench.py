@@ -112,11 +112,13 @@ def main():
         tmax = torch.tensor([wall_s, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall_s, kernel_ms_max = float(tmax[0]), float(tmax[1])
-        # the north star's only collective: gather per-frame compressed sizes (host entropy stage, untimed)
-        mine = torch.tensor([len(T.compress(img[:512, :512], q, ctx=ctx))], dtype=torch.int64, device="cuda")
-        allsz = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allsz, mine)
-        sizes = [int(s[0]) for s in allsz]
+        # the north star's only collective (RCCL all-gather of per-frame compressed sizes), outside the timed
+        # region: each rank entropy-codes a 512x512 crop of its frame on the host and the sizes are gathered
+        from tinyimgcodec_amd.distributed import gather_sizes
+
+        mine = [len(T.compress(img[:512, :512], q, ctx=ctx))]
+        allsz, _ = gather_sizes(mine, world)
+        sizes = [int(v) for v in allsz]
     else:
         kernel_ms_max = kernel_ms
 

@@ -18,6 +18,7 @@
 //            sub-path; any block that trips the guard is redone on the exact path inside the same wave.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "tic_kernels.h"
 #include "tic_math.h"
@@ -602,7 +603,8 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (nfast > 0) {
         // persistent waves: at most kPersistentWGs workgroups, each wave loops over its strips
         int wgs = grid_for(nfast);
-        if (wgs > kPersistentWGs) wgs = kPersistentWGs;
+        static const int cap = getenv("TIC_MAX_WGS") ? atoi(getenv("TIC_MAX_WGS")) : kPersistentWGs; // tuning knob
+        if (wgs > cap) wgs = cap;
         const int min_wgs = (nfast + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
         if (wgs < min_wgs) wgs = min_wgs; // the per-wave trip list holds kMaxStripsPerWave entries
         a.nwaves = wgs * kWavesPerWG;
