@@ -25,6 +25,9 @@ struct DctqArgs {
     // the exact kernel (rem_mode = 1) covers the rest: right-hand partial strips and the bottom partial block row
     int fast_ty, fast_tx;
     int rem_mode;
+    // byte offsets of the hybrid kernel's strip walk (precomputed on the host so the loop needs only scalar adds):
+    // advancing by nwaves strips adds *_step; when the strip column wraps past fast_tx, *_wrap is added as well
+    long in_step, in_wrap, out_step, out_wrap;
 };
 
 struct IdctArgs {

@@ -253,8 +253,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 constexpr int kTStrideDw = kLdsStrideDw;          // the post-pass reuses exact_block(), which assumes this stride
 constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
 constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
-constexpr int kMaxStripsPerWave = 32;             // strips per wave are capped so that the trip list cannot overflow
-constexpr int kListEntries = 8 * kMaxStripsPerWave; // one entry per block in the worst case (1 KiB per wave)
+constexpr int kMaxStripsPerWave = 16;             // strips per wave are capped so that the trip list cannot overflow
+constexpr int kListEntries = 8 * kMaxStripsPerWave; // one entry per block in the worst case (512 B per wave)
+constexpr int kStash = 8;                          // pixels of the first 8 entries of each kind are kept in LDS (1 KiB)
 
 // Quantiser of the fast path.  t = z*mul; adding kMagic rounds t to an integer (half-even) whose two's complement
 // sits in the low mantissa bits (no v_rndne / v_cvt); d = t - rint(t) feeds the guard-band test.
@@ -317,11 +318,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
     __shared__ uint32_t list_all[kWavesPerWG][kListEntries];
+    __shared__ uint2 stash_all[kWavesPerWG][2 * kStash * 8]; // [kind][entry][row] pixel rows of tripped blocks
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *ldsT = ldsT_all[wave];
     char *ldsZ = reinterpret_cast<char *>(ldsZ_all[wave]);
     uint32_t *list = list_all[wave];
+    uint2 *stash = stash_all[wave];
     const DctqConsts *__restrict__ C = a.consts;
 
     const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
@@ -348,26 +351,28 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
         const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
         const long row8 = 8 * a.stride;
 
-        // strip schedule (all scalar); three strips in flight: current (0), next (1), next-next (2).
+        // strip schedule (all scalar, incremental): three strips in flight - current (0), next (1), next-next (2).
         // Loads past the end of the schedule are clamped to the last strip (no branch around a load, so the
         // compiler can keep two loads in flight across the loop back-edge with counted vmcnt waits).
         int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + wave);
-        int ty0 = t0 / a.fast_tx, tx0 = t0 - ty0 * a.fast_tx;
-        int t1 = t0 + a.nwaves, ty1 = ty0 + a.step_ty, tx1 = tx0 + a.step_tx;
-        if (tx1 >= a.fast_tx) { tx1 -= a.fast_tx; ty1 += 1; }
-        auto load_strip = [&](int t, int ty, int tx) -> uint2 {
-            const bool in = t < nfast;
-            const int cy = in ? ty : a.fast_ty - 1, cx = in ? tx : a.fast_tx - 1;
-            const uint8_t *base = a.img + cy * row8 + cx * 64;
-            return *reinterpret_cast<const uint2 *>(base + ld_off);
+        int tx0 = t0 % a.fast_tx;
+        const int ty_first = t0 / a.fast_tx;
+        long out_off = ((long)ty_first * a.bw + (long)tx0 * 8) * 128; // byte offset of strip 0's 1 KiB of coefficients
+        long in_off = (long)ty_first * row8 + (long)tx0 * 64;         // byte offset of the strip being prefetched
+        const long in_last = (long)(a.fast_ty - 1) * row8 + (long)(a.fast_tx - 1) * 64;
+        int tp = t0, txp = tx0;                                        // strip index / column of the prefetch cursor
+        auto load_next = [&]() -> uint2 {
+            const long off = tp < nfast ? in_off : in_last;
+            const uint2 v = *reinterpret_cast<const uint2 *>(a.img + off + ld_off);
+            tp += a.nwaves; txp += a.step_tx; in_off += a.in_step;
+            if (txp >= a.fast_tx) { txp -= a.fast_tx; in_off += a.in_wrap; }
+            return v;
         };
-        uint2 p0 = load_strip(t0, ty0, tx0);
-        uint2 p1 = load_strip(t1, ty1, tx1);
+        uint2 p0 = load_next();
+        uint2 p1 = load_next();
 
         while (t0 < nfast) {
-            int t2 = t1 + a.nwaves, ty2 = ty1 + a.step_ty, tx2 = tx1 + a.step_tx;
-            if (tx2 >= a.fast_tx) { tx2 -= a.fast_tx; ty2 += 1; }
-            const uint2 p2 = load_strip(t2, ty2, tx2);
+            const uint2 p2 = load_next();
 
             // ---- pass 1: along the pixel row (the fast path is free to choose the pass order) ------------------
             const uint32_t lo0 = p0.x, hi0 = p0.y;
@@ -403,8 +408,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
                 quant_magic(e5, m1.y, q5, r5);
                 quant_magic(e6, m1.z, q6, r6);
                 quant_magic(e7, m1.w, q7, r7);
-                const float mA = fmaxf(fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fmaxf(fabsf(r3), fabsf(r5))),
-                                       fmaxf(fabsf(r6), fabsf(r7)));
+                float mA = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
+                mA = fmaxf(fmaxf(mA, fabsf(r5)), fabsf(r6));
+                mA = fmaxf(mA, fabsf(r7));
                 const float mB = fmaxf(fabsf(r0), fabsf(r4));
                 cA = __ballot(mA > thr.x);
                 cB = __ballot(mB > thr.y);
@@ -424,10 +430,18 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
             const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
             if ((mG | mS) != 0ull) { // rare: remember the tripped blocks for the post-pass
                 const uint32_t gm = byte_any(mG), sm = byte_any(mS) & ~gm;
-                const uint32_t blk = (uint32_t)(ty0 * a.bw + tx0 * 8 + b);
+                const uint32_t blk = (uint32_t)(out_off >> 7) + (uint32_t)b;
                 const uint32_t below = (1u << b) - 1u;
                 if (i == 0 && ((sm >> b) & 1u)) list[nS + __builtin_popcount(sm & below)] = blk;
                 if (i == 0 && ((gm >> b) & 1u)) list[kListEntries - 1 - nG - __builtin_popcount(gm & below)] = blk;
+                // keep the pixels of the first few tripped blocks in LDS so the post-pass need not reload them:
+                // this lane still holds pixel row lr of block lb of the strip
+                {
+                    const uint32_t lbelow = (1u << lb) - 1u;
+                    const int es = nS + __builtin_popcount(sm & lbelow), eg = nG + __builtin_popcount(gm & lbelow);
+                    if (((sm >> lb) & 1u) && es < kStash) stash[es * 8 + lr] = p0;
+                    if (((gm >> lb) & 1u) && eg < kStash) stash[(kStash + eg) * 8 + lr] = p0;
+                }
                 nS += __builtin_popcount(sm);
                 nG += __builtin_popcount(gm);
             }
@@ -437,20 +451,21 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
                 val = *zr;
                 wave_lds_fence();
             }
-            char *obase = reinterpret_cast<char *>(a.out) + ((size_t)ty0 * a.bw + (size_t)tx0 * 8) * 128;
-            *reinterpret_cast<uint4 *>(obase + st_off) = val;
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + out_off + st_off) = val;
 
-            t0 = t1; ty0 = ty1; tx0 = tx1; p0 = p1;
-            t1 = t2; ty1 = ty2; tx1 = tx2; p1 = p2;
+            t0 += a.nwaves; tx0 += a.step_tx; out_off += a.out_step;
+            if (tx0 >= a.fast_tx) { tx0 -= a.fast_tx; out_off += a.out_wrap; }
+            p0 = p1; p1 = p2;
         }
     }
 
     // ---- post-pass over the recorded blocks: 8 blocks per wave pass, one per group of 8 lanes ------------------------
+    // (the patches below go to addresses this same wave stored to earlier: same-wave stores to one address stay
+    // in order, so no wait for the fast-path stores is needed)
     if ((nS | nG) == 0 || ABL == 3) return;
-    __builtin_amdgcn_s_waitcnt(0); // the patches below must land after this wave's own fast-path stores
     wave_lds_fence();
     char *zzblk = ldsZ + b * kZzStrideB;
-    for (int base = 0; base < nS; base += 8) { // rational coefficients only (exact ties, ~2 % of blocks)
+    for (int base = 0; base < nS && ABL != 5; base += 8) { // rational coefficients only (exact ties, ~2 % of blocks)
         const bool have = base + b < nS;
         const uint32_t blk = list[have ? base + b : 0];
         Strip s;
@@ -459,8 +474,14 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
         s.valid = true;
         s.oblk = blk;
         uint32_t lo, hi;
-        load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi); // lane 8*b + i: row i of its block
-        transpose8x8_bytes(lo, hi, i);                                         // -> pixel column i
+        if (base + b < kStash) { // lane 8*b + i: row i of its block, from the LDS stash or from memory
+            const uint2 pv = stash[(base + b) * 8 + i];
+            lo = pv.x;
+            hi = pv.y;
+        } else {
+            load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
+        }
+        transpose8x8_bytes(lo, hi, i); // -> pixel column i
         int r0, r4;
         special_block(lo, hi, ldsT, b, i, C, r0, r4);
         if (have && (i & 3) == 0) {
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
             ob[C->zzofs[i * 8 + 4] >> 1] = (int16_t)r4;
         }
     }
-    for (int base = 0; base < nG; base += 8) { // whole blocks on the exact path (~0.3 % of blocks at q=50)
+    for (int base = 0; base < nG && ABL != 4; base += 8) { // whole blocks on the exact path (~0.3 % of blocks at q=50)
         const bool have = base + b < nG;
         const uint32_t blk = list[kListEntries - 1 - (have ? base + b : 0)];
         Strip s;
@@ -478,7 +499,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
         s.valid = true;
         s.oblk = blk;
         uint32_t lo, hi;
-        load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
+        if (base + b < kStash) {
+            const uint2 pv = stash[(kStash + base + b) * 8 + i];
+            lo = pv.x;
+            hi = pv.y;
+        } else {
+            load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
+        }
         transpose8x8_bytes(lo, hi, i);
         int qe[8];
         exact_block(lo, hi, ldsT, b, i, C, qe); // lane i holds frequency row u = i
@@ -610,12 +637,20 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.nwaves = wgs * kWavesPerWG;
         a.step_ty = a.nwaves / a.fast_tx;
         a.step_tx = a.nwaves % a.fast_tx;
+        a.in_step = (long)a.step_ty * 8 * a.stride + (long)a.step_tx * 64;
+        a.in_wrap = 8 * a.stride - (long)a.fast_tx * 64;
+        a.out_step = ((long)a.step_ty * a.bw + (long)a.step_tx * 8) * 128;
+        a.out_wrap = ((long)a.bw - (long)a.fast_tx * 8) * 128;
         if (variant == 10)
             hipLaunchKernelGGL(dctq_hybrid_kernel<1>, dim3(wgs), block, 0, stream, a);
         else if (variant == 11)
             hipLaunchKernelGGL(dctq_hybrid_kernel<2>, dim3(wgs), block, 0, stream, a);
         else if (variant == 12)
             hipLaunchKernelGGL(dctq_hybrid_kernel<3>, dim3(wgs), block, 0, stream, a);
+        else if (variant == 13)
+            hipLaunchKernelGGL(dctq_hybrid_kernel<4>, dim3(wgs), block, 0, stream, a);
+        else if (variant == 14)
+            hipLaunchKernelGGL(dctq_hybrid_kernel<5>, dim3(wgs), block, 0, stream, a);
         else
             hipLaunchKernelGGL(dctq_hybrid_kernel<0>, dim3(wgs), block, 0, stream, a);
     } else {
