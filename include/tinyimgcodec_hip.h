@@ -81,6 +81,11 @@ int tic_memset_dev(tic_ctx *ctx, void *dst, int value, size_t bytes);
 int tic_sync(tic_ctx *ctx);
 int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
                  void *d_coeffs_zz, int variant);
+/* Batch form: `nframes` equally sized frames in ONE launch (grid row per frame).  Frame f starts at
+ * d_images + f*frame_stride bytes and its coefficients at d_coeffs_zz + f*coeff_frame_stride bytes. */
+int tic_dctq_dev_frames(tic_ctx *ctx, const void *d_images, int nframes, int h, int w, ptrdiff_t row_stride,
+                        ptrdiff_t frame_stride, int quality, void *d_coeffs_zz, ptrdiff_t coeff_frame_stride,
+                        int variant);
 /* Times `iters` back-to-back launches of the transform kernel with HIP events recorded on the context's stream
  * (the stream the kernel is launched on).  *ms_total = elapsed milliseconds for all `iters` launches. */
 int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,

@@ -276,6 +276,34 @@ def test_batch_pipeline_matches_single_frame(ctx, manifest):
         assert sha(ac.astype("<i4").tobytes()) == m["ac_i4_sha256"]
 
 
+def test_batched_launch_matches_per_frame(ctx, oracle):
+    """tic_dctq_dev_frames: several frames (ragged size -> remainder strips too) in one launch == oracle per frame."""
+    L = N.load()
+    n, h, w = 5, 100, 200
+    pitch = 256
+    frames = [rand_frame(500 + k, h, w) for k in range(n)]
+    host = np.zeros((n, h + 3, pitch), np.uint8)  # frame stride larger than one frame
+    for k, f in enumerate(frames):
+        host[k, :h, :w] = f
+    nblk = L.tic_num_blocks(h, w)
+    d_img, d_out = C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, host.size, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, n * nblk * 128 + 256 * n, C.byref(d_out)))
+    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, host.ctypes.data, host.size))
+    cstride = nblk * 128 + 256
+    for variant in (N.KERNEL_HYBRID, N.KERNEL_EXACT):
+        ctx.check(L.tic_memset_dev(ctx.handle, d_out, 0x33, n * cstride))
+        ctx.check(L.tic_dctq_dev_frames(ctx.handle, d_img, n, h, w, pitch, (h + 3) * pitch, 75, d_out, cstride, variant))
+        raw = np.empty(n * cstride, np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, raw.ctypes.data, d_out, raw.size))
+        for k in range(n):
+            got = raw[k * cstride : k * cstride + nblk * 128].view(np.int16).reshape(nblk, 64)
+            assert np.array_equal(got, oracle.encode_zz16(frames[k], 75)), (k, variant)
+            assert (raw[k * cstride + nblk * 128 : (k + 1) * cstride] == 0x33).all()  # gap untouched
+    L.tic_dev_free(ctx.handle, d_img)
+    L.tic_dev_free(ctx.handle, d_out)
+
+
 def test_error_paths(ctx):
     L = N.load()
     img = rand_frame(1, 16, 16)

@@ -49,6 +49,10 @@ SIGNATURES = {
     "tic_memset_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_size_t]),
     "tic_sync": (C.c_int, [_ctxp]),
     "tic_dctq_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_int]),
+    "tic_dctq_dev_frames": (
+        C.c_int,
+        [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int],
+    ),
     "tic_dctq_dev_timed": (
         C.c_int,
         [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],

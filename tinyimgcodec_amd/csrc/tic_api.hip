@@ -21,6 +21,19 @@
 
 using namespace tic;
 
+namespace {
+constexpr int kChunk = 16;
+struct Slot {
+    uint8_t *pin_in = nullptr;
+    int16_t *pin_out = nullptr;
+    void *d_img = nullptr;
+    void *d_coef = nullptr;
+    hipEvent_t done = nullptr;
+    int first = 0, count = 0; // frames [first, first+count) are in flight in this slot
+    int remaining = 0;        // frames of the chunk not yet consumed; 0 = slot free
+};
+} // namespace
+
 struct tic_ctx {
     int device = -1;
     hipStream_t stream = nullptr;     // all single-frame work
@@ -35,6 +48,9 @@ struct tic_ctx {
     void *d_coef = nullptr;
     size_t d_coef_cap = 0;
     std::vector<int16_t> h_coef;
+    // batch pipeline buffers, kept across calls (pinned allocations are expensive)
+    std::vector<Slot> bslots;
+    size_t bslot_img_bytes = 0, bslot_coef_bytes = 0;
     std::string err;
     char arch[128] = {0};
 };
@@ -89,6 +105,13 @@ void tic_destroy(tic_ctx *ctx) {
             (void)hipStreamSynchronize(s);
             (void)hipStreamDestroy(s);
         }
+    for (auto &sl : ctx->bslots) {
+        if (sl.pin_in) (void)hipHostFree(sl.pin_in);
+        if (sl.pin_out) (void)hipHostFree(sl.pin_out);
+        if (sl.d_img) (void)hipFree(sl.d_img);
+        if (sl.d_coef) (void)hipFree(sl.d_coef);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->d_img) (void)hipFree(ctx->d_img);
@@ -218,6 +241,9 @@ static DctqArgs make_args(tic_ctx *ctx, const void *d_image, int h, int w, ptrdi
     a.consts = ctx->d_consts + quality;
     a.out = (int16_t *)d_out;
     a.fallback_count = ctx->stats ? ctx->d_fallback : nullptr;
+    a.nframes = 1;
+    a.frame_stride_in = 0;
+    a.frame_stride_out = 0;
     return a;
 }
 
@@ -231,6 +257,26 @@ int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_
         return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
+    HIPCHK(ctx, launch_dctq(a, variant == TIC_KERNEL_EXACT ? 1 : 2, ctx->stream));
+    return TIC_OK;
+}
+
+int tic_dctq_dev_frames(tic_ctx *ctx, const void *d_images, int nframes, int h, int w, ptrdiff_t row_stride,
+                        ptrdiff_t frame_stride, int quality, void *d_coeffs_zz, ptrdiff_t coeff_frame_stride, int variant) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (nframes < 0) return set_err(ctx, TIC_E_ARG, "negative frame count");
+    if (h == 0 || w == 0 || nframes == 0) return TIC_OK;
+    if (!d_images || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "null device pointer");
+    if (nframes > 65535) return set_err(ctx, TIC_E_ARG, "at most 65535 frames per launch");
+    if (frame_stride < (ptrdiff_t)h * row_stride || coeff_frame_stride < (ptrdiff_t)(num_blocks(h, w) * 128))
+        return set_err(ctx, TIC_E_ARG, "frame strides smaller than one frame");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DctqArgs a = make_args(ctx, d_images, h, w, row_stride, quality, d_coeffs_zz);
+    a.aligned8 = a.aligned8 && ((frame_stride & 7) == 0);
+    a.nframes = nframes;
+    a.frame_stride_in = (long)frame_stride;
+    a.frame_stride_out = (long)coeff_frame_stride;
     HIPCHK(ctx, launch_dctq(a, variant == TIC_KERNEL_EXACT ? 1 : 2, ctx->stream));
     return TIC_OK;
 }
@@ -348,17 +394,9 @@ int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row
 }
 
 // ---- batch pipeline (BASELINE config 3) -------------------------------------------------------------------
-namespace {
-struct Slot {
-    uint8_t *pin_in = nullptr;
-    int16_t *pin_out = nullptr;
-    void *d_img = nullptr;
-    void *d_coef = nullptr;
-    hipEvent_t done = nullptr;
-    int frame = -1;      // frame whose results are in flight / being consumed
-    bool busy = false;   // owned by GPU or by a consumer
-};
-} // namespace
+// Frames travel in chunks of up to kChunk frames: one pinned staging buffer, one H2D copy, ONE kernel launch
+// (grid row per frame) and one D2H copy per chunk, alternating between two streams so that the copy of chunk
+// c+1 overlaps the kernel of chunk c and the read-back of chunk c-1.  Worker threads entropy-code frame by frame.
 
 static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
                       int16_t *const *coeffs, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads,
@@ -380,101 +418,114 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
     const bool need_d2h = want_entropy || coeffs != nullptr;
     const size_t pitch = align_up((size_t)w, 256);
     const size_t img_bytes = pitch * (size_t)h, coef_bytes = nblk * 128;
-    const int S = 4;
-    std::vector<Slot> slots(S);
+    const int chunk = n < kChunk ? n : kChunk;
+    const int S = 3;
     int result = TIC_OK;
-    auto cleanup = [&]() {
-        for (auto &s : slots) {
-            if (s.pin_in) (void)hipHostFree(s.pin_in);
-            if (s.pin_out) (void)hipHostFree(s.pin_out);
-            if (s.d_img) (void)hipFree(s.d_img);
-            if (s.d_coef) (void)hipFree(s.d_coef);
-            if (s.done) (void)hipEventDestroy(s.done);
+    const size_t need_img = img_bytes * chunk, need_coef = coef_bytes * chunk;
+    if ((int)ctx->bslots.size() != S || ctx->bslot_img_bytes < need_img || ctx->bslot_coef_bytes < need_coef) {
+        for (auto &sl : ctx->bslots) {
+            if (sl.pin_in) (void)hipHostFree(sl.pin_in);
+            if (sl.pin_out) (void)hipHostFree(sl.pin_out);
+            if (sl.d_img) (void)hipFree(sl.d_img);
+            if (sl.d_coef) (void)hipFree(sl.d_coef);
+            if (sl.done) (void)hipEventDestroy(sl.done);
         }
-    };
-    for (auto &s : slots) {
-        hipError_t e;
-        if ((e = hipHostMalloc((void **)&s.pin_in, img_bytes, hipHostMallocDefault)) != hipSuccess ||
-            (need_d2h && (e = hipHostMalloc((void **)&s.pin_out, coef_bytes, hipHostMallocDefault)) != hipSuccess) ||
-            (e = hipMalloc(&s.d_img, img_bytes)) != hipSuccess || (e = hipMalloc(&s.d_coef, coef_bytes)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) {
-            cleanup();
-            return set_err(ctx, TIC_E_HIP, "batch buffer allocation failed: %s", hipGetErrorString(e));
+        ctx->bslots.assign(S, Slot());
+        ctx->bslot_img_bytes = ctx->bslot_coef_bytes = 0;
+        for (auto &sl : ctx->bslots) {
+            hipError_t e;
+            if ((e = hipHostMalloc((void **)&sl.pin_in, need_img, hipHostMallocDefault)) != hipSuccess ||
+                (e = hipHostMalloc((void **)&sl.pin_out, need_coef, hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc(&sl.d_img, need_img)) != hipSuccess || (e = hipMalloc(&sl.d_coef, need_coef)) != hipSuccess ||
+                (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
+                return set_err(ctx, TIC_E_HIP, "batch buffer allocation failed: %s", hipGetErrorString(e));
         }
+        ctx->bslot_img_bytes = need_img;
+        ctx->bslot_coef_bytes = need_coef;
     }
+    std::vector<Slot> &slots = ctx->bslots;
+    for (auto &sl : slots) sl.remaining = 0;
+    auto cleanup = [&]() {};
 
     std::mutex mu;
     std::condition_variable cv_job, cv_free;
-    std::deque<int> jobs; // slot indices ready for a consumer (GPU work enqueued)
+    std::deque<std::pair<int, int>> jobs; // (slot, frame index inside the chunk)
     bool closing = false;
     std::atomic<int> first_err{TIC_OK};
 
     auto consumer = [&]() {
         (void)hipSetDevice(ctx->device);
         for (;;) {
-            int si;
+            std::pair<int, int> job;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_job.wait(lk, [&] { return !jobs.empty() || closing; });
                 if (jobs.empty()) return;
-                si = jobs.front();
+                job = jobs.front();
                 jobs.pop_front();
             }
-            Slot &s = slots[si];
-            hipError_t e = hipEventSynchronize(s.done);
-            int r = TIC_OK;
-            if (e != hipSuccess) r = TIC_E_HIP;
-            if (r == TIC_OK && want_entropy)
-                r = entropy_encode(s.pin_out, h, w, quality, outs[s.frame], caps[s.frame], &out_lens[s.frame]);
-            if (r == TIC_OK && coeffs && coeffs[s.frame]) memcpy(coeffs[s.frame], s.pin_out, coef_bytes);
+            Slot &s = slots[job.first];
+            const int f = s.first + job.second;
+            int r = hipEventSynchronize(s.done) == hipSuccess ? TIC_OK : TIC_E_HIP;
+            const int16_t *zz = need_d2h ? s.pin_out + (size_t)job.second * nblk * 64 : nullptr;
+            if (r == TIC_OK && want_entropy) r = entropy_encode(zz, h, w, quality, outs[f], caps[f], &out_lens[f]);
+            if (r == TIC_OK && coeffs && coeffs[f]) memcpy(coeffs[f], zz, coef_bytes);
             if (r != TIC_OK) {
                 int exp = TIC_OK;
                 first_err.compare_exchange_strong(exp, r);
             }
+            bool freed;
             {
                 std::lock_guard<std::mutex> lk(mu);
-                s.busy = false;
+                freed = --s.remaining == 0;
             }
-            cv_free.notify_all();
+            if (freed) cv_free.notify_all();
         }
     };
     int nthreads = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
     std::vector<std::thread> pool;
     for (int t = 0; t < nthreads; t++) pool.emplace_back(consumer);
 
-    for (int i = 0; i < n && result == TIC_OK; i++) {
-        const int si = i % S;
+    int c = 0;
+    for (int first = 0; first < n && result == TIC_OK; first += chunk, c++) {
+        const int cnt = n - first < chunk ? n - first : chunk;
+        const int si = c % S;
         Slot &s = slots[si];
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv_free.wait(lk, [&] { return !s.busy; });
-            s.busy = true;
-            s.frame = i;
+            cv_free.wait(lk, [&] { return s.remaining == 0; });
+            s.first = first;
+            s.count = cnt;
+            s.remaining = cnt;
         }
-        hipStream_t st = ctx->bstream[i & 1];
-        // stage the frame into pinned memory (row-pitched), then H2D, kernel, D2H on one of the two streams:
-        // the copy of frame i+1 overlaps the kernel of frame i and the read-back of frame i-1.
-        const uint8_t *src = images[i];
-        for (int y = 0; y < h; y++) memcpy(s.pin_in + (size_t)y * pitch, src + (ptrdiff_t)y * row_stride, (size_t)w);
-        hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes, hipMemcpyHostToDevice, st);
+        hipStream_t st = ctx->bstream[c & 1];
+        for (int k = 0; k < cnt; k++) { // stage into pinned memory, row-pitched
+            const uint8_t *src = images[first + k];
+            uint8_t *dst = s.pin_in + (size_t)k * img_bytes;
+            for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, src + (ptrdiff_t)y * row_stride, (size_t)w);
+        }
+        hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
             a.fallback_count = nullptr;
+            a.nframes = cnt;
+            a.frame_stride_in = (long)img_bytes;
+            a.frame_stride_out = (long)coef_bytes;
             e = launch_dctq(a, 2, st);
         }
-        if (e == hipSuccess && need_d2h) e = hipMemcpyAsync(s.pin_out, s.d_coef, coef_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && need_d2h) e = hipMemcpyAsync(s.pin_out, s.d_coef, coef_bytes * cnt, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(s.done, st);
         if (e != hipSuccess) {
-            result = set_err(ctx, TIC_E_HIP, "batch enqueue failed at frame %d: %s", i, hipGetErrorString(e));
+            result = set_err(ctx, TIC_E_HIP, "batch enqueue failed at frame %d: %s", first, hipGetErrorString(e));
             std::lock_guard<std::mutex> lk(mu);
-            s.busy = false;
+            s.remaining = 0;
             break;
         }
         {
             std::lock_guard<std::mutex> lk(mu);
-            jobs.push_back(si);
+            for (int k = 0; k < cnt; k++) jobs.emplace_back(si, k);
         }
-        cv_job.notify_one();
+        cv_job.notify_all();
     }
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -497,7 +548,7 @@ int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h,
 
 int tic_dctq_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
                    int16_t *const *coeffs) {
-    return batch_impl(ctx, images, n, h, w, row_stride, quality, coeffs, nullptr, nullptr, nullptr, 2, false);
+    return batch_impl(ctx, images, n, h, w, row_stride, quality, coeffs, nullptr, nullptr, nullptr, 4, false);
 }
 
 // ---- decode ---------------------------------------------------------------------------------------------

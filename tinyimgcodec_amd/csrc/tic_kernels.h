@@ -28,6 +28,9 @@ struct DctqArgs {
     // byte offsets of the hybrid kernel's strip walk (precomputed on the host so the loop needs only scalar adds):
     // advancing by nwaves strips adds *_step; when the strip column wraps past fast_tx, *_wrap is added as well
     long in_step, in_wrap, out_step, out_wrap;
+    // batch of equally sized frames in one launch: blockIdx.y = frame; byte strides between frames
+    int nframes;
+    long frame_stride_in, frame_stride_out;
 };
 
 struct IdctArgs {

@@ -201,6 +201,8 @@ __device__ __forceinline__ Strip make_strip(int tile, int ntiles, int tiles_x, i
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerWG][kLdsWaveBytes / 4];
+    a.img += (long)blockIdx.y * a.frame_stride_in; // batch: one grid row per frame
+    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.y * a.frame_stride_out);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = lane >> 3, i = lane & 7;
     uint32_t *lds = lds_all[wave];
@@ -326,6 +328,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
     uint32_t *list = list_all[wave];
     uint2 *stash = stash_all[wave];
     const DctqConsts *__restrict__ C = a.consts;
+    a.img += (long)blockIdx.y * a.frame_stride_in; // batch: one grid row per frame
+    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.y * a.frame_stride_out);
 
     const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
     const int b = lane >> 3, i = lane & 7;   // compute phase: column / frequency v = i of block b
@@ -618,8 +622,9 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     a.nwaves = a.step_ty = a.step_tx = 0;
     a.fast_ty = a.fast_tx = 0;
     a.rem_mode = 0;
+    const int nf = a.nframes > 0 ? a.nframes : 1;
     if (variant == 1) {
-        hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles)), block, 0, stream, a);
+        hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles), nf), block, 0, stream, a);
         return hipGetLastError();
     }
     // hybrid kernel: rectangle of complete 64x8 strips with 8-byte aligned rows; the exact kernel takes the rest
@@ -630,7 +635,9 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (nfast > 0) {
         // persistent waves: at most kPersistentWGs workgroups, each wave loops over its strips
         int wgs = grid_for(nfast);
-        static const int cap = getenv("TIC_MAX_WGS") ? atoi(getenv("TIC_MAX_WGS")) : kPersistentWGs; // tuning knob
+        static const int cap_env = getenv("TIC_MAX_WGS") ? atoi(getenv("TIC_MAX_WGS")) : kPersistentWGs; // tuning knob
+        int cap = cap_env / nf; // a batch shares the chip's wave slots between its frames
+        if (cap < 64) cap = 64;
         if (wgs > cap) wgs = cap;
         const int min_wgs = (nfast + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
         if (wgs < min_wgs) wgs = min_wgs; // the per-wave trip list holds kMaxStripsPerWave entries
@@ -642,24 +649,24 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.out_step = ((long)a.step_ty * a.bw + (long)a.step_tx * 8) * 128;
         a.out_wrap = ((long)a.bw - (long)a.fast_tx * 8) * 128;
         if (variant == 10)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<1>, dim3(wgs), block, 0, stream, a);
+            hipLaunchKernelGGL(dctq_hybrid_kernel<1>, dim3(wgs, nf), block, 0, stream, a);
         else if (variant == 11)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<2>, dim3(wgs), block, 0, stream, a);
+            hipLaunchKernelGGL(dctq_hybrid_kernel<2>, dim3(wgs, nf), block, 0, stream, a);
         else if (variant == 12)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<3>, dim3(wgs), block, 0, stream, a);
+            hipLaunchKernelGGL(dctq_hybrid_kernel<3>, dim3(wgs, nf), block, 0, stream, a);
         else if (variant == 13)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<4>, dim3(wgs), block, 0, stream, a);
+            hipLaunchKernelGGL(dctq_hybrid_kernel<4>, dim3(wgs, nf), block, 0, stream, a);
         else if (variant == 14)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<5>, dim3(wgs), block, 0, stream, a);
+            hipLaunchKernelGGL(dctq_hybrid_kernel<5>, dim3(wgs, nf), block, 0, stream, a);
         else
-            hipLaunchKernelGGL(dctq_hybrid_kernel<0>, dim3(wgs), block, 0, stream, a);
+            hipLaunchKernelGGL(dctq_hybrid_kernel<0>, dim3(wgs, nf), block, 0, stream, a);
     } else {
         a.fast_tx = a.fast_ty = 0;
     }
     const int nrem = bh * (a.tiles_x - a.fast_tx) + (bh - a.fast_ty) * a.fast_tx;
     if (nrem > 0) {
         a.rem_mode = 1;
-        hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(nrem)), block, 0, stream, a);
+        hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(nrem), nf), block, 0, stream, a);
     }
     return hipGetLastError();
 }
