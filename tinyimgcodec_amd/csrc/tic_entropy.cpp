@@ -65,37 +65,43 @@ const EncTables &tables() {
     return t;
 }
 
-// MSB-first bit writer with a 64-bit accumulator.
+// MSB-first bit writer: bits collect at the low end of a 64-bit accumulator; whenever 32 or more are pending the
+// top 32 are stored as one big-endian word.  The caller guarantees 8 spare bytes behind `end`.
 struct BitWriter {
     uint8_t *p, *end;
     uint64_t acc = 0;
     int nacc = 0;
     bool overflow = false;
     BitWriter(uint8_t *b, uint8_t *e) : p(b), end(e) {}
-    inline void put(uint32_t v, int n) { // n <= 32
+    inline void put(uint32_t v, int n) { // n <= 32, v < 2^n
         acc = (acc << n) | v;
         nacc += n;
-        if (nacc >= 32) flush32();
-    }
-    inline void flush32() {
-        while (nacc >= 8) {
-            if (p >= end) {
+        if (nacc >= 32) {
+            nacc -= 32;
+            if (p + 4 > end) {
                 overflow = true;
-                nacc = 0;
                 return;
             }
-            *p++ = (uint8_t)(acc >> (nacc - 8));
-            nacc -= 8;
+            const uint32_t w = __builtin_bswap32((uint32_t)(acc >> nacc));
+            memcpy(p, &w, 4);
+            p += 4;
         }
     }
     inline void finish() {
-        flush32();
+        while (nacc >= 8) {
+            if (p >= end) {
+                overflow = true;
+                return;
+            }
+            nacc -= 8;
+            *p++ = (uint8_t)(acc >> nacc);
+        }
         if (nacc > 0) {
             if (p >= end) {
                 overflow = true;
                 return;
             }
-            *p++ = (uint8_t)((acc << (8 - nacc)) & 0xff); // zero padding
+            *p++ = (uint8_t)((acc << (8 - nacc)) & 0xff); // zero padding (bitbuffer.py:17-18)
             nacc = 0;
         }
     }
@@ -159,12 +165,12 @@ int entropy_encode(const int16_t *zz, int h, int w, int quality, uint8_t *out, s
                 bw.put(T.ac_code[0xF0], T.ac_len[0xF0]);
                 run -= 16;
             }
-            uint32_t a = (uint32_t)(v < 0 ? -v : v);
-            int size = bit_length(a);
+            const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+            const int size = bit_length(a);
             if (size > 10) return TIC_E_RANGE;
-            int sym = (run << 4) | size;
-            bw.put(T.ac_code[sym], T.ac_len[sym]);
-            bw.put((v < 0 ? ~a : a) & ((1u << size) - 1u), size);
+            const int sym = (run << 4) | size;
+            // codeword (<= 16 bits) and value bits (<= 10) in one append; v < 0 -> one's complement of |v|
+            bw.put((T.ac_code[sym] << size) | ((uint32_t)(v + (v >> 31)) & ((1u << size) - 1u)), T.ac_len[sym] + size);
             run = 0;
         }
         bw.put(T.ac_code[0], T.ac_len[0]); // EOB

@@ -172,6 +172,42 @@ __device__ __forceinline__ void exact_block(uint32_t colLo, uint32_t colHi, uint
     for (int v = 0; v < 8; v++) q[v] = (int)rint(c[v] / div[v]); // np.round(X / div): IEEE divide, half-even
 }
 
+// Second-level path for a block whose float32 result tripped its guard band: the same AAN butterflies in float64
+// (error ~1e-13 in coefficient units, against ~1e-12 for the reference itself).  A rounding is decided when no
+// .5 tie lies within 1e-9 (in quantised units) of t; the four rational coefficients (exact ties are common there)
+// and anything still undecided make the function return false for the lane, and the caller falls back to the
+// exact path for that block.  Lane mapping and LDS use as exact_block().
+__device__ __forceinline__ bool second_level_block(uint32_t colLo, uint32_t colHi, uint32_t *lds, int b, int i,
+                                                   const DctqConsts *__restrict__ C, int q[8]) {
+    double c[8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        c[r] = (double)((int)((colLo >> (8 * r)) & 0xffu) - 128);
+        c[r + 4] = (double)((int)((colHi >> (8 * r)) & 0xffu) - 128);
+    }
+    dct8_aan(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+    uint32_t w[8], wh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = (uint32_t)__double2loint(c[k]);
+    transpose8x8_dwords(lds, b, i, w);
+#pragma unroll
+    for (int k = 0; k < 8; k++) wh[k] = (uint32_t)__double2hiint(c[k]);
+    transpose8x8_dwords(lds, b, i, wh);
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = __hiloint2double((int)wh[k], (int)w[k]);
+    dct8_aan(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+    const double *mul = C->mul64 + i * 8;
+    bool ok = true;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        const double t = c[v] * mul[v];
+        const double r = rint(t);
+        ok = ok && (fabs(t - r) < 0.5 - 1e-9);
+        q[v] = (int)r;
+    }
+    return ok;
+}
+
 // Writes the lane's 8 coefficients (natural positions i*8+v) into zig-zag order in LDS, then each lane stores
 // 16 bytes: a wave writes its 8 blocks as one contiguous 1 KiB segment.
 __device__ __forceinline__ void store_zigzag(uint32_t *lds, int b, int i, const uint16_t zz[8], const int q[8],
@@ -374,6 +410,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
         };
         uint2 p0 = load_next();
         uint2 p1 = load_next();
+        if (a.stagger > 0) { // optional de-phasing of the waves that share a SIMD (loads above are already in flight)
+            const int mine = (wave & 1) * a.stagger + ((blockIdx.x >> 3) & 1) * (a.stagger >> 1);
+            for (int k = 0; k < mine; k++) __builtin_amdgcn_s_sleep(1);
+        }
 
         while (t0 < nfast) {
             const uint2 p2 = load_next();
@@ -384,10 +424,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
                   d3 = (float)(lo0 >> 24);
             float d4 = (float)(hi0 & 0xffu), d5 = (float)((hi0 >> 8) & 0xffu), d6 = (float)((hi0 >> 16) & 0xffu),
                   d7 = (float)(hi0 >> 24);
-            if (ABL != 1) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
+            if (ABL != 1 && ABL != 6) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
             d0 -= 1024.0f;
             float e0 = d0, e1 = d1, e2 = d2, e3 = d3, e4 = d4, e5 = d5, e6 = d6, e7 = d7;
-            if (ABL != 2) {
+            if (ABL != 2 && ABL != 6) {
                 tw[0 * 8] = __float_as_uint(d0); tw[1 * 8] = __float_as_uint(d1); tw[2 * 8] = __float_as_uint(d2);
                 tw[3 * 8] = __float_as_uint(d3); tw[4 * 8] = __float_as_uint(d4); tw[5 * 8] = __float_as_uint(d5);
                 tw[6 * 8] = __float_as_uint(d6); tw[7 * 8] = __float_as_uint(d7);
@@ -401,7 +441,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
             // ---- pass 2: down the column of horizontal frequency v = i ------------------------------------------
             uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
             unsigned long long cA = 0, cB = 0; // lanes whose guard band tripped (A: u in 1,2,3,5,6,7; B: u in 0,4)
-            if (ABL != 1) {
+            if (ABL != 1 && ABL != 6) {
                 dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
                 float r0, r1, r2, r3, r4, r5, r6, r7;
                 quant_magic(e0, m0.x, q0, r0);
@@ -423,7 +463,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
                 q4 = __float_as_uint(e4); q5 = __float_as_uint(e5); q6 = __float_as_uint(e6); q7 = __float_as_uint(e7);
             }
             uint4 val;
-            if (ABL != 2) {
+            if (ABL != 2 && ABL != 6) {
                 *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
                 *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
             } else {
@@ -450,7 +490,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
                 nG += __builtin_popcount(gm);
             }
             // ---- zig-zag ordered blocks -> global: 16 B per lane, 1 KiB contiguous per wave ---------------------------
-            if (ABL != 2) {
+            if (ABL != 2 && ABL != 6) {
                 wave_lds_fence();
                 val = *zr;
                 wave_lds_fence();
@@ -463,67 +503,89 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
         }
     }
 
-    // ---- post-pass over the recorded blocks: 8 blocks per wave pass, one per group of 8 lanes ------------------------
-    // (the patches below go to addresses this same wave stored to earlier: same-wave stores to one address stay
-    // in order, so no wait for the fast-path stores is needed)
-    if ((nS | nG) == 0 || ABL == 3) return;
-    wave_lds_fence();
+    // ---- post-pass over the recorded blocks, shared by the workgroup ------------------------------------------------------
+    // All four waves end their loops at about the same time; the recorded blocks are few and each pass over them is
+    // a long dependent float64 chain for a single wave.  So the work is split by kind across the waves of the
+    // workgroup instead of being done serially by the wave that recorded it: waves 0 and 2 take the rational-tie
+    // entries of wave pairs {0,1} and {2,3}, waves 1 and 3 take the full-redo entries of the same pairs.
+    // (Patches go to addresses stored to earlier by another wave of this workgroup: every wave drains its own
+    // stores before the barrier, so the patch is ordered after them.)
+    __shared__ int cnt_all[kWavesPerWG][2];
+    if (lane == 0) {
+        cnt_all[wave][0] = nS;
+        cnt_all[wave][1] = nG;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (ABL == 3) return;
+    const int src0 = wave & 2, src1 = src0 + 1;      // the pair of waves whose entries this wave serves
+    const bool do_ties = (wave & 1) == 0;
+    const int kind = do_ties ? 0 : 1;
+    const int n0 = cnt_all[src0][kind], n1 = cnt_all[src1][kind];
+    const int ntot = n0 + n1;
+    if (ntot == 0) return;
+    if ((do_ties && (ABL == 5 || ABL == 7)) || (!do_ties && ABL == 4)) return;
     char *zzblk = ldsZ + b * kZzStrideB;
-    for (int base = 0; base < nS && ABL != 5; base += 8) { // rational coefficients only (exact ties, ~2 % of blocks)
-        const bool have = base + b < nS;
-        const uint32_t blk = list[have ? base + b : 0];
+    for (int base = 0; base < ntot; base += 8) { // 8 blocks per pass, one per group of 8 lanes
+        const int e = base + b;
+        const bool have = e < ntot;
+        const int ee = have ? e : 0;
+        const int sw = ee < n0 ? src0 : src1;          // source wave and index in its list
+        const int idx = ee < n0 ? ee : ee - n0;
+        const uint32_t blk = do_ties ? list_all[sw][idx] : list_all[sw][kListEntries - 1 - idx];
         Strip s;
         s.by = (int)(blk / (uint32_t)a.bw);
         s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
         s.valid = true;
         s.oblk = blk;
         uint32_t lo, hi;
-        if (base + b < kStash) { // lane 8*b + i: row i of its block, from the LDS stash or from memory
-            const uint2 pv = stash[(base + b) * 8 + i];
+        if (idx < kStash) { // lane 8*b + i: pixel row i of its block, from the recording wave's LDS stash or from memory
+            const uint2 pv = stash_all[sw][((do_ties ? 0 : kStash) + idx) * 8 + i];
             lo = pv.x;
             hi = pv.y;
         } else {
             load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
         }
         transpose8x8_bytes(lo, hi, i); // -> pixel column i
-        int r0, r4;
-        special_block(lo, hi, ldsT, b, i, C, r0, r4);
-        if (have && (i & 3) == 0) {
-            int16_t *ob = a.out + (size_t)blk * 64;
-            ob[C->zzofs[i * 8] >> 1] = (int16_t)r0;
-            ob[C->zzofs[i * 8 + 4] >> 1] = (int16_t)r4;
-        }
-    }
-    for (int base = 0; base < nG && ABL != 4; base += 8) { // whole blocks on the exact path (~0.3 % of blocks at q=50)
-        const bool have = base + b < nG;
-        const uint32_t blk = list[kListEntries - 1 - (have ? base + b : 0)];
-        Strip s;
-        s.by = (int)(blk / (uint32_t)a.bw);
-        s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
-        s.valid = true;
-        s.oblk = blk;
-        uint32_t lo, hi;
-        if (base + b < kStash) {
-            const uint2 pv = stash[(kStash + base + b) * 8 + i];
-            lo = pv.x;
-            hi = pv.y;
-        } else {
-            load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
-        }
-        transpose8x8_bytes(lo, hi, i);
-        int qe[8];
-        exact_block(lo, hi, ldsT, b, i, C, qe); // lane i holds frequency row u = i
-        const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
-        const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+        if (do_ties) {                 // rational coefficients only (exact ties, ~2 % of blocks)
+            int r0, r4;
+            special_block(lo, hi, ldsT, b, i, C, r0, r4);
+            if (have && (i & 3) == 0) {
+                int16_t *ob = a.out + (size_t)blk * 64;
+                ob[C->zzofs[i * 8] >> 1] = (int16_t)r0;
+                ob[C->zzofs[i * 8 + 4] >> 1] = (int16_t)r4;
+            }
+        } else { // whole blocks (~0.3 % of blocks at q=50)
+            int qe[8];
+            if (ABL == 7) {
 #pragma unroll
-        for (int v = 0; v < 8; v++)
-            *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
-        wave_lds_fence();
-        const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
-        wave_lds_fence();
-        if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
+                for (int v = 0; v < 8; v++) qe[v] = (int)(lo >> v) + (int)hi; // timing-only: no exact arithmetic
+            } else {
+                // second level first (float64 butterflies, ~half the work of the exact order); exact order only for
+                // the blocks it cannot decide (a rational-coefficient tie in the same block, or a true tie elsewhere)
+                const bool ok = second_level_block(lo, hi, ldsT, b, i, C, qe);
+                if (__ballot(!ok && have) != 0ull) {
+                    int qx[8];
+                    exact_block(lo, hi, ldsT, b, i, C, qx);
+                    const unsigned long long bad = __ballot(!ok);
+                    if ((bad >> (8 * b)) & 0xffull) {
+#pragma unroll
+                        for (int v = 0; v < 8; v++) qe[v] = qx[v];
+                    }
+                }
+            }
+            const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
+            const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+#pragma unroll
+            for (int v = 0; v < 8; v++)
+                *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
+            wave_lds_fence();
+            const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
+            wave_lds_fence();
+            if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
+        }
     }
-    if (a.fallback_count != nullptr && lane == 0 && nG) atomicAdd(a.fallback_count, (unsigned long long)nG);
+    if (!do_ties && a.fallback_count != nullptr && lane == 0) atomicAdd(a.fallback_count, (unsigned long long)ntot);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -622,6 +684,8 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     a.nwaves = a.step_ty = a.step_tx = 0;
     a.fast_ty = a.fast_tx = 0;
     a.rem_mode = 0;
+    static const int stagger_env = getenv("TIC_STAGGER") ? atoi(getenv("TIC_STAGGER")) : 0;
+    a.stagger = stagger_env;
     const int nf = a.nframes > 0 ? a.nframes : 1;
     if (variant == 1) {
         hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles), nf), block, 0, stream, a);
@@ -658,6 +722,10 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             hipLaunchKernelGGL(dctq_hybrid_kernel<4>, dim3(wgs, nf), block, 0, stream, a);
         else if (variant == 14)
             hipLaunchKernelGGL(dctq_hybrid_kernel<5>, dim3(wgs, nf), block, 0, stream, a);
+        else if (variant == 16)
+            hipLaunchKernelGGL(dctq_hybrid_kernel<7>, dim3(wgs, nf), block, 0, stream, a);
+        else if (variant == 15)
+            hipLaunchKernelGGL(dctq_hybrid_kernel<6>, dim3(wgs, nf), block, 0, stream, a);
         else
             hipLaunchKernelGGL(dctq_hybrid_kernel<0>, dim3(wgs, nf), block, 0, stream, a);
     } else {

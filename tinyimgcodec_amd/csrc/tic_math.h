@@ -101,24 +101,28 @@ TIC_HD void idct8_exact(double &c0, double &c1, double &c2, double &c3, double &
 // the scale is folded into the quantiser multiplier.  o0 and o4 are plain sums/differences of the inputs, hence
 // exact integers when the inputs are (needed by the exact sub-path for coefficients (0,0),(0,4),(4,0),(4,4)).
 // ---------------------------------------------------------------------------------------------------------
-TIC_HD void dct8_aan(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6, float &d7) {
+TIC_HD float tic_fma(float a, float b, float c) { return fmaf(a, b, c); }
+TIC_HD double tic_fma(double a, double b, double c) { return fma(a, b, c); }
+
+template <typename T>
+TIC_HD void dct8_aan(T &d0, T &d1, T &d2, T &d3, T &d4, T &d5, T &d6, T &d7) {
 #pragma clang fp contract(off)
-    const float c707 = 0.70710678118654752440f, c382 = 0.38268343236508977173f;
-    const float c541 = 0.54119610014619698440f, c1306 = 1.30656296487637652786f;
-    float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
-    float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
-    float t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    const T c707 = (T)0.70710678118654752440, c382 = (T)0.38268343236508977173;
+    const T c541 = (T)0.54119610014619698440, c1306 = (T)1.30656296487637652786;
+    T t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    T t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    T t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
     d0 = t10 + t11;
     d4 = t10 - t11;
-    float s = t12 + t13;
-    d2 = fmaf(s, c707, t13);
-    d6 = fmaf(s, -c707, t13);
-    float u10 = t4 + t5, u11 = t5 + t6, u12 = t6 + t7;
-    float z5 = (u10 - u12) * c382;
-    float z2 = fmaf(u10, c541, z5);
-    float z4 = fmaf(u12, c1306, z5);
-    float z11 = fmaf(u11, c707, t7);
-    float z13 = fmaf(u11, -c707, t7);
+    T s = t12 + t13;
+    d2 = tic_fma(s, c707, t13);
+    d6 = tic_fma(s, -c707, t13);
+    T u10 = t4 + t5, u11 = t5 + t6, u12 = t6 + t7;
+    T z5 = (u10 - u12) * c382;
+    T z2 = tic_fma(u10, c541, z5);
+    T z4 = tic_fma(u12, c1306, z5);
+    T z11 = tic_fma(u11, c707, t7);
+    T z13 = tic_fma(u11, -c707, t7);
     d5 = z13 + z2;
     d3 = z13 - z2;
     d1 = z11 + z4;
@@ -137,6 +141,7 @@ static constexpr float kMagic = 12582912.0f;
 struct DctqConsts {
     double div[64];      // natural order u*8+v: (Q*factor)/100 as the reference computes it (utils.py:50-53)
     double rdiv[64];     // fl(1/div)
+    double mul64[64];    // second-level path, index u*8+v: 1 / (aan[u]*aan[v]*8*div[u][v]) in float64
     float mulT[64];      // fast path, index v*8+u: 1 / (aan[u]*aan[v]*8*div[u][v])
     float thrT[16];      // fast path, per column v: [2v] = accept threshold for u in {1,2,3,5,6,7}, [2v+1] = for u in {0,4}
                          // (0.5 - largest guard band kGuardX/div[u][v] of the group; accept when |t - rint(t)| <= thr)
@@ -167,6 +172,7 @@ inline bool build_consts(int quality, DctqConsts *c) {
         for (int v = 0; v < 8; v++) {
             int i = u * 8 + v, t = v * 8 + u;
             c->mulT[t] = (float)(1.0 / (aan[u] * aan[v] * 8.0 * c->div[i]));
+            c->mul64[i] = 1.0 / (aan[u] * aan[v] * 8.0 * c->div[i]);
         }
     for (int v = 0; v < 8; v++) {
         double ga = 0.0, gb = 0.0;

@@ -13,7 +13,7 @@ for dim in (4096, 16384):
     ctx.check(L.tic_dev_alloc(ctx.handle, img.size * 2, C.byref(d_out)))
     ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
     ms = C.c_float()
-    for name, v in (("full hybrid", 2), ("no arithmetic (LDS+mem)", 10), ("no LDS (VALU+mem)", 11), ("no post-pass", 12), ("post-pass: ties only", 13), ("post-pass: exact only", 14), ("exact kernel", 1)):
+    for name, v in (("full hybrid", 2), ("no arithmetic (LDS+mem)", 10), ("no LDS (VALU+mem)", 11), ("no LDS, no arithmetic", 15), ("no post-pass", 12), ("post-pass: ties only", 13), ("post-pass: exact only", 14), ("post-pass: exact w/o arithmetic", 16), ("exact kernel", 1)):
         iters = 50 if dim == 4096 else 10
         ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, h, w, w, 50, d_out, v, 5, C.byref(ms)))
         ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, h, w, w, 50, d_out, v, iters, C.byref(ms)))
