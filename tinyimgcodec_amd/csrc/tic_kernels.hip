@@ -169,7 +169,10 @@ __device__ __forceinline__ void exact_block(uint32_t colLo, uint32_t colHi, uint
     dct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -1: along frequency row u = i
     const double *div = C->div + i * 8;
 #pragma unroll
-    for (int v = 0; v < 8; v++) q[v] = (int)rint(c[v] / div[v]); // np.round(X / div): IEEE divide, half-even
+    for (int v = 0; v < 8; v++) {
+        q[v] = (int)rint(c[v] / div[v]); // np.round(X / div): IEEE divide, half-even
+        __builtin_amdgcn_sched_barrier(0); // one division at a time: keeps the register footprint of the 8 expansions small
+    }
 }
 
 // Second-level path for a block whose float32 result tripped its guard band: the same AAN butterflies in float64
@@ -309,8 +312,19 @@ __device__ __forceinline__ void quant_magic(float z, float mul, uint32_t &bits, 
 // one rounding each, and the row pass outputs 0 and 4 need 8 additions in pocketfft's order.
 // col: the lane's pixel column (lane 8*b + c).  Lanes c = 0 and c = 4 return the two quantised values of
 // frequency row u = c: r0 = (u,0), r4 = (u,4).
+struct RationalConsts { // per-lane constants of special_block(), loaded ahead of the dependent chain
+    double rdiv0, rdiv4, div0, div4;
+};
+__device__ __forceinline__ RationalConsts load_rational_consts(const DctqConsts *__restrict__ C, int i) {
+    RationalConsts k;
+    k.rdiv0 = C->rdiv[i * 8];
+    k.rdiv4 = C->rdiv[i * 8 + 4];
+    k.div0 = C->div[i * 8];
+    k.div4 = C->div[i * 8 + 4];
+    return k;
+}
 __device__ __forceinline__ void special_block(uint32_t colLo, uint32_t colHi, uint32_t *ldsT, int b, int i,
-                                              const DctqConsts *__restrict__ C, int &r0i, int &r4i) {
+                                              const RationalConsts &K, int &r0i, int &r4i) {
 #pragma clang fp contract(off)
     int x0 = colLo & 0xff, x1 = (colLo >> 8) & 0xff, x2 = (colLo >> 16) & 0xff, x3 = colLo >> 24;
     int x4 = colHi & 0xff, x5 = (colHi >> 8) & 0xff, x6 = (colHi >> 16) & 0xff, x7 = colHi >> 24;
@@ -330,11 +344,11 @@ __device__ __forceinline__ void special_block(uint32_t colLo, uint32_t colHi, ui
         double A = p07 + p34, B = p12 + p56;
         double E0 = A + B, E4 = A - B;
         double X0 = E0 * (kSq2h * 0.5), X4 = E4 * (kTW3 * 0.5);
-        double t0 = X0 * C->rdiv[i * 8], t4 = X4 * C->rdiv[i * 8 + 4];
+        double t0 = X0 * K.rdiv0, t4 = X4 * K.rdiv4;
         double r0 = rint(t0), r4 = rint(t4);
         // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
-        if (fabs(fabs(t0 - r0) - 0.5) < 1e-9) r0 = rint(X0 / C->div[i * 8]);
-        if (fabs(fabs(t4 - r4) - 0.5) < 1e-9) r4 = rint(X4 / C->div[i * 8 + 4]);
+        if (fabs(fabs(t0 - r0) - 0.5) < 1e-9) r0 = rint(X0 / K.div0);
+        if (fabs(fabs(t4 - r4) - 0.5) < 1e-9) r4 = rint(X4 / K.div4);
         r0i = (int)r0;
         r4i = (int)r4;
     }
@@ -352,7 +366,7 @@ __device__ __forceinline__ uint32_t byte_any(unsigned long long m) { // bit k = 
 }
 
 template <int ABL>
-__global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqArgs a) {
+__global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
     __shared__ uint32_t list_all[kWavesPerWG][kListEntries];
@@ -525,65 +539,81 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 8) void dctq_hybrid_kernel(DctqAr
     const int ntot = n0 + n1;
     if (ntot == 0) return;
     if ((do_ties && (ABL == 5 || ABL == 7)) || (!do_ties && ABL == 4)) return;
-    char *zzblk = ldsZ + b * kZzStrideB;
-    for (int base = 0; base < ntot; base += 8) { // 8 blocks per pass, one per group of 8 lanes
-        const int e = base + b;
-        const bool have = e < ntot;
+    // entry e of the concatenated lists of the two served waves -> (block id, pixel rows of the block for lane i)
+    auto fetch = [&](int e, bool have, uint32_t &blk, uint32_t &lo, uint32_t &hi) {
         const int ee = have ? e : 0;
-        const int sw = ee < n0 ? src0 : src1;          // source wave and index in its list
+        const int sw = ee < n0 ? src0 : src1; // source wave and index in its list
         const int idx = ee < n0 ? ee : ee - n0;
-        const uint32_t blk = do_ties ? list_all[sw][idx] : list_all[sw][kListEntries - 1 - idx];
-        Strip s;
-        s.by = (int)(blk / (uint32_t)a.bw);
-        s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
-        s.valid = true;
-        s.oblk = blk;
-        uint32_t lo, hi;
-        if (idx < kStash) { // lane 8*b + i: pixel row i of its block, from the recording wave's LDS stash or from memory
+        blk = do_ties ? list_all[sw][idx] : list_all[sw][kListEntries - 1 - idx];
+        if (idx < kStash) { // lane 8*b + i: pixel row i of its block, from the recording wave's LDS stash ...
             const uint2 pv = stash_all[sw][((do_ties ? 0 : kStash) + idx) * 8 + i];
             lo = pv.x;
             hi = pv.y;
-        } else {
+        } else { // ... or from memory
+            Strip s;
+            s.by = (int)(blk / (uint32_t)a.bw);
+            s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
+            s.valid = true;
+            s.oblk = blk;
             load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
         }
         transpose8x8_bytes(lo, hi, i); // -> pixel column i
-        if (do_ties) {                 // rational coefficients only (exact ties, ~2 % of blocks)
+    };
+    const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8); // fetched before the dependent chains start
+    if (do_ties) { // rational coefficients only (exact ties, ~2 % of blocks); 8 blocks per pass
+        const RationalConsts KR = load_rational_consts(C, i);
+        for (int base = 0; base < ntot; base += 8) {
+            const bool have = base + b < ntot;
+            uint32_t blk, lo, hi;
+            fetch(base + b, have, blk, lo, hi);
             int r0, r4;
-            special_block(lo, hi, ldsT, b, i, C, r0, r4);
+            special_block(lo, hi, ldsT, b, i, KR, r0, r4);
             if (have && (i & 3) == 0) {
                 int16_t *ob = a.out + (size_t)blk * 64;
-                ob[C->zzofs[i * 8] >> 1] = (int16_t)r0;
-                ob[C->zzofs[i * 8 + 4] >> 1] = (int16_t)r4;
+                ob[(zo.x & 0xffffu) >> 1] = (int16_t)r0; // zig-zag slots of (u,0) and (u,4)
+                ob[(zo.z & 0xffffu) >> 1] = (int16_t)r4;
             }
-        } else { // whole blocks (~0.3 % of blocks at q=50)
+        }
+        return;
+    }
+    // whole blocks (~0.3 % of blocks at q=50); 8 blocks per pass
+    char *zzblk = ldsZ + b * kZzStrideB;
+    const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+    for (int base = 0; base < ntot; base += 8) {
+        const bool have = base + b < ntot;
+        uint32_t blk, lo, hi;
+        fetch(base + b, have, blk, lo, hi);
+        // second level first (float64 butterflies, ~half the work of the exact order); its results go straight to
+        // the zig-zag staging buffer so that nothing stays live across the exact order, which runs only for blocks
+        // the second level cannot decide (a rational-coefficient tie in the same block, or a true tie elsewhere)
+        bool ok;
+        {
             int qe[8];
             if (ABL == 7) {
+                ok = true;
 #pragma unroll
                 for (int v = 0; v < 8; v++) qe[v] = (int)(lo >> v) + (int)hi; // timing-only: no exact arithmetic
             } else {
-                // second level first (float64 butterflies, ~half the work of the exact order); exact order only for
-                // the blocks it cannot decide (a rational-coefficient tie in the same block, or a true tie elsewhere)
-                const bool ok = second_level_block(lo, hi, ldsT, b, i, C, qe);
-                if (__ballot(!ok && have) != 0ull) {
-                    int qx[8];
-                    exact_block(lo, hi, ldsT, b, i, C, qx);
-                    const unsigned long long bad = __ballot(!ok);
-                    if ((bad >> (8 * b)) & 0xffull) {
-#pragma unroll
-                        for (int v = 0; v < 8; v++) qe[v] = qx[v];
-                    }
-                }
+                ok = second_level_block(lo, hi, ldsT, b, i, C, qe);
             }
-            const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
-            const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
 #pragma unroll
             for (int v = 0; v < 8; v++)
                 *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
-            wave_lds_fence();
-            const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
-            wave_lds_fence();
-            if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
         }
+        const unsigned long long bad = __ballot(!ok && have);
+        if (bad != 0ull) {
+            int qx[8];
+            exact_block(lo, hi, ldsT, b, i, C, qx);
+            if ((bad >> (8 * b)) & 0xffull) {
+#pragma unroll
+                for (int v = 0; v < 8; v++)
+                    *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qx[v];
+            }
+        }
+        wave_lds_fence();
+        const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
+        wave_lds_fence();
+        if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
     }
     if (!do_ties && a.fallback_count != nullptr && lane == 0) atomicAdd(a.fallback_count, (unsigned long long)ntot);
 }
