@@ -102,8 +102,17 @@ int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count);
 int tic_entropy_encode(const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap,
                        size_t *out_len);
 
+/* Entropy stage on the device (same stream bytes as tic_entropy_encode): coefficients in HBM -> stream in HBM.
+ * Bits per block, a 64-bit offset scan and parallel bit packing; synchronous; cap >= tic_compress_bound(). */
+int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, int quality, void *d_out, size_t cap,
+                           size_t *out_len);
+
 /* ---- whole codec ------------------------------------------------------------------------------------- */
-/* compress() codec.py:133 with auto_generate_huffman_table=False: GPU transform + host entropy stage. */
+/* compress() with image and stream both resident in HBM: transform kernels + device entropy stage. */
+int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out,
+                     size_t cap, size_t *out_len);
+/* compress() codec.py:133 with auto_generate_huffman_table=False, host buffers: upload, GPU transform stage, GPU
+ * entropy stage, download of the finished stream. */
 int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, uint8_t *out,
                  size_t cap, size_t *out_len);
 

@@ -304,6 +304,76 @@ def test_batched_launch_matches_per_frame(ctx, oracle):
     L.tic_dev_free(ctx.handle, d_out)
 
 
+def test_device_entropy_stage_matches_reference_streams(ctx, oracle, golden, manifest):
+    """tic_entropy_encode_dev (bit counting + scan + parallel packing on the GPU) == reference compress() bytes,
+    fed with oracle coefficients so that the stage is checked on its own."""
+    L = N.load()
+
+    def dev_entropy(zz, h, w, q):
+        zz = np.ascontiguousarray(zz, dtype=np.int16)
+        cap = L.tic_compress_bound(h, w)
+        d_zz, d_out = C.c_void_p(), C.c_void_p()
+        ctx.check(L.tic_dev_alloc(ctx.handle, max(zz.nbytes, 16), C.byref(d_zz)))
+        ctx.check(L.tic_dev_alloc(ctx.handle, cap, C.byref(d_out)))
+        if zz.nbytes:
+            ctx.check(L.tic_memcpy_h2d(ctx.handle, d_zz, zz.ctypes.data, zz.nbytes))
+        n = C.c_size_t()
+        rc = L.tic_entropy_encode_dev(ctx.handle, d_zz, h, w, q, d_out, cap, C.byref(n))
+        out = np.empty(max(n.value, 1), np.uint8)
+        if rc == 0:
+            ctx.check(L.tic_memcpy_d2h(ctx.handle, out.ctypes.data, d_out, n.value))
+        L.tic_dev_free(ctx.handle, d_zz)
+        L.tic_dev_free(ctx.handle, d_out)
+        return rc, out[: n.value].tobytes()
+
+    d = golden("lenna")
+    for q in (10, 50, 90):
+        rc, bs = dev_entropy(oracle.encode_zz16(d["img"], q), 512, 512, q)
+        assert rc == 0 and bs == d[f"q{q}_bs"].tobytes()
+    s = golden("transform_small")
+    for key in s["names"]:
+        img = s[key + "_img"]
+        q = int(str(key).rsplit("_q", 1)[1])
+        want = s[key + "_bs"].tobytes()
+        rc, bs = dev_entropy(oracle.encode_zz16(img, q), img.shape[0], img.shape[1], q)
+        if want:
+            assert rc == 0 and bs == want, key
+        else:
+            assert rc == N.TIC_E_RANGE, key
+    # long zero runs (ZRL), values at the size-category edges, last coefficient non-zero, all-zero blocks
+    rng = np.random.default_rng(9)
+    zz = np.zeros((64, 64), np.int16)
+    for b in range(64):
+        for _ in range(int(rng.integers(0, 6))):
+            zz[b, int(rng.integers(0, 64))] = int(rng.choice([1, -1, 2, -3, 7, -8, 255, -256, 1023, -1023]))
+    zz[3, 63] = -5
+    zz[:, 0] = rng.integers(-1000, 1000, 64)
+    rc, bs = dev_entropy(zz, 64, 64, 50)
+    assert rc == 0 and bs == T.entropy_encode(zz, 64, 64, 50)
+    img = rand_frame(1234, 1080, 1920)
+    rc, bs = dev_entropy(oracle.encode_zz16(img, 50), 1080, 1920, 50)
+    assert rc == 0 and sha(bs) == manifest["rand1234_1080x1920_q50"]["sha256"]
+
+
+def test_compress_dev_resident(ctx, manifest):
+    """tic_compress_dev: image and stream both resident in HBM (512^2 seed 1234 stream digest of the reference)."""
+    L = N.load()
+    img = rand_frame(1234, 512, 512)
+    cap = L.tic_compress_bound(512, 512)
+    d_img, d_out = C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, cap, C.byref(d_out)))
+    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
+    n = C.c_size_t()
+    ctx.check(L.tic_compress_dev(ctx.handle, d_img, 512, 512, 512, 50, d_out, cap, C.byref(n)))
+    out = np.empty(n.value, np.uint8)
+    ctx.check(L.tic_memcpy_d2h(ctx.handle, out.ctypes.data, d_out, n.value))
+    L.tic_dev_free(ctx.handle, d_img)
+    L.tic_dev_free(ctx.handle, d_out)
+    m = manifest["rand1234_512x512_q50"]
+    assert n.value == m["bytes"] and sha(out.tobytes()) == m["sha256"]
+
+
 def test_error_paths(ctx):
     L = N.load()
     img = rand_frame(1, 16, 16)

@@ -16,6 +16,7 @@
 
 #include "../../include/tinyimgcodec_hip.h"
 #include "tic_entropy.h"
+#include "tic_entropy_gpu.h"
 #include "tic_kernels.h"
 #include "tic_math.h"
 
@@ -48,6 +49,15 @@ struct tic_ctx {
     void *d_coef = nullptr;
     size_t d_coef_cap = 0;
     std::vector<int16_t> h_coef;
+    // device entropy stage workspace
+    HuffDev *d_huff = nullptr;
+    uint32_t *d_nbits = nullptr;
+    unsigned long long *d_bitoff = nullptr;
+    void *d_scan_tmp = nullptr;
+    size_t ent_blocks_cap = 0, scan_tmp_cap = 0;
+    int *d_err = nullptr;
+    void *d_stream_buf = nullptr;
+    size_t d_stream_cap = 0;
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
     std::vector<Slot> bslots;
     size_t bslot_img_bytes = 0, bslot_coef_bytes = 0;
@@ -118,6 +128,12 @@ void tic_destroy(tic_ctx *ctx) {
     if (ctx->d_coef) (void)hipFree(ctx->d_coef);
     if (ctx->d_consts) (void)hipFree(ctx->d_consts);
     if (ctx->d_fallback) (void)hipFree(ctx->d_fallback);
+    if (ctx->d_huff) (void)hipFree(ctx->d_huff);
+    if (ctx->d_nbits) (void)hipFree(ctx->d_nbits);
+    if (ctx->d_bitoff) (void)hipFree(ctx->d_bitoff);
+    if (ctx->d_scan_tmp) (void)hipFree(ctx->d_scan_tmp);
+    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->d_stream_buf) (void)hipFree(ctx->d_stream_buf);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -150,6 +166,13 @@ static int create_impl(tic_ctx *ctx, int device) {
     for (int q = 1; q <= 99; q++) build_consts(q, &all[q]);
     CK(hipMalloc((void **)&ctx->d_consts, all.size() * sizeof(DctqConsts)));
     CK(hipMemcpy(ctx->d_consts, all.data(), all.size() * sizeof(DctqConsts), hipMemcpyHostToDevice));
+    {
+        HuffDev hd;
+        build_huff_dev(&hd);
+        CK(hipMalloc((void **)&ctx->d_huff, sizeof(HuffDev)));
+        CK(hipMemcpy(ctx->d_huff, &hd, sizeof(HuffDev), hipMemcpyHostToDevice));
+        CK(hipMalloc((void **)&ctx->d_err, sizeof(int)));
+    }
     CK(hipMalloc((void **)&ctx->d_fallback, sizeof(unsigned long long)));
     CK(hipMemset(ctx->d_fallback, 0, sizeof(unsigned long long)));
 #undef CK
@@ -378,19 +401,114 @@ int tic_parse_header(const uint8_t *data, size_t len, int *h, int *w, int *quali
     return parse_header(data, len, h, w, quality, flag);
 }
 
+// Device entropy stage: coefficients in HBM -> finished stream in HBM.  Synchronous (the stream length is needed
+// on the host between the counting and the packing step).
+int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, int quality, void *d_out, size_t cap,
+                           size_t *out_len) {
+    if (!ctx || !out_len) return TIC_E_ARG;
+    if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size");
+    if (quality < 1 || quality > 99) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
+    if (!d_out || cap < 16) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = num_blocks(h, w);
+    uint8_t hdr[16];
+    write_header(hdr, h, w, quality);
+    HIPCHK(ctx, hipMemcpyAsync(d_out, hdr, 16, hipMemcpyHostToDevice, ctx->stream));
+    if (n == 0) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *out_len = 16;
+        return TIC_OK;
+    }
+    if (!d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "null coefficient pointer");
+    if (n + 1 > ctx->ent_blocks_cap) {
+        if (ctx->d_nbits) HIPCHK(ctx, hipFree(ctx->d_nbits));
+        if (ctx->d_bitoff) HIPCHK(ctx, hipFree(ctx->d_bitoff));
+        ctx->d_nbits = nullptr;
+        ctx->d_bitoff = nullptr;
+        ctx->ent_blocks_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_nbits, (n + 1) * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_bitoff, (n + 1) * sizeof(unsigned long long)));
+        ctx->ent_blocks_cap = n + 1;
+    }
+    const size_t tmp = entropy_gpu_scan_temp_bytes(n + 1);
+    if (tmp > ctx->scan_tmp_cap) {
+        if (ctx->d_scan_tmp) HIPCHK(ctx, hipFree(ctx->d_scan_tmp));
+        ctx->d_scan_tmp = nullptr;
+        ctx->scan_tmp_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_scan_tmp, tmp ? tmp : 16));
+        ctx->scan_tmp_cap = tmp;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_nbits + n, 0, sizeof(uint32_t), ctx->stream)); // scan n+1 entries: last = total
+    // step 1+2: bits per block, exclusive scan (the entry after the last block receives the payload size in bits)
+    HIPCHK(ctx, entropy_gpu_count((const int16_t *)d_coeffs_zz, n, ctx->d_huff, ctx->d_nbits, ctx->d_bitoff, ctx->d_scan_tmp,
+                                  tmp, ctx->d_err, ctx->stream));
+    // entropy_gpu_count scans n entries; fold the last count in on the host side
+    unsigned long long last_off = 0;
+    uint32_t last_bits = 0;
+    int err = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&last_off, ctx->d_bitoff + (n - 1), sizeof last_off, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&last_bits, ctx->d_nbits + (n - 1), sizeof last_bits, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&err, ctx->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (err) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
+    const unsigned long long total_bits = last_off + last_bits;
+    const size_t payload = (size_t)((total_bits + 7) / 8);
+    const size_t words = (size_t)((total_bits + 31) / 32);
+    if (16 + words * 4 > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small (%zu bytes needed)", 16 + words * 4);
+    // step 3: pack.  Shared words are OR-ed into zeroed memory; the zero fill also is the stream's final padding
+    HIPCHK(ctx, hipMemsetAsync((char *)d_out + 16, 0, words * 4, ctx->stream));
+    HIPCHK(ctx, entropy_gpu_emit((const int16_t *)d_coeffs_zz, n, ctx->d_huff, ctx->d_bitoff, (uint32_t *)((char *)d_out + 16),
+                                 ctx->d_err, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_len = 16 + payload;
+    return TIC_OK;
+}
+
+// compress() with every stage on the device: transform kernels + device entropy stage; image and stream in HBM.
+int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out,
+                     size_t cap, size_t *out_len) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    const size_t n = num_blocks(h, w);
+    rc = ensure_scratch(ctx, 0, n * 128 + 16);
+    if (rc) return rc;
+    rc = tic_dctq_dev(ctx, d_image, h, w, row_stride, quality, ctx->d_coef, TIC_KERNEL_HYBRID);
+    if (rc) return rc;
+    return tic_entropy_encode_dev(ctx, ctx->d_coef, h, w, quality, d_out, cap, out_len);
+}
+
 int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, uint8_t *out,
                  size_t cap, size_t *out_len) {
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!out || !out_len) return set_err(ctx, TIC_E_ARG, "null output pointer");
     const size_t n = num_blocks(h, w);
-    ctx->h_coef.resize(n * 64 + 64);
-    rc = tic_dctq(ctx, image, h, w, row_stride, quality, ctx->h_coef.data());
+    if (n == 0) return entropy_encode(nullptr, h, w, quality, out, cap, out_len);
+    if (!image) return set_err(ctx, TIC_E_ARG, "null image pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // image -> HBM, transform stage, entropy stage, all on the device; only the finished stream returns
+    const size_t pitch = align_up((size_t)w, 256);
+    rc = ensure_scratch(ctx, pitch * (size_t)h, n * 128 + 16);
     if (rc) return rc;
-    rc = entropy_encode(ctx->h_coef.data(), h, w, quality, out, cap, out_len);
-    if (rc == TIC_E_RANGE) set_err(ctx, rc, "coefficient without a Huffman code (reference raises KeyError)");
-    if (rc == TIC_E_SPACE) set_err(ctx, rc, "output buffer too small (%zu bytes)", cap);
-    return rc;
+    const size_t need = compress_bound(h, w);
+    if (need > ctx->d_stream_cap) {
+        if (ctx->d_stream_buf) HIPCHK(ctx, hipFree(ctx->d_stream_buf));
+        ctx->d_stream_buf = nullptr;
+        ctx->d_stream_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_stream_buf, need));
+        ctx->d_stream_cap = need;
+    }
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_img, pitch, image, (size_t)row_stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice,
+                                 ctx->stream));
+    size_t len = 0;
+    rc = tic_compress_dev(ctx, ctx->d_img, h, w, (ptrdiff_t)pitch, quality, ctx->d_stream_buf, ctx->d_stream_cap, &len);
+    if (rc) return rc;
+    if (len > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small (%zu bytes needed, %zu given)", len, cap);
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_stream_buf, len, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_len = len;
+    return TIC_OK;
 }
 
 // ---- batch pipeline (BASELINE config 3) -------------------------------------------------------------------

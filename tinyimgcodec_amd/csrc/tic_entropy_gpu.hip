@@ -1,0 +1,236 @@
+// tic_entropy_gpu.hip - entropy stage on the GPU: run-length + Huffman symbol generation,
+// bit counting, offset scan and parallel bit packing, producing the reference's stream byte for byte.
+//
+// Replaces, on the device, the per-block Python loops of compress() (codec.py:142-162 of the reference):
+// DC DPCM (codec.py:34-35), encode_run_length (huffman.py:12-33), encode_huffman (huffman.py:41-63) and the
+// MSB-first BitBuffer (bitbuffer.py).  The host coder in tic_entropy.cpp remains (it needs no GPU and is what the
+// batch pipeline's worker threads run); this path keeps a whole frame on the device: only the finished stream
+// (about 1/7 of the coefficient bytes on noise, far less on natural images) crosses PCIe.
+//
+// Decomposition: 8 lanes per block, lane k owns zig-zag entries 8k..8k+7 (one 16-byte load).  The only cross-lane
+// dependency of the symbol stream is the run of zeros carried into a lane, an associative "carry-through" scan over
+// the 8 lanes.  Three steps:
+//   1. entropy_bits_kernel<false>: bits per block -> nbits[N]
+//   2. rocPRIM exclusive scan (64-bit) -> bit offset of every block; the last offset + count is the payload size
+//   3. entropy_bits_kernel<true>: every lane re-derives its symbols and writes them at its global bit offset:
+//      whole 32-bit words it owns with plain stores, the two words it shares with its neighbours with atomicOr
+//      into a zeroed buffer.
+#include <hip/hip_runtime.h>
+#include <cstring> // rocPRIM's texture_cache_iterator.hpp uses memset without including it
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+#include <stdint.h>
+
+#include "tic_entropy_gpu.h"
+#include "tic_tables.h"
+
+namespace tic {
+
+void build_huff_dev(HuffDev *t) {
+    for (int i = 0; i < 256; i++) t->ac[i] = 0;
+    for (int i = 0; i < 16; i++) t->dc[i] = 0;
+    unsigned code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < kDcBits[l - 1]; i++) t->dc[kDcVals[k++]] = (code++ << 8) | (unsigned)l;
+        code <<= 1;
+    }
+    code = 0;
+    k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < kAcBits[l - 1]; i++) t->ac[kAcVals[k++]] = (code++ << 8) | (unsigned)l;
+        code <<= 1;
+    }
+}
+
+namespace {
+
+// MSB-first bit sink aligned to the 32-bit words of the output stream.
+struct BitSink {
+    uint32_t *words;        // stream payload as big-endian words
+    unsigned long long pos; // next bit position
+    uint32_t cur;           // bits of the word under construction (host order, MSB = first bit)
+    bool first;             // the word under construction may be shared with the previous lane
+    __device__ __forceinline__ void store_word(unsigned long long index, bool shared) {
+        const uint32_t be = __builtin_bswap32(cur); // the stream is MSB-first bytes
+        if (shared)
+            atomicOr(words + index, be);
+        else
+            words[index] = be;
+    }
+    __device__ __forceinline__ void put(uint32_t v, int n) { // 1 <= n <= 27, v < 2^n
+        const int sh = (int)(pos & 31), avail = 32 - sh;
+        if (n < avail) {
+            cur |= v << (avail - n);
+            pos += n;
+        } else { // completes the word under construction
+            const int rest = n - avail;
+            cur |= v >> rest;
+            // shared with the previous lane only if it is the first word this lane touches; every later word
+            // completed here is covered by this lane's bits alone
+            store_word(pos >> 5, first);
+            first = false;
+            pos += n;
+            cur = rest ? (v << (32 - rest)) : 0u;
+        }
+    }
+    __device__ __forceinline__ void finish() { // leftover bits of the last word: always possibly shared
+        if ((pos & 31) && cur) atomicOr(words + (pos >> 5), __builtin_bswap32(cur));
+    }
+};
+
+template <bool EMIT>
+__device__ __forceinline__ int walk_lane(const int16_t c[8], int k, int carry_run, int dc_diff, const uint32_t *ac_tab,
+                                         const uint32_t *dc_tab, BitSink *sink, int *err) {
+    int bits = 0;
+    int run = carry_run;
+    if (k == 0) { // DC: category code + value bits (huffman.py:41-63 with dc_ac = DC)
+        const int v = dc_diff;
+        const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+        const int sz = 32 - __clz((int)a); // bit length; 0 for a == 0
+        if (sz > 11) {
+            *err = 1;
+        } else {
+            const uint32_t e = dc_tab[sz];
+            const int len = (int)(e & 0xff);
+            bits += len + sz;
+            if (EMIT) sink->put(((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u)), len + sz);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (k == 0 && j == 0) continue;
+        const int v = c[j];
+        if (v == 0) {
+            run++;
+            continue;
+        }
+        while (run >= 16) { // ZRL = (15,0), huffman.py:26-28
+            const uint32_t e = ac_tab[0xF0];
+            bits += (int)(e & 0xff);
+            if (EMIT) sink->put(e >> 8, (int)(e & 0xff));
+            run -= 16;
+        }
+        const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+        const int sz = 32 - __clz((int)a);
+        if (sz > 10) {
+            *err = 1;
+        } else {
+            const uint32_t e = ac_tab[(run << 4) | sz];
+            const int len = (int)(e & 0xff);
+            bits += len + sz;
+            if (EMIT) sink->put(((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u)), len + sz);
+        }
+        run = 0;
+    }
+    if (k == 7) { // EOB = (0,0) always closes the block (huffman.py:33)
+        const uint32_t e = ac_tab[0];
+        bits += (int)(e & 0xff);
+        if (EMIT) sink->put(e >> 8, (int)(e & 0xff));
+    }
+    return bits;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void entropy_bits_kernel(const int16_t *__restrict__ zz, unsigned long long nblocks,
+                                                           const HuffDev *__restrict__ tab, uint32_t *__restrict__ nbits,
+                                                           const unsigned long long *__restrict__ bitoff,
+                                                           uint32_t *__restrict__ out_words, int *__restrict__ err_flag) {
+    __shared__ uint32_t ac_tab[256];
+    __shared__ uint32_t dc_tab[16];
+    ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
+    if (threadIdx.x < 16) dc_tab[threadIdx.x] = tab->dc[threadIdx.x];
+    __syncthreads();
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    const unsigned long long blk = t >> 3;
+    const int k = (int)(t & 7);
+    const bool valid = blk < nblocks;
+    int16_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int dc_diff = 0;
+    if (valid) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(zz + blk * 64 + k * 8);
+        c[0] = (int16_t)(v.x & 0xffff); c[1] = (int16_t)(v.x >> 16); c[2] = (int16_t)(v.y & 0xffff); c[3] = (int16_t)(v.y >> 16);
+        c[4] = (int16_t)(v.z & 0xffff); c[5] = (int16_t)(v.z >> 16); c[6] = (int16_t)(v.w & 0xffff); c[7] = (int16_t)(v.w >> 16);
+        if (k == 0) dc_diff = blk ? (int)c[0] - (int)zz[(blk - 1) * 64] : (int)c[0]; // codec.py:34-35
+    }
+    // zeros carried into this lane: carry-through scan over the 8 lanes of the block.
+    // per lane: az = every AC entry is zero; tz = zeros after its last non-zero entry (all of them if az)
+    int nz_mask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) nz_mask |= (c[j] != 0 && !(k == 0 && j == 0)) ? (1 << j) : 0;
+    const int cnt = (k == 0) ? 7 : 8;
+    int az = nz_mask == 0;
+    int tz = az ? cnt : (__clz(nz_mask) - 24); // bits 7..0: leading zeros of the byte = trailing (later) zero entries
+    // inclusive scan: (A,T) o (a,t) = (A & a, a ? T + t : t)
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const int pa = __shfl_up(az, d, 8), pt = __shfl_up(tz, d, 8);
+        if (k >= d) {
+            tz = az ? pt + tz : tz;
+            az = az & pa;
+        }
+    }
+    int carry = __shfl_up(tz, 1, 8); // exclusive: state after the previous lane
+    if (k == 0) carry = 0;
+
+    int err = 0;
+    const int my_bits = walk_lane<false>(c, k, carry, dc_diff, ac_tab, dc_tab, nullptr, &err);
+    // bits of the block = sum over its 8 lanes; lane prefix for the emit pass
+    int incl = my_bits;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const int p = __shfl_up(incl, d, 8);
+        if (k >= d) incl += p;
+    }
+    if (!EMIT) {
+        if (valid && k == 7) nbits[blk] = (uint32_t)incl;
+        if (err && valid) atomicMax(err_flag, 1);
+        return;
+    }
+    if (!valid) return;
+    BitSink sink;
+    sink.words = out_words;
+    sink.pos = bitoff[blk] + (unsigned long long)(incl - my_bits);
+    sink.cur = 0;
+    sink.first = true;
+    int e2 = 0;
+    walk_lane<true>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &e2);
+    sink.finish();
+}
+
+struct U32ToU64 {
+    __host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
+};
+
+} // namespace
+
+size_t entropy_gpu_scan_temp_bytes(size_t nblocks) {
+    size_t bytes = 0;
+    auto in = rocprim::make_transform_iterator((const uint32_t *)nullptr, U32ToU64());
+    (void)rocprim::exclusive_scan(nullptr, bytes, in, (unsigned long long *)nullptr, 0ull, nblocks,
+                                  rocprim::plus<unsigned long long>(), (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, const HuffDev *d_tab, uint32_t *d_nbits,
+                             unsigned long long *d_bitoff, void *d_temp, size_t temp_bytes, int *d_err, hipStream_t stream) {
+    if (nblocks == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((nblocks * 8 + 255) / 256);
+    hipLaunchKernelGGL(entropy_bits_kernel<false>, dim3(grid), dim3(256), 0, stream, d_zz, (unsigned long long)nblocks, d_tab,
+                       d_nbits, (const unsigned long long *)nullptr, (uint32_t *)nullptr, d_err);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    auto in = rocprim::make_transform_iterator((const uint32_t *)d_nbits, U32ToU64());
+    return rocprim::exclusive_scan(d_temp, temp_bytes, in, d_bitoff, 0ull, nblocks, rocprim::plus<unsigned long long>(), stream);
+}
+
+hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, const HuffDev *d_tab, const unsigned long long *d_bitoff,
+                            uint32_t *d_payload_words, int *d_err, hipStream_t stream) {
+    if (nblocks == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((nblocks * 8 + 255) / 256);
+    hipLaunchKernelGGL(entropy_bits_kernel<true>, dim3(grid), dim3(256), 0, stream, d_zz, (unsigned long long)nblocks, d_tab,
+                       (uint32_t *)nullptr, d_bitoff, d_payload_words, d_err);
+    return hipGetLastError();
+}
+
+} // namespace tic
