@@ -117,8 +117,10 @@ int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row
                  size_t cap, size_t *out_len);
 
 /* Batch of n independent frames of identical geometry (BASELINE config 3): pinned staging buffers, two HIP
- * streams (H2D copy of frame i+1 overlaps the kernel of frame i and the D2H of frame i-1), host entropy coding
- * on `threads` worker threads.  images[i] / outs[i] are host pointers; out_lens[i] receives each size. */
+ * streams (the H2D copy of chunk c+1 overlaps the kernels of chunk c and the read-back of chunk c-1).
+ * threads <= 0: entropy stage on the device (only finished streams cross PCIe); threads > 0: coefficients are
+ * read back and entropy-coded on that many host worker threads.  images[i] / outs[i] are host pointers;
+ * out_lens[i] receives each size. */
 int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
                        int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads);
 

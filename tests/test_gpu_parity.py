@@ -258,10 +258,15 @@ def test_decode_dict_roundtrip(ctx, golden):
 def test_batch_pipeline_matches_single_frame(ctx, manifest):
     """BASELINE config 3 shape (1080p, seeds 1234+i): the stream-overlapped batch == per-frame compress()."""
     frames = [rand_frame(1234 + i, 1080, 1920) for i in range(6)]
-    out = T.compress_batch(frames, 50, threads=4, ctx=ctx)
-    assert sha(out[0]) == manifest["rand1234_1080x1920_q50"]["sha256"]
-    for i in (1, 5):
-        assert out[i] == T.compress(frames[i], 50, ctx=ctx)
+    for threads in (4, 0):  # host entropy workers / device entropy stage
+        out = T.compress_batch(frames, 50, threads=threads, ctx=ctx)
+        assert sha(out[0]) == manifest["rand1234_1080x1920_q50"]["sha256"]
+        for i in (1, 5):
+            assert out[i] == T.compress(frames[i], 50, ctx=ctx)
+    many = [rand_frame(900 + i, 72, 136) for i in range(37)]  # more than two chunks, ragged size
+    got = T.compress_batch(many, 30, ctx=ctx)
+    for i in (0, 15, 16, 17, 36):
+        assert got[i] == T.compress(many[i], 30, ctx=ctx)
     # transform-only batch: coefficient digests of the reference for frames 0..3
     L = N.load()
     n = 4

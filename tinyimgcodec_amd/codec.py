@@ -58,6 +58,8 @@ def _check_quality(quality, packed_first):
 def _as_u8_image(image):
     image = np.asarray(image)
     height, width = image.shape  # ValueError for non 2-D input, as codec.py:27
+    if image.dtype == np.uint8:  # the common case needs no conversion pass
+        return np.ascontiguousarray(image), int(height), int(width)
     a = image.astype(np.int32)  # codec.py:29 (truncation of floats, as the reference)
     if a.size and (a.min() < 0 or a.max() > 255):
         raise ValueError("pixel values must lie in 0..255 (the MI355X path is 8-bit)")
@@ -105,8 +107,10 @@ def compress(image, quality=50, auto_generate_huffman_table=False, ctx=None):
     return out[: n.value].tobytes()
 
 
-def compress_batch(images, quality=50, threads=8, ctx=None):
-    """Batch of equally sized frames through the stream-overlapped pipeline -> list of bytes."""
+def compress_batch(images, quality=50, threads=0, ctx=None):
+    """Batch of equally sized frames through the stream-overlapped pipeline -> list of bytes.
+
+    threads=0: entropy stage on the GPU; threads>0: host entropy coder on that many worker threads."""
     q = _check_quality(quality, packed_first=False)
     frames = [_as_u8_image(im) for im in images]
     if not frames:
@@ -118,7 +122,8 @@ def compress_batch(images, quality=50, threads=8, ctx=None):
     L = N.load()
     n = len(frames)
     cap = L.tic_compress_bound(h, w)
-    outs = [np.empty(cap, dtype=np.uint8) for _ in range(n)]
+    pool = np.empty((n, cap), dtype=np.uint8)  # one mapping; only the bytes actually written are ever touched
+    outs = [pool[i] for i in range(n)]
     inp = (C.c_void_p * n)(*[f[0].ctypes.data for f in frames])
     outp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
     caps = (C.c_size_t * n)(*([cap] * n))

@@ -30,6 +30,14 @@ struct Slot {
     void *d_img = nullptr;
     void *d_coef = nullptr;
     hipEvent_t done = nullptr;
+    // device entropy stage of the chunk
+    uint32_t *d_nbits = nullptr;
+    unsigned long long *d_bitoff = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    unsigned long long *d_lens = nullptr, *h_lens = nullptr; // stream length per frame (device / pinned host)
+    int *d_err = nullptr, *h_err = nullptr;
+    void *d_streams = nullptr;                                // finished streams, one compress_bound() apart
     int first = 0, count = 0; // frames [first, first+count) are in flight in this slot
     int remaining = 0;        // frames of the chunk not yet consumed; 0 = slot free
 };
@@ -61,6 +69,7 @@ struct tic_ctx {
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
     std::vector<Slot> bslots;
     size_t bslot_img_bytes = 0, bslot_coef_bytes = 0;
+    int bslot_h = -1, bslot_w = -1, bslot_chunk = 0;
     std::string err;
     char arch[128] = {0};
 };
@@ -121,6 +130,14 @@ void tic_destroy(tic_ctx *ctx) {
         if (sl.d_img) (void)hipFree(sl.d_img);
         if (sl.d_coef) (void)hipFree(sl.d_coef);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.d_nbits) (void)hipFree(sl.d_nbits);
+        if (sl.d_bitoff) (void)hipFree(sl.d_bitoff);
+        if (sl.d_tmp) (void)hipFree(sl.d_tmp);
+        if (sl.d_lens) (void)hipFree(sl.d_lens);
+        if (sl.h_lens) (void)hipHostFree(sl.h_lens);
+        if (sl.d_err) (void)hipFree(sl.d_err);
+        if (sl.h_err) (void)hipHostFree(sl.h_err);
+        if (sl.d_streams) (void)hipFree(sl.d_streams);
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -441,8 +458,8 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     HIPCHK(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_nbits + n, 0, sizeof(uint32_t), ctx->stream)); // scan n+1 entries: last = total
     // step 1+2: bits per block, exclusive scan (the entry after the last block receives the payload size in bits)
-    HIPCHK(ctx, entropy_gpu_count((const int16_t *)d_coeffs_zz, n, ctx->d_huff, ctx->d_nbits, ctx->d_bitoff, ctx->d_scan_tmp,
-                                  tmp, ctx->d_err, ctx->stream));
+    HIPCHK(ctx, entropy_gpu_count((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_nbits, ctx->d_bitoff,
+                                  ctx->d_scan_tmp, tmp, ctx->d_err, ctx->stream));
     // entropy_gpu_count scans n entries; fold the last count in on the host side
     unsigned long long last_off = 0;
     uint32_t last_bits = 0;
@@ -458,8 +475,8 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     if (16 + words * 4 > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small (%zu bytes needed)", 16 + words * 4);
     // step 3: pack.  Shared words are OR-ed into zeroed memory; the zero fill also is the stream's final padding
     HIPCHK(ctx, hipMemsetAsync((char *)d_out + 16, 0, words * 4, ctx->stream));
-    HIPCHK(ctx, entropy_gpu_emit((const int16_t *)d_coeffs_zz, n, ctx->d_huff, ctx->d_bitoff, (uint32_t *)((char *)d_out + 16),
-                                 ctx->d_err, ctx->stream));
+    HIPCHK(ctx, entropy_gpu_emit((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_bitoff,
+                                 (uint32_t *)((char *)d_out + 16), 0, ctx->d_err, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *out_len = 16 + payload;
     return TIC_OK;
@@ -516,6 +533,72 @@ int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row
 // (grid row per frame) and one D2H copy per chunk, alternating between two streams so that the copy of chunk
 // c+1 overlaps the kernel of chunk c and the read-back of chunk c-1.  Worker threads entropy-code frame by frame.
 
+// Row pitch of staged frames: rows that are already a multiple of 8 bytes are staged back to back (one memcpy per
+// frame when the caller's rows are contiguous too); other widths are padded so that 8-byte row loads stay aligned.
+static inline size_t batch_pitch(int w) { return (w % 8 == 0) ? (size_t)w : align_up((size_t)w, 256); }
+
+static void stage_frame(uint8_t *dst, size_t pitch, const uint8_t *src, ptrdiff_t row_stride, int h, int w) {
+    if ((size_t)row_stride == pitch && pitch == (size_t)w) {
+        memcpy(dst, src, (size_t)h * (size_t)w);
+        return;
+    }
+    for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, src + (ptrdiff_t)y * row_stride, (size_t)w);
+}
+
+static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
+    const int S = 3;
+    const size_t nblk = num_blocks(h, w);
+    const size_t pitch = batch_pitch(w);
+    const size_t img_bytes = pitch * (size_t)h, coef_bytes = nblk * 128;
+    const size_t need_img = img_bytes * chunk, need_coef = coef_bytes * chunk;
+    if ((int)ctx->bslots.size() != S || ctx->bslot_h != h || ctx->bslot_w != w || ctx->bslot_chunk < chunk) {
+        for (auto &sl : ctx->bslots) {
+            if (sl.pin_in) (void)hipHostFree(sl.pin_in);
+            if (sl.pin_out) (void)hipHostFree(sl.pin_out);
+            if (sl.d_img) (void)hipFree(sl.d_img);
+            if (sl.d_coef) (void)hipFree(sl.d_coef);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.d_nbits) (void)hipFree(sl.d_nbits);
+            if (sl.d_bitoff) (void)hipFree(sl.d_bitoff);
+            if (sl.d_tmp) (void)hipFree(sl.d_tmp);
+            if (sl.d_lens) (void)hipFree(sl.d_lens);
+            if (sl.h_lens) (void)hipHostFree(sl.h_lens);
+            if (sl.d_err) (void)hipFree(sl.d_err);
+            if (sl.h_err) (void)hipHostFree(sl.h_err);
+            if (sl.d_streams) (void)hipFree(sl.d_streams);
+        }
+        ctx->bslots.assign(S, Slot());
+        ctx->bslot_img_bytes = ctx->bslot_coef_bytes = 0;
+        ctx->bslot_h = ctx->bslot_w = -1;
+        ctx->bslot_chunk = 0;
+        for (auto &sl : ctx->bslots) {
+            hipError_t e;
+            if ((e = hipHostMalloc((void **)&sl.pin_in, need_img, hipHostMallocDefault)) != hipSuccess ||
+                (e = hipHostMalloc((void **)&sl.pin_out, need_coef, hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc(&sl.d_img, need_img)) != hipSuccess || (e = hipMalloc(&sl.d_coef, need_coef)) != hipSuccess ||
+                (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
+                return set_err(ctx, TIC_E_HIP, "batch buffer allocation failed: %s", hipGetErrorString(e));
+            const size_t nb = nblk * (size_t)chunk;
+            sl.tmp_bytes = entropy_gpu_scan_temp_bytes(nb);
+            if ((e = hipMalloc((void **)&sl.d_nbits, nb * sizeof(uint32_t))) != hipSuccess ||
+                (e = hipMalloc((void **)&sl.d_bitoff, nb * sizeof(unsigned long long))) != hipSuccess ||
+                (e = hipMalloc(&sl.d_tmp, sl.tmp_bytes ? sl.tmp_bytes : 16)) != hipSuccess ||
+                (e = hipMalloc((void **)&sl.d_lens, chunk * sizeof(unsigned long long))) != hipSuccess ||
+                (e = hipHostMalloc((void **)&sl.h_lens, chunk * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&sl.d_err, sizeof(int))) != hipSuccess ||
+                (e = hipHostMalloc((void **)&sl.h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc(&sl.d_streams, align_up(compress_bound(h, w), 16) * (size_t)chunk)) != hipSuccess)
+                return set_err(ctx, TIC_E_HIP, "batch entropy workspace allocation failed: %s", hipGetErrorString(e));
+        }
+        ctx->bslot_img_bytes = need_img;
+        ctx->bslot_coef_bytes = need_coef;
+        ctx->bslot_h = h;
+        ctx->bslot_w = w;
+        ctx->bslot_chunk = chunk;
+    }
+    return TIC_OK;
+}
+
 static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
                       int16_t *const *coeffs, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads,
                       bool want_entropy) {
@@ -534,33 +617,13 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool need_d2h = want_entropy || coeffs != nullptr;
-    const size_t pitch = align_up((size_t)w, 256);
+    const size_t pitch = batch_pitch(w);
     const size_t img_bytes = pitch * (size_t)h, coef_bytes = nblk * 128;
     const int chunk = n < kChunk ? n : kChunk;
     const int S = 3;
     int result = TIC_OK;
-    const size_t need_img = img_bytes * chunk, need_coef = coef_bytes * chunk;
-    if ((int)ctx->bslots.size() != S || ctx->bslot_img_bytes < need_img || ctx->bslot_coef_bytes < need_coef) {
-        for (auto &sl : ctx->bslots) {
-            if (sl.pin_in) (void)hipHostFree(sl.pin_in);
-            if (sl.pin_out) (void)hipHostFree(sl.pin_out);
-            if (sl.d_img) (void)hipFree(sl.d_img);
-            if (sl.d_coef) (void)hipFree(sl.d_coef);
-            if (sl.done) (void)hipEventDestroy(sl.done);
-        }
-        ctx->bslots.assign(S, Slot());
-        ctx->bslot_img_bytes = ctx->bslot_coef_bytes = 0;
-        for (auto &sl : ctx->bslots) {
-            hipError_t e;
-            if ((e = hipHostMalloc((void **)&sl.pin_in, need_img, hipHostMallocDefault)) != hipSuccess ||
-                (e = hipHostMalloc((void **)&sl.pin_out, need_coef, hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc(&sl.d_img, need_img)) != hipSuccess || (e = hipMalloc(&sl.d_coef, need_coef)) != hipSuccess ||
-                (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
-                return set_err(ctx, TIC_E_HIP, "batch buffer allocation failed: %s", hipGetErrorString(e));
-        }
-        ctx->bslot_img_bytes = need_img;
-        ctx->bslot_coef_bytes = need_coef;
-    }
+    rc = ensure_batch_slots(ctx, h, w, chunk);
+    if (rc) return rc;
     std::vector<Slot> &slots = ctx->bslots;
     for (auto &sl : slots) sl.remaining = 0;
     auto cleanup = [&]() {};
@@ -617,11 +680,8 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
             s.remaining = cnt;
         }
         hipStream_t st = ctx->bstream[c & 1];
-        for (int k = 0; k < cnt; k++) { // stage into pinned memory, row-pitched
-            const uint8_t *src = images[first + k];
-            uint8_t *dst = s.pin_in + (size_t)k * img_bytes;
-            for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, src + (ptrdiff_t)y * row_stride, (size_t)w);
-        }
+        for (int k = 0; k < cnt; k++) // stage into pinned memory
+            stage_frame(s.pin_in + (size_t)k * img_bytes, pitch, images[first + k], row_stride, h, w);
         hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
@@ -659,8 +719,103 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
     return result;
 }
 
+// Batch compress with the entropy stage on the device: per chunk one H2D copy, one transform launch, the three
+// entropy steps, then only the finished streams (and 8 bytes of length per frame) come back.
+static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
+                              int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!images || !outs || !caps || !out_lens))) return set_err(ctx, TIC_E_ARG, "bad batch arguments");
+    if (n == 0) return TIC_OK;
+    const size_t nblk = num_blocks(h, w);
+    if (nblk == 0) {
+        for (int i = 0; i < n; i++) {
+            int r = entropy_encode(nullptr, h, w, quality, outs[i], caps[i], &out_lens[i]);
+            if (r) return r;
+        }
+        return TIC_OK;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t pitch = batch_pitch(w);
+    const size_t img_bytes = pitch * (size_t)h, coef_bytes = nblk * 128, bound = align_up(compress_bound(h, w), 16);
+    const int chunk = n < kChunk ? n : kChunk;
+    rc = ensure_batch_slots(ctx, h, w, chunk);
+    if (rc) return rc;
+    std::vector<Slot> &slots = ctx->bslots;
+    const int S = (int)slots.size();
+    int result = TIC_OK;
+    // finishing a chunk: wait for its lengths, then read back exactly the bytes of each stream
+    auto finish = [&](Slot &s, hipStream_t st) -> int {
+        if (s.count == 0) return TIC_OK;
+        if (hipEventSynchronize(s.done) != hipSuccess) return set_err(ctx, TIC_E_HIP, "batch chunk failed");
+        if (*s.h_err) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
+        for (int k = 0; k < s.count; k++) {
+            const size_t len = (size_t)s.h_lens[k];
+            const int f = s.first + k;
+            if (len > caps[f]) return set_err(ctx, TIC_E_SPACE, "output buffer of frame %d too small (%zu bytes needed)", f, len);
+            hipError_t e = hipMemcpyAsync(outs[f], (char *)s.d_streams + (size_t)k * bound, len, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed: %s", hipGetErrorString(e));
+            out_lens[f] = len;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed");
+        s.count = 0;
+        return TIC_OK;
+    };
+    for (auto &sl : slots) sl.count = 0;
+    int c = 0;
+    for (int first = 0; first < n && result == TIC_OK; first += chunk, c++) {
+        const int cnt = n - first < chunk ? n - first : chunk;
+        Slot &s = slots[c % S];
+        hipStream_t st = ctx->bstream[c & 1];
+        if (s.count) result = finish(s, ctx->bstream[(c - S) & 1]); // slot still holds chunk c - S
+        if (result != TIC_OK) break;
+        s.first = first;
+        s.count = cnt;
+        for (int k = 0; k < cnt; k++) // stage into pinned memory
+            stage_frame(s.pin_in + (size_t)k * img_bytes, pitch, images[first + k], row_stride, h, w);
+        const size_t nb = nblk * (size_t)cnt;
+        hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
+            a.fallback_count = nullptr;
+            a.nframes = cnt;
+            a.frame_stride_in = (long)img_bytes;
+            a.frame_stride_out = (long)coef_bytes;
+            e = launch_dctq(a, 2, st);
+        }
+        if (e == hipSuccess) e = hipMemsetAsync(s.d_err, 0, sizeof(int), st);
+        if (e == hipSuccess)
+            e = entropy_gpu_count((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_nbits, s.d_bitoff, s.d_tmp, s.tmp_bytes,
+                                  s.d_err, st);
+        if (e == hipSuccess) e = hipMemsetAsync(s.d_streams, 0, bound * cnt, st); // shared words are OR-ed into zeros
+        if (e == hipSuccess)
+            e = entropy_gpu_finish_frames(s.d_nbits, s.d_bitoff, nblk, cnt, h, w, quality, s.d_streams, bound, s.d_lens, st);
+        if (e == hipSuccess)
+            e = entropy_gpu_emit((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_bitoff,
+                                 (uint32_t *)((char *)s.d_streams + 16), bound, s.d_err, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.h_lens, s.d_lens, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(s.done, st);
+        if (e != hipSuccess) {
+            result = set_err(ctx, TIC_E_HIP, "batch enqueue failed at frame %d: %s", first, hipGetErrorString(e));
+            s.count = 0;
+        }
+    }
+    // drain in submission order
+    for (int k = c - S < 0 ? 0 : c - S; k < c; k++) {
+        Slot &s = slots[k % S];
+        int r = finish(s, ctx->bstream[k & 1]);
+        if (result == TIC_OK) result = r;
+    }
+    (void)hipStreamSynchronize(ctx->bstream[0]);
+    (void)hipStreamSynchronize(ctx->bstream[1]);
+    for (auto &sl : slots) sl.count = 0;
+    return result;
+}
+
 int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
                        uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads) {
+    if (threads <= 0) return compress_batch_gpu(ctx, images, n, h, w, row_stride, quality, outs, caps, out_lens);
     return batch_impl(ctx, images, n, h, w, row_stride, quality, nullptr, outs, caps, out_lens, threads, true);
 }
 

@@ -13,11 +13,19 @@ struct HuffDev {
 void build_huff_dev(HuffDev *t);
 
 size_t entropy_gpu_scan_temp_bytes(size_t nblocks);
-// nbits must hold nblocks entries, bitoff nblocks entries (exclusive scan of nbits, in bits).
-hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, const HuffDev *d_tab, uint32_t *d_nbits,
-                             unsigned long long *d_bitoff, void *d_temp, size_t temp_bytes, int *d_err, hipStream_t stream);
-// payload words must be zero on entry (whole 32-bit words covering the payload bits).
-hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, const HuffDev *d_tab, const unsigned long long *d_bitoff,
-                            uint32_t *d_payload_words, int *d_err, hipStream_t stream);
+// nblocks = blocks of all frames (blocks_per_frame each; DPCM restarts at every frame).  nbits / bitoff hold
+// nblocks entries; bitoff = exclusive scan of nbits over the whole batch, in bits.
+hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
+                             uint32_t *d_nbits, unsigned long long *d_bitoff, void *d_temp, size_t temp_bytes, int *d_err,
+                             hipStream_t stream);
+// d_payload_words = first payload word of frame 0 (16 bytes after its buffer start); frame f's buffer starts
+// out_frame_stride bytes further.  The payload words must be zero on entry.
+hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
+                            const unsigned long long *d_bitoff, uint32_t *d_payload_words, size_t out_frame_stride, int *d_err,
+                            hipStream_t stream);
+// Writes each frame's header at the start of its buffer and its stream length (bytes) into d_lens[f].
+hipError_t entropy_gpu_finish_frames(const uint32_t *d_nbits, const unsigned long long *d_bitoff, size_t blocks_per_frame,
+                                     int nframes, int h, int w, int quality, void *d_out, size_t out_frame_stride,
+                                     unsigned long long *d_lens, hipStream_t stream);
 
 } // namespace tic

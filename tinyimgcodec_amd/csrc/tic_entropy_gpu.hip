@@ -135,7 +135,8 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void entropy_bits_kernel(const int16_t *__restrict__ zz, unsigned long long nblocks,
                                                            const HuffDev *__restrict__ tab, uint32_t *__restrict__ nbits,
                                                            const unsigned long long *__restrict__ bitoff,
-                                                           uint32_t *__restrict__ out_words, int *__restrict__ err_flag) {
+                                                           uint32_t *__restrict__ out_words, int *__restrict__ err_flag,
+                                                           unsigned long long blocks_per_frame, unsigned long long out_frame_stride) {
     __shared__ uint32_t ac_tab[256];
     __shared__ uint32_t dc_tab[16];
     ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(256) void entropy_bits_kernel(const int16_t *__rest
         const uint4 v = *reinterpret_cast<const uint4 *>(zz + blk * 64 + k * 8);
         c[0] = (int16_t)(v.x & 0xffff); c[1] = (int16_t)(v.x >> 16); c[2] = (int16_t)(v.y & 0xffff); c[3] = (int16_t)(v.y >> 16);
         c[4] = (int16_t)(v.z & 0xffff); c[5] = (int16_t)(v.z >> 16); c[6] = (int16_t)(v.w & 0xffff); c[7] = (int16_t)(v.w >> 16);
-        if (k == 0) dc_diff = blk ? (int)c[0] - (int)zz[(blk - 1) * 64] : (int)c[0]; // codec.py:34-35
+        // codec.py:34-35: DPCM over the blocks of one frame in raster order, the first block raw
+        if (k == 0) dc_diff = (blk % blocks_per_frame) ? (int)c[0] - (int)zz[(blk - 1) * 64] : (int)c[0];
     }
     // zeros carried into this lane: carry-through scan over the 8 lanes of the block.
     // per lane: az = every AC entry is zero; tz = zeros after its last non-zero entry (all of them if az)
@@ -189,8 +191,10 @@ __global__ __launch_bounds__(256) void entropy_bits_kernel(const int16_t *__rest
     }
     if (!valid) return;
     BitSink sink;
-    sink.words = out_words;
-    sink.pos = bitoff[blk] + (unsigned long long)(incl - my_bits);
+    // every frame is a stream of its own: its words start at its own buffer, its bits at its own first block
+    const unsigned long long frame = blk / blocks_per_frame;
+    sink.words = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(out_words) + frame * out_frame_stride);
+    sink.pos = bitoff[blk] - bitoff[frame * blocks_per_frame] + (unsigned long long)(incl - my_bits);
     sink.cur = 0;
     sink.first = true;
     int e2 = 0;
@@ -212,24 +216,54 @@ size_t entropy_gpu_scan_temp_bytes(size_t nblocks) {
     return bytes;
 }
 
-hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, const HuffDev *d_tab, uint32_t *d_nbits,
-                             unsigned long long *d_bitoff, void *d_temp, size_t temp_bytes, int *d_err, hipStream_t stream) {
+hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
+                             uint32_t *d_nbits, unsigned long long *d_bitoff, void *d_temp, size_t temp_bytes, int *d_err,
+                             hipStream_t stream) {
     if (nblocks == 0) return hipSuccess;
     const unsigned grid = (unsigned)((nblocks * 8 + 255) / 256);
     hipLaunchKernelGGL(entropy_bits_kernel<false>, dim3(grid), dim3(256), 0, stream, d_zz, (unsigned long long)nblocks, d_tab,
-                       d_nbits, (const unsigned long long *)nullptr, (uint32_t *)nullptr, d_err);
+                       d_nbits, (const unsigned long long *)nullptr, (uint32_t *)nullptr, d_err,
+                       (unsigned long long)blocks_per_frame, 0ull);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     auto in = rocprim::make_transform_iterator((const uint32_t *)d_nbits, U32ToU64());
     return rocprim::exclusive_scan(d_temp, temp_bytes, in, d_bitoff, 0ull, nblocks, rocprim::plus<unsigned long long>(), stream);
 }
 
-hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, const HuffDev *d_tab, const unsigned long long *d_bitoff,
-                            uint32_t *d_payload_words, int *d_err, hipStream_t stream) {
+hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
+                            const unsigned long long *d_bitoff, uint32_t *d_payload_words, size_t out_frame_stride, int *d_err,
+                            hipStream_t stream) {
     if (nblocks == 0) return hipSuccess;
     const unsigned grid = (unsigned)((nblocks * 8 + 255) / 256);
     hipLaunchKernelGGL(entropy_bits_kernel<true>, dim3(grid), dim3(256), 0, stream, d_zz, (unsigned long long)nblocks, d_tab,
-                       (uint32_t *)nullptr, d_bitoff, d_payload_words, d_err);
+                       (uint32_t *)nullptr, d_bitoff, d_payload_words, d_err, (unsigned long long)blocks_per_frame,
+                       (unsigned long long)out_frame_stride);
+    return hipGetLastError();
+}
+
+// Per-frame epilogue of a batch: stream length in bytes and the 16-byte header (make_header, codec.py:102-114).
+__global__ void frame_finish_kernel(const uint32_t *__restrict__ nbits, const unsigned long long *__restrict__ bitoff,
+                                    unsigned long long blocks_per_frame, int nframes, int h, int w, int quality,
+                                    unsigned char *__restrict__ out, unsigned long long out_frame_stride,
+                                    unsigned long long *__restrict__ lens) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    const unsigned long long first = (unsigned long long)f * blocks_per_frame, last = first + blocks_per_frame - 1;
+    const unsigned long long bits = bitoff[last] + nbits[last] - bitoff[first];
+    lens[f] = 16ull + (bits + 7ull) / 8ull;
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(out + (unsigned long long)f * out_frame_stride);
+    hdr[0] = (uint32_t)h; // struct.pack("III") little-endian == native order here
+    hdr[1] = (uint32_t)w;
+    hdr[2] = (uint32_t)quality;
+    hdr[3] = 0u;
+}
+
+hipError_t entropy_gpu_finish_frames(const uint32_t *d_nbits, const unsigned long long *d_bitoff, size_t blocks_per_frame,
+                                     int nframes, int h, int w, int quality, void *d_out, size_t out_frame_stride,
+                                     unsigned long long *d_lens, hipStream_t stream) {
+    hipLaunchKernelGGL(frame_finish_kernel, dim3((nframes + 63) / 64), dim3(64), 0, stream, d_nbits, d_bitoff,
+                       (unsigned long long)blocks_per_frame, nframes, h, w, quality, (unsigned char *)d_out,
+                       (unsigned long long)out_frame_stride, d_lens);
     return hipGetLastError();
 }
 

@@ -49,7 +49,7 @@ def gather_sizes(local_sizes, n_frames, group=None, device=None):
     return sizes.astype(np.int64), offsets
 
 
-def compress_sharded(get_frame, n_frames, quality=50, compress_batch_fn=None, group=None, threads=8):
+def compress_sharded(get_frame, n_frames, quality=50, compress_batch_fn=None, group=None, threads=0):
     """Compress this rank's shard of a batch of n_frames frames and gather all sizes.
 
     get_frame(i) -> 2-D uint8 array of frame i (only called for this rank's frames).

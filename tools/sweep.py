@@ -110,14 +110,57 @@ def config3(n=256):
                       "ms_total": round(dt * 1e3, 2), "Mpix_s": round(px / dt / 1e6, 1),
                       "PCIe_GB_s": round(3 * px / dt / 1e9, 2)}), flush=True)
     # (c) whole compress incl. host entropy coding on worker threads
-    for threads in (16,):
+    for threads in (16, 0):
         t0 = time.perf_counter()
         out = T.compress_batch(frames, 50, threads=threads, ctx=ctx)
         dt = time.perf_counter() - t0
         ok = sha(out[0]) == manifest["rand1234_1080x1920_q50"]["sha256"]
-        print(json.dumps({"config": 3, "what": "compress_batch: pipeline + host Huffman on %d threads" % threads,
+        print(json.dumps({"config": 3, "what": ("compress_batch: pipeline + host Huffman on %d threads" % threads) if threads else "compress_batch: pipeline + device entropy stage",
                           "ms_total": round(dt * 1e3, 1), "Mpix_s": round(px / dt / 1e6, 1),
                           "frame0_stream_matches_reference": bool(ok)}), flush=True)
+
+
+def config3_capi(n=256):
+    """C-ABI level timing of tic_compress_batch (no Python object handling): outputs preallocated and pre-touched."""
+    h, w = 1080, 1920
+    frames = [np.random.default_rng(1234 + i).integers(0, 256, (h, w), dtype=np.uint8) for i in range(n)]
+    px = float(n) * h * w
+    cap = 1 << 20  # 1 MiB per frame is ample for these streams (890 KB); tic_compress_bound() is the safe size
+    pool = np.zeros((n, cap), np.uint8)
+    inp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+    outp = (C.c_void_p * n)(*[pool[i].ctypes.data for i in range(n)])
+    caps = (C.c_size_t * n)(*([cap] * n))
+    lens = (C.c_size_t * n)()
+    for threads in (16, 0):
+        for rep in range(3):
+            t0 = time.perf_counter()
+            ctx.check(L.tic_compress_batch(ctx.handle, inp, n, h, w, w, 50, outp, caps, lens, threads))
+            dt = time.perf_counter() - t0
+        ok = sha(pool[0][: lens[0]].tobytes()) == manifest["rand1234_1080x1920_q50"]["sha256"]
+        print(json.dumps({"config": 3, "what": "tic_compress_batch (C-ABI), 256 x 1080p host frames -> host streams, "
+                          + ("host Huffman on %d threads" % threads if threads else "device entropy stage"),
+                          "ms_total": round(dt * 1e3, 2), "Mpix_s": round(px / dt / 1e6, 1), "frames_per_s": round(n / dt, 1),
+                          "frame0_stream_matches_reference": bool(ok)}), flush=True)
+
+
+def config2_compress():
+    """BASELINE config 2 frame through the whole codec, image and stream resident in HBM (tic_compress_dev)."""
+    h = w = 4096
+    img = np.random.default_rng(1234).integers(0, 256, (h, w), dtype=np.uint8)
+    cap = L.tic_compress_bound(h, w)
+    d_img, d_out = C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, cap, C.byref(d_out)))
+    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
+    nlen = C.c_size_t()
+    for rep in range(5):
+        t0 = time.perf_counter()
+        ctx.check(L.tic_compress_dev(ctx.handle, d_img, h, w, w, 50, d_out, cap, C.byref(nlen)))
+        dt = time.perf_counter() - t0
+    print(json.dumps({"config": 2, "what": "tic_compress_dev: transform + device entropy stage, 4096x4096 resident in HBM",
+                      "ms": round(dt * 1e3, 3), "Mpix_s": round(h * w / dt / 1e6, 1), "stream_bytes": nlen.value}), flush=True)
+    L.tic_dev_free(ctx.handle, d_img)
+    L.tic_dev_free(ctx.handle, d_out)
 
 
 if __name__ == "__main__":
@@ -126,3 +169,6 @@ if __name__ == "__main__":
         config5()
     if "3" in which:
         config3()
+        config3_capi()
+    if "2" in which or len(sys.argv) == 1:
+        config2_compress()
