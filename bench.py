@@ -56,18 +56,27 @@ def main():
 
     dist = None
     torch = None
+    # TIC_BENCH_BACKEND=gloo + TIC_BENCH_SHARE_GPU=1 rehearse the multi-rank flow on a one-GPU box (all ranks on
+    # device 0, CPU tensors for the collectives); the real run uses RCCL with one rank per GPU.
+    backend = os.environ.get("TIC_BENCH_BACKEND", "nccl")
+    share_gpu = os.environ.get("TIC_BENCH_SHARE_GPU", "0") == "1"
+    tdev = "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            tdev = "cuda"
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     import tinyimgcodec_amd as T
     from tinyimgcodec_amd import _native as N
 
     L = N.load()
-    ctx = T.Context(local_rank)  # raises loudly if the HIP library / an MI355X is missing: no fallback
+    ctx = T.Context(0 if share_gpu else local_rank)  # raises loudly if the HIP library / an MI355X is missing
     h, w, q = args.height, args.width, args.quality
     variant = N.KERNEL_HYBRID if args.variant == "hybrid" else N.KERNEL_EXACT
 
@@ -86,7 +95,8 @@ def main():
         ctx.check(L.tic_sync(ctx.handle))
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if tdev == "cuda":
+                torch.cuda.synchronize()
 
     ms = C.c_float(0.0)
     if args.warmup > 0:
@@ -109,7 +119,7 @@ def main():
 
     sizes = None
     if dist is not None:
-        tmax = torch.tensor([wall_s, kernel_ms], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([wall_s, kernel_ms], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall_s, kernel_ms_max = float(tmax[0]), float(tmax[1])
         # the north star's only collective (RCCL all-gather of per-frame compressed sizes), outside the timed
@@ -117,7 +127,7 @@ def main():
         from tinyimgcodec_amd.distributed import gather_sizes
 
         mine = [len(T.compress(img[:512, :512], q, ctx=ctx))]
-        allsz, _ = gather_sizes(mine, world)
+        allsz, _ = gather_sizes(mine, world, device=tdev)
         sizes = [int(v) for v in allsz]
     else:
         kernel_ms_max = kernel_ms

@@ -24,7 +24,7 @@ os.makedirs(P, exist_ok=True)
 
 
 def counter(dirname, name, kernel_substr, grid=None):
-    files = glob.glob(os.path.join(G, dirname, "*", "*counter_collection.csv"))
+    files = sorted(glob.glob(os.path.join(G, dirname, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not files:
         return None
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
@@ -33,7 +33,7 @@ def counter(dirname, name, kernel_substr, grid=None):
 
 
 out = {"round": tag, "units": "KiB as reported by rocprofv3; bytes after correction"}
-ks = glob.glob(os.path.join(G, "prof", "*", "*kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(G, "prof", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if ks:
     shutil.copy(ks[0], os.path.join(P, f"{tag}_rocprofv3_kernel_stats.csv"))
     for r in csv.DictReader(open(ks[0])):
