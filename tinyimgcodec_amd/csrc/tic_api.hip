@@ -49,6 +49,7 @@ struct tic_ctx {
     hipStream_t bstream[2] = {nullptr, nullptr}; // batch pipeline streams
     DctqConsts *d_consts = nullptr;   // [100], index = quality
     unsigned long long *d_fallback = nullptr;
+    void *d_dbg = nullptr; // diagnostic stamp buffer (tic_debug_stamps)
     bool stats = false; // count guard-band fallbacks with a global atomic (diagnostic; serialises at ~12 ns per wave)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the host-buffer entry points
@@ -284,6 +285,7 @@ static DctqArgs make_args(tic_ctx *ctx, const void *d_image, int h, int w, ptrdi
     a.nframes = 1;
     a.frame_stride_in = 0;
     a.frame_stride_out = 0;
+    a.dbg = (unsigned long long *)ctx->d_dbg;
     return a;
 }
 
@@ -334,6 +336,21 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return TIC_OK;
+}
+
+int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
+                     unsigned long long *host_out, size_t n_u64) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_dbg) HIPCHK(ctx, hipMalloc(&ctx->d_dbg, 8192 * 4 * 8 * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg, 0, 8192 * 4 * 8 * sizeof(unsigned long long), ctx->stream));
+    DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
+    HIPCHK(ctx, launch_dctq(a, 17, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    size_t n = n_u64 < 8192 * 4 * 8 ? n_u64 : 8192 * 4 * 8;
+    HIPCHK(ctx, hipMemcpy(host_out, ctx->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return TIC_OK;
 }
 

@@ -177,11 +177,11 @@ __device__ __forceinline__ void exact_block(uint32_t colLo, uint32_t colHi, uint
 
 // Second-level path for a block whose float32 result tripped its guard band: the same AAN butterflies in float64
 // (error ~1e-13 in coefficient units, against ~1e-12 for the reference itself).  A rounding is decided when no
-// .5 tie lies within 1e-9 (in quantised units) of t; the four rational coefficients (exact ties are common there)
-// and anything still undecided make the function return false for the lane, and the caller falls back to the
-// exact path for that block.  Lane mapping and LDS use as exact_block().
+// .5 tie lies within 1e-9 (in quantised units) of t.  Undecided rational coefficients (exact ties are common there)
+// are reported through ok_rational and settled by special_block(); anything else undecided makes the function
+// return false for the lane, and the caller falls back to the exact order for that block.  Lane mapping and LDS use as exact_block().
 __device__ __forceinline__ bool second_level_block(uint32_t colLo, uint32_t colHi, uint32_t *lds, int b, int i,
-                                                   const DctqConsts *__restrict__ C, int q[8]) {
+                                                   const DctqConsts *__restrict__ C, int q[8], bool &ok_rational) {
     double c[8];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -201,11 +201,17 @@ __device__ __forceinline__ bool second_level_block(uint32_t colLo, uint32_t colH
     dct8_aan(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
     const double *mul = C->mul64 + i * 8;
     bool ok = true;
+    ok_rational = true;
+    const bool rat_lane = (i & 3) == 0; // frequency rows u = 0 and u = 4 hold the rational coefficients at v = 0, 4
 #pragma unroll
     for (int v = 0; v < 8; v++) {
         const double t = c[v] * mul[v];
         const double r = rint(t);
-        ok = ok && (fabs(t - r) < 0.5 - 1e-9);
+        const bool decided = fabs(t - r) < 0.5 - 1e-9;
+        if (rat_lane && (v == 0 || v == 4))
+            ok_rational = ok_rational && decided; // an exact tie: settled by the rational sub-path, not the exact order
+        else
+            ok = ok && decided;
         q[v] = (int)r;
     }
     return ok;
@@ -365,6 +371,12 @@ __device__ __forceinline__ uint32_t byte_any(unsigned long long m) { // bit k = 
     return (uint32_t)((m * 0x0102040810204080ull) >> 56);
 }
 
+#define TIC_STAMP(k)                                                                                  \
+    do {                                                                                              \
+        if (ABL == 8 && a.dbg != nullptr && lane == 0)                                                \
+            a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 template <int ABL>
 __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
@@ -422,6 +434,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
             if (txp >= a.fast_tx) { txp -= a.fast_tx; in_off += a.in_wrap; }
             return v;
         };
+        TIC_STAMP(0);
         uint2 p0 = load_next();
         uint2 p1 = load_next();
         if (a.stagger > 0) { // optional de-phasing of the waves that share a SIMD (loads above are already in flight)
@@ -524,19 +537,23 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
     // entries of wave pairs {0,1} and {2,3}, waves 1 and 3 take the full-redo entries of the same pairs.
     // (Patches go to addresses stored to earlier by another wave of this workgroup: every wave drains its own
     // stores before the barrier, so the patch is ordered after them.)
+    TIC_STAMP(1); // end of main loop
     __shared__ int cnt_all[kWavesPerWG][2];
     if (lane == 0) {
         cnt_all[wave][0] = nS;
         cnt_all[wave][1] = nG;
     }
     __builtin_amdgcn_s_waitcnt(0);
+    TIC_STAMP(2); // own stores drained
     __syncthreads();
+    TIC_STAMP(3); // barrier passed
     if (ABL == 3) return;
     const int src0 = wave & 2, src1 = src0 + 1;      // the pair of waves whose entries this wave serves
     const bool do_ties = (wave & 1) == 0;
     const int kind = do_ties ? 0 : 1;
     const int n0 = cnt_all[src0][kind], n1 = cnt_all[src1][kind];
     const int ntot = n0 + n1;
+    if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + 7] = (unsigned long long)ntot;
     if (ntot == 0) return;
     if ((do_ties && (ABL == 5 || ABL == 7)) || (!do_ties && ABL == 4)) return;
     // entry e of the concatenated lists of the two served waves -> (block id, pixel rows of the block for lane i)
@@ -566,14 +583,18 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
             const bool have = base + b < ntot;
             uint32_t blk, lo, hi;
             fetch(base + b, have, blk, lo, hi);
+            TIC_STAMP(4); // pixels fetched + transposed
             int r0, r4;
             special_block(lo, hi, ldsT, b, i, KR, r0, r4);
+            TIC_STAMP(5); // rational sub-path done
             if (have && (i & 3) == 0) {
                 int16_t *ob = a.out + (size_t)blk * 64;
                 ob[(zo.x & 0xffffu) >> 1] = (int16_t)r0; // zig-zag slots of (u,0) and (u,4)
                 ob[(zo.z & 0xffffu) >> 1] = (int16_t)r4;
             }
         }
+        __builtin_amdgcn_s_waitcnt(0);
+        TIC_STAMP(6); // patches landed
         return;
     }
     // whole blocks (~0.3 % of blocks at q=50); 8 blocks per pass
@@ -583,6 +604,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         const bool have = base + b < ntot;
         uint32_t blk, lo, hi;
         fetch(base + b, have, blk, lo, hi);
+        TIC_STAMP(4);
         // second level first (float64 butterflies, ~half the work of the exact order); its results go straight to
         // the zig-zag staging buffer so that nothing stays live across the exact order, which runs only for blocks
         // the second level cannot decide (a rational-coefficient tie in the same block, or a true tie elsewhere)
@@ -594,12 +616,23 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
 #pragma unroll
                 for (int v = 0; v < 8; v++) qe[v] = (int)(lo >> v) + (int)hi; // timing-only: no exact arithmetic
             } else {
-                ok = second_level_block(lo, hi, ldsT, b, i, C, qe);
+                bool ok_rat;
+                ok = second_level_block(lo, hi, ldsT, b, i, C, qe, ok_rat);
+                if (__ballot(!ok_rat && have) != 0ull) { // a rational tie inside a redo block: exact sub-path (cheap)
+                    const RationalConsts KR = load_rational_consts(C, i);
+                    int r0, r4;
+                    special_block(lo, hi, ldsT, b, i, KR, r0, r4);
+                    if ((i & 3) == 0) {
+                        qe[0] = r0;
+                        qe[4] = r4;
+                    }
+                }
             }
 #pragma unroll
             for (int v = 0; v < 8; v++)
                 *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
         }
+        TIC_STAMP(5); // second level done
         const unsigned long long bad = __ballot(!ok && have);
         if (bad != 0ull) {
             int qx[8];
@@ -614,6 +647,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
         wave_lds_fence();
         if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
+    }
+    if (ABL == 8) {
+        __builtin_amdgcn_s_waitcnt(0);
+        TIC_STAMP(6);
     }
     if (!do_ties && a.fallback_count != nullptr && lane == 0) atomicAdd(a.fallback_count, (unsigned long long)ntot);
 }
@@ -716,6 +753,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     a.rem_mode = 0;
     static const int stagger_env = getenv("TIC_STAGGER") ? atoi(getenv("TIC_STAGGER")) : 0;
     a.stagger = stagger_env;
+    if (variant != 17) a.dbg = nullptr;
     const int nf = a.nframes > 0 ? a.nframes : 1;
     if (variant == 1) {
         hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles), nf), block, 0, stream, a);
@@ -729,7 +767,19 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (nfast > 0) {
         // persistent waves: at most kPersistentWGs workgroups, each wave loops over its strips
         int wgs = grid_for(nfast);
-        static const int cap_env = getenv("TIC_MAX_WGS") ? atoi(getenv("TIC_MAX_WGS")) : kPersistentWGs; // tuning knob
+        // persistent grid = exactly the workgroups the chip holds at once (CUs x resident workgroups per CU): a larger
+        // grid runs in two uneven rounds, a smaller one leaves wave slots empty (measured: 15.0 us at 1280 workgroups
+        // vs 16.3 us at 2048 on a 4096^2 frame)
+        static const int resident = [] {
+            int dev = 0, cus = 256, per_cu = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_hybrid_kernel<0>, kWavesPerWG * 64, 0) != hipSuccess ||
+                per_cu < 1)
+                per_cu = 4;
+            return cus * per_cu;
+        }();
+        static const int cap_env = getenv("TIC_MAX_WGS") ? atoi(getenv("TIC_MAX_WGS")) : resident; // tuning knob
         int cap = cap_env / nf; // a batch shares the chip's wave slots between its frames
         if (cap < 64) cap = 64;
         if (wgs > cap) wgs = cap;
@@ -754,6 +804,8 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             hipLaunchKernelGGL(dctq_hybrid_kernel<5>, dim3(wgs, nf), block, 0, stream, a);
         else if (variant == 16)
             hipLaunchKernelGGL(dctq_hybrid_kernel<7>, dim3(wgs, nf), block, 0, stream, a);
+        else if (variant == 17)
+            hipLaunchKernelGGL(dctq_hybrid_kernel<8>, dim3(wgs, nf), block, 0, stream, a);
         else if (variant == 15)
             hipLaunchKernelGGL(dctq_hybrid_kernel<6>, dim3(wgs, nf), block, 0, stream, a);
         else
