@@ -160,6 +160,35 @@ def test_lenna_streams_byte_exact(ctx, golden, manifest):
     assert (info["height"], info["width"], info["quality"]) == (512, 512, 50)
 
 
+def test_natural_image_quality_sweep_vs_oracle(ctx, oracle, golden):
+    """Lenna (smooth content: many zero runs, few guard trips) at a spread of qualities: stream == oracle stream."""
+    img = golden("lenna")["img"]
+    for q in (1, 5, 25, 50, 75, 95, 99):
+        zz = T.dctq(img, q, ctx=ctx)
+        assert np.array_equal(zz, oracle.encode_zz16(img, q)), q
+        try:
+            want = oracle.compress(img, q)
+        except oracle.OracleError:  # |coefficient| >= 1024 has no Huffman code (reference: KeyError)
+            with pytest.raises(KeyError):
+                T.compress(img, q, ctx=ctx)
+            continue
+        assert T.compress(img, q, ctx=ctx) == want, q
+
+
+def test_cli_counterpart_of_encode_py(ctx, golden, manifest, tmp_path, capsys):
+    """python -m tinyimgcodec_amd.encode_cli: same two output lines and the same file bytes as the reference's encode.py."""
+    from tinyimgcodec_amd import encode_cli as cli
+
+    src = tmp_path / "lenna.npy"
+    dst = tmp_path / "out.img"
+    np.save(src, golden("lenna")["img"])
+    assert cli.main([str(src), str(dst)]) == 0
+    out = capsys.readouterr().out.splitlines()
+    n = manifest["lenna_q50"]["bytes"]
+    assert out[0] == f"{n} bytes" and out[1] == f"Compression Ratio: {512 * 512 / n}:1"
+    assert dst.read_bytes() == golden("lenna")["q50_bs"].tobytes()
+
+
 def test_input_dtypes_and_layouts(ctx, golden):
     """Any numeric dtype / F-order / strided input gives the same bytes; the input is not modified."""
     d = golden("lenna")

@@ -129,10 +129,23 @@ TIC_HD void dct8_aan(T &d0, T &d1, T &d2, T &d3, T &d4, T &d5, T &d6, T &d7) {
     d7 = z11 - z4;
 }
 
-// Guard band of the fast path, in coefficient (X) units: |X_fast - X_reference| stays below this for any uint8
-// block (worst case found by search 3.7e-4, rigorous bound ~8e-4) plus the rounding of the quantiser
-// multiply (<= 1024 * 2^-23 = 1.2e-4).
-static constexpr double kGuardX = 1.0e-3;
+// Guard band of the fast path per coefficient (u = vertical, v = horizontal frequency), in coefficient (X) units: a
+// rigorous forward error bound of dct8_aan() in float32, rows then columns, for uint8 pixels (every operation
+// contributes 2^-24 * |result|max, exact integer additions nothing, errors propagate linearly;
+// tools/fastpath_error_bound.py), plus the rounding of the quantiser multiply (1024 * 2^-23), times 1.05.  The largest
+// error an adversarial search found (tools/fastpath_error_search.py) is 4.6e-4, a factor 4-8 below the bounds of
+// the worst positions.  |X_fast - X_reference| < kGuard[u][v] for every input, so a rounding decided outside the
+// band is the reference's rounding.
+static constexpr double kGuard[64] = {
+    1.2817e-04, 4.3501e-04, 3.6408e-04, 4.4856e-04, 1.2817e-04, 4.9276e-04, 3.6408e-04, 7.3890e-04,
+    2.6147e-04, 5.4881e-04, 4.6611e-04, 5.6482e-04, 2.6147e-04, 6.1707e-04, 4.6611e-04, 9.0801e-04,
+    1.8715e-04, 4.4296e-04, 3.7804e-04, 4.5547e-04, 1.8715e-04, 4.9631e-04, 3.7804e-04, 7.2371e-04,
+    2.7502e-04, 5.3390e-04, 4.5962e-04, 5.4838e-04, 2.7502e-04, 5.9563e-04, 4.5962e-04, 8.5871e-04,
+    1.2817e-04, 4.3501e-04, 3.6408e-04, 4.4856e-04, 1.2817e-04, 4.9276e-04, 3.6408e-04, 7.3890e-04,
+    3.1923e-04, 7.0935e-04, 5.9767e-04, 7.3103e-04, 3.1923e-04, 8.0174e-04, 5.9767e-04, 1.1955e-03,
+    1.8715e-04, 8.1255e-04, 6.5436e-04, 8.4277e-04, 1.8715e-04, 9.4136e-04, 6.5436e-04, 1.4904e-03,
+    5.6536e-04, 2.0317e-03, 1.6119e-03, 2.1123e-03, 5.6536e-04, 2.3749e-03, 1.6119e-03, 3.8376e-03,
+};
 // Adding 1.5*2^23 to a float |t| < 2^22 rounds it to an integer (half-even) whose two's complement sits in the
 // low mantissa bits: the quantiser needs no v_rndne / v_cvt.
 static constexpr float kMagic = 12582912.0f;
@@ -144,7 +157,7 @@ struct DctqConsts {
     double mul64[64];    // second-level path, index u*8+v: 1 / (aan[u]*aan[v]*8*div[u][v]) in float64
     float mulT[64];      // fast path, index v*8+u: 1 / (aan[u]*aan[v]*8*div[u][v])
     float thrT[16];      // fast path, per column v: [2v] = accept threshold for u in {1,2,3,5,6,7}, [2v+1] = for u in {0,4}
-                         // (0.5 - largest guard band kGuardX/div[u][v] of the group; accept when |t - rint(t)| <= thr)
+                         // (0.5 - largest guard band kGuard[u][v]/div[u][v] of the group; accept when |t - rint(t)| <= thr)
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
     uint16_t zzofsT[64]; // index v*8+u: same offsets, transposed (lane v holds u = 0..7)
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
@@ -177,7 +190,7 @@ inline bool build_consts(int quality, DctqConsts *c) {
     for (int v = 0; v < 8; v++) {
         double ga = 0.0, gb = 0.0;
         for (int u = 0; u < 8; u++) {
-            double g = kGuardX / c->div[u * 8 + v];
+            double g = kGuard[u * 8 + v] / c->div[u * 8 + v];
             if (u == 0 || u == 4)
                 gb = g > gb ? g : gb;
             else

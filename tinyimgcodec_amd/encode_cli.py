@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Command-line counterpart of the reference's encode.py (encode.py:1-19): image in, .img stream out.
 
-    python -m tinyimgcodec_amd.encode input.(gif|png|jpg|npy|raw) output.img [--quality 50] [--shape H W]
+    python -m tinyimgcodec_amd.encode_cli input.(gif|png|jpg|npy|raw) output.img [--quality 50] [--shape H W]
 
 Prints "<n> bytes" and "Compression Ratio: <w*h/n>:1" exactly as the reference does.  Inputs: anything Pillow
 opens (converted to "L" as the reference does), a .npy array, or headerless 8-bit gray (.raw with --shape) so that
