@@ -36,8 +36,8 @@ BYTES_PER_PIXEL = 3.0  # 1 B uint8 read + 2 B int16 writ
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--quality", type=int, default=50)

@@ -20,14 +20,22 @@ struct DctqArgs {
     unsigned long long *fallback_count; // device counter of blocks redone on the exact path (may be null)
     // persistent-wave schedule of the hybrid kernel: wave g handles strips g, g + nwaves, g + 2*nwaves, ...
     int nwaves;          // waves in the grid
+    // generalised walk: workgroup w starts at strip w*wg_stride (+ wave index), a wave advances by tstep strips and
+    // stops at min(nfast, w*wg_stride + wg_span).  Strided schedule: wg_stride 4, tstep nwaves, wg_span = all;
+    // chunked schedule (large frames): wg_stride = wg_span = 4*S, tstep 4 - a workgroup streams S*4 adjacent strips
+    int wg_stride, tstep, wg_span;
+    // round-interleaved schedule (round_wgs > 0): workgroups [r*round_wgs, (r+1)*round_wgs) share round r, a dense range
+    // of round_wgs*wg_span strips which they walk together with stride round_wgs*4 (wg_stride = 4 inside the round)
+    int round_wgs;
     int step_ty, step_tx; // nwaves / fast_tx and nwaves % fast_tx (strip coordinates advance without a division)
     // the hybrid kernel covers the rectangle of complete, 8-byte aligned strips [0,fast_ty) x [0,fast_tx);
     // the exact kernel (rem_mode = 1) covers the rest: right-hand partial strips and the bottom partial block row
     int fast_ty, fast_tx;
     int rem_mode;
-    // byte offsets of the hybrid kernel's strip walk (precomputed on the host so the loop needs only scalar adds):
-    // advancing by nwaves strips adds *_step; when the strip column wraps past fast_tx, *_wrap is added as well
-    long in_step, in_wrap, out_step, out_wrap;
+    // the hybrid kernel's strip walk, precomputed on the host so the loop needs only 32-bit scalar adds: advancing by
+    // tstep strips adds in_step32 bytes to the pixel offset and oblk_step to the block index; when the strip column
+    // wraps past fast_tx the *_wrap terms are added as well (frames handled by this kernel are < 4 GiB)
+    uint32_t in_step32, in_wrap32, oblk_step, oblk_wrap;
     // batch of equally sized frames in one launch: blockIdx.y = frame; byte strides between frames
     int nframes;
     long frame_stride_in, frame_stride_out;

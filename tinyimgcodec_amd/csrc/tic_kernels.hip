@@ -400,53 +400,90 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
 
     {
         // per-lane constants for horizontal frequency v = i (L2-resident; loaded once per wave)
-        const float4 m0 = *reinterpret_cast<const float4 *>(C->mulT + i * 8);
-        const float4 m1 = *reinterpret_cast<const float4 *>(C->mulT + i * 8 + 4);
-        const float2 thr = *reinterpret_cast<const float2 *>(C->thrT + i * 2);
-        const uint4 zzv = *reinterpret_cast<const uint4 *>(C->zzofsT + i * 8);
+        // (issued with inline assembly like the pixel loads below, so that every VMEM instruction of the loop phase is
+        // counted by hand: a compiler-inserted wait for these would not know about the pixel loads issued after them
+        // and would drain all of them on the first strip)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        f32x4 m0, m1;
+        f32x2 thr;
+        u32x4 zzv;
+        {
+            const uint32_t o32 = (uint32_t)i * 32u, o16 = (uint32_t)i * 16u, o8 = (uint32_t)i * 8u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(m0) : "v"(o32), "s"(C->mulT) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(m1) : "v"(o32), "s"(C->mulT) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(thr) : "v"(o8), "s"(C->thrT) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zzv) : "v"(o16), "s"(C->zzofsT) : "memory");
+        }
+        uint32_t *tw = ldsT + lb * kTStrideDw + lr;                                          // transpose write: [block][v*8 + row]
+        const uint4 *tr = reinterpret_cast<const uint4 *>(
+            __builtin_assume_aligned(ldsT + b * kTStrideDw + i * 8, 16));                    // read: the 8 rows of column v
+        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
+        const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
+        const long row8 = 8 * a.stride;
+
+        // Strip walk (all scalar): ONE cursor, that of the prefetch.  It yields, per strip, the 32-bit byte offset of
+        // the strip's first pixel and the raster index of its first block; the block index travels to the store
+        // with the pixel register (both rotate by name in the unrolled loop), so nothing is recomputed.
+        int t_first;
+        long t_lim;
+        if (a.round_wgs > 0) {
+            const int rho = blockIdx.x / a.round_wgs, wl = blockIdx.x - rho * a.round_wgs;
+            const long base = (long)rho * a.round_wgs * a.wg_span;
+            t_first = __builtin_amdgcn_readfirstlane((int)base + wl * kWavesPerWG + wave);
+            t_lim = base + (long)a.round_wgs * a.wg_span;
+        } else {
+            t_first = __builtin_amdgcn_readfirstlane(blockIdx.x * a.wg_stride + wave);
+            t_lim = (long)blockIdx.x * a.wg_stride + a.wg_span;
+        }
+        const int t_end = t_lim < (long)nfast ? (int)t_lim : nfast; // first strip past this wave's walk
+        const int n_my = t_first < t_end ? (t_end - t_first + a.tstep - 1) / a.tstep : 0; // strips of this wave
+        int txp = t_first % a.fast_tx;
+        const int ty_first = t_first / a.fast_tx;
+        uint32_t in_off = (uint32_t)ty_first * (uint32_t)row8 + (uint32_t)txp * 64u; // frames are < 4 GiB (launcher)
+        uint32_t oblk = (uint32_t)ty_first * (uint32_t)a.bw + (uint32_t)txp * 8u;
+        uint32_t src_off = 0; // a load past the end of the walk re-reads the wave's last strip (strip 0 if it has none)
+        int n_issued = 0;
+        // Pixel loads are issued with inline assembly and waited for with explicit, counted s_waitcnt: the compiler's
+        // own bookkeeping waits for the newest load at the loop's back-edge (it takes the minimum over the entry and
+        // back-edge paths, and a register rotation by copy needs the copied load to have landed), which shortens the
+        // prefetch distance to one strip.  Contract: between two TIC_LOADs there is exactly one other VMEM
+        // instruction, the strip's 1 KiB store (the "memory" clobbers keep it on its side of the asm statements).
+        const uint8_t *img_s = a.img;
+#define TIC_LOAD(P, OB)                                                                                      \
+    do {                                                                                                     \
+        src_off = n_issued < n_my ? in_off : src_off;                                                        \
+        OB = oblk;                                                                                           \
+        const uint8_t *src = img_s + src_off;                                                                \
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory");         \
+        n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
+        if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
+    } while (0)
+#define TIC_WAIT(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(P) : : "memory")
+        TIC_STAMP(0);
+        unsigned long long p0, p1, p2;
+        uint32_t ob0, ob1, ob2;
+        TIC_LOAD(p0, ob0);
+        TIC_LOAD(p1, ob1);
+        // the four constant loads are older than the pixel loads: they have landed when only those are in flight
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(m0), "+v"(m1), "+v"(thr), "+v"(zzv) : : "memory");
         char *zzblk = ldsZ + b * kZzStrideB;
         int16_t *zp0 = reinterpret_cast<int16_t *>(zzblk + (zzv.x & 0xffff)), *zp1 = reinterpret_cast<int16_t *>(zzblk + (zzv.x >> 16));
         int16_t *zp2 = reinterpret_cast<int16_t *>(zzblk + (zzv.y & 0xffff)), *zp3 = reinterpret_cast<int16_t *>(zzblk + (zzv.y >> 16));
         int16_t *zp4 = reinterpret_cast<int16_t *>(zzblk + (zzv.z & 0xffff)), *zp5 = reinterpret_cast<int16_t *>(zzblk + (zzv.z >> 16));
         int16_t *zp6 = reinterpret_cast<int16_t *>(zzblk + (zzv.w & 0xffff)), *zp7 = reinterpret_cast<int16_t *>(zzblk + (zzv.w >> 16));
-        uint32_t *tw = ldsT + lb * kTStrideDw + lr;                                          // transpose write: [block][v*8 + row]
-        const uint4 *tr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsT + b * kTStrideDw + i * 8, 16));                    // read: the 8 rows of column v
         const uint4 *zr = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(zzblk + i * 16, 16));
-        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
-        const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
-        const long row8 = 8 * a.stride;
-
-        // strip schedule (all scalar, incremental): three strips in flight - current (0), next (1), next-next (2).
-        // Loads past the end of the schedule are clamped to the last strip (no branch around a load, so the
-        // compiler can keep two loads in flight across the loop back-edge with counted vmcnt waits).
-        int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + wave);
-        int tx0 = t0 % a.fast_tx;
-        const int ty_first = t0 / a.fast_tx;
-        long out_off = ((long)ty_first * a.bw + (long)tx0 * 8) * 128; // byte offset of strip 0's 1 KiB of coefficients
-        long in_off = (long)ty_first * row8 + (long)tx0 * 64;         // byte offset of the strip being prefetched
-        const long in_last = (long)(a.fast_ty - 1) * row8 + (long)(a.fast_tx - 1) * 64;
-        int tp = t0, txp = tx0;                                        // strip index / column of the prefetch cursor
-        auto load_next = [&]() -> uint2 {
-            const long off = tp < nfast ? in_off : in_last;
-            const uint2 v = *reinterpret_cast<const uint2 *>(a.img + off + ld_off);
-            tp += a.nwaves; txp += a.step_tx; in_off += a.in_step;
-            if (txp >= a.fast_tx) { txp -= a.fast_tx; in_off += a.in_wrap; }
-            return v;
-        };
-        TIC_STAMP(0);
-        uint2 p0 = load_next();
-        uint2 p1 = load_next();
         if (a.stagger > 0) { // optional de-phasing of the waves that share a SIMD (loads above are already in flight)
             const int mine = (wave & 1) * a.stagger + ((blockIdx.x >> 3) & 1) * (a.stagger >> 1);
             for (int k = 0; k < mine; k++) __builtin_amdgcn_s_sleep(1);
         }
 
-        while (t0 < nfast) {
-            const uint2 p2 = load_next();
-
+        // one strip: everything from the pixel row held in px to the 1 KiB store, then the schedule advances
+        int left = n_my;
+        auto process = [&](const unsigned long long px, const uint32_t ob) {
             // ---- pass 1: along the pixel row (the fast path is free to choose the pass order) ------------------
-            const uint32_t lo0 = p0.x, hi0 = p0.y;
+            const uint32_t lo0 = (uint32_t)px, hi0 = (uint32_t)(px >> 32);
             float d0 = (float)(lo0 & 0xffu), d1 = (float)((lo0 >> 8) & 0xffu), d2 = (float)((lo0 >> 16) & 0xffu),
                   d3 = (float)(lo0 >> 24);
             float d4 = (float)(hi0 & 0xffu), d5 = (float)((hi0 >> 8) & 0xffu), d6 = (float)((hi0 >> 16) & 0xffu),
@@ -497,11 +534,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
                 val = make_uint4((q0 & 0xffff) | (q1 << 16), (q2 & 0xffff) | (q3 << 16), (q4 & 0xffff) | (q5 << 16), (q6 & 0xffff) | (q7 << 16));
             }
             // ---- guard band bookkeeping, all scalar: lanes v in {0,4} hold the rational coefficients at u in {0,4} ------
-            const unsigned long long kRat = 0x1111111111111111ull;
-            const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
-            if ((mG | mS) != 0ull) { // rare: remember the tripped blocks for the post-pass
+            if (__builtin_expect((cA | cB) != 0ull, 0)) { // rare: remember the tripped blocks for the post-pass
+                const unsigned long long kRat = 0x1111111111111111ull;
+                const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
                 const uint32_t gm = byte_any(mG), sm = byte_any(mS) & ~gm;
-                const uint32_t blk = (uint32_t)(out_off >> 7) + (uint32_t)b;
+                const uint32_t blk = ob + (uint32_t)b;
                 const uint32_t below = (1u << b) - 1u;
                 if (i == 0 && ((sm >> b) & 1u)) list[nS + __builtin_popcount(sm & below)] = blk;
                 if (i == 0 && ((gm >> b) & 1u)) list[kListEntries - 1 - nG - __builtin_popcount(gm & below)] = blk;
@@ -510,8 +547,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
                 {
                     const uint32_t lbelow = (1u << lb) - 1u;
                     const int es = nS + __builtin_popcount(sm & lbelow), eg = nG + __builtin_popcount(gm & lbelow);
-                    if (((sm >> lb) & 1u) && es < kStash) stash[es * 8 + lr] = p0;
-                    if (((gm >> lb) & 1u) && eg < kStash) stash[(kStash + eg) * 8 + lr] = p0;
+                    if (((sm >> lb) & 1u) && es < kStash) stash[es * 8 + lr] = make_uint2(lo0, hi0);
+                    if (((gm >> lb) & 1u) && eg < kStash) stash[(kStash + eg) * 8 + lr] = make_uint2(lo0, hi0);
                 }
                 nS += __builtin_popcount(sm);
                 nG += __builtin_popcount(gm);
@@ -522,12 +559,29 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
                 val = *zr;
                 wave_lds_fence();
             }
-            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + out_off + st_off) = val;
-
-            t0 += a.nwaves; tx0 += a.step_tx; out_off += a.out_step;
-            if (tx0 >= a.fast_tx) { tx0 -= a.fast_tx; out_off += a.out_wrap; }
-            p0 = p1; p1 = p2;
-        }
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off) = val;
+            left--;
+        };
+        // Two strips ahead (loads L, stores S): strip j is consumed after L(j+2) is issued; in steady state the
+        // instructions younger than L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.
+        // The three pixel registers rotate by name (loop unrolled by three).  Three strips ahead measured 2 % slower.
+        do {
+            if (left == 0) break;
+            TIC_LOAD(p2, ob2); TIC_WAIT(p0, 2); process(p0, ob0);
+            if (left == 0) break;
+            TIC_LOAD(p0, ob0); TIC_WAIT(p1, 3); process(p1, ob1);
+            while (left != 0) {
+                TIC_LOAD(p1, ob1); TIC_WAIT(p2, 4); process(p2, ob2);
+                if (left == 0) break;
+                TIC_LOAD(p2, ob2); TIC_WAIT(p0, 4); process(p0, ob0);
+                if (left == 0) break;
+                TIC_LOAD(p0, ob0); TIC_WAIT(p1, 4); process(p1, ob1);
+            }
+        } while (0);
+        // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
+#undef TIC_LOAD
+#undef TIC_WAIT
     }
 
     // ---- post-pass over the recorded blocks, shared by the workgroup ------------------------------------------------------
@@ -743,7 +797,24 @@ __global__ void selftest_transpose_kernel(const uint2 *in, uint2 *out_dpp, uint2
 
 // ---- launchers ---------------------------------------------------------------------------------------------
 static inline int grid_for(int ntiles) { return (ntiles + kWavesPerWG - 1) / kWavesPerWG; }
-constexpr int kPersistentWGs = 256 * 8; // 256 CUs x 8 workgroups of 4 waves = every wave slot of the chip
+
+// Tuning knobs (environment): read once, or at every launch when TIC_TUNE is set (experiment scripts).
+struct Tunables {
+    int max_wgs, sched, chunk;
+};
+static Tunables read_tunables() {
+    auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
+    Tunables t;
+    t.max_wgs = geti("TIC_MAX_WGS", 0);             // persistent grid size (0: resident workgroups of the chip)
+    t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
+    t.chunk = geti("TIC_CHUNK", kMaxStripsPerWave); // strips per wave of schedules 1 and 2
+    return t;
+}
+static Tunables tunables() {
+    static const bool live = getenv("TIC_TUNE") != nullptr;
+    static const Tunables once = read_tunables();
+    return live ? read_tunables() : once;
+}
 
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (a.ntiles <= 0) return hipSuccess;
@@ -761,7 +832,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     }
     // hybrid kernel: rectangle of complete 64x8 strips with 8-byte aligned rows; the exact kernel takes the rest
     const int bh = a.ntiles / a.tiles_x;
-    a.fast_tx = a.aligned8 ? a.w / 64 : 0;
+    a.fast_tx = (a.aligned8 && (long)a.h * a.stride < (1L << 32)) ? a.w / 64 : 0; // 32-bit pixel offsets in the walk
     a.fast_ty = a.h / 8;
     const int nfast = a.fast_tx * a.fast_ty;
     if (nfast > 0) {
@@ -779,37 +850,54 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
                 per_cu = 4;
             return cus * per_cu;
         }();
-        static const int cap_env = getenv("TIC_MAX_WGS") ? atoi(getenv("TIC_MAX_WGS")) : resident; // tuning knob
+        const Tunables tune = tunables();
+        const int cap_env = tune.max_wgs > 0 ? tune.max_wgs : resident;
         int cap = cap_env / nf; // a batch shares the chip's wave slots between its frames
         if (cap < 64) cap = 64;
         if (wgs > cap) wgs = cap;
         const int min_wgs = (nfast + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
         if (wgs < min_wgs) wgs = min_wgs; // the per-wave trip list holds kMaxStripsPerWave entries
         a.nwaves = wgs * kWavesPerWG;
-        a.step_ty = a.nwaves / a.fast_tx;
-        a.step_tx = a.nwaves % a.fast_tx;
-        a.in_step = (long)a.step_ty * 8 * a.stride + (long)a.step_tx * 64;
-        a.in_wrap = 8 * a.stride - (long)a.fast_tx * 64;
-        a.out_step = ((long)a.step_ty * a.bw + (long)a.step_tx * 8) * 128;
-        a.out_wrap = ((long)a.bw - (long)a.fast_tx * 8) * 128;
-        if (variant == 10)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<1>, dim3(wgs, nf), block, 0, stream, a);
-        else if (variant == 11)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<2>, dim3(wgs, nf), block, 0, stream, a);
-        else if (variant == 12)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<3>, dim3(wgs, nf), block, 0, stream, a);
-        else if (variant == 13)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<4>, dim3(wgs, nf), block, 0, stream, a);
-        else if (variant == 14)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<5>, dim3(wgs, nf), block, 0, stream, a);
-        else if (variant == 16)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<7>, dim3(wgs, nf), block, 0, stream, a);
-        else if (variant == 17)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<8>, dim3(wgs, nf), block, 0, stream, a);
-        else if (variant == 15)
-            hipLaunchKernelGGL(dctq_hybrid_kernel<6>, dim3(wgs, nf), block, 0, stream, a);
-        else
-            hipLaunchKernelGGL(dctq_hybrid_kernel<0>, dim3(wgs, nf), block, 0, stream, a);
+        a.wg_stride = kWavesPerWG;
+        a.tstep = a.nwaves;
+        a.wg_span = nfast;
+        const int sched_env = tune.sched, chunk_env = tune.chunk;
+        a.round_wgs = 0;
+        const int S = chunk_env < 1 ? 1 : (chunk_env > kMaxStripsPerWave ? kMaxStripsPerWave : chunk_env);
+        const bool multi_round = (long)min_wgs * nf > (long)cap_env; // more workgroups than the chip holds at once
+        if (sched_env == 1 && multi_round) { // each workgroup streams a contiguous chunk of 4*S strips
+            a.wg_stride = a.wg_span = kWavesPerWG * S;
+            a.tstep = kWavesPerWG;
+            wgs = (nfast + a.wg_stride - 1) / a.wg_stride;
+            a.nwaves = wgs * kWavesPerWG;
+        } else if (sched_env == 2 && multi_round && nf == 1) { // rounds of `resident` workgroups walking a dense range together
+            a.round_wgs = cap_env;
+            a.wg_span = kWavesPerWG * S;
+            a.tstep = a.round_wgs * kWavesPerWG;
+            wgs = (nfast + a.wg_span - 1) / a.wg_span; // the last round may hold workgroups with nothing to do
+            wgs = (wgs + a.round_wgs - 1) / a.round_wgs * a.round_wgs;
+            a.nwaves = wgs * kWavesPerWG;
+        }
+        a.step_ty = a.tstep / a.fast_tx;
+        a.step_tx = a.tstep % a.fast_tx;
+        a.in_step32 = (uint32_t)((long)a.step_ty * 8 * a.stride + (long)a.step_tx * 64);
+        a.in_wrap32 = (uint32_t)(8 * a.stride - (long)a.fast_tx * 64);
+        a.oblk_step = (uint32_t)((long)a.step_ty * a.bw + (long)a.step_tx * 8);
+        a.oblk_wrap = (uint32_t)((long)a.bw - (long)a.fast_tx * 8);
+        const dim3 grid(wgs, nf);
+#define TIC_LAUNCH(ABL) hipLaunchKernelGGL(dctq_hybrid_kernel<ABL>, grid, block, 0, stream, a)
+        switch (variant) {
+        case 10: TIC_LAUNCH(1); break;
+        case 11: TIC_LAUNCH(2); break;
+        case 12: TIC_LAUNCH(3); break;
+        case 13: TIC_LAUNCH(4); break;
+        case 14: TIC_LAUNCH(5); break;
+        case 15: TIC_LAUNCH(6); break;
+        case 16: TIC_LAUNCH(7); break;
+        case 17: TIC_LAUNCH(8); break;
+        default: TIC_LAUNCH(0); break;
+        }
+#undef TIC_LAUNCH
     } else {
         a.fast_tx = a.fast_ty = 0;
     }
