@@ -27,6 +27,12 @@ struct DctqArgs {
     // round-interleaved schedule (round_wgs > 0): workgroups [r*round_wgs, (r+1)*round_wgs) share round r, a dense range
     // of round_wgs*wg_span strips which they walk together with stride round_wgs*4 (wg_stride = 4 inside the round)
     int round_wgs;
+    // team schedule (team_count > 0; grids that fit the chip at once): workgroups w, w + team_count, w + 2*team_count ...
+    // form a team (in practice: the workgroups resident on one CU, dispatched one round after the other).  The frame is
+    // cut into rows of team_count*4 strips; round r of every team takes rows [split[r], split[r+1]) - later rounds start
+    // later (their prologues compete with running waves) and get fewer rows, so that all waves end together.
+    int team_count;
+    int split[9];
     int step_ty, step_tx; // nwaves / fast_tx and nwaves % fast_tx (strip coordinates advance without a division)
     // the hybrid kernel covers the rectangle of complete, 8-byte aligned strips [0,fast_ty) x [0,fast_tx);
     // the exact kernel (rem_mode = 1) covers the rest: right-hand partial strips and the bottom partial block row

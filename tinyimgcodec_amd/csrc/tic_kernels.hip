@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "tic_kernels.h"
 #include "tic_math.h"
@@ -297,7 +298,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 // other trip (~0.3 % at q=50) are redone entirely on the exact path.  Keeping this out of the loop keeps the loop's
 // register footprint small.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kTStrideDw = kLdsStrideDw;          // the post-pass reuses exact_block(), which assumes this stride
 constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
 constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
 constexpr int kMaxStripsPerWave = 16;             // strips per wave are capped so that the trip list cannot overflow
@@ -383,6 +383,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
     __shared__ uint32_t list_all[kWavesPerWG][kListEntries];
     __shared__ uint2 stash_all[kWavesPerWG][2 * kStash * 8]; // [kind][entry][row] pixel rows of tripped blocks
+    // timing-only builds (ABL != 0; their outputs are wrong by construction): which parts of the loop are present
+    constexpr bool kArith = !(ABL == 1 || ABL == 6 || ABL == 11); // butterflies, quantiser, guard test
+    constexpr bool kLds = !(ABL == 2 || ABL == 6 || ABL == 10);   // the two LDS hand-offs
+    constexpr bool kMem = !(ABL == 9 || ABL == 10 || ABL == 11);  // pixel loads and coefficient stores
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *ldsT = ldsT_all[wave];
@@ -416,9 +420,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
             asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(thr) : "v"(o8), "s"(C->thrT) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zzv) : "v"(o16), "s"(C->zzofsT) : "memory");
         }
-        uint32_t *tw = ldsT + lb * kTStrideDw + lr;                                          // transpose write: [block][v*8 + row]
+        // LDS layouts of the loop (bank model: MI355X_MICROARCH.md, LDS; enumerated in tools/lds_bank_model.py).  Both
+        // staging buffers are arrays of 16-byte slots without padding.
+        // Transpose: Y[r][v] of block b lives in slot (r>>2)*64 + v*8 + (b ^ 4*((v>>1)&1)), dword r&3.  A write
+        // instruction (fixed v; lanes = (block, row)) covers all 32 banks once per 32-lane group; a 16-byte read
+        // (lanes = (block, v)) covers all 64 banks once per 16-lane group: no conflicts on either side (the padded
+        // [block][v][r] layout used before had 2-way conflicts on every read).
+        uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // v in {0,1,4,5}: + v*32 dwords
+        uint32_t *twB = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * (lb ^ 4); // v in {2,3,6,7}
         const uint4 *tr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsT + b * kTStrideDw + i * 8, 16));                    // read: the 8 rows of column v
+            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // rows 0..3; rows 4..7 at +64 slots
         const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
         const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
         const long row8 = 8 * a.stride;
@@ -428,7 +439,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         // with the pixel register (both rotate by name in the unrolled loop), so nothing is recomputed.
         int t_first;
         long t_lim;
-        if (a.round_wgs > 0) {
+        if (a.team_count > 0) {
+            const int r = blockIdx.x / a.team_count, t = blockIdx.x - r * a.team_count;
+            int row0 = 0, row1 = 0; // (constant indices only: a dynamic index would move the argument struct to scratch)
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (r == k) { row0 = a.split[k]; row1 = a.split[k + 1]; }
+            const int rows = row1 - row0;
+            t_first = __builtin_amdgcn_readfirstlane((row0 * a.team_count + t) * kWavesPerWG + wave);
+            t_lim = (long)t_first + (long)rows * a.tstep;
+        } else if (a.round_wgs > 0) {
             const int rho = blockIdx.x / a.round_wgs, wl = blockIdx.x - rho * a.round_wgs;
             const long base = (long)rho * a.round_wgs * a.wg_span;
             t_first = __builtin_amdgcn_readfirstlane((int)base + wl * kWavesPerWG + wave);
@@ -443,6 +463,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         const int ty_first = t_first / a.fast_tx;
         uint32_t in_off = (uint32_t)ty_first * (uint32_t)row8 + (uint32_t)txp * 64u; // frames are < 4 GiB (launcher)
         uint32_t oblk = (uint32_t)ty_first * (uint32_t)a.bw + (uint32_t)txp * 8u;
+        const uint32_t ob_first = oblk;
         uint32_t src_off = 0; // a load past the end of the walk re-reads the wave's last strip (strip 0 if it has none)
         int n_issued = 0;
         // Pixel loads are issued with inline assembly and waited for with explicit, counted s_waitcnt: the compiler's
@@ -456,7 +477,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         src_off = n_issued < n_my ? in_off : src_off;                                                        \
         OB = oblk;                                                                                           \
         const uint8_t *src = img_s + src_off;                                                                \
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory");         \
+        if (!kMem) P = ((unsigned long long)(ld_off * 2654435761u + src_off) << 24) ^ (ld_off + oblk); /* compute-only build */ \
+        else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory");    \
         n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
         if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
     } while (0)
@@ -468,12 +490,15 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         TIC_LOAD(p1, ob1);
         // the four constant loads are older than the pixel loads: they have landed when only those are in flight
         asm volatile("s_waitcnt vmcnt(2)" : "+v"(m0), "+v"(m1), "+v"(thr), "+v"(zzv) : : "memory");
-        char *zzblk = ldsZ + b * kZzStrideB;
-        int16_t *zp0 = reinterpret_cast<int16_t *>(zzblk + (zzv.x & 0xffff)), *zp1 = reinterpret_cast<int16_t *>(zzblk + (zzv.x >> 16));
-        int16_t *zp2 = reinterpret_cast<int16_t *>(zzblk + (zzv.y & 0xffff)), *zp3 = reinterpret_cast<int16_t *>(zzblk + (zzv.y >> 16));
-        int16_t *zp4 = reinterpret_cast<int16_t *>(zzblk + (zzv.z & 0xffff)), *zp5 = reinterpret_cast<int16_t *>(zzblk + (zzv.z >> 16));
-        int16_t *zp6 = reinterpret_cast<int16_t *>(zzblk + (zzv.w & 0xffff)), *zp7 = reinterpret_cast<int16_t *>(zzblk + (zzv.w >> 16));
-        const uint4 *zr = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(zzblk + i * 16, 16));
+        // Zig-zag staging: scan positions 8c..8c+7 of block b live in slot c*8 + (b ^ 4*((c>>1)&1)).  The eight 2-byte
+        // scatter writes then cost their 4-cycle issue minimum (at most 2-way conflicts), the 16-byte read none.
+        auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
+            return reinterpret_cast<int16_t *>(ldsZ + (ofs >> 4) * 128 + (ofs & 15) + 16 * (b ^ (4 * ((ofs >> 5) & 1))));
+        };
+        int16_t *zp0 = zz_ptr(zzv.x & 0xffff), *zp1 = zz_ptr(zzv.x >> 16), *zp2 = zz_ptr(zzv.y & 0xffff), *zp3 = zz_ptr(zzv.y >> 16);
+        int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
+        const uint4 *zr = reinterpret_cast<const uint4 *>(
+            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (4 * ((i >> 1) & 1)))), 16));
         if (a.stagger > 0) { // optional de-phasing of the waves that share a SIMD (loads above are already in flight)
             const int mine = (wave & 1) * a.stagger + ((blockIdx.x >> 3) & 1) * (a.stagger >> 1);
             for (int k = 0; k < mine; k++) __builtin_amdgcn_s_sleep(1);
@@ -481,22 +506,30 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
 
         // one strip: everything from the pixel row held in px to the 1 KiB store, then the schedule advances
         int left = n_my;
+        uint4 acc = make_uint4(0, 0, 0, 0);
         auto process = [&](const unsigned long long px, const uint32_t ob) {
             // ---- pass 1: along the pixel row (the fast path is free to choose the pass order) ------------------
             const uint32_t lo0 = (uint32_t)px, hi0 = (uint32_t)(px >> 32);
-            float d0 = (float)(lo0 & 0xffu), d1 = (float)((lo0 >> 8) & 0xffu), d2 = (float)((lo0 >> 16) & 0xffu),
-                  d3 = (float)(lo0 >> 24);
-            float d4 = (float)(hi0 & 0xffu), d5 = (float)((hi0 >> 8) & 0xffu), d6 = (float)((hi0 >> 16) & 0xffu),
-                  d7 = (float)(hi0 >> 24);
-            if (ABL != 1 && ABL != 6) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
+            // (assembly: from C casts the compiler makes SDWA integer adds of the first butterfly stage followed by
+            // v_cvt_f32_i32 - 28 instructions where these 8 conversions and 8 float adds do)
+            float d0, d1, d2, d3, d4, d5, d6, d7;
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d0) : "v"(lo0));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d1) : "v"(lo0));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d2) : "v"(lo0));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d3) : "v"(lo0));
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d4) : "v"(hi0));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d5) : "v"(hi0));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d6) : "v"(hi0));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d7) : "v"(hi0));
+            if (kArith) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
             d0 -= 1024.0f;
             float e0 = d0, e1 = d1, e2 = d2, e3 = d3, e4 = d4, e5 = d5, e6 = d6, e7 = d7;
-            if (ABL != 2 && ABL != 6) {
-                tw[0 * 8] = __float_as_uint(d0); tw[1 * 8] = __float_as_uint(d1); tw[2 * 8] = __float_as_uint(d2);
-                tw[3 * 8] = __float_as_uint(d3); tw[4 * 8] = __float_as_uint(d4); tw[5 * 8] = __float_as_uint(d5);
-                tw[6 * 8] = __float_as_uint(d6); tw[7 * 8] = __float_as_uint(d7);
+            if (kLds) {
+                twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
+                twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
+                twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
                 wave_lds_fence();
-                const uint4 ra = tr[0], rb = tr[1];
+                const uint4 ra = tr[0], rb = tr[64];
                 wave_lds_fence();
                 e0 = __uint_as_float(ra.x); e1 = __uint_as_float(ra.y); e2 = __uint_as_float(ra.z);
                 e3 = __uint_as_float(ra.w); e4 = __uint_as_float(rb.x); e5 = __uint_as_float(rb.y);
@@ -505,7 +538,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
             // ---- pass 2: down the column of horizontal frequency v = i ------------------------------------------
             uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
             unsigned long long cA = 0, cB = 0; // lanes whose guard band tripped (A: u in 1,2,3,5,6,7; B: u in 0,4)
-            if (ABL != 1 && ABL != 6) {
+            if (kArith) {
                 dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
                 float r0, r1, r2, r3, r4, r5, r6, r7;
                 quant_magic(e0, m0.x, q0, r0);
@@ -527,7 +560,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
                 q4 = __float_as_uint(e4); q5 = __float_as_uint(e5); q6 = __float_as_uint(e6); q7 = __float_as_uint(e7);
             }
             uint4 val;
-            if (ABL != 2 && ABL != 6) {
+            if (kLds) {
                 *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
                 *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
             } else {
@@ -554,12 +587,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
                 nG += __builtin_popcount(gm);
             }
             // ---- zig-zag ordered blocks -> global: 16 B per lane, 1 KiB contiguous per wave ---------------------------
-            if (ABL != 2 && ABL != 6) {
+            if (kLds) {
                 wave_lds_fence();
                 val = *zr;
                 wave_lds_fence();
             }
-            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off) = val;
+            if (!kMem) { acc.x ^= val.x; acc.y ^= val.y; acc.z ^= val.z; acc.w ^= val.w; } // compute-only build: no store
+            else *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off) = val;
             left--;
         };
         // Two strips ahead (loads L, stores S): strip j is consumed after L(j+2) is issued; in steady state the
@@ -580,6 +614,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         } while (0);
         // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
+        if (!kMem) { // one store per wave, to its first strip (always inside the frame)
+            if (n_my > 0) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob_first << 7) + st_off) = acc;
+            return;
+        }
 #undef TIC_LOAD
 #undef TIC_WAIT
     }
@@ -710,6 +748,338 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Kernel 2b: one block per lane (explored alternative; variant 40).
+//
+// The strip kernel above is bounded by the CU's LDS store path and by VALU in equal parts (68 LDS cycles per strip,
+// serialised over the four SIMDs).  Here a lane owns a whole 8x8 block: its eight 8-byte row loads
+// are, per instruction, 512 contiguous bytes of the wave's 64 consecutive blocks; both DCT passes, the quantiser, the
+// guard test and the zig-zag order (a renaming of registers) stay in the lane's registers.  LDS is used once, to turn
+// "128 bytes per lane" into 1 KiB-contiguous store instructions (2 LDS cycles per block against 8.5).
+// A wave = 64 consecutive blocks of the fast rectangle, a workgroup = 4 independent waves (no barrier, no loop): the
+// hardware dispatcher overlaps the load, compute and store phases of different waves.  Quantiser multipliers and
+// thresholds are wave-uniform (scalar registers).
+// Pass order: down the columns first, as the reference (axis -2, then -1).  Outputs 0 and 4 of the column pass are
+// exact integers, which is all the exact float64 sub-path of the four rational coefficients needs: it runs in the
+// lane, right after the row passes u = 0 and u = 4, under a wave-uniform branch (taken when any of the 64 blocks
+// has such a coefficient inside its guard band).  Blocks with any other coefficient inside its band (0.3 %) are
+// redone after the wave's stores by the 8-lanes-per-block float64 routines above, 8 blocks per pass.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kStageStrideB = 144;                       // bytes per block in the store-staging buffer (128 + 16 pad)
+constexpr int kStageWaveBytes = 64 * kStageStrideB;      // 9216 B per wave
+
+// Exact float64 sub-path of the rational coefficients (u,0) and (u,4), u in {0,4}, from the eight exact column-pass
+// outputs e[c] (integers; special_block() is the 8-lanes-per-block form of the same arithmetic, pocketfft's order).
+__device__ __forceinline__ void rational_row_exact(const float e[8], double kcol, double rdiv0, double rdiv4, double div0,
+                                                   double div4, int &r0i, int &r4i) {
+#pragma clang fp contract(off)
+    const double a0 = (double)e[0] * kcol, a1 = (double)e[1] * kcol, a2 = (double)e[2] * kcol, a3 = (double)e[3] * kcol;
+    const double a4 = (double)e[4] * kcol, a5 = (double)e[5] * kcol, a6 = (double)e[6] * kcol, a7 = (double)e[7] * kcol;
+    const double p07 = a0 + a7, p34 = a3 + a4, p12 = a1 + a2, p56 = a5 + a6;
+    const double A = p07 + p34, B = p12 + p56;
+    const double E0 = A + B, E4 = A - B;
+    const double X0 = E0 * (kSq2h * 0.5), X4 = E4 * (kTW3 * 0.5);
+    const double t0 = X0 * rdiv0, t4 = X4 * rdiv4;
+    double r0 = rint(t0), r4 = rint(t4);
+    // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
+    if (fabs(fabs(t0 - r0) - 0.5) < 1e-9) r0 = rint(X0 / div0);
+    if (fabs(fabs(t4 - r4) - 0.5) < 1e-9) r4 = rint(X4 / div4);
+    r0i = (int)r0;
+    r4i = (int)r4;
+}
+
+// Rare path of the one-block-per-lane kernel: one lane per (tie block, row u in {0,4}) runs the exact sub-path from the column-pass
+// outputs parked in the owner's slot and leaves the two results at slot + 128.
+__device__ __forceinline__ void lane_tie_pass(char *stage, const DctqConsts *__restrict__ C, unsigned long long m_tie, int lane) {
+    wave_lds_fence();
+    const int ntie = __builtin_popcountll(m_tie);
+    for (int base = 0; base < ntie; base += 32) {
+        int src = -1; // lane that owns the block of entry base + (lane >> 1)
+        unsigned long long todo = m_tie;
+        for (int k = 0; k < base + 32 && todo != 0ull; k++) {
+            const int pos = __builtin_ctzll(todo);
+            if (k == base + (lane >> 1)) src = pos;
+            todo &= todo - 1ull;
+        }
+        if (src >= 0) {
+            const bool row4 = (lane & 1) != 0;
+            const float4 *slot = reinterpret_cast<const float4 *>(stage + src * kStageStrideB + 64 + (lane & 1) * 32);
+            const float4 ea = slot[0], eb = slot[1];
+            const float e[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+            const double rdiv0 = row4 ? C->rdiv[32] : C->rdiv[0], rdiv4 = row4 ? C->rdiv[36] : C->rdiv[4];
+            const double div0 = row4 ? C->div[32] : C->div[0], div4 = row4 ? C->div[36] : C->div[4];
+            int r0, r4;
+            rational_row_exact(e, row4 ? kTW3 * 0.5 : kSq2h * 0.5, rdiv0, rdiv4, div0, div4, r0, r4);
+            *reinterpret_cast<int2 *>(stage + src * kStageStrideB + 128 + (lane & 1) * 8) = make_int2(r0, r4);
+        }
+    }
+}
+
+// Rare path: float64 recompute of block `src` (pixels parked in its owner's slot) by the whole wave, straight from the
+// definition.  Lane (u,c) first forms t[u][c] = sum_r M[u][r] x[r][c], then X[u][v=c] = sum_k M[v][k] t[u][k]; decided
+// roundings go to their zig-zag slot of the 128-byte block image.  Returns whether some coefficient other than the
+// rational four stayed undecided (a true tie: the block then needs the exact operation order).
+__device__ __forceinline__ bool lane_redo_block(const char *stage, const double *cos_tab, double *tbuf, char *img128,
+                                             const DctqConsts *__restrict__ C, int src, int lane) {
+    const int u = lane >> 3, c = lane & 7;
+    const uint8_t *xs = reinterpret_cast<const uint8_t *>(stage + src * kStageStrideB);
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) t += cos_tab[u * 8 + r] * (double)((int)xs[r * 8 + c] - 128);
+    tbuf[u * 8 + c] = t;
+    wave_lds_fence();
+    double X = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) X += cos_tab[c * 8 + k] * tbuf[u * 8 + k];
+    const double tq = X / C->div[lane], rq = rint(tq);
+    const bool decided = fabs(tq - rq) < 0.5 - 1e-9;
+    if (decided) *reinterpret_cast<int16_t *>(img128 + C->zzofs[lane]) = (int16_t)(int)rq;
+    const bool rational = (lane & 0x1b) == 0; // (u,v) in {0,4} x {0,4}
+    const bool slow = __ballot(!decided && !rational) != 0ull;
+    wave_lds_fence();
+    return slow;
+}
+
+template <int ABL>
+__global__ __launch_bounds__(kWavesPerWG * 64, 4) void dctq_lane_kernel(DctqArgs a) {
+    // Per lane a 144-byte slot: [0,64) the block's pixels, [64,128) column-pass outputs 0 and 4, [128,144) results of the
+    // rational sub-path; at the end the first 128 bytes become the store-staging area.
+    __shared__ __attribute__((aligned(16))) char stage_all[kWavesPerWG][kStageWaveBytes];
+    __shared__ __attribute__((aligned(16))) double redo_all[kWavesPerWG][64 + 16]; // per wave: t[8][8] and a 128-byte block image
+    __shared__ __attribute__((aligned(16))) double cos_tab[64]; // every wave writes the same values (no barrier needed)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const DctqConsts *__restrict__ C = a.consts;
+    a.img += (long)blockIdx.y * a.frame_stride_in; // batch: one grid row per frame
+    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.y * a.frame_stride_out);
+    const double cos_mine = C->cosm[lane];
+
+    const int fbw = a.fast_tx * 8;                 // blocks per row of the fast rectangle
+    const int nbf = a.fast_ty * fbw;               // blocks in it
+    const int B0 = (blockIdx.x * kWavesPerWG + wave) * 64;
+    if (B0 >= nbf) return;
+    const bool valid = B0 + lane < nbf;
+    const int B = valid ? B0 + lane : nbf - 1;     // lanes past the end compute on the last block, store nothing
+    const int by = B / fbw, bx = B - by * fbw;
+    const uint32_t oblk = (uint32_t)by * (uint32_t)a.bw + (uint32_t)bx;
+
+    // ---- load: row r of every lane's block; per instruction the wave reads 512 contiguous bytes per block row ------
+    const uint8_t *pix = a.img + (long)by * 8 * a.stride + bx * 8;
+    uint2 px[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) px[r] = *reinterpret_cast<const uint2 *>(pix + (long)r * a.stride);
+    char *stage = stage_all[wave];
+    cos_tab[lane] = cos_mine;
+    {
+        uint4 *slot = reinterpret_cast<uint4 *>(stage + lane * kStageStrideB); // pixels parked for the rare paths
+#pragma unroll
+        for (int r = 0; r < 4; r++) slot[r] = make_uint4(px[2 * r].x, px[2 * r].y, px[2 * r + 1].x, px[2 * r + 1].y);
+    }
+
+    // ---- bytes -> float.  (Assembly: written as C casts the compiler turns the first butterfly stage into SDWA integer
+    // adds followed by v_cvt_f32_i32 - 28 instructions per 8 pixels where 8 conversions and 8 float adds do.) ----------
+    float y[8][8]; // y[r][c], then Y[u][c] after the column pass, then Z[u][v]
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t lo = px[r].x, hi = px[r].y;
+        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(y[r][0]) : "v"(lo));
+        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(y[r][1]) : "v"(lo));
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(y[r][2]) : "v"(lo));
+        asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(y[r][3]) : "v"(lo));
+        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(y[r][4]) : "v"(hi));
+        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(y[r][5]) : "v"(hi));
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(y[r][6]) : "v"(hi));
+        asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(y[r][7]) : "v"(hi));
+    }
+    // ---- pass 1 down the columns; the level shift is folded into output 0 (column sum - 8 * 128, an exact integer) -----
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        if (ABL != 1) dct8_aan(y[0][c], y[1][c], y[2][c], y[3][c], y[4][c], y[5][c], y[6][c], y[7][c]);
+        y[0][c] -= 1024.0f;
+    }
+    // outputs 0 and 4 of the column pass are exact integers: parked in the lane's (still unused) staging slot for the
+    // exact sub-path of the rational coefficients, should one of them land in its guard band
+    {
+        float4 *slot = reinterpret_cast<float4 *>(stage + lane * kStageStrideB + 64);
+        slot[0] = make_float4(y[0][0], y[0][1], y[0][2], y[0][3]);
+        slot[1] = make_float4(y[0][4], y[0][5], y[0][6], y[0][7]);
+        slot[2] = make_float4(y[4][0], y[4][1], y[4][2], y[4][3]);
+        slot[3] = make_float4(y[4][4], y[4][5], y[4][6], y[4][7]);
+    }
+    // ---- pass 2 along the rows, quantise (index v*8+u of mulT is the multiplier of coefficient (u,v)) -------------------
+    // Rows in order; a scan pair (zig-zag positions 2k, 2k+1) is packed into its output dword as soon as the later of
+    // its two rows is done, so that at most ~8 unpacked values are alive at a time (register pressure).
+    uint32_t bits[64];   // natural index u*8+v: rint(t) in the low 16 bits
+    uint32_t w[32];      // output dwords, zig-zag order
+    float mx[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // max |t - rint(t)| per guard class; [4] = class 0 of row 4
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (ABL != 1) dct8_aan(y[u][0], y[u][1], y[u][2], y[u][3], y[u][4], y[u][5], y[u][6], y[u][7]);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            float d;
+            quant_magic(y[u][v], C->mulT[v * 8 + u], bits[u * 8 + v], d);
+            const int k = (u == 4 && kLaneClass[u * 8 + v] == 0) ? 4 : kLaneClass[u * 8 + v];
+            mx[k] = fmaxf(mx[k], fabsf(d));
+        }
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const int p0 = kZigzag[2 * k], p1 = kZigzag[2 * k + 1]; // natural indices of the scan pair
+            const int last_row = (p0 >> 3) > (p1 >> 3) ? (p0 >> 3) : (p1 >> 3);
+            if (last_row == u) w[k] = perm_b32(bits[p1], bits[p0], 0x05040100u);
+        }
+        // One row at a time: left alone, the compiler interleaves three rows for instruction-level parallelism that the
+        // four resident waves already provide, and spills ~35 registers doing so.  The empty asm ties the next row's
+        // inputs to this row's results (a scheduling barrier alone does not order pure arithmetic).
+        if (u < 7)
+            asm volatile("" : "+v"(y[u + 1][0]), "+v"(y[u + 1][1]), "+v"(y[u + 1][2]), "+v"(y[u + 1][3]), "+v"(y[u + 1][4]),
+                         "+v"(y[u + 1][5]), "+v"(y[u + 1][6]), "+v"(y[u + 1][7])
+                         : "v"(bits[u * 8]), "v"(bits[u * 8 + 1]), "v"(bits[u * 8 + 2]), "v"(bits[u * 8 + 3]), "v"(bits[u * 8 + 4]),
+                           "v"(bits[u * 8 + 5]), "v"(bits[u * 8 + 6]), "v"(bits[u * 8 + 7]), "v"(mx[0]), "v"(mx[1]), "v"(mx[2]),
+                           "v"(mx[3]), "v"(mx[4]));
+    }
+    const bool tie0 = (mx[0] > C->thrC[0]) && valid, tie4 = (mx[4] > C->thrC[0]) && valid;
+    // ---- rational coefficients inside their guard band (exact ties, ~2 % of blocks): exact float64 sub-path, one lane
+    // per (block, row u in {0,4}), from the parked column-pass outputs; the owners then patch their registers ---------
+    {
+        const unsigned long long m_tie = __ballot(tie0 | tie4);
+        if (ABL != 3 && ABL != 4 && m_tie != 0ull) {
+            lane_tie_pass(stage, C, m_tie, lane);
+            wave_lds_fence();
+            const int4 fix = *reinterpret_cast<const int4 *>(stage + lane * kStageStrideB + 128);
+            // scan positions of (0,0), (0,4), (4,0), (4,4): 0, 14, 10, 39 -> halves of w[0], w[7], w[5], w[19]
+            static_assert(kZigzag[0] == 0 && kZigzag[14] == 4 && kZigzag[10] == 32 && kZigzag[39] == 36, "zig-zag slots");
+            w[0] = tie0 ? perm_b32(w[0], (uint32_t)fix.x, 0x07060100u) : w[0];   // low half
+            w[7] = tie0 ? perm_b32(w[7], (uint32_t)fix.y, 0x07060100u) : w[7];   // position 14: low half
+            w[5] = tie4 ? perm_b32(w[5], (uint32_t)fix.z, 0x07060100u) : w[5];   // position 10: low half
+            w[19] = tie4 ? perm_b32((uint32_t)fix.w, w[19], 0x05040100u) : w[19]; // position 39: high half
+            wave_lds_fence();
+        }
+    }
+    const bool trip_redo = ((mx[1] > C->thrC[1]) | (mx[2] > C->thrC[2]) | (mx[3] > C->thrC[3])) && valid;
+
+    // ---- blocks with another coefficient inside its guard band (0.3 %): the whole wave recomputes the block in float64
+    // straight from the definition (lane (u,c): t[u][c] = sum_r M[u][r] x[r][c]; lane (u,v): X = sum_c M[v][c] t[u][c];
+    // error ~1e-13 against ~1e-12 of the reference itself).  A rounding is decided when no .5 tie lies within 1e-9; the
+    // decided values replace the owner's packed words.  Undecided ones: rational ties (already settled above) or a true
+    // tie elsewhere - then the block goes to the exact-order routine after the stores.
+    unsigned long long m_slow = 0ull;
+    if (ABL == 4) w[31] += (uint32_t)(tie0 | tie4 | trip_redo); // timing build: guard arithmetic kept, rare paths not taken
+    {
+        const unsigned long long m_redo = __ballot(trip_redo);
+        if (ABL != 3 && ABL != 4 && m_redo != 0ull) {
+            double *tbuf = redo_all[wave];                                  // t[8][8]
+            char *img128 = reinterpret_cast<char *>(redo_all[wave] + 64);   // the block's 128 output bytes
+            wave_lds_fence();
+            for (unsigned long long todo = m_redo; todo != 0ull; todo &= todo - 1ull) {
+                const int src = __builtin_ctzll(todo);
+                if (lane == src) {
+                    uint4 *o = reinterpret_cast<uint4 *>(img128);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+                }
+                wave_lds_fence();
+                if (lane_redo_block(stage, cos_tab, tbuf, img128, C, src, lane)) m_slow |= 1ull << src;
+                {
+                    const uint4 *o = reinterpret_cast<const uint4 *>(img128);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint4 v4 = o[j];
+                        if (lane == src) { w[4 * j] = v4.x; w[4 * j + 1] = v4.y; w[4 * j + 2] = v4.z; w[4 * j + 3] = v4.w; }
+                    }
+                }
+                wave_lds_fence();
+            }
+            if (a.fallback_count != nullptr && lane == 0) atomicAdd(a.fallback_count, (unsigned long long)__builtin_popcountll(m_redo));
+        }
+    }
+
+    // ---- zig-zag order is a renaming; pack two int16 per dword, stage 128 B per lane, store 1 KiB per instruction ----
+    wave_lds_fence();
+    {
+        uint4 *mine = reinterpret_cast<uint4 *>(stage + lane * kStageStrideB);
+#pragma unroll
+        for (int j = 0; j < 8; j++) mine[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        // 16-byte piece c = 64*j + lane of the wave's 1024 pieces: piece (c & 7) of the block of lane (c >> 3)
+        const int src = 8 * j + (lane >> 3);
+        const uint4 val = *reinterpret_cast<const uint4 *>(stage + src * kStageStrideB + (lane & 7) * 16);
+        const uint32_t ob = (uint32_t)__shfl((int)oblk, src, 64);
+        if (B0 + src < nbf)
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + (lane & 7) * 16) = val;
+    }
+
+    // ---- blocks the float64 recompute could not decide: exact-order routine, 8 lanes per block, after the stores ------
+    // (never seen on real data: needs a coefficient other than the rational four within 1e-9 of a tie)
+    const unsigned long long m_redo = m_slow;
+    if (m_redo == 0ull) return;
+    __builtin_amdgcn_s_waitcnt(0);
+    wave_lds_fence();
+    const int nredo = __builtin_popcountll(m_redo);
+    const int b = lane >> 3, i = lane & 7;
+    uint32_t *ldsT = reinterpret_cast<uint32_t *>(stage);                        // 2176 B of the (now free) staging buffer
+    char *zzblk = stage + kLdsWaveBytes + b * kZzStrideB;                        // 1152 B behind it
+    const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
+    const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+    unsigned long long todo = m_redo;
+    for (int base = 0; base < nredo; base += 8) {
+        const bool have = base + b < nredo;
+        int src = 0; // lane that owns the block of entry base + b
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int pos = todo ? __builtin_ctzll(todo) : 0;
+            if (b == k) src = pos;
+            todo &= todo - 1ull;
+        }
+        const uint32_t blk = (uint32_t)__shfl((int)oblk, src, 64);
+        uint32_t lo, hi;
+        {
+            Strip s;
+            s.by = (int)(blk / (uint32_t)a.bw);
+            s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
+            s.valid = true;
+            s.oblk = blk;
+            load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
+            transpose8x8_bytes(lo, hi, i); // -> pixel column i
+        }
+        bool ok;
+        {
+            int qe[8];
+            bool ok_rat;
+            ok = second_level_block(lo, hi, ldsT, b, i, C, qe, ok_rat);
+            if (__ballot(!ok_rat && have) != 0ull) { // a rational tie inside a redo block: exact sub-path (cheap)
+                const RationalConsts KR = load_rational_consts(C, i);
+                int r0, r4;
+                special_block(lo, hi, ldsT, b, i, KR, r0, r4);
+                if ((i & 3) == 0) {
+                    qe[0] = r0;
+                    qe[4] = r4;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 8; v++)
+                *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
+        }
+        const unsigned long long bad = __ballot(!ok && have);
+        if (bad != 0ull) {
+            int qx[8];
+            exact_block(lo, hi, ldsT, b, i, C, qx);
+            if ((bad >> (8 * b)) & 0xffull) {
+#pragma unroll
+                for (int v = 0; v < 8; v++)
+                    *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qx[v];
+            }
+        }
+        wave_lds_fence();
+        const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
+        wave_lds_fence();
+        if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Kernel 3: decode side - dequantise (utils.py:52), inverse DCT (utils.py:40-45, exact order), +128, clip,
 // truncating cast (codec.py:68-70), crop.  Input: int16 [N][64] zig-zag, DC already integrated (np.cumsum).
 // ---------------------------------------------------------------------------------------------------------
@@ -800,7 +1170,8 @@ static inline int grid_for(int ntiles) { return (ntiles + kWavesPerWG - 1) / kWa
 
 // Tuning knobs (environment): read once, or at every launch when TIC_TUNE is set (experiment scripts).
 struct Tunables {
-    int max_wgs, sched, chunk;
+    int max_wgs, sched, chunk, lds_pad;
+    int split[8];
 };
 static Tunables read_tunables() {
     auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
@@ -808,6 +1179,15 @@ static Tunables read_tunables() {
     t.max_wgs = geti("TIC_MAX_WGS", 0);             // persistent grid size (0: resident workgroups of the chip)
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
     t.chunk = geti("TIC_CHUNK", kMaxStripsPerWave); // strips per wave of schedules 1 and 2
+    // per-round row weights of the team schedule ("0" disables it)
+    const char *sp = getenv("TIC_SPLIT") ? getenv("TIC_SPLIT") : "10,9,7,4,2";
+    for (int k = 0; k < 8; k++) t.split[k] = 0;
+    for (int k = 0; k < 8 && sp && *sp; k++) {
+        t.split[k] = atoi(sp);
+        sp = strchr(sp, ',');
+        if (sp) sp++;
+    }
+    t.lds_pad = geti("TIC_LDS_PAD", 0);             // experiment: extra dynamic LDS per workgroup (lowers occupancy)
     return t;
 }
 static Tunables tunables() {
@@ -835,14 +1215,24 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     a.fast_tx = (a.aligned8 && (long)a.h * a.stride < (1L << 32)) ? a.w / 64 : 0; // 32-bit pixel offsets in the walk
     a.fast_ty = a.h / 8;
     const int nfast = a.fast_tx * a.fast_ty;
-    if (nfast > 0) {
-        // persistent waves: at most kPersistentWGs workgroups, each wave loops over its strips
+    const bool lane_kernel = variant == 40 || variant == 41;
+    if (nfast > 0 && lane_kernel) {
+        // one block per lane (explored alternative): 64 blocks per wave, 256 per workgroup, no loop
+        const long nbf = (long)nfast * 8;
+        const dim3 grid((unsigned)((nbf + kWavesPerWG * 64 - 1) / (kWavesPerWG * 64)), nf);
+        if (variant == 41)
+            hipLaunchKernelGGL(dctq_lane_kernel<4>, grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL(dctq_lane_kernel<0>, grid, block, 0, stream, a);
+    } else if (nfast > 0) {
+        // strip kernel (variant 2 and its timing builds 10-20), persistent waves: each wave loops over its strips
         int wgs = grid_for(nfast);
         // persistent grid = exactly the workgroups the chip holds at once (CUs x resident workgroups per CU): a larger
         // grid runs in two uneven rounds, a smaller one leaves wave slots empty (measured: 15.0 us at 1280 workgroups
         // vs 16.3 us at 2048 on a 4096^2 frame)
+        static int cus = 256;
         static const int resident = [] {
-            int dev = 0, cus = 256, per_cu = 0;
+            int dev = 0, per_cu = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_hybrid_kernel<0>, kWavesPerWG * 64, 0) != hipSuccess ||
@@ -863,6 +1253,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.wg_span = nfast;
         const int sched_env = tune.sched, chunk_env = tune.chunk;
         a.round_wgs = 0;
+        a.team_count = 0;
         const int S = chunk_env < 1 ? 1 : (chunk_env > kMaxStripsPerWave ? kMaxStripsPerWave : chunk_env);
         const bool multi_round = (long)min_wgs * nf > (long)cap_env; // more workgroups than the chip holds at once
         if (sched_env == 1 && multi_round) { // each workgroup streams a contiguous chunk of 4*S strips
@@ -878,6 +1269,24 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             wgs = (wgs + a.round_wgs - 1) / a.round_wgs * a.round_wgs;
             a.nwaves = wgs * kWavesPerWG;
         }
+        if (!multi_round && nf == 1 && tune.split[0] > 0 && wgs == cap_env && wgs % cus == 0 && wgs / cus <= 8) {
+            // the whole grid is resident: teams of wgs/cus workgroups, rows split by the per-round weights
+            const int R = wgs / cus;
+            a.team_count = cus;
+            a.tstep = cus * kWavesPerWG;
+            const int rows_total = (nfast + a.tstep - 1) / a.tstep;
+            double wsum = 0;
+            for (int r = 0; r < R; r++) wsum += tune.split[r] > 0 ? tune.split[r] : 1;
+            double acc = 0;
+            a.split[0] = 0;
+            for (int r = 0; r < R; r++) {
+                acc += tune.split[r] > 0 ? tune.split[r] : 1;
+                a.split[r + 1] = (int)(rows_total * acc / wsum + 0.5);
+                if (a.split[r + 1] - a.split[r] > kMaxStripsPerWave) a.team_count = 0; // trip list capacity: fall back
+            }
+            a.split[R] = rows_total;
+            if (a.team_count == 0) a.tstep = a.nwaves;
+        }
         a.step_ty = a.tstep / a.fast_tx;
         a.step_tx = a.tstep % a.fast_tx;
         a.in_step32 = (uint32_t)((long)a.step_ty * 8 * a.stride + (long)a.step_tx * 64);
@@ -885,7 +1294,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.oblk_step = (uint32_t)((long)a.step_ty * a.bw + (long)a.step_tx * 8);
         a.oblk_wrap = (uint32_t)((long)a.bw - (long)a.fast_tx * 8);
         const dim3 grid(wgs, nf);
-#define TIC_LAUNCH(ABL) hipLaunchKernelGGL(dctq_hybrid_kernel<ABL>, grid, block, 0, stream, a)
+#define TIC_LAUNCH(ABL) hipLaunchKernelGGL(dctq_hybrid_kernel<ABL>, grid, block, tune.lds_pad, stream, a)
         switch (variant) {
         case 10: TIC_LAUNCH(1); break;
         case 11: TIC_LAUNCH(2); break;
@@ -895,6 +1304,9 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         case 15: TIC_LAUNCH(6); break;
         case 16: TIC_LAUNCH(7); break;
         case 17: TIC_LAUNCH(8); break;
+        case 18: TIC_LAUNCH(9); break;
+        case 19: TIC_LAUNCH(10); break;
+        case 20: TIC_LAUNCH(11); break;
         default: TIC_LAUNCH(0); break;
         }
 #undef TIC_LAUNCH

@@ -146,6 +146,23 @@ static constexpr double kGuard[64] = {
     1.8715e-04, 8.1255e-04, 6.5436e-04, 8.4277e-04, 1.8715e-04, 9.4136e-04, 6.5436e-04, 1.4904e-03,
     5.6536e-04, 2.0317e-03, 1.6119e-03, 2.1123e-03, 5.6536e-04, 2.3749e-03, 1.6119e-03, 3.8376e-03,
 };
+// Guard classes of the one-block-per-lane kernel: every lane quantises all 64 coefficients, so the accept test is a
+// max over the coefficients of a class against one threshold per class (0.5 - largest guard/div of the class).  That
+// kernel takes the passes columns first, so its guard at (u,v) is kGuard[v][u] (the bound is symmetric under
+// transposition of block and algorithm).
+// Class 0 = the four rational coefficients (tie-only entries of the post-pass); classes 1-3 = the other 60, cut where
+// the sum over classes of (members x largest guard) is smallest (the expected number of trips; 20 % below the
+// per-column grouping of the strip kernel).  The pattern kGuard/Q does not depend on the quality.
+static constexpr unsigned char kLaneClass[64] = {
+    0, 2, 2, 2, 0, 1, 1, 1,
+    3, 3, 3, 3, 2, 2, 2, 3,
+    2, 3, 2, 2, 1, 1, 1, 3,
+    3, 3, 2, 2, 1, 1, 1, 3,
+    0, 2, 1, 1, 0, 1, 1, 1,
+    2, 2, 1, 1, 1, 1, 1, 2,
+    1, 1, 1, 1, 1, 1, 1, 2,
+    1, 1, 1, 1, 1, 2, 2, 3,
+};
 // Adding 1.5*2^23 to a float |t| < 2^22 rounds it to an integer (half-even) whose two's complement sits in the
 // low mantissa bits: the quantiser needs no v_rndne / v_cvt.
 static constexpr float kMagic = 12582912.0f;
@@ -158,6 +175,8 @@ struct DctqConsts {
     float mulT[64];      // fast path, index v*8+u: 1 / (aan[u]*aan[v]*8*div[u][v])
     float thrT[16];      // fast path, per column v: [2v] = accept threshold for u in {1,2,3,5,6,7}, [2v+1] = for u in {0,4}
                          // (0.5 - largest guard band kGuard[u][v]/div[u][v] of the group; accept when |t - rint(t)| <= thr)
+    float thrC[4];       // one-block-per-lane kernel: accept threshold per guard class (kLaneClass)
+    double cosm[64];     // orthonormal DCT-II matrix, index k*8+n: c(k) cos((2n+1) k pi / 16) (direct float64 recompute)
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
     uint16_t zzofsT[64]; // index v*8+u: same offsets, transposed (lane v holds u = 0..7)
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
@@ -199,6 +218,17 @@ inline bool build_consts(int quality, DctqConsts *c) {
         c->thrT[2 * v] = (float)(0.5 - ga);
         c->thrT[2 * v + 1] = (float)(0.5 - gb);
     }
+    {
+        double gmax[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < 64; i++) {
+            const double g = kGuard[(i & 7) * 8 + (i >> 3)] / c->div[i]; // columns-first: transposed bound
+            if (g > gmax[kLaneClass[i]]) gmax[kLaneClass[i]] = g;
+        }
+        for (int k = 0; k < 4; k++) c->thrC[k] = (float)(0.5 - gmax[k]);
+    }
+    for (int k = 0; k < 8; k++)
+        for (int n = 0; n < 8; n++)
+            c->cosm[k * 8 + n] = (k == 0 ? sqrt(0.125) : 0.5) * cos((2 * n + 1) * k * 3.14159265358979323846 / 16.0);
     for (int k = 0; k < 64; k++) {
         int nat = kZigzag[k], u = nat >> 3, v = nat & 7;
         c->zzofs[nat] = (uint16_t)(2 * k);

@@ -1,0 +1,89 @@
+import itertools
+G128 = [ [0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27], [4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31] ]
+G128 = G128 + [[l+32 for l in g] for g in G128]
+G32 = [list(range(32)), list(range(32,64))]
+def cyc_read128(addr_dw):  # addr_dw[lane] = start dword (4 consecutive)
+    tot=0
+    for g in G128:
+        banks={}
+        for l in g:
+            for k in range(4):
+                a=addr_dw[l]+k
+                banks.setdefault(a%64,set()).add(a)
+        tot+=max(len(s) for s in banks.values())
+    return tot
+def cyc_write32(addr_dw, nb=32):
+    tot=0
+    for g in G32:
+        banks={}
+        for l in g:
+            a=addr_dw[l]
+            banks.setdefault(a%nb,set()).add(a)
+        tot+=max(len(s) for s in banks.values())
+    return tot
+def transpose_cost(B, verbose=False):
+    # write phase lanes: lb=L&7, lr=L>>3 ; addr = B[lb] + lr + 8u
+    w=0
+    for u in range(8):
+        w+=cyc_write32([B[L&7]+(L>>3)+8*u for L in range(64)])
+    r=0
+    for half in range(2):
+        r+=cyc_read128([B[L>>3]+8*(L&7)+4*half for L in range(64)])
+    return w,r
+print("stride 68:", transpose_cost([68*b for b in range(8)]))
+print("stride 72:", transpose_cost([72*b for b in range(8)]))
+print("stride 64:", transpose_cost([64*b for b in range(8)]))
+best=None
+# search block bases: B[b] = 64*b + off[b], off multiple of 4 in 0..60 (buffer grows to 8*64+64)
+import random
+cands=[]
+for offs in itertools.product(range(0,64,4), repeat=4):
+    B=[64*b+offs[b] for b in range(4)]+[64*(b+4)+offs[b] for b in range(4)]
+    w,r=transpose_cost(B)
+    cands.append((w+r,w,r,offs))
+cands.sort()
+print(cands[:10])
+print("manual", transpose_cost([0,64,128+36,192+36,256+8,320+8,384+44,448+44]))
+# full search over 4 offsets again but print best by reads
+cands.sort(key=lambda c:(c[2],c[1]))
+print(cands[:5])
+print("=== new transpose layout")
+def A(b,v,r): return ((r>>2)*64 + v*8 + ((b + 4*((v>>1)&1))&7))*4 + (r&3)
+w=0
+for v in range(8):
+    w+=cyc_write32([A(L&7, v, L>>3) for L in range(64)])
+r=0
+for h in range(2):
+    r+=cyc_read128([A(L>>3, L&7, 4*h) for L in range(64)])
+print("writes",w,"reads",r)
+# zigzag
+def zigzag():
+    order=[]
+    for s in range(15):
+        pts=[(i,s-i) for i in range(s+1) if i<8 and s-i<8]
+        if s%2==0: pts=pts[::-1]
+        order+=pts
+    return {uv:k for k,uv in enumerate(order)}
+pos=zigzag()
+def zz_cost(Q):
+    tot=0; arr=0
+    for u in range(8):
+        c=cyc_write32([ Q(L>>3, pos[(u,L&7)]>>3)*4 + ((pos[(u,L&7)]&7)>>1) for L in range(64)])
+        arr+=c; tot+=max(4,c)
+    rd=cyc_read128([Q(L>>3, L&7)*4 for L in range(64)])
+    return tot,arr,rd
+print("current stride 144B:", zz_cost(lambda b,c: b*9+c))   # 144 B = 9 slots
+print("swizzled:", zz_cost(lambda b,c: c*8 + ((b + 4*((c>>1)&1))&7)))
+print("plain [c][b]:", zz_cost(lambda b,c: c*8 + b))
+import random
+best=(999,)
+random.seed(1)
+# search permutations: Q(b,c)= c*8 + ((b + g[c])&7), g[c] in 0..7
+import itertools
+res=[]
+for g in itertools.product(range(8), repeat=8):
+    if g[0]!=0: continue
+    t=zz_cost(lambda b,c: c*8 + ((b+g[c])&7))
+    res.append((t[0]+t[2]*1,t,g))
+res.sort()
+print(res[:5])
