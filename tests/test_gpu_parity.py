@@ -50,6 +50,17 @@ class DevFrame:
         ctx.check(L.tic_memcpy_d2h(ctx.handle, zz.ctypes.data, self.d_out, self.n * 128))
         return zz
 
+    def run_variant(self, quality, variant):
+        """One launch of an internal kernel variant (>= 10) through the timing entry point, then read back."""
+        ctx, L = self.ctx, self.L
+        ctx.check(L.tic_memset_dev(ctx.handle, self.d_out, 0x5A, max(self.n, 1) * 128))
+        ms = C.c_float()
+        ctx.check(L.tic_dctq_dev_timed(ctx.handle, self.d_img, self.h, self.w, self.pitch, quality, self.d_out, variant, 1,
+                                       C.byref(ms)))
+        zz = np.empty((self.n, 64), dtype=np.int16)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, zz.ctypes.data, self.d_out, self.n * 128))
+        return zz
+
     def fallbacks(self):
         c = C.c_ulonglong()
         self.ctx.check(self.L.tic_last_fallback_blocks(self.ctx.handle, C.byref(c)))
@@ -233,6 +244,38 @@ def test_config2_4096_coefficient_digest(ctx, manifest, q):
     assert sha(dc.astype("<i4").tobytes()) == m["dc_i4_sha256"]
     assert sha(ac.astype("<i4").tobytes()) == m["ac_i4_sha256"]
     assert 0 < fb < 0.08 * 262144, fb  # guard band trips on a small fraction of blocks only
+
+
+@pytest.mark.parametrize("shape", [(4096, 4096), (1080, 1920), (200, 328), (64, 64), (8, 4096)])
+def test_one_block_per_lane_kernel_matches_exact(ctx, golden, shape):
+    """The explored one-block-per-lane kernel (variant 40) is bit-identical too: random frames (ties and
+    redo blocks occur at 4096^2), partial strips, and the tie-stress blocks of the goldens."""
+    h, w = shape
+    for q in (10, 50, 90):
+        f = DevFrame(ctx, rand_frame(99, h, w))
+        assert np.array_equal(f.run_variant(q, 40), f.run(q, N.KERNEL_EXACT)), (shape, q)
+        f.free()
+    f = DevFrame(ctx, golden("tie_blocks")["img"].astype(np.uint8))  # blocks built to sit on rounding ties
+    for q in (50, 90):
+        assert np.array_equal(f.run_variant(q, 40), f.run(q, N.KERNEL_EXACT)), q
+    f.free()
+
+
+def test_strip_schedules_are_equivalent(ctx, monkeypatch):
+    """Team / strided / chunked / round-interleaved walks (tuning knobs of launch_dctq) produce the same coefficients."""
+    monkeypatch.setenv("TIC_TUNE", "1")  # re-read the knobs at every launch
+    frames = {"small grid": rand_frame(5, 1024, 1024), "large grid": rand_frame(6, 4096, 8192)}
+    for name, img in frames.items():
+        f = DevFrame(ctx, img)
+        ref = f.run(50, N.KERNEL_EXACT)
+        for knobs in ({}, {"TIC_SPLIT": "0"}, {"TIC_SPLIT": "1,1,1,1,1"}, {"TIC_SCHED": "0"}, {"TIC_SCHED": "1", "TIC_CHUNK": "5"},
+                      {"TIC_SCHED": "2"}, {"TIC_MAX_WGS": "512"}):
+            for k in ("TIC_SPLIT", "TIC_SCHED", "TIC_CHUNK", "TIC_MAX_WGS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in knobs.items():
+                monkeypatch.setenv(k, v)
+            assert np.array_equal(f.run(50, N.KERNEL_HYBRID), ref), (name, knobs)
+        f.free()
 
 
 @pytest.mark.parametrize("q", [10, 50, 90])

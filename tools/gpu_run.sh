@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs a list of GPU steps on the gpurun box, each under its own timeout; stops at the first step that is killed
 # by its timeout (never starts another GPU step after a hang).  Usage: tools/gpu_run.sh step1 step2 ...
-# Steps: microbench | tests | tests_fast | smoke | bench | bench_exact | prof | pmc | bench16k
+# Steps: microbench[2|3] | tests | tests_fast | tests_all | smoke | bench | bench_exact | bench16k | sweep | ablate | ab |
+#        stamps | prof | pmc_rd | pmc_wr | pmc_sq | pmc_sq2 | pmc_cal | pmc_cal_wr   (binaries: make -C tools)
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
@@ -18,6 +19,11 @@ run() { # name timeout cmd...
 for step in "$@"; do
   case $step in
     microbench) run microbench 240 ./tools/bin/microbench ;;
+    microbench2) run microbench2 240 ./tools/bin/microbench2 ;;
+    microbench3) run microbench3 240 ./tools/bin/microbench3 ;;
+    ablate)     run ablate 300 python tools/ablate.py ;;
+    stamps)     run stamps 200 python tools/stamps.py ;;
+    ab)         run ab 600 python tools/ab.py --variants 2,12,15,18,20 "" ;;
     tests)      run pytest_gpu 900 python -m pytest tests -m gpu -x -q ;;
     tests_fast) run pytest_gpu_fast 600 python -m pytest tests -m gpu -x -q -k "not 16384" ;;
     tests_all)  run pytest_gpu_all 900 python -m pytest tests -m gpu -q ;;
