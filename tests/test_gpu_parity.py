@@ -460,6 +460,20 @@ def test_error_paths(ctx):
     assert L.tic_dctq(ctx.handle, img.ctypes.data, 16, 16, 8, 50, zz.ctypes.data) == N.TIC_E_ARG
     assert b"stride" in L.tic_last_error(ctx.handle)
     assert T.compress(np.zeros((0, 8), np.uint8), 50, ctx=ctx).hex() == "00000000080000003200000000000000"
+    # device entropy stage: a stream buffer that is too small is reported, never overrun (guard bytes stay intact)
+    img = rand_frame(2, 256, 256)
+    f = DevFrame(ctx, img)
+    cap, guard = 4096, 4096
+    d_s = C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, cap + guard, C.byref(d_s)))
+    ctx.check(L.tic_memset_dev(ctx.handle, d_s, 0xA5, cap + guard))
+    n = C.c_size_t()
+    assert L.tic_compress_dev(ctx.handle, f.d_img, 256, 256, f.pitch, 50, d_s, cap, C.byref(n)) == N.TIC_E_SPACE
+    tail = np.empty(guard, np.uint8)
+    ctx.check(L.tic_memcpy_d2h(ctx.handle, tail.ctypes.data, C.c_void_p(d_s.value + cap), guard))
+    assert (tail == 0xA5).all()
+    L.tic_dev_free(ctx.handle, d_s)
+    f.free()
 
 
 def test_coefficient_without_huffman_code_raises_keyerror(ctx, golden):

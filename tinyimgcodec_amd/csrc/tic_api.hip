@@ -65,6 +65,7 @@ struct tic_ctx {
     void *d_scan_tmp = nullptr;
     size_t ent_blocks_cap = 0, scan_tmp_cap = 0;
     int *d_err = nullptr;
+    unsigned long long *d_total_bits = nullptr; // payload size of the last device entropy stage
     void *d_stream_buf = nullptr;
     size_t d_stream_cap = 0;
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
@@ -150,7 +151,7 @@ void tic_destroy(tic_ctx *ctx) {
     if (ctx->d_nbits) (void)hipFree(ctx->d_nbits);
     if (ctx->d_bitoff) (void)hipFree(ctx->d_bitoff);
     if (ctx->d_scan_tmp) (void)hipFree(ctx->d_scan_tmp);
-    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->d_total_bits) (void)hipFree(ctx->d_total_bits); // d_err lives in the same block
     if (ctx->d_stream_buf) (void)hipFree(ctx->d_stream_buf);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -189,7 +190,9 @@ static int create_impl(tic_ctx *ctx, int device) {
         build_huff_dev(&hd);
         CK(hipMalloc((void **)&ctx->d_huff, sizeof(HuffDev)));
         CK(hipMemcpy(ctx->d_huff, &hd, sizeof(HuffDev), hipMemcpyHostToDevice));
-        CK(hipMalloc((void **)&ctx->d_err, sizeof(int)));
+        // one 16-byte status block: payload bits of the last device entropy stage, then its error flag
+        CK(hipMalloc((void **)&ctx->d_total_bits, 16));
+        ctx->d_err = reinterpret_cast<int *>(ctx->d_total_bits + 1);
     }
     CK(hipMalloc((void **)&ctx->d_fallback, sizeof(unsigned long long)));
     CK(hipMemset(ctx->d_fallback, 0, sizeof(unsigned long long)));
@@ -443,12 +446,13 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size");
     if (quality < 1 || quality > 99) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
     if (!d_out || cap < 16) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+    if (((uintptr_t)d_out & 15u) != 0) return set_err(ctx, TIC_E_ARG, "device output buffer must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = num_blocks(h, w);
-    uint8_t hdr[16];
-    write_header(hdr, h, w, quality);
-    HIPCHK(ctx, hipMemcpyAsync(d_out, hdr, 16, hipMemcpyHostToDevice, ctx->stream));
     if (n == 0) {
+        uint8_t hdr[16];
+        write_header(hdr, h, w, quality);
+        HIPCHK(ctx, hipMemcpyAsync(d_out, hdr, 16, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         *out_len = 16;
         return TIC_OK;
@@ -472,29 +476,27 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
         HIPCHK(ctx, hipMalloc(&ctx->d_scan_tmp, tmp ? tmp : 16));
         ctx->scan_tmp_cap = tmp;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_nbits + n, 0, sizeof(uint32_t), ctx->stream)); // scan n+1 entries: last = total
-    // step 1+2: bits per block, exclusive scan (the entry after the last block receives the payload size in bits)
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_total_bits, 0, 16, ctx->stream)); // status block: size and error flag
+    // step 1+2: bits per block, exclusive scan
     HIPCHK(ctx, entropy_gpu_count((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_nbits, ctx->d_bitoff,
                                   ctx->d_scan_tmp, tmp, ctx->d_err, ctx->stream));
-    // entropy_gpu_count scans n entries; fold the last count in on the host side
-    unsigned long long last_off = 0;
-    uint32_t last_bits = 0;
-    int err = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&last_off, ctx->d_bitoff + (n - 1), sizeof last_off, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&last_bits, ctx->d_nbits + (n - 1), sizeof last_bits, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&err, ctx->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (err) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
-    const unsigned long long total_bits = last_off + last_bits;
-    const size_t payload = (size_t)((total_bits + 7) / 8);
-    const size_t words = (size_t)((total_bits + 31) / 32);
-    if (16 + words * 4 > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small (%zu bytes needed)", 16 + words * 4);
-    // step 3: pack.  Shared words are OR-ed into zeroed memory; the zero fill also is the stream's final padding
-    HIPCHK(ctx, hipMemsetAsync((char *)d_out + 16, 0, words * 4, ctx->stream));
+    // step 3: pack, without a host round trip in between: a small kernel publishes the payload size and zeroes exactly
+    // those words (shared words are OR-ed into zeros; the zero fill also is the stream's final padding), the emit kernel
+    // refuses to write past the caller's buffer
+    const size_t cap_words = ((cap - 16) / 16) * 4; // whole 16-byte units behind the header
+    HIPCHK(ctx, entropy_gpu_zero_payload(ctx->d_nbits, ctx->d_bitoff, n, (uint32_t *)((char *)d_out + 16), cap_words,
+                                         ctx->d_total_bits, ctx->d_err, h, w, quality, ctx->stream));
     HIPCHK(ctx, entropy_gpu_emit((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_bitoff,
-                                 (uint32_t *)((char *)d_out + 16), 0, ctx->d_err, ctx->stream));
+                                 (uint32_t *)((char *)d_out + 16), 0, cap_words, ctx->d_err, ctx->stream));
+    unsigned long long status[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_total_bits, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long total_bits = status[0];
+    const int err = (int)(status[1] & 0xffffffffull);
+    if (err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
+    const size_t payload = (size_t)((total_bits + 7) / 8);
+    if (err == 2 || 16 + payload > cap)
+        return set_err(ctx, TIC_E_SPACE, "output buffer too small (%zu bytes needed)", 16 + (size_t)((total_bits + 31) / 32) * 4);
     *out_len = 16 + payload;
     return TIC_OK;
 }
@@ -765,7 +767,8 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     auto finish = [&](Slot &s, hipStream_t st) -> int {
         if (s.count == 0) return TIC_OK;
         if (hipEventSynchronize(s.done) != hipSuccess) return set_err(ctx, TIC_E_HIP, "batch chunk failed");
-        if (*s.h_err) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
+        if (*s.h_err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
+        if (*s.h_err) return set_err(ctx, TIC_E_SPACE, "device entropy stage: stream buffer too small");
         for (int k = 0; k < s.count; k++) {
             const size_t len = (size_t)s.h_lens[k];
             const int f = s.first + k;
@@ -809,7 +812,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
             e = entropy_gpu_finish_frames(s.d_nbits, s.d_bitoff, nblk, cnt, h, w, quality, s.d_streams, bound, s.d_lens, st);
         if (e == hipSuccess)
             e = entropy_gpu_emit((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_bitoff,
-                                 (uint32_t *)((char *)s.d_streams + 16), bound, s.d_err, st);
+                                 (uint32_t *)((char *)s.d_streams + 16), bound, (bound - 16) / 4, s.d_err, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_lens, s.d_lens, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(s.done, st);

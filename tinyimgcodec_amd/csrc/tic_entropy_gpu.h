@@ -19,10 +19,18 @@ hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, size_t blocks_
                              uint32_t *d_nbits, unsigned long long *d_bitoff, void *d_temp, size_t temp_bytes, int *d_err,
                              hipStream_t stream);
 // d_payload_words = first payload word of frame 0 (16 bytes after its buffer start); frame f's buffer starts
-// out_frame_stride bytes further.  The payload words must be zero on entry.
+// out_frame_stride bytes further and holds cap_words payload words.  The payload words must be zero on entry.
+// *d_err becomes 2 if a frame's payload does not fit.
 hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
-                            const unsigned long long *d_bitoff, uint32_t *d_payload_words, size_t out_frame_stride, int *d_err,
-                            hipStream_t stream);
+                            const unsigned long long *d_bitoff, uint32_t *d_payload_words, size_t out_frame_stride,
+                            size_t cap_words, int *d_err, hipStream_t stream);
+// One frame, no host round trip: publishes the payload size in bits (d_nbits/d_bitoff of entropy_gpu_count), writes
+// the 16-byte header in front of the payload and zeroes the payload words (at most cap_words; *d_err becomes 2 when
+// the payload needs more).  cap_words*4 must be a
+// multiple of 16 or the buffer must extend to the next 16-byte boundary.
+hipError_t entropy_gpu_zero_payload(const uint32_t *d_nbits, const unsigned long long *d_bitoff, size_t nblocks,
+                                    uint32_t *d_payload_words, size_t cap_words, unsigned long long *d_total_bits, int *d_err,
+                                    int h, int w, int quality, hipStream_t stream);
 // Writes each frame's header at the start of its buffer and its stream length (bytes) into d_lens[f].
 hipError_t entropy_gpu_finish_frames(const uint32_t *d_nbits, const unsigned long long *d_bitoff, size_t blocks_per_frame,
                                      int nframes, int h, int w, int quality, void *d_out, size_t out_frame_stride,
