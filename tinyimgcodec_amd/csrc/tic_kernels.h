@@ -46,7 +46,6 @@ struct DctqArgs {
     int nframes;
     long frame_stride_in, frame_stride_out;
     unsigned long long *dbg; // diagnostic builds only: per-wave s_memtime stamps (8 per wave), else null
-    int stagger; // tuning: waves with an odd index start after ~64*stagger cycles (de-phases the waves of a SIMD)
 };
 
 struct IdctArgs {

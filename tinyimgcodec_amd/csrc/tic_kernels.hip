@@ -499,10 +499,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
         const uint4 *zr = reinterpret_cast<const uint4 *>(
             __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (4 * ((i >> 1) & 1)))), 16));
-        if (a.stagger > 0) { // optional de-phasing of the waves that share a SIMD (loads above are already in flight)
-            const int mine = (wave & 1) * a.stagger + ((blockIdx.x >> 3) & 1) * (a.stagger >> 1);
-            for (int k = 0; k < mine; k++) __builtin_amdgcn_s_sleep(1);
-        }
 
         // one strip: everything from the pixel row held in px to the 1 KiB store, then the schedule advances
         int left = n_my;
@@ -1170,7 +1166,7 @@ static inline int grid_for(int ntiles) { return (ntiles + kWavesPerWG - 1) / kWa
 
 // Tuning knobs (environment): read once, or at every launch when TIC_TUNE is set (experiment scripts).
 struct Tunables {
-    int max_wgs, sched, chunk, lds_pad;
+    int max_wgs, sched, chunk, lds_pad, nocap;
     int split[8];
 };
 static Tunables read_tunables() {
@@ -1187,6 +1183,7 @@ static Tunables read_tunables() {
         sp = strchr(sp, ',');
         if (sp) sp++;
     }
+    t.nocap = geti("TIC_NOCAP", 0);                 // experiment, timing builds only: ignore the trip-list capacity
     t.lds_pad = geti("TIC_LDS_PAD", 0);             // experiment: extra dynamic LDS per workgroup (lowers occupancy)
     return t;
 }
@@ -1202,8 +1199,6 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     a.nwaves = a.step_ty = a.step_tx = 0;
     a.fast_ty = a.fast_tx = 0;
     a.rem_mode = 0;
-    static const int stagger_env = getenv("TIC_STAGGER") ? atoi(getenv("TIC_STAGGER")) : 0;
-    a.stagger = stagger_env;
     if (variant != 17) a.dbg = nullptr;
     const int nf = a.nframes > 0 ? a.nframes : 1;
     if (variant == 1) {
@@ -1246,7 +1241,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         if (cap < 64) cap = 64;
         if (wgs > cap) wgs = cap;
         const int min_wgs = (nfast + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
-        if (wgs < min_wgs) wgs = min_wgs; // the per-wave trip list holds kMaxStripsPerWave entries
+        if (wgs < min_wgs && !(tune.nocap && variant >= 10)) wgs = min_wgs; // the per-wave trip list holds kMaxStripsPerWave entries
         a.nwaves = wgs * kWavesPerWG;
         a.wg_stride = kWavesPerWG;
         a.tstep = a.nwaves;
@@ -1255,7 +1250,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.round_wgs = 0;
         a.team_count = 0;
         const int S = chunk_env < 1 ? 1 : (chunk_env > kMaxStripsPerWave ? kMaxStripsPerWave : chunk_env);
-        const bool multi_round = (long)min_wgs * nf > (long)cap_env; // more workgroups than the chip holds at once
+        const bool multi_round = (long)min_wgs * nf > (long)cap_env && !(tune.nocap && variant >= 10); // more workgroups than the chip holds at once
         if (sched_env == 1 && multi_round) { // each workgroup streams a contiguous chunk of 4*S strips
             a.wg_stride = a.wg_span = kWavesPerWG * S;
             a.tstep = kWavesPerWG;

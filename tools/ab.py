@@ -14,7 +14,7 @@ ap.add_argument("--variants", default="2,12,15")
 ap.add_argument("settings", nargs="*", default=[""])
 args = ap.parse_args()
 L = N.load(); ctx = T.Context(0)
-KNOBS = ("TIC_MAX_WGS", "TIC_SCHED", "TIC_CHUNK", "TIC_LDS_PAD", "TIC_SPLIT")
+KNOBS = ("TIC_MAX_WGS", "TIC_SCHED", "TIC_CHUNK", "TIC_LDS_PAD", "TIC_SPLIT", "TIC_NOCAP")
 names = {2: "full", 12: "no post-pass", 15: "skeleton", 10: "no arithmetic", 1: "exact", 18: "compute only", 19: "compute only, no LDS", 20: "compute only, no arithmetic", 40: "lane kernel", 41: "lane kernel, rare paths off"}
 def apply(setting):
     for k in KNOBS: os.environ.pop(k, None)
