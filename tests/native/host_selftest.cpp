@@ -1,0 +1,102 @@
+// host_selftest.cpp - the product's host entropy coder (tic_entropy.cpp) against the oracle's (tic_oracle.c) on random and
+// adversarial coefficient blocks, built with AddressSanitizer + UBSan (CPU only; tests/test_host_cpu.py runs it).
+// Checks: identical streams, decode(encode(x)) == x, bounded writes (exact-size buffers), clean errors on truncated
+// and corrupted streams.  The oracle is the checker here, as everywhere under tests/.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../tinyimgcodec_amd/csrc/tic_entropy.h"
+extern "C" {
+#include "../../oracle/tic_oracle.h"
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd() {
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return (uint32_t)(rng_state >> 32);
+}
+
+static int fail(const char *what, int h, int w, int mode) {
+    fprintf(stderr, "FAIL %s (h=%d w=%d mode=%d)\n", what, h, w, mode);
+    return 1;
+}
+
+int main() {
+    static const int kZig[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    (void)kZig;
+    int cases = 0;
+    const int shapes[][2] = {{8, 8}, {1, 1}, {8, 72}, {40, 24}, {17, 33}, {64, 64}, {0, 8}};
+    for (auto &sh : shapes) {
+        const int h = sh[0], w = sh[1];
+        const size_t n = tic::num_blocks(h, w);
+        for (int mode = 0; mode < 6; mode++) {
+            // zig-zag int16 coefficients with un-differenced DC, as the transform kernels produce them
+            std::vector<int16_t> zz(n * 64 + 1);
+            for (size_t b = 0; b < n; b++)
+                for (int k = 0; k < 64; k++) {
+                    int v = 0;
+                    const uint32_t r = rnd();
+                    switch (mode) {
+                    case 0: v = (int)(r % 41) - 20; break;                                  // dense small values
+                    case 1: v = (r % 7 == 0) ? (int)(r >> 8) % 2047 - 1023 : 0; break;      // sparse, full AC range
+                    case 2: v = (k == 0) ? (int)(r % 2047) - 1023 : 0; break;               // DC only (EOB right away)
+                    case 3: v = (k == 63 || k == 0) ? 1 : 0; break;                         // longest zero run + ZRLs
+                    case 4: v = (k % 17 == 16) ? -1023 : 0; break;                          // runs of exactly 16
+                    default: v = (int)(r % 2047) - 1023; break;                             // everything maximal
+                    }
+                    if (k == 0) v = (v > 1023) ? 1023 : (v < -1023 ? -1023 : v);            // keeps DC differences codable
+                    zz[b * 64 + k] = (int16_t)v;
+                }
+            std::vector<int32_t> dc(n + 1), ac(n * 63 + 1);
+            for (size_t b = 0; b < n; b++) {
+                dc[b] = (int32_t)zz[b * 64] - (b ? (int32_t)zz[(b - 1) * 64] : 0);
+                for (int k = 1; k < 64; k++) ac[b * 63 + k - 1] = zz[b * 64 + k];
+            }
+            const size_t bound = tic::compress_bound(h, w);
+            std::vector<uint8_t> ref(bound + 16);
+            size_t ref_len = 0;
+            const int rc_ref = tico_entropy_encode(dc.data(), ac.data(), h, w, 50, ref.data(), ref.size(), &ref_len);
+            size_t got_len = 0;
+            std::vector<uint8_t> probe(bound);
+            const int rc = tic::entropy_encode(zz.data(), h, w, 50, probe.data(), probe.size(), &got_len);
+            if ((rc == 0) != (rc_ref == 0)) return fail("encoders disagree on codability", h, w, mode);
+            cases++;
+            if (rc != 0) continue; // |DC difference| > 2047 has no code in either coder
+            if (got_len != ref_len || memcmp(probe.data(), ref.data(), ref_len) != 0) return fail("stream mismatch", h, w, mode);
+            // exact-size output buffer (ASan guards its end), then one byte too small
+            std::vector<uint8_t> exact(got_len);
+            size_t l2 = 0;
+            if (tic::entropy_encode(zz.data(), h, w, 50, exact.data(), exact.size(), &l2) != 0 || l2 != got_len)
+                return fail("exact-size buffer rejected", h, w, mode);
+            if (got_len > 16) {
+                std::vector<uint8_t> small(got_len - 1);
+                if (tic::entropy_encode(zz.data(), h, w, 50, small.data(), small.size(), &l2) == 0)
+                    return fail("undersized buffer accepted", h, w, mode);
+            }
+            // decode
+            std::vector<int16_t> back(n * 64 + 1, (int16_t)0x5A5A);
+            if (tic::entropy_decode(exact.data(), exact.size(), h, w, back.data()) != 0) return fail("decode failed", h, w, mode);
+            if (n && memcmp(back.data(), zz.data(), n * 128) != 0) return fail("round trip mismatch", h, w, mode);
+            // truncated and corrupted streams must fail or decode within bounds, never touch memory outside
+            for (size_t cut = 16; cut < exact.size(); cut += 1 + exact.size() / 23) {
+                std::vector<uint8_t> t(exact.begin(), exact.begin() + cut);
+                (void)tic::entropy_decode(t.data(), t.size(), h, w, back.data());
+            }
+            for (int k = 0; k < 32 && exact.size() > 16; k++) {
+                std::vector<uint8_t> t(exact);
+                t[16 + rnd() % (t.size() - 16)] ^= (uint8_t)(1u << (rnd() & 7));
+                (void)tic::entropy_decode(t.data(), t.size(), h, w, back.data());
+            }
+        }
+    }
+    printf("host_selftest ok: %d cases\n", cases);
+    return 0;
+}

@@ -138,3 +138,23 @@ def test_entropy_errors():
         T.entropy_encode(zz, 8, 8, 50)
     zz[0, 5] = 1023
     assert len(T.entropy_encode(zz, 8, 8, 50)) > 16
+
+
+def test_host_entropy_coder_under_sanitizers(tmp_path):
+    """The product's host Huffman/RLE coder and decoder, built with AddressSanitizer + UBSan, against the oracle's coder
+    on dense / sparse / maximal / long-run coefficient blocks: same streams, exact-size and undersized buffers, round
+    trips, truncated and corrupted streams (GPU sanitizers are not available on the pool; this is the CPU build)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None or shutil.which("gcc") is None:
+        pytest.skip("no host compiler")
+    exe = tmp_path / "host_selftest"
+    obj = tmp_path / "tic_oracle.o"
+    flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    subprocess.run(["gcc", "-c", *flags, "-o", str(obj), os.path.join(root, "oracle", "tic_oracle.c")], check=True)
+    subprocess.run(["g++", "-std=c++17", *flags, "-o", str(exe), os.path.join(root, "tests", "native", "host_selftest.cpp"),
+                    os.path.join(root, "tinyimgcodec_amd", "csrc", "tic_entropy.cpp"), str(obj), "-lm"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host_selftest ok" in r.stdout
