@@ -31,7 +31,8 @@ struct Slot {
     void *d_coef = nullptr;
     hipEvent_t done = nullptr;
     // device entropy stage of the chunk
-    uint32_t *d_nbits = nullptr;
+    uint32_t *d_nbits = nullptr; // nb_cap block counts, then nb_cap x 8 per-lane counts (bytes)
+    size_t nb_cap = 0;
     unsigned long long *d_bitoff = nullptr;
     void *d_tmp = nullptr;
     size_t tmp_bytes = 0;
@@ -464,7 +465,7 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
         ctx->d_nbits = nullptr;
         ctx->d_bitoff = nullptr;
         ctx->ent_blocks_cap = 0;
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_nbits, (n + 1) * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_nbits, (n + 1) * sizeof(uint32_t) + n * 8)); // + bits per lane (8 per block)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_bitoff, (n + 1) * sizeof(unsigned long long)));
         ctx->ent_blocks_cap = n + 1;
     }
@@ -478,7 +479,8 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_total_bits, 0, 16, ctx->stream)); // status block: size and error flag
     // step 1+2: bits per block, exclusive scan
-    HIPCHK(ctx, entropy_gpu_count((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_nbits, ctx->d_bitoff,
+    uint8_t *d_lanebits = reinterpret_cast<uint8_t *>(ctx->d_nbits + (n + 1));
+    HIPCHK(ctx, entropy_gpu_count((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_nbits, d_lanebits, ctx->d_bitoff,
                                   ctx->d_scan_tmp, tmp, ctx->d_err, ctx->stream));
     // step 3: pack, without a host round trip in between: a small kernel publishes the payload size and zeroes exactly
     // those words (shared words are OR-ed into zeros; the zero fill also is the stream's final padding), the emit kernel
@@ -486,7 +488,7 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     const size_t cap_words = ((cap - 16) / 16) * 4; // whole 16-byte units behind the header
     HIPCHK(ctx, entropy_gpu_zero_payload(ctx->d_nbits, ctx->d_bitoff, n, (uint32_t *)((char *)d_out + 16), cap_words,
                                          ctx->d_total_bits, ctx->d_err, h, w, quality, ctx->stream));
-    HIPCHK(ctx, entropy_gpu_emit((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_bitoff,
+    HIPCHK(ctx, entropy_gpu_emit((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_bitoff, d_lanebits,
                                  (uint32_t *)((char *)d_out + 16), 0, cap_words, ctx->d_err, ctx->stream));
     unsigned long long status[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_total_bits, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -598,8 +600,9 @@ static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
                 (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
                 return set_err(ctx, TIC_E_HIP, "batch buffer allocation failed: %s", hipGetErrorString(e));
             const size_t nb = nblk * (size_t)chunk;
+            sl.nb_cap = nb;
             sl.tmp_bytes = entropy_gpu_scan_temp_bytes(nb);
-            if ((e = hipMalloc((void **)&sl.d_nbits, nb * sizeof(uint32_t))) != hipSuccess ||
+            if ((e = hipMalloc((void **)&sl.d_nbits, nb * sizeof(uint32_t) + nb * 8)) != hipSuccess || // + bits per lane
                 (e = hipMalloc((void **)&sl.d_bitoff, nb * sizeof(unsigned long long))) != hipSuccess ||
                 (e = hipMalloc(&sl.d_tmp, sl.tmp_bytes ? sl.tmp_bytes : 16)) != hipSuccess ||
                 (e = hipMalloc((void **)&sl.d_lens, chunk * sizeof(unsigned long long))) != hipSuccess ||
@@ -805,13 +808,13 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         }
         if (e == hipSuccess) e = hipMemsetAsync(s.d_err, 0, sizeof(int), st);
         if (e == hipSuccess)
-            e = entropy_gpu_count((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_nbits, s.d_bitoff, s.d_tmp, s.tmp_bytes,
-                                  s.d_err, st);
+            e = entropy_gpu_count((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_nbits, (uint8_t *)(s.d_nbits + s.nb_cap),
+                                  s.d_bitoff, s.d_tmp, s.tmp_bytes, s.d_err, st);
         if (e == hipSuccess) e = hipMemsetAsync(s.d_streams, 0, bound * cnt, st); // shared words are OR-ed into zeros
         if (e == hipSuccess)
             e = entropy_gpu_finish_frames(s.d_nbits, s.d_bitoff, nblk, cnt, h, w, quality, s.d_streams, bound, s.d_lens, st);
         if (e == hipSuccess)
-            e = entropy_gpu_emit((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_bitoff,
+            e = entropy_gpu_emit((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_bitoff, (const uint8_t *)(s.d_nbits + s.nb_cap),
                                  (uint32_t *)((char *)s.d_streams + 16), bound, (bound - 16) / 4, s.d_err, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_lens, s.d_lens, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err, sizeof(int), hipMemcpyDeviceToHost, st);

@@ -14,16 +14,17 @@ void build_huff_dev(HuffDev *t);
 
 size_t entropy_gpu_scan_temp_bytes(size_t nblocks);
 // nblocks = blocks of all frames (blocks_per_frame each; DPCM restarts at every frame).  nbits / bitoff hold
-// nblocks entries; bitoff = exclusive scan of nbits over the whole batch, in bits.
+// nblocks entries; bitoff = exclusive scan of nbits over the whole batch, in bits.  d_lanebits (8 bytes per block) receives
+// the bits of each of the 8 lanes of a block for the emit kernel.
 hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
-                             uint32_t *d_nbits, unsigned long long *d_bitoff, void *d_temp, size_t temp_bytes, int *d_err,
-                             hipStream_t stream);
+                             uint32_t *d_nbits, uint8_t *d_lanebits, unsigned long long *d_bitoff, void *d_temp,
+                             size_t temp_bytes, int *d_err, hipStream_t stream);
 // d_payload_words = first payload word of frame 0 (16 bytes after its buffer start); frame f's buffer starts
 // out_frame_stride bytes further and holds cap_words payload words.  The payload words must be zero on entry.
 // *d_err becomes 2 if a frame's payload does not fit.
 hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
-                            const unsigned long long *d_bitoff, uint32_t *d_payload_words, size_t out_frame_stride,
-                            size_t cap_words, int *d_err, hipStream_t stream);
+                            const unsigned long long *d_bitoff, const uint8_t *d_lanebits, uint32_t *d_payload_words,
+                            size_t out_frame_stride, size_t cap_words, int *d_err, hipStream_t stream);
 // One frame, no host round trip: publishes the payload size in bits (d_nbits/d_bitoff of entropy_gpu_count), writes
 // the 16-byte header in front of the payload and zeroes the payload words (at most cap_words; *d_err becomes 2 when
 // the payload needs more).  cap_words*4 must be a

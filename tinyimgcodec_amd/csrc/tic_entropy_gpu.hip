@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void entropy_bits_kernel(const int16_t *__rest
                                                            const HuffDev *__restrict__ tab, uint32_t *__restrict__ nbits,
                                                            const unsigned long long *__restrict__ bitoff,
                                                            uint32_t *__restrict__ out_words, int *__restrict__ err_flag,
-                                                           unsigned long long blocks_per_frame, unsigned long long out_frame_stride) {
+                                                           unsigned long long blocks_per_frame, unsigned long long out_frame_stride,
+                                                           uint8_t *__restrict__ lanebits) {
     __shared__ uint32_t ac_tab[256];
     __shared__ uint32_t dc_tab[16];
     ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void entropy_bits_kernel(const int16_t *__rest
         if (k >= d) incl += p;
     }
     if (!EMIT) {
+        if (valid && lanebits) lanebits[t] = (uint8_t)my_bits; // at most 8 x 27 bits: the emit kernel need not walk twice
         if (valid && k == 7) nbits[blk] = (uint32_t)incl;
         if (err && valid) atomicMax(err_flag, 1);
         return;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void entropy_emit_kernel(const int16_t *__rest
                                                            uint32_t *__restrict__ out_words, int *__restrict__ err_flag,
                                                            unsigned long long blocks_per_frame, int nframes,
                                                            unsigned long long waves_per_frame, unsigned long long out_frame_stride,
-                                                           unsigned long long cap_words) {
+                                                           unsigned long long cap_words, const uint8_t *__restrict__ lanebits) {
     __shared__ uint32_t ac_tab[256];
     __shared__ uint32_t dc_tab[16];
     __shared__ uint32_t image_all[4][kWaveImageWords];
@@ -281,8 +283,7 @@ __global__ __launch_bounds__(256) void entropy_emit_kernel(const int16_t *__rest
     }
     int carry = __shfl_up(tz, 1, 8);
     if (k == 0) carry = 0;
-    int err = 0;
-    const int my_bits = valid ? walk_lane<false>(c, k, carry, dc_diff, ac_tab, dc_tab, (LdsSink *)nullptr, &err) : 0;
+    const int my_bits = valid ? (int)lanebits[blk * 8ull + (unsigned long long)k] : 0; // counted by entropy_bits_kernel
     int incl = my_bits;
 #pragma unroll
     for (int d = 1; d < 8; d <<= 1) {
@@ -342,13 +343,13 @@ size_t entropy_gpu_scan_temp_bytes(size_t nblocks) {
 }
 
 hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
-                             uint32_t *d_nbits, unsigned long long *d_bitoff, void *d_temp, size_t temp_bytes, int *d_err,
-                             hipStream_t stream) {
+                             uint32_t *d_nbits, uint8_t *d_lanebits, unsigned long long *d_bitoff, void *d_temp,
+                             size_t temp_bytes, int *d_err, hipStream_t stream) {
     if (nblocks == 0) return hipSuccess;
     const unsigned grid = (unsigned)((nblocks * 8 + 255) / 256);
     hipLaunchKernelGGL(entropy_bits_kernel<false>, dim3(grid), dim3(256), 0, stream, d_zz, (unsigned long long)nblocks, d_tab,
                        d_nbits, (const unsigned long long *)nullptr, (uint32_t *)nullptr, d_err,
-                       (unsigned long long)blocks_per_frame, 0ull);
+                       (unsigned long long)blocks_per_frame, 0ull, d_lanebits);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     auto in = rocprim::make_transform_iterator((const uint32_t *)d_nbits, U32ToU64());
@@ -356,15 +357,15 @@ hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, size_t blocks_
 }
 
 hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
-                            const unsigned long long *d_bitoff, uint32_t *d_payload_words, size_t out_frame_stride,
-                            size_t cap_words, int *d_err, hipStream_t stream) {
+                            const unsigned long long *d_bitoff, const uint8_t *d_lanebits, uint32_t *d_payload_words,
+                            size_t out_frame_stride, size_t cap_words, int *d_err, hipStream_t stream) {
     if (nblocks == 0 || blocks_per_frame == 0) return hipSuccess;
     const size_t nframes = nblocks / blocks_per_frame;
     const size_t waves_per_frame = (blocks_per_frame + 7) / 8;
     const unsigned grid = (unsigned)((nframes * waves_per_frame + 3) / 4);
     hipLaunchKernelGGL(entropy_emit_kernel, dim3(grid), dim3(256), 0, stream, d_zz, d_tab, d_bitoff, d_payload_words, d_err,
                        (unsigned long long)blocks_per_frame, (int)nframes, (unsigned long long)waves_per_frame,
-                       (unsigned long long)out_frame_stride, (unsigned long long)cap_words);
+                       (unsigned long long)out_frame_stride, (unsigned long long)cap_words, d_lanebits);
     return hipGetLastError();
 }
 

@@ -13,9 +13,10 @@
 //
 // Two arithmetic paths, bit-identical results:
 //   exact  : float64, scipy/pocketfft operation order for all 64 coefficients (tic_math.h dct8_exact).
-//   hybrid : float32 AAN butterflies for 60 coefficients, accepted only outside a guard band around the .5
-//            rounding ties; the 4 rational coefficients (0,0),(0,4),(4,0),(4,4) always on an exact float64
-//            sub-path; any block that trips the guard is redone on the exact path inside the same wave.
+//   hybrid : float32 AAN butterflies, every rounding accepted only outside a rigorous guard band around the .5 ties;
+//            blocks with a coefficient inside its band are settled after the loop in float64 (exact ties of the four
+//            rational coefficients by an exact sub-path, anything else by a second level and, if need be, the exact
+//            order).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -282,21 +283,27 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 // ---------------------------------------------------------------------------------------------------------
 // Kernel 2: hybrid path (the production kernel).
 //
-// Persistent waves: wave g of the grid owns strips g, g + nwaves, ... (strip = 8 horizontally adjacent blocks).
-// Main loop, per strip (lean: ~64 VGPRs, 8 waves per SIMD):
-//   load   : lane 8*r + b reads the 8 bytes of pixel row r of block b -> every 8 lanes read 64 contiguous bytes;
-//            two strips are kept in flight in registers (prefetch depth 2).
+// Persistent waves, each walking its strips (strip = 8 horizontally adjacent blocks) in the order the launcher chose:
+// team schedule when the grid fits the chip at once, chunked schedule for larger grids (launch_dctq).
+// Main loop, per strip (unrolled x3, pixel registers rotate by name; 94 VGPRs, 5 waves per SIMD):
+//   load   : lane 8*r + b reads the 8 bytes of pixel row r of block b -> every 8 lanes read 64 contiguous bytes; inline
+//            assembly + hand-counted vmcnt keep two strips in flight.
 //   pass 1 : float32 AAN along the pixel row held by the lane (no cross-lane traffic); the level shift is folded
 //            into output 0 (row sum - 1024, an exact integer).
-//   xpose  : 8x8 dword transpose per block through wave-private LDS; lane 8*b + v then holds column v.
-//   pass 2 : float32 AAN down that column; quantise by t = Z*mul with the magic-number rounding trick, twice
-//            (t+g and t-g): the two roundings differ exactly when a .5 tie lies inside the guard band.
+//   xpose  : 8x8 dword transpose per block through wave-private LDS (conflict-free slot layout); lane 8*b + v then
+//            holds column v.
+//   pass 2 : float32 AAN down that column; quantise by t = Z*mul with the magic-number rounding trick; the guard test is
+//            max |t - rint(t)| per lane against two per-column thresholds.
 //   store  : int16 results scattered to zig-zag order in LDS, read back 16 B per lane, 1 KiB contiguous per wave.
-//   trips  : a strip in which any lane tripped its guard band is recorded (8 bytes) in a wave-private LDS list.
-// After the loop the wave revisits its recorded strips: blocks whose only trips are exact ties of the four
-// rational coefficients (~2 % of blocks) get those four values from the exact float64 sub-path; blocks with any
-// other trip (~0.3 % at q=50) are redone entirely on the exact path.  Keeping this out of the loop keeps the loop's
+//   trips  : blocks of a strip in which a lane tripped its guard band are recorded in a wave-private LDS list, their
+//            pixels stashed.
+// After the loop the workgroup shares the recorded blocks: blocks whose only trips are exact ties of the four rational
+// coefficients (~2 % of blocks) get those four values from the exact float64 sub-path; blocks with any other trip
+// (~0.3 % at q=50) are redone on the float64 second level / exact path.  Keeping this out of the loop keeps the loop's
 // register footprint small.
+// Template parameter ABL: 0 = production; every other value is a timing-only build whose output is wrong by
+// construction (tools/ablate.py): 1 no arithmetic, 2 no LDS, 6 neither, 3 no post-pass, 4/5/7 parts of the post-pass,
+// 8 in-kernel stamps, 9/10/11 no memory traffic (all / without LDS / without arithmetic).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
 constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
