@@ -264,7 +264,10 @@ def test_one_block_per_lane_kernel_matches_exact(ctx, golden, shape):
 def test_strip_schedules_are_equivalent(ctx, monkeypatch):
     """Team / strided / chunked / round-interleaved walks (tuning knobs of launch_dctq) produce the same coefficients."""
     monkeypatch.setenv("TIC_TUNE", "1")  # re-read the knobs at every launch
-    frames = {"small grid": rand_frame(5, 1024, 1024), "large grid": rand_frame(6, 4096, 8192)}
+    frames = {"small grid": rand_frame(5, 1024, 1024), "large grid": rand_frame(6, 4096, 8192),
+              "team schedule, 65 strips per row": rand_frame(7, 2560, 4160),
+              "team schedule falls back (more than 16 rows in round 0)": rand_frame(8, 6144, 6144),
+              "ragged": rand_frame(9, 1999, 4171)}
     for name, img in frames.items():
         f = DevFrame(ctx, img)
         ref = f.run(50, N.KERNEL_EXACT)
