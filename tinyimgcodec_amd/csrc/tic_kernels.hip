@@ -661,13 +661,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
             const uint2 pv = stash_all[sw][((do_ties ? 0 : kStash) + idx) * 8 + i];
             lo = pv.x;
             hi = pv.y;
-        } else { // ... or from memory
-            Strip s;
-            s.by = (int)(blk / (uint32_t)a.bw);
-            s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
-            s.valid = true;
-            s.oblk = blk;
-            load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
+        } else { // ... or from memory: blocks of the fast rectangle are complete and 8-byte aligned
+            const uint32_t by = blk / (uint32_t)a.bw, bx = blk - by * (uint32_t)a.bw;
+            const uint2 pv = *reinterpret_cast<const uint2 *>(a.img + ((long)by * 8 + i) * a.stride + (long)bx * 8);
+            lo = pv.x;
+            hi = pv.y;
         }
         transpose8x8_bytes(lo, hi, i); // -> pixel column i
     };
