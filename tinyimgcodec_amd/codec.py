@@ -122,7 +122,11 @@ def compress_batch(images, quality=50, threads=0, ctx=None):
     L = N.load()
     n = len(frames)
     cap = L.tic_compress_bound(h, w)
-    pool = np.empty((n, cap), dtype=np.uint8)  # one mapping; only the bytes actually written are ever touched
+    # one mapping, kept on the context: only the bytes actually written are ever touched, and a second batch of the same
+    # geometry finds them already faulted in (first-touch page faults cost more than the whole GPU pipeline)
+    pool = getattr(ctx, "_batch_pool", None)
+    if pool is None or pool.shape[0] < n or pool.shape[1] != cap:
+        pool = ctx._batch_pool = np.empty((n, cap), dtype=np.uint8)
     outs = [pool[i] for i in range(n)]
     inp = (C.c_void_p * n)(*[f[0].ctypes.data for f in frames])
     outp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
