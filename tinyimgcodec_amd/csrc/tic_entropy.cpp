@@ -31,10 +31,28 @@ struct EncTables {
         uint16_t count[17];
         uint16_t base[17];
         uint8_t sym[256];
+        // fast path: the next 16 stream bits -> (code length << 8) | symbol, 0 when no codeword is a prefix of them
+        uint16_t lut[65536];
+        uint16_t lut11[2048]; // same for codewords of at most 11 bits (L1-resident); 0 = look in lut
     } dcd, acd;
     EncTables() {
         build(kDcBits, kDcVals, dc_code, dc_len, 16, dcd);
         build(kAcBits, kAcVals, ac_code, ac_len, 256, acd);
+        build_lut(dcd);
+        build_lut(acd);
+    }
+    static void build_lut(Dec &d) {
+        for (int i = 0; i < 65536; i++) d.lut[i] = 0;
+        for (int l = 1; l <= 16; l++)
+            for (int i = 0; i < d.count[l]; i++) {
+                const unsigned code = (unsigned)d.first[l] + (unsigned)i;
+                const unsigned lo = code << (16 - l), hi = lo + (1u << (16 - l));
+                for (unsigned v = lo; v < hi; v++) d.lut[v] = (uint16_t)((l << 8) | d.sym[d.base[l] + i]);
+            }
+        for (int i = 0; i < 2048; i++) {
+            const uint16_t e = d.lut[i << 5];
+            d.lut11[i] = (e >> 8) <= 11 ? e : 0;
+        }
     }
     static void build(const uint8_t bits[16], const uint8_t *vals, uint32_t *code_out, uint8_t *len_out, int nsym,
                       Dec &d) {
@@ -209,8 +227,23 @@ struct BitReader {
     }
 };
 
+// Fast path while at least 64 bits remain: the 32 stream bits starting at the read position (MSB first).
+inline uint32_t peek32(const BitReader &r) {
+    uint64_t w;
+    memcpy(&w, r.p + (r.pos >> 3), 8); // one unaligned load; the caller guarantees 8 readable bytes
+    return (uint32_t)((__builtin_bswap64(w) << (r.pos & 7)) >> 32);
+}
+
 // huffman.py:66-74: grow the prefix bit by bit; fail (ValueError) after 17 reads.
 inline bool read_code(BitReader &r, const EncTables::Dec &d, int &sym) {
+    if (r.pos + 64 <= r.nbits) { // table lookup; an invalid prefix falls through to the bit-serial walk and its quirks
+        const uint16_t e = d.lut[peek32(r) >> 16];
+        if (e) {
+            sym = e & 0xff;
+            r.pos += e >> 8;
+            return true;
+        }
+    }
     unsigned code = 0;
     int len = 0;
     for (int i = 0; i <= 16; i++) {
@@ -235,6 +268,12 @@ inline bool read_int(BitReader &r, int size, int &out) {
         out = 0;
         return true;
     }
+    if (r.pos + 64 <= r.nbits) { // size <= 15 bits, all present
+        const uint32_t v = peek32(r) >> (32 - size);
+        r.pos += (size_t)size;
+        out = (v >> (size - 1)) ? (int)v : -(int)((~v) & ((1u << size) - 1u));
+        return true;
+    }
     uint32_t v = 0;
     int first = -1, got = 0;
     for (int i = 0; i < size; i++) {
@@ -255,6 +294,30 @@ inline bool read_int(BitReader &r, int size, int &out) {
 
 inline int16_t sat16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
 
+// One symbol and its value bits (huffman.py:77-98).  While 64 bits remain, a single 32-bit peek covers the codeword
+// (<= 16 bits) and the value (<= 15 bits); otherwise, and for prefixes that are no codeword, the bit-serial readers
+// above reproduce the reference's behaviour at the end of the stream.
+inline bool read_symbol(BitReader &r, const EncTables::Dec &d, int &sym, int &val) {
+    if (r.pos + 64 <= r.nbits) {
+        const uint32_t pk = peek32(r);
+        uint16_t e = d.lut11[pk >> 21];
+        if (!e) e = d.lut[pk >> 16];
+        if (e) {
+            const int len = e >> 8, size = e & 15;
+            sym = e & 0xff;
+            if (size == 0) {
+                val = 0;
+            } else {
+                const uint32_t v = (pk << len) >> (32 - size);
+                val = (v >> (size - 1)) ? (int)v : -(int)((~v) & ((1u << size) - 1u));
+            }
+            r.pos += (size_t)(len + size);
+            return true;
+        }
+    }
+    return read_code(r, d, sym) && read_int(r, sym & 15, val);
+}
+
 } // namespace
 
 int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
@@ -266,7 +329,74 @@ int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
     for (size_t b = 0; b < n; b++) {
         int16_t *c = zz + b * 64;
         int sym, v;
-        bool have_dc = read_code(r, T.dcd, sym) && read_int(r, sym, v);
+        // Fast path for a whole block while the stream is long enough for any valid block (<= 64 x 27 bits): table
+        // look-ups, coefficients written in place.  Anything unusual - a prefix that is no codeword, more than 63
+        // coefficients - rewinds to the block's first bit and takes the bit-serial path below, which reproduces the
+        // reference's behaviour on malformed streams.
+        if (r.pos + 2048 <= r.nbits) {
+            const size_t pos0 = r.pos;
+            // bit buffer in a register: `cnt` valid bits at the top of `buf`; branch-free refill to >= 56 bits before
+            // every symbol (a data-dependent refill branch mispredicts every few symbols and doubles the time)
+            const uint8_t *bp = r.p + (pos0 >> 3);
+            uint64_t buf;
+            memcpy(&buf, bp, 8);
+            buf = __builtin_bswap64(buf) << (pos0 & 7);
+            int cnt = 64 - (int)(pos0 & 7);
+            bp += 8;
+            size_t used = 0;
+            auto refill = [&]() {
+                uint64_t w8;
+                memcpy(&w8, bp, 8);
+                buf |= cnt < 64 ? __builtin_bswap64(w8) >> cnt : 0;
+                bp += (63 - (cnt > 63 ? 63 : cnt)) >> 3;
+                cnt |= 56;
+            };
+            auto value = [](uint64_t bits, int len, int size) -> int { // value bits follow the codeword
+                // branch-free (the sign bit is a coin flip): x with its top bit clear stands for x - (2^size - 1)
+                const int x = (int)(((bits << len) >> 1) >> (63 - size)); // size = 0 gives 0
+                const int half = (1 << size) >> 1;
+                const int neg_mask = (x - half) >> 31; // all ones when the top bit is clear
+                return x + (neg_mask & (1 - (1 << size)));
+            };
+            bool good = false;
+            uint16_t e = T.dcd.lut11[buf >> 53];
+            if (e) { // DC categories are at most 9 bits long
+                int len = e >> 8, size = e & 15;
+                const int dc = running_dc + value(buf, len, size);
+                buf <<= len + size;
+                cnt -= len + size;
+                used += (size_t)(len + size);
+                int k = 1;
+                for (;;) {
+                    refill();
+                    e = T.acd.lut11[buf >> 53];
+                    if (!e) e = T.acd.lut[buf >> 48];
+                    if (!e) break;
+                    len = e >> 8;
+                    size = e & 15;
+                    const uint64_t bits = buf;
+                    buf <<= len + size;
+                    cnt -= len + size;
+                    used += (size_t)(len + size);
+                    if ((e & 0xff) == 0) { // EOB
+                        good = true;
+                        break;
+                    }
+                    k += (e >> 4) & 15;
+                    if (k > 63) break;
+                    c[k++] = (int16_t)value(bits, len, size);
+                }
+                if (good) {
+                    running_dc = dc;
+                    c[0] = sat16(running_dc);
+                    r.pos = pos0 + used;
+                    continue;
+                }
+            }
+            memset(c, 0, 64 * sizeof(int16_t));
+            r.pos = pos0;
+        }
+        bool have_dc = read_symbol(r, T.dcd, sym, v);
         if (have_dc) running_dc += v;
         c[0] = sat16(running_dc);
         if (!have_dc) continue; // exception before the AC loop: block stays zero (codec.py:185-186)
@@ -274,15 +404,11 @@ int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
         int m = 0;
         bool ok = true;
         for (;;) {
-            if (!read_code(r, T.acd, sym)) {
+            if (!read_symbol(r, T.acd, sym, v)) {
                 ok = false;
                 break;
             }
-            int run = sym >> 4, size = sym & 15;
-            if (!read_int(r, size, v)) {
-                ok = false;
-                break;
-            }
+            const int run = sym >> 4;
             if (m + run + 1 > 1090) {
                 ok = false;
                 break;
