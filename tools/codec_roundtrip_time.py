@@ -1,3 +1,5 @@
+"""Host-level round-trip times of the codec on random frames (Python compress / decompress, C-ABI tic_idctq and
+tic_compress with preallocated buffers)."""
 import sys, time; sys.path.insert(0,'.')
 import numpy as np, tinyimgcodec_amd as T
 ctx = T.Context(0)
@@ -24,7 +26,7 @@ for k in range(3):
     t = time.perf_counter()
     ctx.check(L.tic_idctq(ctx.handle, zz.ctypes.data, dim, dim, 50, out.ctypes.data, out.size))
     dt = time.perf_counter() - t
-print("tic_idctq 4096^2 host->host: %.1f ms" % (dt * 1e3), "pixels match:", bool(np.abs(out.astype(int) - img.astype(int)).max() < 64))
+print("tic_idctq 4096^2 host->host: %.1f ms" % (dt * 1e3), "| decoded == decompress(compress(img)):", bool(np.array_equal(out, T.decompress(T.compress(img, 50, ctx=ctx), ctx=ctx))))
 # C-ABI tic_compress with a preallocated, pre-touched output buffer (no Python object handling)
 cap = L.tic_compress_bound(dim, dim)
 outb = np.zeros(cap, np.uint8)
