@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 //
 // Persistent waves, each walking its strips (strip = 8 horizontally adjacent blocks) in the order the launcher chose:
 // team schedule when the grid fits the chip at once, chunked schedule for larger grids (launch_dctq).
-// Main loop, per strip (unrolled x3, pixel registers rotate by name; 94 VGPRs, 5 waves per SIMD):
+// Main loop, per strip (unrolled x3, pixel registers rotate by name; 96 VGPRs, 5 waves per SIMD):
 //   load   : lane 8*r + b reads the 8 bytes of pixel row r of block b -> every 8 lanes read 64 contiguous bytes; inline
 //            assembly + hand-counted vmcnt keep two strips in flight.
 //   pass 1 : float32 AAN along the pixel row held by the lane (no cross-lane traffic); the level shift is folded
