@@ -94,10 +94,6 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
  * when measuring) the blocks it had to redo on the exact path; tic_last_fallback_blocks returns the count
  * accumulated since the previous call and resets it. */
 int tic_set_stats(tic_ctx *ctx, int enable);
-/* Diagnostic build of the HYBRID kernel that records s_memtime stamps (8 per wave: loop start/end, store drain,
- * barrier, post-pass phases) into host_out; timing analysis only (tools/stamps.py). */
-int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
-                     unsigned long long *host_out, size_t n_u64);
 int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count);
 
 /* ---- entropy stage (host): replaces the per-block loops of compress() codec.py:133-164:

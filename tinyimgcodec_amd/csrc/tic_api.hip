@@ -103,6 +103,10 @@ static int set_err(tic_ctx *ctx, int code, const char *fmt, ...) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" {
+#ifdef TIC_ABLATION
+int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
+                     unsigned long long *host_out, size_t n_u64, int variant);
+#endif
 
 const char *tic_version(void) { return "tinyimgcodec_amd 0.1.0 (gfx950)"; }
 
@@ -334,7 +338,13 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
     if (!ms_total || iters < 1 || !d_image || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
-    const int v = variant == TIC_KERNEL_EXACT ? 1 : (variant >= 10 ? variant : 2); // >= 10: timing-only ablation builds
+#ifdef TIC_ABLATION
+    const int v = variant == TIC_KERNEL_EXACT ? 1 : (variant >= 10 ? variant : 2); // >= 10: experiment builds (tools/)
+#else
+    if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
+        return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+    const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
+#endif
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++) HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -343,20 +353,23 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
     return TIC_OK;
 }
 
+#ifdef TIC_ABLATION
+// Experiment library only (tools/): one launch of a stamp build (variant 17 or 52), per-wave s_memtime stamps to host_out.
 int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
-                     unsigned long long *host_out, size_t n_u64) {
+                     unsigned long long *host_out, size_t n_u64, int variant) {
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_dbg) HIPCHK(ctx, hipMalloc(&ctx->d_dbg, 8192 * 4 * 8 * sizeof(unsigned long long)));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg, 0, 8192 * 4 * 8 * sizeof(unsigned long long), ctx->stream));
     DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
-    HIPCHK(ctx, launch_dctq(a, 17, ctx->stream));
+    HIPCHK(ctx, launch_dctq(a, variant == 52 ? 52 : 17, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     size_t n = n_u64 < 8192 * 4 * 8 ? n_u64 : 8192 * 4 * 8;
     HIPCHK(ctx, hipMemcpy(host_out, ctx->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return TIC_OK;
 }
+#endif
 
 int tic_set_stats(tic_ctx *ctx, int enable) {
     if (!ctx) return TIC_E_ARG;

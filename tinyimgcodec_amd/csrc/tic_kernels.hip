@@ -183,7 +183,7 @@ __device__ __forceinline__ void exact_block(uint32_t colLo, uint32_t colHi, uint
 // are reported through ok_rational and settled by special_block(); anything else undecided makes the function
 // return false for the lane, and the caller falls back to the exact order for that block.  Lane mapping and LDS use as exact_block().
 __device__ __forceinline__ bool second_level_block(uint32_t colLo, uint32_t colHi, uint32_t *lds, int b, int i,
-                                                   const DctqConsts *__restrict__ C, int q[8], bool &ok_rational) {
+                                                   const double *mul64, int q[8], bool &ok_rational) {
     double c[8];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -201,7 +201,7 @@ __device__ __forceinline__ bool second_level_block(uint32_t colLo, uint32_t colH
 #pragma unroll
     for (int k = 0; k < 8; k++) c[k] = __hiloint2double((int)wh[k], (int)w[k]);
     dct8_aan(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
-    const double *mul = C->mul64 + i * 8;
+    const double *mul = mul64 + i * 8; // index u*8+v (global constants or the wave's LDS copy)
     bool ok = true;
     ok_rational = true;
     const bool rat_lane = (i & 3) == 0; // frequency rows u = 0 and u = 4 hold the rational coefficients at v = 0, 4
@@ -384,7 +384,19 @@ __device__ __forceinline__ uint32_t byte_any(unsigned long long m) { // bit k = 
             a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-template <int ABL>
+// ST / LD: cache policy of the coefficient stores / pixel loads (0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt).
+template <int ST>
+__device__ __forceinline__ void store16_policy(void *p, const uint4 &v) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+    if (ST == 0) *reinterpret_cast<uint4 *>(p) = v;
+    else if (ST == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(d) : "memory");
+    else if (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
+    else if (ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(d) : "memory");
+}
+
+template <int ABL, int ST = 0, int LD = 0>
 __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
     constexpr bool kArith = !(ABL == 1 || ABL == 6 || ABL == 11); // butterflies, quantiser, guard test
     constexpr bool kLds = !(ABL == 2 || ABL == 6 || ABL == 10);   // the two LDS hand-offs
     constexpr bool kMem = !(ABL == 9 || ABL == 10 || ABL == 11);  // pixel loads and coefficient stores
+    if (ABL == 12) return; // timing-only: launch + dispatch of the grid, nothing else
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *ldsT = ldsT_all[wave];
@@ -485,12 +498,20 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         OB = oblk;                                                                                           \
         const uint8_t *src = img_s + src_off;                                                                \
         if (!kMem) P = ((unsigned long long)(ld_off * 2654435761u + src_off) << 24) ^ (ld_off + oblk); /* compute-only build */ \
-        else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory");    \
+        else if (LD == 0) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        else if (LD == 1) asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        else if (LD == 2) asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        else if (LD == 3) asm volatile("global_load_dwordx2 %0, %1, %2 sc0 sc1" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        else asm volatile("global_load_dwordx2 %0, %1, %2 sc1 nt" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
         n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
         if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
     } while (0)
 #define TIC_WAIT(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(P) : : "memory")
         TIC_STAMP(0);
+        if (ABL == 13) { // timing-only: prologue (arguments, constants, walk set-up), no strips
+            if (n_my < 0) a.out[lane] = (int16_t)(m0.x + m1.x + thr.x + (float)zzv.x + (float)in_off + (float)oblk);
+            return;
+        }
         unsigned long long p0, p1, p2;
         uint32_t ob0, ob1, ob2;
         TIC_LOAD(p0, ob0);
@@ -596,7 +617,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
                 wave_lds_fence();
             }
             if (!kMem) { acc.x ^= val.x; acc.y ^= val.y; acc.z ^= val.z; acc.w ^= val.w; } // compute-only build: no store
-            else *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off) = val;
+            else store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off, val);
             left--;
         };
         // Two strips ahead (loads L, stores S): strip j is consumed after L(j+2) is issued; in steady state the
@@ -710,7 +731,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
                 for (int v = 0; v < 8; v++) qe[v] = (int)(lo >> v) + (int)hi; // timing-only: no exact arithmetic
             } else {
                 bool ok_rat;
-                ok = second_level_block(lo, hi, ldsT, b, i, C, qe, ok_rat);
+                ok = second_level_block(lo, hi, ldsT, b, i, C->mul64, qe, ok_rat);
                 if (__ballot(!ok_rat && have) != 0ull) { // a rational tie inside a redo block: exact sub-path (cheap)
                     const RationalConsts KR = load_rational_consts(C, i);
                     int r0, r4;
@@ -746,6 +767,336 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
         TIC_STAMP(6);
     }
     if (!do_ties && a.fallback_count != nullptr && lane == 0) atomicAdd(a.fallback_count, (unsigned long long)ntot);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel 2 (round 2): the strip kernel with wave-local rare paths - no post-pass, no barrier, no trip lists.
+//
+// Same main loop as above.  What differs is what happens when a lane's guard band trips (about one strip in five at
+// q=50): the wave settles the strip right there, before its 1 KiB store leaves -
+//   * the pixel rows held by the lanes go through the (now idle) transpose buffer so that lane 8*b + i holds pixel column
+//     i of block b (8 bytes in, DPP byte transpose);
+//   * a trip of any of the 60 irrational coefficients: all eight blocks of the strip are recomputed on the float64
+//     second level and the decided roundings overwrite the staged fast-path values (they are equal wherever the fast
+//     path had accepted);
+//   * a trip of one of the four rational coefficients (exact .5 ties are common there), or a second-level result that
+//     is still undecided for them: the exact float64 sub-path computes the four rational coefficients of all eight
+//     blocks in pocketfft's operation order and overwrites them;
+//   * anything the second level cannot decide for an irrational coefficient (a true tie: A + B*sqrt(2) with B = 0) sets
+//     the strip's bit in a per-wave mask; after the loop the wave redoes those strips in the exact operation order
+//     (practically never on real data; a frame made of such blocks runs at the exact kernel's speed).
+// Other waves of the SIMD keep streaming while one wave is in its rare path, so its ~1 us latency overlaps; the old
+// post-pass ran when the chip was otherwise idle (12 % of a 4096^2 launch).  The constants of the rare paths live in
+// wave-private LDS (filled once, behind the same counted wait as the loop's own constants).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxStripsPerWave2 = 64;                 // one bit per strip of a wave's walk in the exact-redo mask
+constexpr int kCstWaveBytes = 512 + 128 + 64;          // mul64[64] doubles, natural-order zig-zag offsets, div/rdiv of the rational four
+
+template <int ABL, int ST = 0, int LD = 0>
+__global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
+    __shared__ __attribute__((aligned(16))) double cst_all[kWavesPerWG][kCstWaveBytes / 8];
+    constexpr bool kArith = !(ABL == 1 || ABL == 6 || ABL == 11); // timing-only builds, as in the kernel above
+    constexpr bool kLds = !(ABL == 2 || ABL == 6 || ABL == 10);
+    constexpr bool kMem = !(ABL == 9 || ABL == 10 || ABL == 11);
+    constexpr bool kRare = !(ABL == 3); // ABL 3: rare paths compiled out (timing only)
+    unsigned long long t_entry = 0;
+    if (ABL == 8) t_entry = __builtin_amdgcn_s_memtime();
+    if (ABL == 12) return; // timing-only: launch + dispatch of the grid, nothing else
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *ldsT = ldsT_all[wave];
+    char *ldsZ = reinterpret_cast<char *>(ldsZ_all[wave]);
+    double *cst_mul64 = cst_all[wave];                                              // [64] index u*8+v
+    uint16_t *cst_zz = reinterpret_cast<uint16_t *>(cst_all[wave] + 64);            // [64] index u*8+v
+    double *cst_rat = cst_all[wave] + 64 + 16;                                      // div[4] then rdiv[4]: (0,0) (0,4) (4,0) (4,4)
+    const DctqConsts *__restrict__ C = a.consts;
+    a.img += (long)blockIdx.y * a.frame_stride_in; // batch: one grid row per frame
+    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.y * a.frame_stride_out);
+
+    const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
+    const int b = lane >> 3, i = lane & 7;   // compute phase: column / frequency v = i of block b
+    const int nfast = a.fast_ty * a.fast_tx; // strips handled here: complete, 8-byte aligned, no padding
+    unsigned long long mask_exact = 0;       // strips of this wave's walk to redo in the exact order (wave-uniform)
+    uint32_t n_second = 0;                   // blocks sent to the second level (statistics)
+    int t_first, n_my;
+    {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        f32x4 m0, m1;
+        f32x2 thr;
+        u32x4 zzv;
+        u32x2 c_mul, c_div, c_rdiv;
+        uint32_t c_zz;
+        {
+            // every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_WAIT)
+            const uint32_t o32 = (uint32_t)i * 32u, o16 = (uint32_t)i * 16u, o8 = (uint32_t)i * 8u;
+            const uint32_t l8 = (uint32_t)lane * 8u, l2 = (uint32_t)lane * 2u;
+            const uint32_t r8 = (((uint32_t)lane & 2u) ? 32u : 0u) * 8u + (((uint32_t)lane & 1u) ? 4u : 0u) * 8u; // natural indices 0, 4, 32, 36
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c_mul) : "v"(l8), "s"(C->mul64) : "memory");
+            asm volatile("global_load_ushort %0, %1, %2" : "=v"(c_zz) : "v"(l2), "s"(C->zzofs) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c_div) : "v"(r8), "s"(C->div) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c_rdiv) : "v"(r8), "s"(C->rdiv) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(m0) : "v"(o32), "s"(C->mulT) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(m1) : "v"(o32), "s"(C->mulT) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(thr) : "v"(o8), "s"(C->thrT) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zzv) : "v"(o16), "s"(C->zzofsT) : "memory");
+        }
+        // LDS layouts of the loop: as in the kernel above (conflict-free transpose and zig-zag staging)
+        uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // v in {0,1,4,5}: + v*32 dwords
+        uint32_t *twB = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * (lb ^ 4); // v in {2,3,6,7}
+        const uint4 *tr = reinterpret_cast<const uint4 *>(
+            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // rows 0..3; rows 4..7 at +64 slots
+        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
+        const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
+        const long row8 = 8 * a.stride;
+
+        // strip walk: one scalar cursor (that of the prefetch), see the kernel above
+        long t_lim;
+        if (a.team_count > 0) {
+            const int r = blockIdx.x / a.team_count, t = blockIdx.x - r * a.team_count;
+            int row0 = 0, row1 = 0; // (constant indices only: a dynamic index would move the argument struct to scratch)
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (r == k) { row0 = a.split[k]; row1 = a.split[k + 1]; }
+            const int rows = row1 - row0;
+            t_first = __builtin_amdgcn_readfirstlane((row0 * a.team_count + t) * kWavesPerWG + wave);
+            t_lim = (long)t_first + (long)rows * a.tstep;
+        } else if (a.round_wgs > 0) {
+            const int rho = blockIdx.x / a.round_wgs, wl = blockIdx.x - rho * a.round_wgs;
+            const long base = (long)rho * a.round_wgs * a.wg_span;
+            t_first = __builtin_amdgcn_readfirstlane((int)base + wl * kWavesPerWG + wave);
+            t_lim = base + (long)a.round_wgs * a.wg_span;
+        } else {
+            t_first = __builtin_amdgcn_readfirstlane(blockIdx.x * a.wg_stride + wave);
+            t_lim = (long)blockIdx.x * a.wg_stride + a.wg_span;
+        }
+        const int t_end = t_lim < (long)nfast ? (int)t_lim : nfast; // first strip past this wave's walk
+        n_my = t_first < t_end ? (t_end - t_first + a.tstep - 1) / a.tstep : 0; // strips of this wave
+        int txp = t_first % a.fast_tx;
+        const int ty_first = t_first / a.fast_tx;
+        uint32_t in_off = (uint32_t)ty_first * (uint32_t)row8 + (uint32_t)txp * 64u; // frames are < 4 GiB (launcher)
+        uint32_t oblk = (uint32_t)ty_first * (uint32_t)a.bw + (uint32_t)txp * 8u;
+        const uint32_t ob_first = oblk;
+        uint32_t src_off = 0; // a load past the end of the walk re-reads the wave's last strip (strip 0 if it has none)
+        int n_issued = 0;
+        const uint8_t *img_s = a.img;
+#define TIC_LOAD(P, OB)                                                                                      \
+    do {                                                                                                     \
+        src_off = n_issued < n_my ? in_off : src_off;                                                        \
+        OB = oblk;                                                                                           \
+        const uint8_t *src = img_s + src_off;                                                                \
+        if (!kMem) P = ((unsigned long long)(ld_off * 2654435761u + src_off) << 24) ^ (ld_off + oblk); /* compute-only build */ \
+        else if (LD == 0) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        else if (LD == 1) asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        else if (LD == 2) asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        else if (LD == 3) asm volatile("global_load_dwordx2 %0, %1, %2 sc0 sc1" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        else asm volatile("global_load_dwordx2 %0, %1, %2 sc1 nt" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
+        if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
+    } while (0)
+#define TIC_WAIT(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(P) : : "memory")
+        if (ABL == 8 && a.dbg != nullptr && lane == 0) {
+            unsigned long long *d = a.dbg + ((size_t)blockIdx.x * kWavesPerWG + wave) * 8;
+            d[0] = t_entry;
+            d[1] = __builtin_amdgcn_s_memtime(); // set-up done, first pixel load about to issue
+        }
+        if (ABL == 13) { // timing-only: prologue (arguments, constants, walk set-up), no strips
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(thr), "+v"(zzv), "+v"(c_mul), "+v"(c_zz), "+v"(c_div), "+v"(c_rdiv) : : "memory");
+            if (n_my < 0) a.out[lane] = (int16_t)(m0.x + m1.x + thr.x + (float)zzv.x + (float)in_off + (float)oblk + (float)c_mul.x + (float)c_zz + (float)c_div.x + (float)c_rdiv.x);
+            return;
+        }
+        unsigned long long p0, p1, p2;
+        uint32_t ob0, ob1, ob2;
+        TIC_LOAD(p0, ob0);
+        TIC_LOAD(p1, ob1);
+        // the eight constant loads are older than the pixel loads: they have landed when only those are in flight
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(m0), "+v"(m1), "+v"(thr), "+v"(zzv), "+v"(c_mul), "+v"(c_zz), "+v"(c_div), "+v"(c_rdiv) : : "memory");
+        // constants of the rare paths -> wave-private LDS
+        *reinterpret_cast<u32x2 *>(cst_mul64 + lane) = c_mul;
+        cst_zz[lane] = (uint16_t)c_zz;
+        if (lane < 4) {
+            *reinterpret_cast<u32x2 *>(cst_rat + lane) = c_div;
+            *reinterpret_cast<u32x2 *>(cst_rat + 4 + lane) = c_rdiv;
+        }
+        auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
+            return reinterpret_cast<int16_t *>(ldsZ + (ofs >> 4) * 128 + (ofs & 15) + 16 * (b ^ (4 * ((ofs >> 5) & 1))));
+        };
+        int16_t *zp0 = zz_ptr(zzv.x & 0xffff), *zp1 = zz_ptr(zzv.x >> 16), *zp2 = zz_ptr(zzv.y & 0xffff), *zp3 = zz_ptr(zzv.y >> 16);
+        int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
+        const uint4 *zr = reinterpret_cast<const uint4 *>(
+            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (4 * ((i >> 1) & 1)))), 16));
+        wave_lds_fence();
+
+        int left = n_my;
+        uint32_t kstrip = 0; // ordinal of the strip in this wave's walk
+        uint4 acc = make_uint4(0, 0, 0, 0);
+        auto process = [&](const unsigned long long px, const uint32_t ob) {
+            // ---- pass 1: along the pixel row ------------------------------------------------------------------
+            const uint32_t lo0 = (uint32_t)px, hi0 = (uint32_t)(px >> 32);
+            float d0, d1, d2, d3, d4, d5, d6, d7;
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d0) : "v"(lo0));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d1) : "v"(lo0));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d2) : "v"(lo0));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d3) : "v"(lo0));
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d4) : "v"(hi0));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d5) : "v"(hi0));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d6) : "v"(hi0));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d7) : "v"(hi0));
+            if (kArith) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
+            d0 -= 1024.0f;
+            float e0 = d0, e1 = d1, e2 = d2, e3 = d3, e4 = d4, e5 = d5, e6 = d6, e7 = d7;
+            if (kLds) {
+                twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
+                twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
+                twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
+                wave_lds_fence();
+                const uint4 ra = tr[0], rb = tr[64];
+                wave_lds_fence();
+                e0 = __uint_as_float(ra.x); e1 = __uint_as_float(ra.y); e2 = __uint_as_float(ra.z);
+                e3 = __uint_as_float(ra.w); e4 = __uint_as_float(rb.x); e5 = __uint_as_float(rb.y);
+                e6 = __uint_as_float(rb.z); e7 = __uint_as_float(rb.w);
+            }
+            // ---- pass 2: down the column of horizontal frequency v = i ----------------------------------------
+            uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
+            unsigned long long cA = 0, cB = 0; // lanes whose guard band tripped (A: u in 1,2,3,5,6,7; B: u in 0,4)
+            if (kArith) {
+                dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
+                float r0, r1, r2, r3, r4, r5, r6, r7;
+                quant_magic(e0, m0.x, q0, r0);
+                quant_magic(e1, m0.y, q1, r1);
+                quant_magic(e2, m0.z, q2, r2);
+                quant_magic(e3, m0.w, q3, r3);
+                quant_magic(e4, m1.x, q4, r4);
+                quant_magic(e5, m1.y, q5, r5);
+                quant_magic(e6, m1.z, q6, r6);
+                quant_magic(e7, m1.w, q7, r7);
+                float mA = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
+                mA = fmaxf(fmaxf(mA, fabsf(r5)), fabsf(r6));
+                mA = fmaxf(mA, fabsf(r7));
+                const float mB = fmaxf(fabsf(r0), fabsf(r4));
+                cA = __ballot(mA > thr.x);
+                cB = __ballot(mB > thr.y);
+            } else {
+                q0 = __float_as_uint(e0); q1 = __float_as_uint(e1); q2 = __float_as_uint(e2); q3 = __float_as_uint(e3);
+                q4 = __float_as_uint(e4); q5 = __float_as_uint(e5); q6 = __float_as_uint(e6); q7 = __float_as_uint(e7);
+            }
+            uint4 val;
+            if (kLds) {
+                *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
+                *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
+            } else {
+                val = make_uint4((q0 & 0xffff) | (q1 << 16), (q2 & 0xffff) | (q3 << 16), (q4 & 0xffff) | (q5 << 16), (q6 & 0xffff) | (q7 << 16));
+            }
+            // ---- a guard band tripped somewhere in the strip (rare): settle it before the store ----------------------
+            if (kRare && kLds && __builtin_expect((cA | cB) != 0ull, 0)) {
+                const unsigned long long kRat = 0x1111111111111111ull; // lanes v in {0,4}: rational coefficients at u in {0,4}
+                const unsigned long long mG = cA | (cB & ~kRat);
+                bool need_rat = (cB & kRat) != 0ull;
+                // pixel rows -> lane 8*b + i holds row i of block b -> byte transpose -> pixel column i
+                uint2 *pb = reinterpret_cast<uint2 *>(ldsT);
+                pb[lb * 8 + lr] = make_uint2(lo0, hi0);
+                wave_lds_fence();
+                const uint2 rowv = pb[lane];
+                wave_lds_fence();
+                uint32_t lo = rowv.x, hi = rowv.y;
+                transpose8x8_bytes(lo, hi, i);
+                // zig-zag staging addresses of the coefficients (u = i, v = 0..7) this lane produces on the float64 paths
+                const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8);
+                if (mG != 0ull) { // second level for the whole strip
+                    int qe[8];
+                    bool ok_rat;
+                    const bool ok = second_level_block(lo, hi, ldsT, b, i, cst_mul64, qe, ok_rat);
+                    const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+#pragma unroll
+                    for (int v = 0; v < 8; v++) *zz_ptr((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) = (int16_t)qe[v];
+                    need_rat = need_rat || __ballot(!ok_rat) != 0ull;
+                    if (__ballot(!ok) != 0ull) mask_exact |= 1ull << kstrip; // a true tie: exact order, after the loop
+                    n_second += (uint32_t)__builtin_popcount(byte_any(mG));
+                }
+                if (need_rat) { // the four rational coefficients of every block, exact sub-path
+                    RationalConsts KR;
+                    KR.div0 = cst_rat[(i >> 2) * 2];
+                    KR.div4 = cst_rat[(i >> 2) * 2 + 1];
+                    KR.rdiv0 = cst_rat[4 + (i >> 2) * 2];
+                    KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
+                    int r0, r4;
+                    special_block(lo, hi, ldsT, b, i, KR, r0, r4);
+                    if ((i & 3) == 0) { // lane i = 0: (0,0) and (0,4); lane i = 4: (4,0) and (4,4)
+                        *zz_ptr(zo.x & 0xffffu) = (int16_t)r0;
+                        *zz_ptr(zo.z & 0xffffu) = (int16_t)r4;
+                    }
+                }
+            }
+            // ---- zig-zag ordered blocks -> global: 16 B per lane, 1 KiB contiguous per wave ---------------------------
+            if (kLds) {
+                wave_lds_fence();
+                val = *zr;
+                wave_lds_fence();
+            }
+            if (!kMem) { acc.x ^= val.x; acc.y ^= val.y; acc.z ^= val.z; acc.w ^= val.w; } // compute-only build: no store
+            else store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off, val);
+            left--;
+            kstrip++;
+        };
+        // Two strips ahead: strip j is consumed after L(j+2) is issued; in steady state the instructions younger than
+        // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.
+        do {
+            if (left == 0) break;
+            TIC_LOAD(p2, ob2); TIC_WAIT(p0, 2);
+            if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
+            process(p0, ob0);
+            if (left == 0) break;
+            TIC_LOAD(p0, ob0); TIC_WAIT(p1, 3); process(p1, ob1);
+            while (left != 0) {
+                TIC_LOAD(p1, ob1); TIC_WAIT(p2, 4); process(p2, ob2);
+                if (left == 0) break;
+                TIC_LOAD(p2, ob2); TIC_WAIT(p0, 4); process(p0, ob0);
+                if (left == 0) break;
+                TIC_LOAD(p0, ob0); TIC_WAIT(p1, 4); process(p1, ob1);
+            }
+        } while (0);
+        // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
+        if (!kMem) { // one store per wave, to its first strip (always inside the frame)
+            if (n_my > 0) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob_first << 7) + st_off) = acc;
+            return;
+        }
+#undef TIC_LOAD
+#undef TIC_WAIT
+    }
+    if (ABL == 8 && a.dbg != nullptr && lane == 0) {
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * kWavesPerWG + wave) * 8;
+        d[3] = __builtin_amdgcn_s_memtime(); // loop left, all of the wave's stores have landed (vmcnt(0) above)
+        d[6] = (unsigned long long)n_my | ((unsigned long long)n_second << 32);
+        d[7] = mask_exact;
+    }
+    if (a.fallback_count != nullptr && lane == 0 && n_second != 0) atomicAdd(a.fallback_count, (unsigned long long)n_second);
+    // ---- strips with a true tie of an irrational coefficient: the exact operation order, whole strip ----------------
+    // (the wave's own stores to these strips have landed: vmcnt(0) above)
+    if (mask_exact == 0ull) return;
+    const uint4 zzn = *reinterpret_cast<const uint4 *>(cst_zz + i * 8);
+    const uint16_t zz[8] = {(uint16_t)zzn.x, (uint16_t)(zzn.x >> 16), (uint16_t)zzn.y, (uint16_t)(zzn.y >> 16),
+                            (uint16_t)zzn.z, (uint16_t)(zzn.z >> 16), (uint16_t)zzn.w, (uint16_t)(zzn.w >> 16)};
+    for (unsigned long long todo = mask_exact; todo != 0ull; todo &= todo - 1ull) {
+        const int k = __builtin_ctzll(todo);
+        const long t = (long)t_first + (long)k * a.tstep; // strip index inside the fast rectangle
+        const int ty = (int)(t / a.fast_tx), tx = (int)(t - (long)ty * a.fast_tx);
+        Strip s;
+        s.by = ty;
+        s.bx = tx * 8 + b;
+        s.valid = true;
+        s.oblk = (size_t)ty * a.bw + s.bx;
+        uint32_t lo, hi;
+        load_block_row(a.img, a.h, a.w, a.stride, true, s, i, lo, hi);
+        transpose8x8_bytes(lo, hi, i);
+        int q[8];
+        exact_block(lo, hi, ldsT, b, i, C, q);
+        store_zigzag(reinterpret_cast<uint32_t *>(ldsZ), b, i, zz, q, a.out, s);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1049,7 +1400,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 4) void dctq_lane_kernel(DctqArgs
         {
             int qe[8];
             bool ok_rat;
-            ok = second_level_block(lo, hi, ldsT, b, i, C, qe, ok_rat);
+            ok = second_level_block(lo, hi, ldsT, b, i, C->mul64, qe, ok_rat);
             if (__ballot(!ok_rat && have) != 0ull) { // a rational tie inside a redo block: exact sub-path (cheap)
                 const RationalConsts KR = load_rational_consts(C, i);
                 int r0, r4;
@@ -1188,8 +1539,11 @@ static Tunables read_tunables() {
         sp = strchr(sp, ',');
         if (sp) sp++;
     }
-    t.nocap = geti("TIC_NOCAP", 0);                 // experiment, timing builds only: ignore the trip-list capacity
+    t.nocap = t.lds_pad = 0;
+#ifdef TIC_ABLATION
+    t.nocap = geti("TIC_NOCAP", 0);                 // experiment, timing builds only: ignore the strips-per-wave bound
     t.lds_pad = geti("TIC_LDS_PAD", 0);             // experiment: extra dynamic LDS per workgroup (lowers occupancy)
+#endif
     return t;
 }
 static Tunables tunables() {
@@ -1204,7 +1558,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     a.nwaves = a.step_ty = a.step_tx = 0;
     a.fast_ty = a.fast_tx = 0;
     a.rem_mode = 0;
-    if (variant != 17) a.dbg = nullptr;
+    if (variant != 17 && variant != 52) a.dbg = nullptr;
     const int nf = a.nframes > 0 ? a.nframes : 1;
     if (variant == 1) {
         hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles), nf), block, 0, stream, a);
@@ -1215,8 +1569,14 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     a.fast_tx = (a.aligned8 && (long)a.h * a.stride < (1L << 32)) ? a.w / 64 : 0; // 32-bit pixel offsets in the walk
     a.fast_ty = a.h / 8;
     const int nfast = a.fast_tx * a.fast_ty;
+#ifdef TIC_ABLATION
     const bool lane_kernel = variant == 40 || variant == 41;
+#else
+    const bool lane_kernel = false;
+    if (variant != 2) return hipErrorInvalidValue; // the product library holds the exact and the production kernel only
+#endif
     if (nfast > 0 && lane_kernel) {
+#ifdef TIC_ABLATION
         // one block per lane (explored alternative): 64 blocks per wave, 256 per workgroup, no loop
         const long nbf = (long)nfast * 8;
         const dim3 grid((unsigned)((nbf + kWavesPerWG * 64 - 1) / (kWavesPerWG * 64)), nf);
@@ -1224,14 +1584,19 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             hipLaunchKernelGGL(dctq_lane_kernel<4>, grid, block, 0, stream, a);
         else
             hipLaunchKernelGGL(dctq_lane_kernel<0>, grid, block, 0, stream, a);
+#endif
     } else if (nfast > 0) {
-        // strip kernel (variant 2 and its timing builds 10-20), persistent waves: each wave loops over its strips
+        // strip kernels, persistent waves: each wave loops over its strips.  Variants 2, 10-22, 1xx, 2xx: round-1 kernel with
+        // the workgroup-shared post-pass (trip lists: at most 16 strips per wave); 50-59, 3xx, 4xx: wave-local rare paths
+        // (one mask bit per strip: at most 64 strips per wave).
+        const bool new_kernel = (variant >= 50 && variant < 60) || variant >= 300;
+        const int max_strips = new_kernel ? kMaxStripsPerWave2 : kMaxStripsPerWave;
         int wgs = grid_for(nfast);
         // persistent grid = exactly the workgroups the chip holds at once (CUs x resident workgroups per CU): a larger
         // grid runs in two uneven rounds, a smaller one leaves wave slots empty (measured: 15.0 us at 1280 workgroups
         // vs 16.3 us at 2048 on a 4096^2 frame)
         static int cus = 256;
-        static const int resident = [] {
+        static const int resident_old = [] {
             int dev = 0, per_cu = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
@@ -1240,13 +1605,21 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
                 per_cu = 4;
             return cus * per_cu;
         }();
+        static const int resident_new = [] {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0>, kWavesPerWG * 64, 0) != hipSuccess ||
+                per_cu < 1)
+                per_cu = 4;
+            return cus * per_cu;
+        }();
+        const int resident = new_kernel ? resident_new : resident_old;
         const Tunables tune = tunables();
         const int cap_env = tune.max_wgs > 0 ? tune.max_wgs : resident;
         int cap = cap_env / nf; // a batch shares the chip's wave slots between its frames
         if (cap < 64) cap = 64;
         if (wgs > cap) wgs = cap;
-        const int min_wgs = (nfast + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
-        if (wgs < min_wgs && !(tune.nocap && variant >= 10)) wgs = min_wgs; // the per-wave trip list holds kMaxStripsPerWave entries
+        const int min_wgs = (nfast + kWavesPerWG * max_strips - 1) / (kWavesPerWG * max_strips);
+        if (wgs < min_wgs && !(tune.nocap && variant >= 10)) wgs = min_wgs; // strips per wave are bounded (trip list / mask)
         a.nwaves = wgs * kWavesPerWG;
         a.wg_stride = kWavesPerWG;
         a.tstep = a.nwaves;
@@ -1254,8 +1627,9 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         const int sched_env = tune.sched, chunk_env = tune.chunk;
         a.round_wgs = 0;
         a.team_count = 0;
-        const int S = chunk_env < 1 ? 1 : (chunk_env > kMaxStripsPerWave ? kMaxStripsPerWave : chunk_env);
-        const bool multi_round = (long)min_wgs * nf > (long)cap_env && !(tune.nocap && variant >= 10); // more workgroups than the chip holds at once
+        const int S = chunk_env < 1 ? 1 : (chunk_env > max_strips ? max_strips : chunk_env);
+        const int min_wgs16 = (nfast + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
+        const bool multi_round = (long)min_wgs16 * nf > (long)cap_env && !(tune.nocap && variant >= 10); // more workgroups than the chip holds at once
         if (sched_env == 1 && multi_round) { // each workgroup streams a contiguous chunk of 4*S strips
             a.wg_stride = a.wg_span = kWavesPerWG * S;
             a.tstep = kWavesPerWG;
@@ -1282,7 +1656,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             for (int r = 0; r < R; r++) {
                 acc += tune.split[r] > 0 ? tune.split[r] : 1;
                 a.split[r + 1] = (int)(rows_total * acc / wsum + 0.5);
-                if (a.split[r + 1] - a.split[r] > kMaxStripsPerWave) a.team_count = 0; // trip list capacity: fall back
+                if (a.split[r + 1] - a.split[r] > max_strips) a.team_count = 0; // strips per wave are bounded: fall back
             }
             a.split[R] = rows_total;
             if (a.team_count == 0) a.tstep = a.nwaves;
@@ -1295,7 +1669,9 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.oblk_wrap = (uint32_t)((long)a.bw - (long)a.fast_tx * 8);
         const dim3 grid(wgs, nf);
 #define TIC_LAUNCH(ABL) hipLaunchKernelGGL(dctq_hybrid_kernel<ABL>, grid, block, tune.lds_pad, stream, a)
+#define TIC_LAUNCH2(ABL) hipLaunchKernelGGL(dctq_strip_kernel<ABL>, grid, block, tune.lds_pad, stream, a)
         switch (variant) {
+#ifdef TIC_ABLATION
         case 10: TIC_LAUNCH(1); break;
         case 11: TIC_LAUNCH(2); break;
         case 12: TIC_LAUNCH(3); break;
@@ -1307,9 +1683,29 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         case 18: TIC_LAUNCH(9); break;
         case 19: TIC_LAUNCH(10); break;
         case 20: TIC_LAUNCH(11); break;
+        case 21: TIC_LAUNCH(12); break;
+        case 22: TIC_LAUNCH(13); break;
+        case 50: TIC_LAUNCH2(0); break;
+        case 51: TIC_LAUNCH2(3); break;  // rare paths compiled out
+        case 52: TIC_LAUNCH2(8); break;  // stamps
+        case 53: TIC_LAUNCH2(12); break; // empty
+        case 54: TIC_LAUNCH2(13); break; // prologue only
+        case 55: TIC_LAUNCH2(6); break;  // streaming skeleton
+        case 56: TIC_LAUNCH2(1); break;  // no arithmetic
+        case 57: TIC_LAUNCH2(9); break;  // compute only
+#define TIC_POL(S, L)                                                                                                  \
+    case 100 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<0, S, L>), grid, block, tune.lds_pad, stream, a); break; \
+    case 200 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<6, S, L>), grid, block, tune.lds_pad, stream, a); break; \
+    case 300 + 10 * S + L: hipLaunchKernelGGL((dctq_strip_kernel<0, S, L>), grid, block, tune.lds_pad, stream, a); break;  \
+    case 400 + 10 * S + L: hipLaunchKernelGGL((dctq_strip_kernel<6, S, L>), grid, block, tune.lds_pad, stream, a); break;
+        TIC_POL(1, 0) TIC_POL(2, 0) TIC_POL(3, 0) TIC_POL(4, 0) TIC_POL(0, 1) TIC_POL(0, 2) TIC_POL(0, 4)
+        TIC_POL(2, 1) TIC_POL(2, 2) TIC_POL(4, 1) TIC_POL(3, 1) TIC_POL(1, 1)
+#undef TIC_POL
+#endif
         default: TIC_LAUNCH(0); break;
         }
 #undef TIC_LAUNCH
+#undef TIC_LAUNCH2
     } else {
         a.fast_tx = a.fast_ty = 0;
     }

@@ -4,6 +4,8 @@ all settings alike.  Usage: python tools/ab.py [--dims 4096,16384] [--rounds 7] 
 import argparse, ctypes as C, os, statistics, sys
 os.environ["TIC_TUNE"] = "1"
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+import _ablate  # noqa: F401  (experiment build of the library)
 import numpy as np
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N
@@ -11,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dims", default="4096,16384")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--variants", default="2,12,15")
+ap.add_argument("--iters", type=int, default=0, help="launches per sample (default 50 at 4096^2, 8 above)")
 ap.add_argument("settings", nargs="*", default=[""])
 args = ap.parse_args()
 L = N.load(); ctx = T.Context(0)
@@ -28,7 +31,7 @@ for dim in [int(x) for x in args.dims.split(",")]:
     ctx.check(L.tic_dev_alloc(ctx.handle, img.size * 2, C.byref(d_out)))
     ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
     ms = C.c_float()
-    iters = 50 if dim <= 4096 else 8
+    iters = args.iters or (50 if dim <= 4096 else 8)
     variants = [int(v) for v in args.variants.split(",")]
     res = {(s, v): [] for s in args.settings for v in variants}
     for rnd in range(args.rounds + 1):

@@ -1,6 +1,8 @@
 """Timing-only ablations of the hybrid kernel (outputs of variants >= 10 are wrong by construction)."""
 import ctypes as C, sys
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+import _ablate  # noqa: F401  (experiment build of the library)
 import numpy as np
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N

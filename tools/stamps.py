@@ -1,6 +1,8 @@
 """In-kernel s_memtime stamps of the hybrid kernel's phases (diagnostic build; shares, not absolute time)."""
 import ctypes as C, sys
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+import _ablate  # noqa: F401  (experiment build of the library)
 import numpy as np
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N
@@ -14,7 +16,7 @@ ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
 n = 2048 * 4 * 8
 buf = (C.c_ulonglong * n)()
 for rep in range(3):
-    ctx.check(L.tic_debug_stamps(ctx.handle, d_img, h, w, w, 50, d_out, buf, n))
+    ctx.check(L.tic_debug_stamps(ctx.handle, d_img, h, w, w, 50, d_out, buf, n, 17))
 s = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 4, 8).astype(np.int64)
 wg_ids = np.nonzero(s[:, 0, 0] > 0)[0]
 s = s[s[:, 0, 0] > 0]                     # workgroups that ran
