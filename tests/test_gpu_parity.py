@@ -50,17 +50,6 @@ class DevFrame:
         ctx.check(L.tic_memcpy_d2h(ctx.handle, zz.ctypes.data, self.d_out, self.n * 128))
         return zz
 
-    def run_variant(self, quality, variant):
-        """One launch of an internal kernel variant (>= 10) through the timing entry point, then read back."""
-        ctx, L = self.ctx, self.L
-        ctx.check(L.tic_memset_dev(ctx.handle, self.d_out, 0x5A, max(self.n, 1) * 128))
-        ms = C.c_float()
-        ctx.check(L.tic_dctq_dev_timed(ctx.handle, self.d_img, self.h, self.w, self.pitch, quality, self.d_out, variant, 1,
-                                       C.byref(ms)))
-        zz = np.empty((self.n, 64), dtype=np.int16)
-        ctx.check(L.tic_memcpy_d2h(ctx.handle, zz.ctypes.data, self.d_out, self.n * 128))
-        return zz
-
     def fallbacks(self):
         c = C.c_ulonglong()
         self.ctx.check(self.L.tic_last_fallback_blocks(self.ctx.handle, C.byref(c)))
@@ -246,19 +235,40 @@ def test_config2_4096_coefficient_digest(ctx, manifest, q):
     assert 0 < fb < 0.08 * 262144, fb  # guard band trips on a small fraction of blocks only
 
 
-@pytest.mark.parametrize("shape", [(4096, 4096), (1080, 1920), (200, 328), (64, 64), (8, 4096)])
-def test_one_block_per_lane_kernel_matches_exact(ctx, golden, shape):
-    """The explored one-block-per-lane kernel (variant 40) is bit-identical too: random frames (ties and
-    redo blocks occur at 4096^2), partial strips, and the tie-stress blocks of the goldens."""
-    h, w = shape
-    for q in (10, 50, 90):
-        f = DevFrame(ctx, rand_frame(99, h, w))
-        assert np.array_equal(f.run_variant(q, 40), f.run(q, N.KERNEL_EXACT)), (shape, q)
+def _true_tie_block():
+    """X(2,2) = (2(P+Q) + sqrt2 (P-Q+R)) / 16 with P-Q+R = 0 and (P+Q)/128 = 0.5: an exact .5 tie of an IRRATIONAL coefficient
+    at q=50 (scipy gives 0.49999999999999994 -> 0); only the exact operation order settles it."""
+    blk = np.full((8, 8), 128, np.int32)
+    blk[0, 0] += 64
+    blk[0, 1] -= 64
+    return blk.astype(np.uint8)
+
+
+def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden):
+    """Every rare path of the production kernel against the exact kernel and the oracle: the wave's batch (ties, second level,
+    exact order inside the batch), batch overflow with rational ties only (exact sub-path inside the loop: flat areas with an
+    odd grey level tie on DC in every block), batch overflow with irrational trips (whole strip redone in the exact order)."""
+    tt = _true_tie_block()
+    mix = rand_frame(5, 1024, 2048)
+    for k in range(0, 128 * 256, 37):
+        by, bx = divmod(k, 256)
+        mix[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = tt
+    half = rand_frame(11, 512, 1024)
+    half[:, 512:] = 77  # right half flat and odd: eight DC ties per strip there, none in the random half
+    frames = {
+        "flat odd grey (DC tie in every block)": (np.full((1024, 2048), 129, np.uint8), (50, 90)),
+        "irrational true tie in every block": (np.tile(tt, (128, 256)), (50,)),
+        "random + scattered irrational true ties": (mix, (50,)),
+        "tie goldens tiled": (np.tile(golden("tie_blocks")["img"].astype(np.uint8), (8, 16)), (50, 37, 90)),
+        "half random, half flat odd": (half, (50,)),
+    }
+    for name, (img, quals) in frames.items():
+        f = DevFrame(ctx, img)
+        for q in quals:
+            want = oracle.encode_zz16(img, q)
+            assert np.array_equal(f.run(q, N.KERNEL_EXACT), want), (name, q, "exact kernel")
+            assert np.array_equal(f.run(q, N.KERNEL_HYBRID), want), (name, q, "production kernel")
         f.free()
-    f = DevFrame(ctx, golden("tie_blocks")["img"].astype(np.uint8))  # blocks built to sit on rounding ties
-    for q in (50, 90):
-        assert np.array_equal(f.run_variant(q, 40), f.run(q, N.KERNEL_EXACT)), q
-    f.free()
 
 
 def test_strip_schedules_are_equivalent(ctx, monkeypatch):

@@ -46,6 +46,11 @@ struct DctqArgs {
     int nframes;
     long frame_stride_in, frame_stride_out;
     unsigned long long *dbg; // diagnostic builds only: per-wave s_memtime stamps (8 per wave), else null
+    // strip kernel (round 2): division-free prologue.  q = mulhi(n, magic) with magic = floor(2^32 / d) + 1 is n / d for
+    // n * d < 2^32 (checked by the launcher).  The team schedule runs on a 2-D grid (x = team, y = round) and takes the
+    // rows of round r from byte r of split_lo (byte 8: split_hi).
+    uint32_t magic_fast_tx, magic_tstep;
+    unsigned long long split_lo, split_hi;
 };
 
 struct IdctArgs {

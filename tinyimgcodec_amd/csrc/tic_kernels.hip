@@ -320,6 +320,16 @@ __device__ __forceinline__ void quant_magic(float z, float mul, uint32_t &bits, 
     d = t - (s - kMagic);
 }
 
+// Round-2 form with fused multiply-adds: s = RN(z*mul + magic) is rint(z*mul) of the EXACT product (one rounding, half-even),
+// d = RN(z*mul - rint(z*mul)).  Three instructions per coefficient instead of four (v_fmaak, v_sub, v_fmac), and the
+// float32 rounding of the product - 1024 * 2^-23 of every guard band - no longer occurs (the bands are kept as they are).
+__device__ __forceinline__ void quant_fma(float z, float mul, uint32_t &bits, float &d) {
+    const float s = fmaf(z, mul, kMagic);
+    bits = __float_as_uint(s);
+    const float nr = kMagic - s; // -rint(z*mul), exact
+    d = fmaf(z, mul, nr);
+}
+
 // Rational coefficients (u,v) in {0,4}x{0,4} of the lane's block on their exact float64 sub-path (SURVEY
 // Appendix A, consequence 2): for integer pixels the column pass outputs 0 and 4 are (integer sum) * constant,
 // one rounding each, and the row pass outputs 0 and 4 need 8 additions in pocketfft's order.
@@ -378,12 +388,6 @@ __device__ __forceinline__ uint32_t byte_any(unsigned long long m) { // bit k = 
     return (uint32_t)((m * 0x0102040810204080ull) >> 56);
 }
 
-#define TIC_STAMP(k)                                                                                  \
-    do {                                                                                              \
-        if (ABL == 8 && a.dbg != nullptr && lane == 0)                                                \
-            a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-
 // ST / LD: cache policy of the coefficient stores / pixel loads (0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt).
 template <int ST>
 __device__ __forceinline__ void store16_policy(void *p, const uint4 &v) {
@@ -395,6 +399,13 @@ __device__ __forceinline__ void store16_policy(void *p, const uint4 &v) {
     else if (ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(d) : "memory");
 }
+
+#ifdef TIC_ABLATION // the round-1 kernel: kept in the experiment library as the A/B baseline
+#define TIC_STAMP(k)                                                                                  \
+    do {                                                                                              \
+        if (ABL == 8 && a.dbg != nullptr && lane == 0)                                                \
+            a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 
 template <int ABL, int ST = 0, int LD = 0>
 __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqArgs a) {
@@ -769,81 +780,85 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
     if (!do_ties && a.fallback_count != nullptr && lane == 0) atomicAdd(a.fallback_count, (unsigned long long)ntot);
 }
 
+#endif // TIC_ABLATION
+
 // ---------------------------------------------------------------------------------------------------------
-// Kernel 2 (round 2): the strip kernel with wave-local rare paths - no post-pass, no barrier, no trip lists.
+// Kernel 2 (round 2): the strip kernel with a wave-local batch pass - no barrier, no store drain, no global patches.
 //
-// Same main loop as above.  What differs is what happens when a lane's guard band trips (about one strip in five at
-// q=50): the wave settles the strip right there, before its 1 KiB store leaves -
-//   * the pixel rows held by the lanes go through the (now idle) transpose buffer so that lane 8*b + i holds pixel column
-//     i of block b (8 bytes in, DPP byte transpose);
-//   * a trip of any of the 60 irrational coefficients: all eight blocks of the strip are recomputed on the float64
-//     second level and the decided roundings overwrite the staged fast-path values (they are equal wherever the fast
-//     path had accepted);
-//   * a trip of one of the four rational coefficients (exact .5 ties are common there), or a second-level result that
-//     is still undecided for them: the exact float64 sub-path computes the four rational coefficients of all eight
-//     blocks in pocketfft's operation order and overwrites them;
-//   * anything the second level cannot decide for an irrational coefficient (a true tie: A + B*sqrt(2) with B = 0) sets
-//     the strip's bit in a per-wave mask; after the loop the wave redoes those strips in the exact operation order
-//     (practically never on real data; a frame made of such blocks runs at the exact kernel's speed).
-// Other waves of the SIMD keep streaming while one wave is in its rare path, so its ~1 us latency overlaps; the old
-// post-pass ran when the chip was otherwise idle (12 % of a 4096^2 launch).  The constants of the rare paths live in
-// wave-private LDS (filled once, behind the same counted wait as the loop's own constants).
+// Same main loop as above.  What differs is the fate of a block whose guard band tripped:
+//   * the block joins the wave's batch (at most 8 entries in wave-private LDS): block id + kind, its 8x8 pixels (64 B,
+//     the lanes that loaded them still hold them) and its 128 output bytes as the fast path staged them;
+//   * after the loop the wave settles its batch in ONE pass, 8 lanes per block: float64 second level if an entry tripped
+//     on one of the 60 irrational coefficients, exact float64 sub-path for the four rational coefficients (exact .5 ties
+//     are common there: 2.2 % of random blocks at q=50; every flat block with an odd grey level), exact operation order
+//     for what the second level cannot decide; results patch the 128-byte images in LDS, which then leave with 16-byte
+//     stores.  Constants of the pass sit in wave-private LDS (filled behind the same counted wait as the loop's own).
+//   * a batch that would overflow (tie-dense content): if the strip's trips are rational ties only, the wave runs the
+//     exact sub-path for the whole strip right there, before its store; otherwise the strip's bit is set in a per-wave
+//     mask and the strip is redone in the exact operation order after the loop.
+// Measured against the alternatives on a 4096^2 frame (profiles/r02_*): workgroup-shared post-pass behind a barrier
+// (round 1) +2.0 us over the loop; settling every tripped strip inside the loop +2.9 us (a wave with four tripped
+// strips ends 2 us after its neighbours: static schedule, dependent float64 chains); this batch pass +0.x us.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxStripsPerWave2 = 64;                 // one bit per strip of a wave's walk in the exact-redo mask
-constexpr int kCstWaveBytes = 512 + 128 + 64;          // mul64[64] doubles, natural-order zig-zag offsets, div/rdiv of the rational four
+constexpr int kBatch = 8;                              // entries of the wave's batch
+constexpr int kBatchWaveBytes = kBatch * (128 + 64) + 64; // images, pixel rows, ids
 
-template <int ABL, int ST = 0, int LD = 0>
+// OPT: A/B switches of the experiment library (bit 0: fused quantiser, bit 1: tripped blocks sit out the strip's store);
+// the product is built with all of them on.
+template <int ABL, int ST = 0, int LD = 0, int OPT = 3>
 __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
-    __shared__ __attribute__((aligned(16))) double cst_all[kWavesPerWG][kCstWaveBytes / 8];
+    __shared__ __attribute__((aligned(16))) unsigned char cst_blk[kStripBlkBytes]; // constants, shared by the workgroup
+    __shared__ __attribute__((aligned(16))) uint32_t bat_all[kWavesPerWG][kBatchWaveBytes / 4];
     constexpr bool kArith = !(ABL == 1 || ABL == 6 || ABL == 11); // timing-only builds, as in the kernel above
     constexpr bool kLds = !(ABL == 2 || ABL == 6 || ABL == 10);
+    constexpr bool kLdsT = kLds && ABL != 21; // timing-only: without the transpose through LDS
+    constexpr bool kLdsZ = kLds && ABL != 20; // timing-only: without the zig-zag staging through LDS
     constexpr bool kMem = !(ABL == 9 || ABL == 10 || ABL == 11);
-    constexpr bool kRare = !(ABL == 3); // ABL 3: rare paths compiled out (timing only)
-    unsigned long long t_entry = 0;
+    constexpr bool kRare = !(ABL == 3 || ABL == 22); // ABL 3: tripped blocks are ignored (timing only); 22: guard test kept, no branch
+    constexpr bool kBatchPass = ABL != 23;           // ABL 23: blocks join the batch but the batch pass is skipped (timing only)
+    unsigned long long t_entry = 0, t_karg = 0, t_desc = 0;
     if (ABL == 8) t_entry = __builtin_amdgcn_s_memtime();
     if (ABL == 12) return; // timing-only: launch + dispatch of the grid, nothing else
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *ldsT = ldsT_all[wave];
     char *ldsZ = reinterpret_cast<char *>(ldsZ_all[wave]);
-    double *cst_mul64 = cst_all[wave];                                              // [64] index u*8+v
-    uint16_t *cst_zz = reinterpret_cast<uint16_t *>(cst_all[wave] + 64);            // [64] index u*8+v
-    double *cst_rat = cst_all[wave] + 64 + 16;                                      // div[4] then rdiv[4]: (0,0) (0,4) (4,0) (4,4)
+    const double *cst_mul64 = reinterpret_cast<const double *>(cst_blk + 448);     // [64] index u*8+v
+    const uint16_t *cst_zz = reinterpret_cast<const uint16_t *>(cst_blk + 960);    // [64] index u*8+v
+    const double *cst_rat = reinterpret_cast<const double *>(cst_blk + 1088);      // div[4] then rdiv[4]: (0,0) (0,4) (4,0) (4,4)
+    uint4 *bat_img = reinterpret_cast<uint4 *>(bat_all[wave]);                      // [kBatch][8] 16-byte pieces: zig-zag images
+    uint2 *bat_pix = reinterpret_cast<uint2 *>(bat_all[wave] + kBatch * 32);        // [kBatch][8] pixel rows
+    uint32_t *bat_id = bat_all[wave] + kBatch * 48;                                 // [kBatch] block index | kind << 31
     const DctqConsts *__restrict__ C = a.consts;
-    a.img += (long)blockIdx.y * a.frame_stride_in; // batch: one grid row per frame
-    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.y * a.frame_stride_out);
+    a.img += (long)blockIdx.z * a.frame_stride_in; // batch of frames: one grid plane per frame
+    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.z * a.frame_stride_out);
 
     const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
     const int b = lane >> 3, i = lane & 7;   // compute phase: column / frequency v = i of block b
-    const int nfast = a.fast_ty * a.fast_tx; // strips handled here: complete, 8-byte aligned, no padding
     unsigned long long mask_exact = 0;       // strips of this wave's walk to redo in the exact order (wave-uniform)
     uint32_t n_second = 0;                   // blocks sent to the second level (statistics)
+    int nE = 0;                              // entries in the batch (wave-uniform)
     int t_first, n_my;
+    const uint32_t st_off = (uint32_t)lane * 16u; // lane offset inside a strip's 1 KiB output
     {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         f32x4 m0, m1;
         f32x2 thr;
         u32x4 zzv;
-        u32x2 c_mul, c_div, c_rdiv;
-        uint32_t c_zz;
+        // Constants: the workgroup copies the quality's 1152-byte block into LDS, 18 lanes of every wave one 16-byte piece
+        // each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
+        // loads per wave in front of the first pixel load: four such loads more cost 0.67 us on a 4096^2 launch).
+        // Every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_WAIT).
+        u32x4 c_fill;
         {
-            // every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_WAIT)
-            const uint32_t o32 = (uint32_t)i * 32u, o16 = (uint32_t)i * 16u, o8 = (uint32_t)i * 8u;
-            const uint32_t l8 = (uint32_t)lane * 8u, l2 = (uint32_t)lane * 2u;
-            const uint32_t r8 = (((uint32_t)lane & 2u) ? 32u : 0u) * 8u + (((uint32_t)lane & 1u) ? 4u : 0u) * 8u; // natural indices 0, 4, 32, 36
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c_mul) : "v"(l8), "s"(C->mul64) : "memory");
-            asm volatile("global_load_ushort %0, %1, %2" : "=v"(c_zz) : "v"(l2), "s"(C->zzofs) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c_div) : "v"(r8), "s"(C->div) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c_rdiv) : "v"(r8), "s"(C->rdiv) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(m0) : "v"(o32), "s"(C->mulT) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(m1) : "v"(o32), "s"(C->mulT) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(thr) : "v"(o8), "s"(C->thrT) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zzv) : "v"(o16), "s"(C->zzofsT) : "memory");
+            const uint32_t piece = lane < 18 ? (uint32_t)(wave * 18 + lane) : 71u;
+            const uint32_t fo = piece * 16u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c_fill) : "v"(fo), "s"(C->strip_blk) : "memory");
         }
         // LDS layouts of the loop: as in the kernel above (conflict-free transpose and zig-zag staging)
         uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // v in {0,1,4,5}: + v*32 dwords
@@ -851,35 +866,42 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
         const uint4 *tr = reinterpret_cast<const uint4 *>(
             __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // rows 0..3; rows 4..7 at +64 slots
         const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
-        const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
-        const long row8 = 8 * a.stride;
 
-        // strip walk: one scalar cursor (that of the prefetch), see the kernel above
-        long t_lim;
-        if (a.team_count > 0) {
-            const int r = blockIdx.x / a.team_count, t = blockIdx.x - r * a.team_count;
-            int row0 = 0, row1 = 0; // (constant indices only: a dynamic index would move the argument struct to scratch)
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (r == k) { row0 = a.split[k]; row1 = a.split[k + 1]; }
-            const int rows = row1 - row0;
-            t_first = __builtin_amdgcn_readfirstlane((row0 * a.team_count + t) * kWavesPerWG + wave);
-            t_lim = (long)t_first + (long)rows * a.tstep;
+        // Strip walk: one scalar cursor (that of the prefetch), see the kernel above.  Its start state takes ~25 scalar
+        // instructions: no division (magic multipliers from the launcher), no per-workgroup memory.  (Measured: the round-1
+        // prologue's ~250 scalar instructions per wave - four integer divisions - made the last of a CU's five workgroups
+        // issue its first load 3,000 cycles after the first, the 20 waves of a CU share one scalar unit; a table of
+        // per-wave start states read with s_load was as slow: the scalar cache serves misses to distinct lines one by one.)
+        uint32_t tf, t_lim;
+        if (a.team_count > 0) { // 2-D grid: x = team, y = round
+            const uint32_t r = blockIdx.y;
+            const uint32_t row0 = (uint32_t)((r < 8u ? a.split_lo >> (8u * r) : a.split_hi) & 0xffull);
+            const uint32_t row1 = (uint32_t)((r < 7u ? a.split_lo >> (8u * r + 8u) : a.split_hi) & 0xffull);
+            tf = (row0 * (uint32_t)a.team_count + blockIdx.x) * kWavesPerWG + (uint32_t)wave;
+            t_lim = tf + (row1 - row0) * (uint32_t)a.tstep;
         } else if (a.round_wgs > 0) {
-            const int rho = blockIdx.x / a.round_wgs, wl = blockIdx.x - rho * a.round_wgs;
-            const long base = (long)rho * a.round_wgs * a.wg_span;
-            t_first = __builtin_amdgcn_readfirstlane((int)base + wl * kWavesPerWG + wave);
-            t_lim = base + (long)a.round_wgs * a.wg_span;
+            const uint32_t rho = a.magic_tstep ? __umulhi(blockIdx.x, a.magic_tstep /* = magic of round_wgs in this schedule */) : blockIdx.x;
+            const uint32_t wl = blockIdx.x - rho * (uint32_t)a.round_wgs;
+            const uint32_t base = rho * (uint32_t)a.round_wgs * (uint32_t)a.wg_span;
+            tf = base + wl * kWavesPerWG + (uint32_t)wave;
+            t_lim = base + (uint32_t)a.round_wgs * (uint32_t)a.wg_span;
         } else {
-            t_first = __builtin_amdgcn_readfirstlane(blockIdx.x * a.wg_stride + wave);
-            t_lim = (long)blockIdx.x * a.wg_stride + a.wg_span;
+            tf = blockIdx.x * (uint32_t)a.wg_stride + (uint32_t)wave;
+            t_lim = blockIdx.x * (uint32_t)a.wg_stride + (uint32_t)a.wg_span;
         }
-        const int t_end = t_lim < (long)nfast ? (int)t_lim : nfast; // first strip past this wave's walk
-        n_my = t_first < t_end ? (t_end - t_first + a.tstep - 1) / a.tstep : 0; // strips of this wave
-        int txp = t_first % a.fast_tx;
-        const int ty_first = t_first / a.fast_tx;
-        uint32_t in_off = (uint32_t)ty_first * (uint32_t)row8 + (uint32_t)txp * 64u; // frames are < 4 GiB (launcher)
-        uint32_t oblk = (uint32_t)ty_first * (uint32_t)a.bw + (uint32_t)txp * 8u;
+        tf = __builtin_amdgcn_readfirstlane(tf);
+        const uint32_t nfast = (uint32_t)a.fast_ty * (uint32_t)a.fast_tx; // strips handled here: complete, 8-byte aligned, no padding
+        const uint32_t t_end = t_lim < nfast ? t_lim : nfast;                 // first strip past this wave's walk
+        n_my = 0;
+        if (tf < t_end) n_my = (a.round_wgs > 0 || a.magic_tstep == 0u) ? (int)((t_end - tf + (uint32_t)a.tstep - 1u) / (uint32_t)a.tstep)
+                                                                        : (int)__umulhi(t_end - tf + (uint32_t)a.tstep - 1u, a.magic_tstep);
+        if (n_my == 0) tf = 0; // a wave without strips loads (and discards) strip 0
+        t_first = (int)tf;
+        const uint32_t ty_first = a.magic_fast_tx ? __umulhi(tf, a.magic_fast_tx) : tf; // (magic 0: one strip per row)
+        int txp = (int)(tf - ty_first * (uint32_t)a.fast_tx);
+        uint32_t in_off = ty_first * (uint32_t)(8 * a.stride) + (uint32_t)txp * 64u; // frames are < 4 GiB (launcher)
+        uint32_t oblk = ty_first * (uint32_t)a.bw + (uint32_t)txp * 8u;
+        if (ABL == 8) t_desc = __builtin_amdgcn_s_memtime(); // start state known
         const uint32_t ob_first = oblk;
         uint32_t src_off = 0; // a load past the end of the walk re-reads the wave's last strip (strip 0 if it has none)
         int n_issued = 0;
@@ -900,28 +922,30 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
     } while (0)
 #define TIC_WAIT(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(P) : : "memory")
         if (ABL == 8 && a.dbg != nullptr && lane == 0) {
-            unsigned long long *d = a.dbg + ((size_t)blockIdx.x * kWavesPerWG + wave) * 8;
+            unsigned long long *d = a.dbg + (((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8;
             d[0] = t_entry;
             d[1] = __builtin_amdgcn_s_memtime(); // set-up done, first pixel load about to issue
+            d[5] = t_karg;
+            d[7] = t_desc;
         }
         if (ABL == 13) { // timing-only: prologue (arguments, constants, walk set-up), no strips
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(thr), "+v"(zzv), "+v"(c_mul), "+v"(c_zz), "+v"(c_div), "+v"(c_rdiv) : : "memory");
-            if (n_my < 0) a.out[lane] = (int16_t)(m0.x + m1.x + thr.x + (float)zzv.x + (float)in_off + (float)oblk + (float)c_mul.x + (float)c_zz + (float)c_div.x + (float)c_rdiv.x);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(c_fill) : : "memory");
+            if (n_my < 0) a.out[lane] = (int16_t)((float)c_fill.x + (float)in_off + (float)oblk);
             return;
         }
         unsigned long long p0, p1, p2;
         uint32_t ob0, ob1, ob2;
         TIC_LOAD(p0, ob0);
         TIC_LOAD(p1, ob1);
-        // the eight constant loads are older than the pixel loads: they have landed when only those are in flight
-        asm volatile("s_waitcnt vmcnt(2)" : "+v"(m0), "+v"(m1), "+v"(thr), "+v"(zzv), "+v"(c_mul), "+v"(c_zz), "+v"(c_div), "+v"(c_rdiv) : : "memory");
-        // constants of the rare paths -> wave-private LDS
-        *reinterpret_cast<u32x2 *>(cst_mul64 + lane) = c_mul;
-        cst_zz[lane] = (uint16_t)c_zz;
-        if (lane < 4) {
-            *reinterpret_cast<u32x2 *>(cst_rat + lane) = c_div;
-            *reinterpret_cast<u32x2 *>(cst_rat + 4 + lane) = c_rdiv;
-        }
+        // the constant piece is older than the pixel loads: it has landed when only those are in flight
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(c_fill) : : "memory");
+        if (lane < 18) *reinterpret_cast<u32x4 *>(cst_blk + (wave * 18 + lane) * 16) = c_fill;
+        // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+        m0 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32);
+        m1 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32 + 16);
+        thr = *reinterpret_cast<const f32x2 *>(cst_blk + 256 + i * 8);
+        zzv = *reinterpret_cast<const u32x4 *>(cst_blk + 320 + i * 16);
         auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
             return reinterpret_cast<int16_t *>(ldsZ + (ofs >> 4) * 128 + (ofs & 15) + 16 * (b ^ (4 * ((ofs >> 5) & 1))));
         };
@@ -949,7 +973,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
             if (kArith) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
             d0 -= 1024.0f;
             float e0 = d0, e1 = d1, e2 = d2, e3 = d3, e4 = d4, e5 = d5, e6 = d6, e7 = d7;
-            if (kLds) {
+            if (kLdsT) {
                 twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
                 twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
                 twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
@@ -966,14 +990,14 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
             if (kArith) {
                 dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
                 float r0, r1, r2, r3, r4, r5, r6, r7;
-                quant_magic(e0, m0.x, q0, r0);
-                quant_magic(e1, m0.y, q1, r1);
-                quant_magic(e2, m0.z, q2, r2);
-                quant_magic(e3, m0.w, q3, r3);
-                quant_magic(e4, m1.x, q4, r4);
-                quant_magic(e5, m1.y, q5, r5);
-                quant_magic(e6, m1.z, q6, r6);
-                quant_magic(e7, m1.w, q7, r7);
+                if (OPT & 1) quant_fma(e0, m0.x, q0, r0); else quant_magic(e0, m0.x, q0, r0);
+                if (OPT & 1) quant_fma(e1, m0.y, q1, r1); else quant_magic(e1, m0.y, q1, r1);
+                if (OPT & 1) quant_fma(e2, m0.z, q2, r2); else quant_magic(e2, m0.z, q2, r2);
+                if (OPT & 1) quant_fma(e3, m0.w, q3, r3); else quant_magic(e3, m0.w, q3, r3);
+                if (OPT & 1) quant_fma(e4, m1.x, q4, r4); else quant_magic(e4, m1.x, q4, r4);
+                if (OPT & 1) quant_fma(e5, m1.y, q5, r5); else quant_magic(e5, m1.y, q5, r5);
+                if (OPT & 1) quant_fma(e6, m1.z, q6, r6); else quant_magic(e6, m1.z, q6, r6);
+                if (OPT & 1) quant_fma(e7, m1.w, q7, r7); else quant_magic(e7, m1.w, q7, r7);
                 float mA = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
                 mA = fmaxf(fmaxf(mA, fabsf(r5)), fabsf(r6));
                 mA = fmaxf(mA, fabsf(r7));
@@ -985,39 +1009,50 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
                 q4 = __float_as_uint(e4); q5 = __float_as_uint(e5); q6 = __float_as_uint(e6); q7 = __float_as_uint(e7);
             }
             uint4 val;
-            if (kLds) {
+            if (kLdsZ) {
                 *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
                 *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
+                wave_lds_fence();
+                val = *zr;
+                wave_lds_fence();
             } else {
-                val = make_uint4((q0 & 0xffff) | (q1 << 16), (q2 & 0xffff) | (q3 << 16), (q4 & 0xffff) | (q5 << 16), (q6 & 0xffff) | (q7 << 16));
+                val = make_uint4(perm_b32(q1, q0, 0x05040100u), perm_b32(q3, q2, 0x05040100u), perm_b32(q5, q4, 0x05040100u), perm_b32(q7, q6, 0x05040100u));
             }
-            // ---- a guard band tripped somewhere in the strip (rare): settle it before the store ----------------------
-            if (kRare && kLds && __builtin_expect((cA | cB) != 0ull, 0)) {
+            char *dst = reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off;
+            if (ABL == 22) mask_exact += cA ^ (cB << 1); // timing-only: the guard test's result is consumed, nothing else happens
+            // ---- a guard band tripped somewhere in the strip (one strip in five at q=50) ------------------------------
+            if (kRare && kLdsT && kLdsZ && kMem && __builtin_expect((cA | cB) != 0ull, 0)) {
                 const unsigned long long kRat = 0x1111111111111111ull; // lanes v in {0,4}: rational coefficients at u in {0,4}
-                const unsigned long long mG = cA | (cB & ~kRat);
-                bool need_rat = (cB & kRat) != 0ull;
-                // pixel rows -> lane 8*b + i holds row i of block b -> byte transpose -> pixel column i
-                uint2 *pb = reinterpret_cast<uint2 *>(ldsT);
-                pb[lb * 8 + lr] = make_uint2(lo0, hi0);
-                wave_lds_fence();
-                const uint2 rowv = pb[lane];
-                wave_lds_fence();
-                uint32_t lo = rowv.x, hi = rowv.y;
-                transpose8x8_bytes(lo, hi, i);
-                // zig-zag staging addresses of the coefficients (u = i, v = 0..7) this lane produces on the float64 paths
-                const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8);
-                if (mG != 0ull) { // second level for the whole strip
-                    int qe[8];
-                    bool ok_rat;
-                    const bool ok = second_level_block(lo, hi, ldsT, b, i, cst_mul64, qe, ok_rat);
-                    const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
-#pragma unroll
-                    for (int v = 0; v < 8; v++) *zz_ptr((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) = (int16_t)qe[v];
-                    need_rat = need_rat || __ballot(!ok_rat) != 0ull;
-                    if (__ballot(!ok) != 0ull) mask_exact |= 1ull << kstrip; // a true tie: exact order, after the loop
-                    n_second += (uint32_t)__builtin_popcount(byte_any(mG));
-                }
-                if (need_rat) { // the four rational coefficients of every block, exact sub-path
+                const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
+                const uint32_t gm = byte_any(mG), fm = gm | byte_any(mS); // blocks with an irrational trip / with any trip
+                const int nnew = __builtin_popcount(fm);
+                if (nE + nnew <= kBatch && (fm != 0xffu || !(OPT & 2))) {
+                    // the blocks join the batch: id + kind, pixel rows (this lane holds row lr of block lb), staged image
+                    const uint32_t below = (1u << b) - 1u, lbelow = (1u << lb) - 1u;
+                    const bool mine = (fm >> b) & 1u;
+                    const int e = nE + __builtin_popcount(fm & below);
+                    if (mine) bat_img[e * 8 + i] = val;
+                    if (mine && i == 0) bat_id[e] = (ob + (uint32_t)b) | (((gm >> b) & 1u) << 31);
+                    if ((fm >> lb) & 1u) bat_pix[(nE + __builtin_popcount(fm & lbelow)) * 8 + lr] = make_uint2(lo0, hi0);
+                    // the tripped blocks leave with the batch pass; the others now (at least one lane stores: the strip's one
+                    // vector-memory instruction is issued on every path, which the counted waits rely on)
+                    if (!mine || !(OPT & 2)) store16_policy<ST>(dst, val);
+                    nE += nnew;
+                    n_second += (uint32_t)__builtin_popcount(gm);
+                } else if (gm != 0u) {
+                    // no room and an irrational trip: the whole strip is redone in the exact order after the loop
+                    mask_exact |= 1ull << kstrip;
+                    store16_policy<ST>(dst, val);
+                } else {
+                    // no room, rational ties only (tie-dense content, e.g. flat areas with an odd grey level): exact sub-path
+                    // for the four rational coefficients of all eight blocks, here and now
+                    uint2 *pb = reinterpret_cast<uint2 *>(ldsT);
+                    pb[lb * 8 + lr] = make_uint2(lo0, hi0);
+                    wave_lds_fence();
+                    const uint2 rowv = pb[lane]; // row i of block b
+                    wave_lds_fence();
+                    uint32_t lo = rowv.x, hi = rowv.y;
+                    transpose8x8_bytes(lo, hi, i); // -> pixel column i
                     RationalConsts KR;
                     KR.div0 = cst_rat[(i >> 2) * 2];
                     KR.div4 = cst_rat[(i >> 2) * 2 + 1];
@@ -1025,29 +1060,27 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
                     KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
                     int r0, r4;
                     special_block(lo, hi, ldsT, b, i, KR, r0, r4);
-                    if ((i & 3) == 0) { // lane i = 0: (0,0) and (0,4); lane i = 4: (4,0) and (4,4)
-                        *zz_ptr(zo.x & 0xffffu) = (int16_t)r0;
-                        *zz_ptr(zo.z & 0xffffu) = (int16_t)r4;
+                    if ((i & 3) == 0) { // lane i = 0: (0,0) and (0,4) at scan positions 0, 14; lane i = 4: (4,0), (4,4) at 10, 39
+                        *zz_ptr(i ? 20u : 0u) = (int16_t)r0;
+                        *zz_ptr(i ? 78u : 28u) = (int16_t)r4;
                     }
+                    wave_lds_fence();
+                    val = *zr;
+                    wave_lds_fence();
+                    store16_policy<ST>(dst, val);
                 }
-            }
-            // ---- zig-zag ordered blocks -> global: 16 B per lane, 1 KiB contiguous per wave ---------------------------
-            if (kLds) {
-                wave_lds_fence();
-                val = *zr;
-                wave_lds_fence();
-            }
-            if (!kMem) { acc.x ^= val.x; acc.y ^= val.y; acc.z ^= val.z; acc.w ^= val.w; } // compute-only build: no store
-            else store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off, val);
+            } else if (!kMem) { acc.x ^= val.x; acc.y ^= val.y; acc.z ^= val.z; acc.w ^= val.w; } // compute-only build: no store
+            else store16_policy<ST>(dst, val); // 16 B per lane, 1 KiB contiguous per wave
             left--;
             kstrip++;
         };
         // Two strips ahead: strip j is consumed after L(j+2) is issued; in steady state the instructions younger than
-        // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.
+        // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.  (A rare branch issues at most
+        // the same single store per strip.)
         do {
             if (left == 0) break;
             TIC_LOAD(p2, ob2); TIC_WAIT(p0, 2);
-            if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
+            if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
             process(p0, ob0);
             if (left == 0) break;
             TIC_LOAD(p0, ob0); TIC_WAIT(p1, 3); process(p1, ob1);
@@ -1059,25 +1092,82 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
                 TIC_LOAD(p0, ob0); TIC_WAIT(p1, 4); process(p1, ob1);
             }
         } while (0);
-        // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
         if (!kMem) { // one store per wave, to its first strip (always inside the frame)
             if (n_my > 0) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob_first << 7) + st_off) = acc;
             return;
         }
+        if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 3] = __builtin_amdgcn_s_memtime(); // loop left
+        // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved until
+        // only the wave's last store is outstanding
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
 #undef TIC_LOAD
 #undef TIC_WAIT
     }
+    // ---- the batch pass: lane 8*b + i serves entry b ---------------------------------------------------------------------
+    if (ABL == 22 && mask_exact == 0x123456789ull) a.out[lane] = 1; // (keeps the accumulated value alive)
+    if (ABL == 22) mask_exact = 0;
+    if (kBatchPass && nE != 0) {
+        const bool have = b < nE;
+        const int e = have ? b : 0;
+        const uint32_t id = bat_id[e];
+        const bool isG = have && (id >> 31) != 0u && ABL != 24; // (ABL 24, timing only: no second level, every entry is treated as a tie entry)
+        const uint32_t blk = id & 0x7fffffffu;
+        const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
+        uint32_t lo = rowv.x, hi = rowv.y;
+        transpose8x8_bytes(lo, hi, i); // -> pixel column i
+        const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8); // byte offsets in the image of (u = i, v = 0..7)
+        const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+        int16_t *img16 = reinterpret_cast<int16_t *>(bat_img + e * 8);
+        bool need_rat = have && !isG; // tie entries: the four rational coefficients
+        if (__ballot(isG) != 0ull) {
+            int qe[8];
+            bool ok_rat;
+            const bool ok = second_level_block(lo, hi, ldsT, b, i, cst_mul64, qe, ok_rat);
+            if (isG) {
+#pragma unroll
+                for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qe[v];
+            }
+            need_rat = need_rat || (isG && !ok_rat);
+            const unsigned long long bad = __ballot(isG && !ok); // a true tie of an irrational coefficient: exact order
+            if (bad != 0ull) {
+                int qx[8];
+                exact_block(lo, hi, ldsT, b, i, C, qx);
+                if ((bad >> (8 * b)) & 0xffull) {
+#pragma unroll
+                    for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qx[v];
+                    need_rat = false;
+                }
+            }
+        }
+        const unsigned long long m_rat = __ballot(need_rat);
+        if (m_rat != 0ull) {
+            RationalConsts KR;
+            KR.div0 = cst_rat[(i >> 2) * 2];
+            KR.div4 = cst_rat[(i >> 2) * 2 + 1];
+            KR.rdiv0 = cst_rat[4 + (i >> 2) * 2];
+            KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
+            int r0, r4;
+            special_block(lo, hi, ldsT, b, i, KR, r0, r4);
+            if ((i & 3) == 0 && ((m_rat >> (8 * b)) & 0xffull) != 0ull) {
+                img16[(zo.x & 0xffffu) >> 1] = (int16_t)r0; // (i,0)
+                img16[(zo.z & 0xffffu) >> 1] = (int16_t)r4; // (i,4)
+            }
+        }
+        wave_lds_fence();
+        const uint4 val = bat_img[e * 8 + i];
+        if (!(OPT & 2)) asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); // A/B: the loop stored the tripped blocks too; wait for those stores
+        if (have) store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)blk << 7) + (uint32_t)i * 16u, val);
+    }
     if (ABL == 8 && a.dbg != nullptr && lane == 0) {
-        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * kWavesPerWG + wave) * 8;
-        d[3] = __builtin_amdgcn_s_memtime(); // loop left, all of the wave's stores have landed (vmcnt(0) above)
-        d[6] = (unsigned long long)n_my | ((unsigned long long)n_second << 32);
-        d[7] = mask_exact;
+        unsigned long long *d = a.dbg + (((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8;
+        d[4] = __builtin_amdgcn_s_memtime(); // batch pass done (its stores issued)
+        d[6] = (unsigned long long)n_my | ((unsigned long long)(n_second & 0xffffu) << 32) | ((unsigned long long)nE << 48) |
+               ((unsigned long long)(mask_exact != 0ull) << 63);
     }
     if (a.fallback_count != nullptr && lane == 0 && n_second != 0) atomicAdd(a.fallback_count, (unsigned long long)n_second);
-    // ---- strips with a true tie of an irrational coefficient: the exact operation order, whole strip ----------------
-    // (the wave's own stores to these strips have landed: vmcnt(0) above)
+    // ---- strips the batch had no room for: the exact operation order, whole strip ---------------------------------------
     if (mask_exact == 0ull) return;
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); // the wave's fast-path stores to these strips must have landed
     const uint4 zzn = *reinterpret_cast<const uint4 *>(cst_zz + i * 8);
     const uint16_t zz[8] = {(uint16_t)zzn.x, (uint16_t)(zzn.x >> 16), (uint16_t)zzn.y, (uint16_t)(zzn.y >> 16),
                             (uint16_t)zzn.z, (uint16_t)(zzn.z >> 16), (uint16_t)zzn.w, (uint16_t)(zzn.w >> 16)};
@@ -1099,6 +1189,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
     }
 }
 
+#ifdef TIC_ABLATION // explored alternative, experiment library only
 // ---------------------------------------------------------------------------------------------------------
 // Kernel 2b: one block per lane (explored alternative; variant 40).
 //
@@ -1431,6 +1522,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 4) void dctq_lane_kernel(DctqArgs
     }
 }
 
+#endif // TIC_ABLATION
+
 // ---------------------------------------------------------------------------------------------------------
 // Kernel 3: decode side - dequantise (utils.py:52), inverse DCT (utils.py:40-45, exact order), +128, clip,
 // truncating cast (codec.py:68-70), crop.  Input: int16 [N][64] zig-zag, DC already integrated (np.cumsum).
@@ -1589,30 +1682,34 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         // strip kernels, persistent waves: each wave loops over its strips.  Variants 2, 10-22, 1xx, 2xx: round-1 kernel with
         // the workgroup-shared post-pass (trip lists: at most 16 strips per wave); 50-59, 3xx, 4xx: wave-local rare paths
         // (one mask bit per strip: at most 64 strips per wave).
-        const bool new_kernel = (variant >= 50 && variant < 60) || variant >= 300;
+        const bool new_kernel = variant == 2 || (variant >= 50 && variant < 70) || variant >= 300;
         const int max_strips = new_kernel ? kMaxStripsPerWave2 : kMaxStripsPerWave;
         int wgs = grid_for(nfast);
         // persistent grid = exactly the workgroups the chip holds at once (CUs x resident workgroups per CU): a larger
         // grid runs in two uneven rounds, a smaller one leaves wave slots empty (measured: 15.0 us at 1280 workgroups
         // vs 16.3 us at 2048 on a 4096^2 frame)
         static int cus = 256;
-        static const int resident_old = [] {
+        static const int resident_new = [] {
             int dev = 0, per_cu = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0, 2, 0, 3>, kWavesPerWG * 64, 0) != hipSuccess ||
+                per_cu < 1)
+                per_cu = 4;
+            return cus * per_cu;
+        }();
+#ifdef TIC_ABLATION
+        static const int resident_old = [] {
+            int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_hybrid_kernel<0>, kWavesPerWG * 64, 0) != hipSuccess ||
                 per_cu < 1)
                 per_cu = 4;
             return cus * per_cu;
         }();
-        static const int resident_new = [] {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0>, kWavesPerWG * 64, 0) != hipSuccess ||
-                per_cu < 1)
-                per_cu = 4;
-            return cus * per_cu;
-        }();
         const int resident = new_kernel ? resident_new : resident_old;
+#else
+        const int resident = resident_new;
+#endif
         const Tunables tune = tunables();
         const int cap_env = tune.max_wgs > 0 ? tune.max_wgs : resident;
         int cap = cap_env / nf; // a batch shares the chip's wave slots between its frames
@@ -1659,6 +1756,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
                 if (a.split[r + 1] - a.split[r] > max_strips) a.team_count = 0; // strips per wave are bounded: fall back
             }
             a.split[R] = rows_total;
+            if (new_kernel && rows_total > 255) a.team_count = 0; // the round-2 kernel takes the row boundaries as bytes
             if (a.team_count == 0) a.tstep = a.nwaves;
         }
         a.step_ty = a.tstep / a.fast_tx;
@@ -1668,8 +1766,36 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.oblk_step = (uint32_t)((long)a.step_ty * a.bw + (long)a.step_tx * 8);
         a.oblk_wrap = (uint32_t)((long)a.bw - (long)a.fast_tx * 8);
         const dim3 grid(wgs, nf);
+        // round-2 kernel: division-free prologue (magic multipliers), team schedule on a 2-D grid
+        dim3 grid2(wgs, 1, nf);
+        bool launch_fast = true;
+        if (new_kernel) {
+            // exactness of the magic divisions: n * d < 2^32 for every dividend n the prologue can form; frames beyond that
+            // (more than ~10^5 pixels wide and millions of strips) go through the exact kernel as a whole
+            const unsigned long long dmax = (unsigned long long)(a.round_wgs > 0 ? a.round_wgs : a.tstep);
+            if ((unsigned long long)nfast * (unsigned long long)a.fast_tx >= (1ull << 32) ||
+                ((unsigned long long)nfast + dmax) * dmax >= (1ull << 32)) {
+                launch_fast = false;
+                a.fast_tx = a.fast_ty = 0;
+            }
+        }
+        if (launch_fast) {
+            auto magic = [](long d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (unsigned long long)d + 1ull); }; // 0: divisor 1
+            a.magic_fast_tx = magic(a.fast_tx);
+            a.magic_tstep = magic(a.round_wgs > 0 ? a.round_wgs : a.tstep);
+            a.split_lo = a.split_hi = 0;
+            if (a.team_count > 0) {
+                const int R = wgs / a.team_count;
+                for (int k = 0; k <= R; k++) {
+                    if (k < 8) a.split_lo |= (unsigned long long)(a.split[k] & 0xff) << (8 * k);
+                    else a.split_hi = (unsigned long long)(a.split[k] & 0xff);
+                }
+                grid2 = dim3(a.team_count, R, nf);
+            }
+#ifdef TIC_ABLATION
 #define TIC_LAUNCH(ABL) hipLaunchKernelGGL(dctq_hybrid_kernel<ABL>, grid, block, tune.lds_pad, stream, a)
-#define TIC_LAUNCH2(ABL) hipLaunchKernelGGL(dctq_strip_kernel<ABL>, grid, block, tune.lds_pad, stream, a)
+#define TIC_LAUNCH2(ABL) hipLaunchKernelGGL(dctq_strip_kernel<ABL>, grid2, block, tune.lds_pad, stream, a)
+#endif
         switch (variant) {
 #ifdef TIC_ABLATION
         case 10: TIC_LAUNCH(1); break;
@@ -1693,19 +1819,34 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         case 55: TIC_LAUNCH2(6); break;  // streaming skeleton
         case 56: TIC_LAUNCH2(1); break;  // no arithmetic
         case 57: TIC_LAUNCH2(9); break;  // compute only
+        case 60: hipLaunchKernelGGL((dctq_strip_kernel<20, 2>), grid2, block, tune.lds_pad, stream, a); break; // no zig-zag staging
+        case 61: hipLaunchKernelGGL((dctq_strip_kernel<21, 2>), grid2, block, tune.lds_pad, stream, a); break; // no transpose
+        case 62: hipLaunchKernelGGL((dctq_strip_kernel<2, 2>), grid2, block, tune.lds_pad, stream, a); break;  // no LDS in the loop
+        case 63: hipLaunchKernelGGL((dctq_strip_kernel<3, 2>), grid2, block, tune.lds_pad, stream, a); break;  // tripped blocks ignored
+        case 64: hipLaunchKernelGGL((dctq_strip_kernel<1, 2>), grid2, block, tune.lds_pad, stream, a); break;  // no arithmetic
+        case 65: hipLaunchKernelGGL((dctq_strip_kernel<9, 2>), grid2, block, tune.lds_pad, stream, a); break;  // compute only
+        case 66: hipLaunchKernelGGL((dctq_strip_kernel<22, 2>), grid2, block, tune.lds_pad, stream, a); break; // guard test only
+        case 67: hipLaunchKernelGGL((dctq_strip_kernel<23, 2>), grid2, block, tune.lds_pad, stream, a); break; // no batch pass
+        case 68: hipLaunchKernelGGL((dctq_strip_kernel<24, 2>), grid2, block, tune.lds_pad, stream, a); break; // batch pass without the second level
+        case 500: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 0>), grid2, block, tune.lds_pad, stream, a); break;
+        case 501: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 1>), grid2, block, tune.lds_pad, stream, a); break;
+        case 502: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 2>), grid2, block, tune.lds_pad, stream, a); break;
+        case 503: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 3>), grid2, block, tune.lds_pad, stream, a); break;
 #define TIC_POL(S, L)                                                                                                  \
     case 100 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<0, S, L>), grid, block, tune.lds_pad, stream, a); break; \
     case 200 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<6, S, L>), grid, block, tune.lds_pad, stream, a); break; \
-    case 300 + 10 * S + L: hipLaunchKernelGGL((dctq_strip_kernel<0, S, L>), grid, block, tune.lds_pad, stream, a); break;  \
-    case 400 + 10 * S + L: hipLaunchKernelGGL((dctq_strip_kernel<6, S, L>), grid, block, tune.lds_pad, stream, a); break;
+    case 300 + 10 * S + L: hipLaunchKernelGGL((dctq_strip_kernel<0, S, L>), grid2, block, tune.lds_pad, stream, a); break; \
+    case 400 + 10 * S + L: hipLaunchKernelGGL((dctq_strip_kernel<6, S, L>), grid2, block, tune.lds_pad, stream, a); break;
         TIC_POL(1, 0) TIC_POL(2, 0) TIC_POL(3, 0) TIC_POL(4, 0) TIC_POL(0, 1) TIC_POL(0, 2) TIC_POL(0, 4)
         TIC_POL(2, 1) TIC_POL(2, 2) TIC_POL(4, 1) TIC_POL(3, 1) TIC_POL(1, 1)
 #undef TIC_POL
+        case 9: TIC_LAUNCH(0); break; // the round-1 kernel (plain stores)
 #endif
-        default: TIC_LAUNCH(0); break;
+        default: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 3>), grid2, block, 0, stream, a); break; // the production kernel
         }
 #undef TIC_LAUNCH
 #undef TIC_LAUNCH2
+        }
     } else {
         a.fast_tx = a.fast_ty = 0;
     }

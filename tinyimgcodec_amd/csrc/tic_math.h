@@ -7,6 +7,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "tic_tables.h"
 
@@ -180,7 +181,12 @@ struct DctqConsts {
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
     uint16_t zzofsT[64]; // index v*8+u: same offsets, transposed (lane v holds u = 0..7)
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
+    // Everything the strip kernel needs, packed as the image its workgroups copy into LDS with one 16-byte load per lane
+    // (72 lanes): [0,256) mulT, [256,320) thrT, [320,448) zzofsT, [448,960) mul64, [960,1088) zzofs, [1088,1152) div then rdiv
+    // of the rational coefficients (0,0) (0,4) (4,0) (4,4).
+    alignas(16) unsigned char strip_blk[1152];
 };
+constexpr int kStripBlkBytes = 1152;
 
 // utils.py:50-53 divisor recipe.  Returns false when quality is outside 1..99.
 inline bool build_consts(int quality, DctqConsts *c) {
@@ -234,6 +240,19 @@ inline bool build_consts(int quality, DctqConsts *c) {
         c->zzofs[nat] = (uint16_t)(2 * k);
         c->zzofsT[v * 8 + u] = (uint16_t)(2 * k);
         c->zznat[k] = (uint8_t)nat;
+    }
+    {
+        unsigned char *p = c->strip_blk;
+        memcpy(p, c->mulT, 256);
+        memcpy(p + 256, c->thrT, 64);
+        memcpy(p + 320, c->zzofsT, 128);
+        memcpy(p + 448, c->mul64, 512);
+        memcpy(p + 960, c->zzofs, 128);
+        const int rat[4] = {0, 4, 32, 36};
+        for (int k = 0; k < 4; k++) {
+            memcpy(p + 1088 + 8 * k, &c->div[rat[k]], 8);
+            memcpy(p + 1120 + 8 * k, &c->rdiv[rat[k]], 8);
+        }
     }
     return true;
 }
