@@ -363,7 +363,7 @@ int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t 
     if (!ctx->d_dbg) HIPCHK(ctx, hipMalloc(&ctx->d_dbg, 8192 * 4 * 8 * sizeof(unsigned long long)));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg, 0, 8192 * 4 * 8 * sizeof(unsigned long long), ctx->stream));
     DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
-    HIPCHK(ctx, launch_dctq(a, variant == 52 ? 52 : 17, ctx->stream));
+    HIPCHK(ctx, launch_dctq(a, (variant == 52 || variant == 71) ? variant : 17, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     size_t n = n_u64 < 8192 * 4 * 8 ? n_u64 : 8192 * 4 * 8;
     HIPCHK(ctx, hipMemcpy(host_out, ctx->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -51,6 +51,9 @@ struct DctqArgs {
     // rows of round r from byte r of split_lo (byte 8: split_hi).
     uint32_t magic_fast_tx, magic_tstep;
     unsigned long long split_lo, split_hi;
+    // queue kernel: teams (= gridDim.x) of q_waves waves share a ticket counter; a ticket is one strip, runs of
+    // 2^q_run_shift adjacent strips belong to one team
+    int q_teams, q_waves, q_run_shift, q_ppw;
 };
 
 struct IdctArgs {

@@ -1189,6 +1189,403 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Kernel 2c (round 2): the strip kernel with a dynamic strip queue.
+//
+// Same strip loop and the same wave-local batch pass as dctq_strip_kernel above.  What differs is who processes which
+// strip: a workgroup is a TEAM of up to 16 waves (one team per CU on frames that fill the chip) sharing a ticket counter
+// in LDS.  Ticket c of team g is strip ((c >> rs) * G + g) << rs | (c & (2^rs - 1)): runs of 2^rs adjacent strips per
+// team, teams interleaved (the address pattern of the static team schedule).  A wave takes its first two tickets
+// statically (wave, wave + W), every further one with an LDS atomic requested one strip ahead of its use.
+// Why: with a static walk the launch ends when the slowest wave ends, and waves differ - the ones whose strips tripped
+// run a batch pass (1,500 cycles, 3,000 with a second-level entry), late-dispatched workgroups get fewer issue slots
+// (age-ordered arbitration).  In-kernel stamps of the static kernel on a 4096^2 frame: median wave end 14,200 cycles,
+// last wave 17,600.  With tickets a wave that is slow simply takes fewer strips.
+// Tie-dense content cannot overflow anything: a wave whose batch is more than half full (or that holds two strips for
+// the exact-order redo) stops taking tickets, drains its pipeline, settles batch and redo list and starts over.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kQMaxWaves = 16;
+constexpr int kQXList = 16;                                               // strips waiting for the exact-order redo
+constexpr int kQWaveBytes = kTWaveBytes + kZzWaveBytes + kBatchWaveBytes + kQXList * 4 + 256; // 5248 B per wave (the last 256: ticket scratch)
+constexpr int kQHeadBytes = kStripBlkBytes + 16;                         // constants + ticket counter
+
+template <int ABL, int ST = 2>
+__global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    constexpr bool kRare = !(ABL == 3);
+    unsigned long long t_entry = 0;
+    if (ABL == 8) t_entry = __builtin_amdgcn_s_memtime();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t W = (uint32_t)a.q_waves, G = (uint32_t)a.q_teams, rs = (uint32_t)a.q_run_shift, g = blockIdx.x;
+    unsigned char *cst_blk = lds_dyn;
+    uint32_t *q_ctr = reinterpret_cast<uint32_t *>(lds_dyn + kStripBlkBytes);
+    unsigned char *wbase = lds_dyn + kQHeadBytes + wave * kQWaveBytes;
+    uint32_t *ldsT = reinterpret_cast<uint32_t *>(wbase);
+    char *ldsZ = reinterpret_cast<char *>(wbase + kTWaveBytes);
+    uint32_t *bat = reinterpret_cast<uint32_t *>(wbase + kTWaveBytes + kZzWaveBytes);
+    uint4 *bat_img = reinterpret_cast<uint4 *>(bat);                   // [kBatch][8] 16-byte pieces: zig-zag images
+    uint2 *bat_pix = reinterpret_cast<uint2 *>(bat + kBatch * 32);     // [kBatch][8] pixel rows
+    uint32_t *bat_id = bat + kBatch * 48;                              // [kBatch] block index | kind << 31
+    uint32_t *xlist = reinterpret_cast<uint32_t *>(wbase + kTWaveBytes + kZzWaveBytes + kBatchWaveBytes); // [kQXList] strip indices
+    const double *cst_mul64 = reinterpret_cast<const double *>(cst_blk + 448);  // [64] index u*8+v
+    const uint16_t *cst_zz = reinterpret_cast<const uint16_t *>(cst_blk + 960); // [64] index u*8+v
+    const double *cst_rat = reinterpret_cast<const double *>(cst_blk + 1088);   // div[4] then rdiv[4]: (0,0) (0,4) (4,0) (4,4)
+    const DctqConsts *__restrict__ C = a.consts;
+    a.img += (long)blockIdx.z * a.frame_stride_in; // batch of frames: one grid plane per frame
+    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.z * a.frame_stride_out);
+
+    const uint32_t nfast = (uint32_t)a.fast_ty * (uint32_t)a.fast_tx; // strips of the frame's fast rectangle
+    uint32_t n_second = 0, n_strips = 0, n_flush = 0;
+    int nE = 0, nX = 0;      // entries in the batch / in the redo list (wave-uniform)
+    bool stop = false;       // take no further tickets until batch and redo list are settled
+    bool exhausted = false;  // the team's queue is empty
+    if (threadIdx.x == 0) *q_ctr = 2u * W; // the first two tickets of every wave are static
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // constants: the team copies the quality's 1152-byte block into LDS, one 16-byte piece per lane of the first lanes of
+    // every wave (every vector-memory instruction from here to the end of the strip loop is issued by hand and counted)
+    u32x4 c_fill;
+    const uint32_t ppw = (uint32_t)a.q_ppw; // pieces per wave = ceil(72 / W)
+    {
+        const uint32_t piece = (uint32_t)lane < ppw ? (uint32_t)wave * ppw + (uint32_t)lane : 71u;
+        const uint32_t fo = (piece < 72u ? piece : 71u) * 16u;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c_fill) : "v"(fo), "s"(C->strip_blk) : "memory");
+    }
+    // ticket -> strip: index inside the fast rectangle, byte offset of its first pixel, raster index of its first block
+    const uint32_t run_mask = (1u << rs) - 1u, row8 = (uint32_t)(8 * a.stride);
+    auto strip_of = [&](uint32_t c, uint32_t &t, uint32_t &in_off, uint32_t &ob) -> bool {
+        t = ((((c >> rs) * G) + g) << rs) + (c & run_mask);
+        if (t >= nfast) return false;
+        const uint32_t ty = a.magic_fast_tx ? __umulhi(t, a.magic_fast_tx) : t; // (magic 0: one strip per row)
+        const uint32_t tx = t - ty * (uint32_t)a.fast_tx;
+        in_off = ty * row8 + tx * 64u; // frames are < 4 GiB (launcher)
+        ob = ty * (uint32_t)a.bw + tx * 8u;
+        return true;
+    };
+    // Ticket = LDS atomic add issued by hand: lane 0 on the team's counter, the other lanes on scratch words of their own
+    // (no exec juggling), result picked up one strip later behind an explicit wait.  (Written as atomicAdd under
+    // `if (lane == 0)` the compiler's atomic optimiser turns it into mbcnt + ds_add + readfirstlane with the wait right
+    // behind it: every strip then stalls for an LDS round trip under load, 8.5 us instead of 6.8 for a 4096^2 frame.)
+    const uint32_t tk_addr = lane == 0 ? (uint32_t)(uintptr_t)q_ctr
+                                       : (uint32_t)(uintptr_t)(wbase + kQWaveBytes - 256) + (uint32_t)lane * 4u;
+    const uint32_t tk_one = 1u;
+    auto take_ticket = [&]() -> uint32_t {
+        uint32_t v;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(v) : "v"(tk_addr), "v"(tk_one) : "memory");
+        return v;
+    };
+    auto ticket_value = [&](uint32_t v) -> uint32_t { // wait for the atomic, lane 0's result
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    const uint8_t *img_s = a.img;
+    // one pixel load (always issued, so that the counted waits hold; an invalid slot re-reads strip 0)
+#define TIC_QLOAD(P, IO, VLD)                                                                               \
+    do {                                                                                                    \
+        const uint8_t *src = img_s + __builtin_amdgcn_readfirstlane((VLD) ? (IO) : 0u);                     \
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory");       \
+    } while (0)
+#define TIC_WAIT(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(P) : : "memory")
+
+    bool first = true;
+    for (;;) {
+        // Everything the strip loop keeps in registers is (re)derived here, from a lane id the compiler cannot see through:
+        // nothing of it stays live across the batch pass at the end of this block (the pass needs the registers: with the
+        // loop's 40 lane-constant values hoisted out, the kernel spilled).
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int lr = lane_l >> 3, lb = lane_l & 7; // load phase: pixel row lr of block lb
+        const int b = lane_l >> 3, i = lane_l & 7;   // compute phase: column / frequency v = i of block b
+        const uint32_t st_off = (uint32_t)lane_l * 16u; // lane offset inside a strip's 1 KiB output
+        uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // transpose, v in {0,1,4,5}: + v*32 dwords
+        uint32_t *twB = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * (lb ^ 4); // v in {2,3,6,7}
+        const uint4 *tr = reinterpret_cast<const uint4 *>(
+            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // rows 0..3; rows 4..7 at +64 slots
+        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
+        auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
+            return reinterpret_cast<int16_t *>(ldsZ + (ofs >> 4) * 128 + (ofs & 15) + 16 * (b ^ (4 * ((ofs >> 5) & 1))));
+        };
+        const uint4 *zr = reinterpret_cast<const uint4 *>(
+            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (4 * ((i >> 1) & 1)))), 16));
+        // ---- prime the pipeline: two strips in flight ------------------------------------------------------------------
+        unsigned long long p0, p1, p2;
+        uint32_t ob0 = 0, ob1 = 0, ob2 = 0, t0 = 0, t1 = 0, t2 = 0, io = 0;
+        bool v0, v1, v2 = false;
+        {
+            uint32_t c0, c1;
+            if (first) {
+                c0 = (uint32_t)wave;
+                c1 = (uint32_t)wave + W;
+            } else {
+                const uint32_t k0 = take_ticket(), k1 = take_ticket();
+                c0 = ticket_value(k0);
+                c1 = ticket_value(k1);
+            }
+            v0 = strip_of(c0, t0, io, ob0);
+            TIC_QLOAD(p0, io, v0);
+            v1 = strip_of(c1, t1, io, ob1);
+            TIC_QLOAD(p1, io, v1);
+            if (!v1) exhausted = true;
+        }
+        if (first) {
+            if (ABL == 8 && a.dbg != nullptr && lane == 0) {
+                unsigned long long *d = a.dbg + ((size_t)blockIdx.x * kQMaxWaves + wave) * 8;
+                d[0] = t_entry;
+                d[1] = __builtin_amdgcn_s_memtime(); // first pixel loads issued
+            }
+            // the constant piece is older than the pixel loads: it has landed when only those are in flight
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(c_fill) : : "memory");
+            if ((uint32_t)lane < ppw && (uint32_t)wave * ppw + (uint32_t)lane < 72u)
+                *reinterpret_cast<u32x4 *>(cst_blk + ((uint32_t)wave * ppw + (uint32_t)lane) * 16u) = c_fill;
+            // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about);
+            // it also publishes the ticket counter
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+            first = false;
+        }
+        const f32x4 m0 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32);
+        const f32x4 m1 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32 + 16);
+        const f32x2 thr = *reinterpret_cast<const f32x2 *>(cst_blk + 256 + i * 8);
+        const u32x4 zzv = *reinterpret_cast<const u32x4 *>(cst_blk + 320 + i * 16);
+        int16_t *zp0 = zz_ptr(zzv.x & 0xffff), *zp1 = zz_ptr(zzv.x >> 16), *zp2 = zz_ptr(zzv.y & 0xffff), *zp3 = zz_ptr(zzv.y >> 16);
+        int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
+        uint32_t tk_pending = 0;      // ticket requested one strip ahead (lane 0)
+        bool have_pending = false;
+        if (!stop && !exhausted) { tk_pending = take_ticket(); have_pending = true; }
+
+        // one strip: everything from the pixel row held in px to the 1 KiB store
+        auto process = [&](const unsigned long long px, const uint32_t ob, const uint32_t tcur) {
+            // ---- pass 1: along the pixel row ------------------------------------------------------------------
+            const uint32_t lo0 = (uint32_t)px, hi0 = (uint32_t)(px >> 32);
+            float d0, d1, d2, d3, d4, d5, d6, d7;
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d0) : "v"(lo0));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d1) : "v"(lo0));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d2) : "v"(lo0));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d3) : "v"(lo0));
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d4) : "v"(hi0));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d5) : "v"(hi0));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d6) : "v"(hi0));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d7) : "v"(hi0));
+            dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
+            d0 -= 1024.0f;
+            twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
+            twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
+            twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
+            wave_lds_fence();
+            const uint4 ra = tr[0], rb = tr[64];
+            wave_lds_fence();
+            float e0 = __uint_as_float(ra.x), e1 = __uint_as_float(ra.y), e2 = __uint_as_float(ra.z), e3 = __uint_as_float(ra.w);
+            float e4 = __uint_as_float(rb.x), e5 = __uint_as_float(rb.y), e6 = __uint_as_float(rb.z), e7 = __uint_as_float(rb.w);
+            // ---- pass 2: down the column of horizontal frequency v = i ----------------------------------------
+            dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
+            uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
+            float r0, r1, r2, r3, r4, r5, r6, r7;
+            quant_fma(e0, m0.x, q0, r0);
+            quant_fma(e1, m0.y, q1, r1);
+            quant_fma(e2, m0.z, q2, r2);
+            quant_fma(e3, m0.w, q3, r3);
+            quant_fma(e4, m1.x, q4, r4);
+            quant_fma(e5, m1.y, q5, r5);
+            quant_fma(e6, m1.z, q6, r6);
+            quant_fma(e7, m1.w, q7, r7);
+            float mA = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
+            mA = fmaxf(fmaxf(mA, fabsf(r5)), fabsf(r6));
+            mA = fmaxf(mA, fabsf(r7));
+            const float mB = fmaxf(fabsf(r0), fabsf(r4));
+            const unsigned long long cA = __ballot(mA > thr.x); // lanes whose guard band tripped: u in 1,2,3,5,6,7
+            const unsigned long long cB = __ballot(mB > thr.y); // u in 0,4
+            *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
+            *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
+            wave_lds_fence();
+            uint4 val = *zr;
+            wave_lds_fence();
+            char *dst = reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off;
+            // ---- a guard band tripped somewhere in the strip (one strip in five at q=50) ------------------------------
+            if (kRare && __builtin_expect((cA | cB) != 0ull, 0)) {
+                const unsigned long long kRat = 0x1111111111111111ull; // lanes v in {0,4}: rational coefficients at u in {0,4}
+                const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
+                const uint32_t gm = byte_any(mG), fm = gm | byte_any(mS); // blocks with an irrational trip / with any trip
+                const int nnew = __builtin_popcount(fm);
+                if (nE + nnew <= kBatch && fm != 0xffu) {
+                    // the blocks join the batch: id + kind, pixel rows (this lane holds row lr of block lb), staged image
+                    const uint32_t below = (1u << b) - 1u, lbelow = (1u << lb) - 1u;
+                    const bool mine = (fm >> b) & 1u;
+                    const int e = nE + __builtin_popcount(fm & below);
+                    if (mine) bat_img[e * 8 + i] = val;
+                    if (mine && i == 0) bat_id[e] = (ob + (uint32_t)b) | (((gm >> b) & 1u) << 31);
+                    if ((fm >> lb) & 1u) bat_pix[(nE + __builtin_popcount(fm & lbelow)) * 8 + lr] = make_uint2(lo0, hi0);
+                    // the tripped blocks leave with the batch pass; the others now (at least one lane stores: the strip's one
+                    // vector-memory instruction is issued on every path, which the counted waits rely on)
+                    if (!mine) store16_policy<ST>(dst, val);
+                    nE += nnew;
+                    n_second += (uint32_t)__builtin_popcount(gm);
+                } else if (gm != 0u) {
+                    // no room and an irrational trip: the whole strip is redone in the exact order by the flush below
+                    xlist[nX < kQXList ? nX : kQXList - 1] = tcur;
+                    nX++;
+                    store16_policy<ST>(dst, val);
+                } else {
+                    // no room, rational ties only (tie-dense content, e.g. flat areas with an odd grey level): exact sub-path
+                    // for the four rational coefficients of all eight blocks, here and now
+                    uint2 *pb = reinterpret_cast<uint2 *>(ldsT);
+                    pb[lb * 8 + lr] = make_uint2(lo0, hi0);
+                    wave_lds_fence();
+                    const uint2 rowv = pb[lane]; // row i of block b
+                    wave_lds_fence();
+                    uint32_t lo = rowv.x, hi = rowv.y;
+                    transpose8x8_bytes(lo, hi, i); // -> pixel column i
+                    RationalConsts KR;
+                    KR.div0 = cst_rat[(i >> 2) * 2];
+                    KR.div4 = cst_rat[(i >> 2) * 2 + 1];
+                    KR.rdiv0 = cst_rat[4 + (i >> 2) * 2];
+                    KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
+                    int s0, s4;
+                    special_block(lo, hi, ldsT, b, i, KR, s0, s4);
+                    if ((i & 3) == 0) { // lane i = 0: (0,0) and (0,4) at scan positions 0, 14; lane i = 4: (4,0), (4,4) at 10, 39
+                        *zz_ptr(i ? 20u : 0u) = (int16_t)s0;
+                        *zz_ptr(i ? 78u : 28u) = (int16_t)s4;
+                    }
+                    wave_lds_fence();
+                    val = *zr;
+                    wave_lds_fence();
+                    store16_policy<ST>(dst, val);
+                }
+                if (nE > kBatch / 2 || nX >= 2) stop = true; // settle before taking more work (tie-dense content only)
+            } else store16_policy<ST>(dst, val); // 16 B per lane, 1 KiB contiguous per wave
+            n_strips++;
+        };
+        // the next slot: consume the pending ticket (if any), request the one after it, issue the slot's load
+#define TIC_QNEXT(P, OB, TT, VLD)                                                                           \
+    do {                                                                                                    \
+        VLD = false;                                                                                        \
+        if (have_pending) {                                                                                 \
+            const uint32_t c_ = ticket_value(tk_pending);                                                   \
+            have_pending = false;                                                                           \
+            VLD = strip_of(c_, TT, io, OB);                                                                 \
+            if (!(VLD)) exhausted = true;                                                                   \
+        }                                                                                                   \
+        if (!stop && !exhausted) { tk_pending = take_ticket(); have_pending = true; }                       \
+        TIC_QLOAD(P, io, VLD);                                                                              \
+    } while (0)
+        // Two strips ahead (loads L, stores S): strip j is consumed after L(j+2) is issued; in steady state the instructions
+        // younger than L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips of a run see 2 and 3.
+        do {
+            if (!v0) break;
+            TIC_QNEXT(p2, ob2, t2, v2); TIC_WAIT(p0, 2);
+            if (ABL == 8 && a.dbg != nullptr && lane == 0 && n_strips == 0) a.dbg[((size_t)blockIdx.x * kQMaxWaves + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
+            process(p0, ob0, t0);
+            if (!v1) break;
+            TIC_QNEXT(p0, ob0, t0, v0); TIC_WAIT(p1, 3); process(p1, ob1, t1);
+            while (v2) {
+                TIC_QNEXT(p1, ob1, t1, v1); TIC_WAIT(p2, 4); process(p2, ob2, t2);
+                if (!v0) break;
+                TIC_QNEXT(p2, ob2, t2, v2); TIC_WAIT(p0, 4); process(p0, ob0, t0);
+                if (!v1) break;
+                TIC_QNEXT(p0, ob0, t0, v0); TIC_WAIT(p1, 4); process(p1, ob1, t1);
+            }
+        } while (0);
+        // (a pending ticket cannot be left over: the loop only ends on a slot that got no strip, and such a slot is created
+        // only when no ticket was pending or the queue was empty)
+        if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[((size_t)blockIdx.x * kQMaxWaves + wave) * 8 + 3] = __builtin_amdgcn_s_memtime(); // loop left
+        // loads of slots without a strip may still be in flight: their registers stay reserved until then
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
+
+        // ---- the batch pass: lane 8*b + i serves entry b ------------------------------------------------------------------
+        if (nE != 0) {
+            const bool have = b < nE;
+            const int e = have ? b : 0;
+            const uint32_t id = bat_id[e];
+            const bool isG = have && (id >> 31) != 0u;
+            const uint32_t blk = id & 0x7fffffffu;
+            const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
+            uint32_t lo = rowv.x, hi = rowv.y;
+            transpose8x8_bytes(lo, hi, i); // -> pixel column i
+            const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8); // byte offsets in the image of (u = i, v = 0..7)
+            const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+            int16_t *img16 = reinterpret_cast<int16_t *>(bat_img + e * 8);
+            bool need_rat = have && !isG; // tie entries: the four rational coefficients
+            if (__ballot(isG) != 0ull) {
+                int qe[8];
+                bool ok_rat;
+                const bool ok = second_level_block(lo, hi, ldsT, b, i, cst_mul64, qe, ok_rat);
+                if (isG) {
+#pragma unroll
+                    for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qe[v];
+                }
+                need_rat = need_rat || (isG && !ok_rat);
+                const unsigned long long bad = __ballot(isG && !ok); // a true tie of an irrational coefficient: exact order
+                if (bad != 0ull) {
+                    int qx[8];
+                    exact_block(lo, hi, ldsT, b, i, C, qx);
+                    if ((bad >> (8 * b)) & 0xffull) {
+#pragma unroll
+                        for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qx[v];
+                        need_rat = false;
+                    }
+                }
+            }
+            const unsigned long long m_rat = __ballot(need_rat);
+            if (m_rat != 0ull) {
+                RationalConsts KR;
+                KR.div0 = cst_rat[(i >> 2) * 2];
+                KR.div4 = cst_rat[(i >> 2) * 2 + 1];
+                KR.rdiv0 = cst_rat[4 + (i >> 2) * 2];
+                KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
+                int s0, s4;
+                special_block(lo, hi, ldsT, b, i, KR, s0, s4);
+                if ((i & 3) == 0 && ((m_rat >> (8 * b)) & 0xffull) != 0ull) {
+                    img16[(zo.x & 0xffffu) >> 1] = (int16_t)s0; // (i,0)
+                    img16[(zo.z & 0xffffu) >> 1] = (int16_t)s4; // (i,4)
+                }
+            }
+            wave_lds_fence();
+            const uint4 val = bat_img[e * 8 + i];
+            wave_lds_fence();
+            if (have) store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)blk << 7) + (uint32_t)i * 16u, val);
+            nE = 0;
+        }
+        // ---- strips the batch had no room for: the exact operation order, whole strip -----------------------------------
+        if (nX != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); // the wave's fast-path stores to these strips must have landed
+            const uint4 zzn = *reinterpret_cast<const uint4 *>(cst_zz + i * 8);
+            const uint16_t zz[8] = {(uint16_t)zzn.x, (uint16_t)(zzn.x >> 16), (uint16_t)zzn.y, (uint16_t)(zzn.y >> 16),
+                                    (uint16_t)zzn.z, (uint16_t)(zzn.z >> 16), (uint16_t)zzn.w, (uint16_t)(zzn.w >> 16)};
+            const int n = nX < kQXList ? nX : kQXList;
+            for (int k = 0; k < n; k++) {
+                const uint32_t t = xlist[k];
+                const uint32_t ty = t / (uint32_t)a.fast_tx, tx = t - ty * (uint32_t)a.fast_tx;
+                Strip s;
+                s.by = (int)ty;
+                s.bx = (int)tx * 8 + b;
+                s.valid = true;
+                s.oblk = (size_t)ty * a.bw + s.bx;
+                uint32_t lo, hi;
+                load_block_row(a.img, a.h, a.w, a.stride, true, s, i, lo, hi);
+                transpose8x8_bytes(lo, hi, i);
+                int q[8];
+                exact_block(lo, hi, ldsT, b, i, C, q);
+                store_zigzag(reinterpret_cast<uint32_t *>(ldsZ), b, i, zz, q, a.out, s);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            nX = 0;
+        }
+        n_flush++;
+        if (exhausted) break;
+        stop = false;
+    }
+#undef TIC_QLOAD
+#undef TIC_QNEXT
+#undef TIC_WAIT
+    if (ABL == 8 && a.dbg != nullptr && lane == 0) {
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * kQMaxWaves + wave) * 8;
+        d[4] = __builtin_amdgcn_s_memtime();
+        d[6] = (unsigned long long)n_strips | ((unsigned long long)(n_second & 0xffffu) << 32) | ((unsigned long long)n_flush << 48);
+    }
+    if (a.fallback_count != nullptr && lane == 0 && n_second != 0) atomicAdd(a.fallback_count, (unsigned long long)n_second);
+}
+
 #ifdef TIC_ABLATION // explored alternative, experiment library only
 // ---------------------------------------------------------------------------------------------------------
 // Kernel 2b: one block per lane (explored alternative; variant 40).
@@ -1616,6 +2013,7 @@ static inline int grid_for(int ntiles) { return (ntiles + kWavesPerWG - 1) / kWa
 // Tuning knobs (environment): read once, or at every launch when TIC_TUNE is set (experiment scripts).
 struct Tunables {
     int max_wgs, sched, chunk, lds_pad, nocap;
+    int q_waves, q_teams, q_run; // queue kernel: waves per team, teams, log2 of the run length (0 / 0 / -1 = defaults)
     int split[8];
 };
 static Tunables read_tunables() {
@@ -1632,6 +2030,9 @@ static Tunables read_tunables() {
         sp = strchr(sp, ',');
         if (sp) sp++;
     }
+    t.q_waves = geti("TIC_QWAVES", 0);
+    t.q_teams = geti("TIC_QTEAMS", 0);
+    t.q_run = geti("TIC_QRUN", -1);
     t.nocap = t.lds_pad = 0;
 #ifdef TIC_ABLATION
     t.nocap = geti("TIC_NOCAP", 0);                 // experiment, timing builds only: ignore the strips-per-wave bound
@@ -1651,7 +2052,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     a.nwaves = a.step_ty = a.step_tx = 0;
     a.fast_ty = a.fast_tx = 0;
     a.rem_mode = 0;
-    if (variant != 17 && variant != 52) a.dbg = nullptr;
+    if (variant != 17 && variant != 52 && variant != 71) a.dbg = nullptr;
     const int nf = a.nframes > 0 ? a.nframes : 1;
     if (variant == 1) {
         hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles), nf), block, 0, stream, a);
@@ -1666,7 +2067,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     const bool lane_kernel = variant == 40 || variant == 41;
 #else
     const bool lane_kernel = false;
-    if (variant != 2) return hipErrorInvalidValue; // the product library holds the exact and the production kernel only
+    if (variant != 2 && variant != 70) return hipErrorInvalidValue; // the product library holds the exact and the production kernels only
 #endif
     if (nfast > 0 && lane_kernel) {
 #ifdef TIC_ABLATION
@@ -1678,6 +2079,56 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         else
             hipLaunchKernelGGL(dctq_lane_kernel<0>, grid, block, 0, stream, a);
 #endif
+    } else if (nfast > 0 && variant >= 70 && variant < 80) {
+        // queue kernel: teams of W waves with a ticket counter in LDS (dctq_queue_kernel)
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        const Tunables tune = tunables();
+        if ((unsigned long long)nfast * (unsigned long long)a.fast_tx >= (1ull << 32)) {
+            a.fast_tx = a.fast_ty = 0; // the magic division of the ticket -> strip mapping would not be exact: exact kernel
+        } else {
+            int W, G;
+            if (nf == 1) {
+                if (nfast >= cus * kQMaxWaves * 2) { W = kQMaxWaves; G = cus; }                 // one team per CU
+                else { W = 4; G = (nfast + 7) / 8; if (G > cus * 4) G = cus * 4; if (G < 1) G = 1; } // small frames: teams of 4 waves, >= 2 strips per wave
+            } else { // a batch: every frame has its own teams (grid plane per frame)
+                W = nfast >= kQMaxWaves * 8 ? kQMaxWaves : 4;
+                G = nfast / (W * 16);
+                if (G < 1) G = 1;
+                if (G > cus) G = cus;
+            }
+            if (tune.q_waves > 0) W = tune.q_waves > kQMaxWaves ? kQMaxWaves : tune.q_waves;
+            if (tune.q_teams > 0) G = tune.q_teams;
+            a.q_waves = W;
+            a.q_teams = G;
+            a.q_run_shift = tune.q_run >= 0 ? tune.q_run : 2;
+            a.q_ppw = (72 + W - 1) / W;
+            a.magic_fast_tx = a.fast_tx <= 1 ? 0u : (uint32_t)((1ull << 32) / (unsigned long long)a.fast_tx + 1ull);
+            const size_t lds = (size_t)kQHeadBytes + (size_t)W * kQWaveBytes;
+            const dim3 qgrid(G, 1, nf), qblock(W * 64);
+#define TIC_QLAUNCH(ABL)                                                                                            \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dctq_queue_kernel<ABL, 2>),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kQHeadBytes + kQMaxWaves * kQWaveBytes); \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((dctq_queue_kernel<ABL, 2>), qgrid, qblock, lds, stream, a);                              \
+    } while (0)
+            switch (variant) {
+#ifdef TIC_ABLATION
+            case 71: TIC_QLAUNCH(8); break; // stamps
+            case 72: TIC_QLAUNCH(3); break; // tripped blocks ignored (timing only)
+#endif
+            default: TIC_QLAUNCH(0); break;
+            }
+#undef TIC_QLAUNCH
+        }
     } else if (nfast > 0) {
         // strip kernels, persistent waves: each wave loops over its strips.  Variants 2, 10-22, 1xx, 2xx: round-1 kernel with
         // the workgroup-shared post-pass (trip lists: at most 16 strips per wave); 50-59, 3xx, 4xx: wave-local rare paths

@@ -26,6 +26,7 @@ for step in "$@"; do
     ab_pol)     run ab_pol 600 python tools/ab.py --dims 4096 --rounds 5 --iters 400 --variants ${TIC_AB_VARIANTS:-2,50} "" ;;
     ab_pol16k)  run ab_pol16k 600 python tools/ab.py --dims 16384 --rounds 4 --iters 20 --variants ${TIC_AB_VARIANTS16:-2,50} "" ;;
     stamps2)    run stamps2 200 python tools/stamps2.py ;;
+    stamps3)    run stamps3 200 python tools/stamps3.py ;;
     ablate)     run ablate 300 python tools/ablate.py ;;
     stamps)     run stamps 200 python tools/stamps.py ;;
     ab)         run ab 600 python tools/ab.py --variants 2,12,15,18,20 "" ;;
