@@ -1189,8 +1189,14 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
     }
 }
 
+#ifdef TIC_ABLATION
 // ---------------------------------------------------------------------------------------------------------
-// Kernel 2c (round 2): the strip kernel with a dynamic strip queue.
+// Kernel 2c (round 2, explored alternative; experiment library only, variant 70): the strip kernel with a dynamic strip queue.
+// Parity-green, but slower than the static walk: 11.5 us against 10.4 us on a 4096^2 frame in the same run (8.1 against
+// 7.1 with the rare paths compiled out).  The tickets cost ~45 scalar instructions and an LDS atomic per strip, the
+// prologue grows to ~200 scalar instructions (the waves of a CU share one scalar unit: first loads issued after
+// 1,600-3,300 cycles), 16 waves per CU instead of 20, and the queue hands the last strips to the youngest - slowest -
+// waves (2,500 cycles per strip against 1,300 for the oldest), so the tail it was meant to remove stays.
 //
 // Same strip loop and the same wave-local batch pass as dctq_strip_kernel above.  What differs is who processes which
 // strip: a workgroup is a TEAM of up to 16 waves (one team per CU on frames that fill the chip) sharing a ticket counter
@@ -1265,16 +1271,20 @@ __global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs
         ob = ty * (uint32_t)a.bw + tx * 8u;
         return true;
     };
-    // Ticket = LDS atomic add issued by hand: lane 0 on the team's counter, the other lanes on scratch words of their own
-    // (no exec juggling), result picked up one strip later behind an explicit wait.  (Written as atomicAdd under
-    // `if (lane == 0)` the compiler's atomic optimiser turns it into mbcnt + ds_add + readfirstlane with the wait right
-    // behind it: every strip then stalls for an LDS round trip under load, 8.5 us instead of 6.8 for a 4096^2 frame.)
-    const uint32_t tk_addr = lane == 0 ? (uint32_t)(uintptr_t)q_ctr
-                                       : (uint32_t)(uintptr_t)(wbase + kQWaveBytes - 256) + (uint32_t)lane * 4u;
+    // Ticket = LDS atomic add issued by hand at the start of a strip and picked up at its end, in the same straight-line
+    // code: lane 0 on the team's counter, the other lanes (and lane 0 too when no ticket is wanted) on scratch words of
+    // their own - no exec juggling, no branch around the instruction.  (Written as atomicAdd under `if (lane == 0)` the
+    // compiler's atomic optimiser turns it into mbcnt + ds_add + readfirstlane with the wait right behind it: every strip
+    // then stalls for an LDS round trip under load, 8.5 us instead of 6.8 for a 4096^2 frame.  And the result must not
+    // travel through a loop-carried vector register: the compiler may copy that register before the atomic has returned -
+    // it cannot know - and the copy holds garbage.)
+    const uint32_t tk_junk = (uint32_t)(uintptr_t)(wbase + kQWaveBytes - 256) + (uint32_t)lane * 4u;
+    const uint32_t tk_addr = lane == 0 ? (uint32_t)(uintptr_t)q_ctr : tk_junk;
     const uint32_t tk_one = 1u;
-    auto take_ticket = [&]() -> uint32_t {
+    auto take_ticket = [&](bool want) -> uint32_t {
         uint32_t v;
-        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(v) : "v"(tk_addr), "v"(tk_one) : "memory");
+        const uint32_t ad = want ? tk_addr : tk_junk;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(v) : "v"(ad), "v"(tk_one) : "memory");
         return v;
     };
     auto ticket_value = [&](uint32_t v) -> uint32_t { // wait for the atomic, lane 0's result
@@ -1320,9 +1330,8 @@ __global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs
                 c0 = (uint32_t)wave;
                 c1 = (uint32_t)wave + W;
             } else {
-                const uint32_t k0 = take_ticket(), k1 = take_ticket();
-                c0 = ticket_value(k0);
-                c1 = ticket_value(k1);
+                c0 = ticket_value(take_ticket(true));
+                c1 = ticket_value(take_ticket(true));
             }
             v0 = strip_of(c0, t0, io, ob0);
             TIC_QLOAD(p0, io, v0);
@@ -1351,12 +1360,14 @@ __global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs
         const u32x4 zzv = *reinterpret_cast<const u32x4 *>(cst_blk + 320 + i * 16);
         int16_t *zp0 = zz_ptr(zzv.x & 0xffff), *zp1 = zz_ptr(zzv.x >> 16), *zp2 = zz_ptr(zzv.y & 0xffff), *zp3 = zz_ptr(zzv.y >> 16);
         int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
-        uint32_t tk_pending = 0;      // ticket requested one strip ahead (lane 0)
-        bool have_pending = false;
-        if (!stop && !exhausted) { tk_pending = take_ticket(); have_pending = true; }
+        uint32_t c_next = 0;   // ticket of the next slot (scalar; taken during the previous strip)
+        bool has_next = false;
+        if (!stop && !exhausted) { c_next = ticket_value(take_ticket(true)); has_next = true; }
 
         // one strip: everything from the pixel row held in px to the 1 KiB store
         auto process = [&](const unsigned long long px, const uint32_t ob, const uint32_t tcur) {
+            const bool want = !stop && !exhausted;
+            const uint32_t tkv = take_ticket(want); // the ticket after next: requested now, read at the end of this strip
             // ---- pass 1: along the pixel row ------------------------------------------------------------------
             const uint32_t lo0 = (uint32_t)px, hi0 = (uint32_t)(px >> 32);
             float d0, d1, d2, d3, d4, d5, d6, d7;
@@ -1455,18 +1466,18 @@ __global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs
                 if (nE > kBatch / 2 || nX >= 2) stop = true; // settle before taking more work (tie-dense content only)
             } else store16_policy<ST>(dst, val); // 16 B per lane, 1 KiB contiguous per wave
             n_strips++;
+            c_next = ticket_value(tkv);
+            has_next = want; // (a ticket taken is a strip owed, even if `stop` was raised meanwhile)
         };
-        // the next slot: consume the pending ticket (if any), request the one after it, issue the slot's load
+        // the next slot: the ticket taken during the previous strip (if any), and the slot's load
 #define TIC_QNEXT(P, OB, TT, VLD)                                                                           \
     do {                                                                                                    \
         VLD = false;                                                                                        \
-        if (have_pending) {                                                                                 \
-            const uint32_t c_ = ticket_value(tk_pending);                                                   \
-            have_pending = false;                                                                           \
-            VLD = strip_of(c_, TT, io, OB);                                                                 \
+        if (has_next) {                                                                                     \
+            has_next = false;                                                                               \
+            VLD = strip_of(c_next, TT, io, OB);                                                             \
             if (!(VLD)) exhausted = true;                                                                   \
         }                                                                                                   \
-        if (!stop && !exhausted) { tk_pending = take_ticket(); have_pending = true; }                       \
         TIC_QLOAD(P, io, VLD);                                                                              \
     } while (0)
         // Two strips ahead (loads L, stores S): strip j is consumed after L(j+2) is issued; in steady state the instructions
@@ -1585,6 +1596,8 @@ __global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs
     }
     if (a.fallback_count != nullptr && lane == 0 && n_second != 0) atomicAdd(a.fallback_count, (unsigned long long)n_second);
 }
+
+#endif // TIC_ABLATION
 
 #ifdef TIC_ABLATION // explored alternative, experiment library only
 // ---------------------------------------------------------------------------------------------------------
@@ -2067,7 +2080,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     const bool lane_kernel = variant == 40 || variant == 41;
 #else
     const bool lane_kernel = false;
-    if (variant != 2 && variant != 70) return hipErrorInvalidValue; // the product library holds the exact and the production kernels only
+    if (variant != 2) return hipErrorInvalidValue; // the product library holds the exact and the production kernel only
 #endif
     if (nfast > 0 && lane_kernel) {
 #ifdef TIC_ABLATION
@@ -2079,6 +2092,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         else
             hipLaunchKernelGGL(dctq_lane_kernel<0>, grid, block, 0, stream, a);
 #endif
+#ifdef TIC_ABLATION
     } else if (nfast > 0 && variant >= 70 && variant < 80) {
         // queue kernel: teams of W waves with a ticket counter in LDS (dctq_queue_kernel)
         static int cus = 0;
@@ -2129,6 +2143,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             }
 #undef TIC_QLAUNCH
         }
+#endif
     } else if (nfast > 0) {
         // strip kernels, persistent waves: each wave loops over its strips.  Variants 2, 10-22, 1xx, 2xx: round-1 kernel with
         // the workgroup-shared post-pass (trip lists: at most 16 strips per wave); 50-59, 3xx, 4xx: wave-local rare paths
