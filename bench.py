@@ -5,22 +5,30 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the transform stage (level shift -> 2-D DCT -> quantise -> zig-zag, i.e. the reference's
-encode(), codec.py:26-43) over one synthetic frame per GPU, input already resident in HBM.  At N = 1 the workload is
-BASELINE config 2: one 4096x4096 random uint8 frame (numpy default_rng(1234)), quality 50.  At N > 1 every rank
-runs the same per-GPU workload on its own frame (independent frames, no data-path collective: weak scaling); RCCL is
-used only where the north star has it - an all-gather of per-frame compressed sizes, outside the timed region.
+A "step" is one launch of the transform stage (level shift -> 2-D DCT -> quantise -> zig-zag, i.e. the reference's
+encode(), codec.py:26-43) over this rank's input, already resident in HBM.
 
-Rank 0 prints ONE JSON line.  `value` = whole-job Mpixel/s = (frames x pixels x K) / max-over-ranks wall time.
-`roofline.achieved` = algorithmic bytes (3 B/pixel: 1 B read + 2 B written) / average kernel duration measured
-with HIP events recorded on the library's own stream around the same K launches.  `cpu_baseline` = the oracle (C
-restatement of the reference's CPU path, single thread) timed on this host on the same frame.
+  N = 1   BASELINE config 2: ONE 4096x4096 random uint8 frame (numpy default_rng(1234)), quality 50, one launch per step.
+  N > 1   BASELINE config 4: a batch of 256*N 1920x1080 frames (seed 1234 + i), contiguous shards of 256 frames per
+          rank (shard_range), one batched launch of the rank's 256 resident frames per step; afterwards every rank sends its
+          shard through the whole pipeline host -> host (tic_compress_batch: pinned staging, H2D || kernels || D2H, entropy
+          stage on the device) and the ACTUAL 256 stream sizes of every rank are all-gathered with RCCL (tic_gather_sizes).
+          No torch anywhere: torch.distributed.run only spawns the ranks; barrier and max-over-ranks use RCCL too.
+
+Rank 0 prints ONE JSON line.  `value` = whole-job Mpixel/s = pixels of all ranks x K / max-over-ranks wall time of the K
+steps.  `roofline.achieved` = algorithmic bytes per launch (3 B/pixel: 1 B read + 2 B written) / average launch duration
+measured with HIP events recorded on the library's own stream around the same K launches; `roofline.cold` = the same with
+12 distinct frame/coefficient buffer pairs in rotation (604 MB > the 256 MiB Infinity Cache: every launch streams from and
+to HBM).  `cpu_baseline` / `cpu_baseline_all_cores` = the oracle (C restatement of the reference's CPU path) on this host,
+1 thread / row bands on several threads.  `config4` = the 256-frame shard of this rank, kernel-only and host -> host.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,19 +39,37 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 BYTES_PER_PIXEL = 3.0  # 1 B uint8 read + 2 B int16 written
+COLD_PAIRS = 12        # 12 x (16.8 MB frame + 33.6 MB coefficients) = 604 MB in rotation
+
+
+def rand_frame(seed, h, w):
+    return np.random.default_rng(seed).integers(0, 256, (h, w), dtype=np.uint8)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--quality", type=int, default=50)
     ap.add_argument("--variant", choices=["hybrid", "exact"], default="hybrid")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="N=1 only: skip the 256-frame shard measurements")
+    ap.add_argument("--shard-frames", type=int, default=256, help="frames per rank of BASELINE config 4")
     ap.add_argument("--settle-ms", type=float, default=60.0, help="untimed back-to-back launches before the warm-up steps (clock settling)")
     args = ap.parse_args()
 
@@ -55,51 +81,132 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
 
-    dist = None
-    torch = None
-    # TIC_BENCH_BACKEND=gloo + TIC_BENCH_SHARE_GPU=1 rehearse the multi-rank flow on a one-GPU box (all ranks on
-    # device 0, CPU tensors for the collectives); the real run uses RCCL with one rank per GPU.
-    backend = os.environ.get("TIC_BENCH_BACKEND", "nccl")
-    share_gpu = os.environ.get("TIC_BENCH_SHARE_GPU", "0") == "1"
-    tdev = "cpu"
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            tdev = "cuda"
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(backend=backend)
-
     import tinyimgcodec_amd as T
     from tinyimgcodec_amd import _native as N
+    from tinyimgcodec_amd.distributed import RcclComm, TorchComm, gather_sizes, shard_range
 
     L = N.load()
+    # The real run: one rank per GPU, RCCL.  TIC_BENCH_BACKEND=gloo + TIC_BENCH_SHARE_GPU=1 rehearse the multi-rank flow on a
+    # one-GPU box: every rank on device 0 (RCCL needs one GPU per rank, so the rehearsal exchanges over gloo).
+    share_gpu = os.environ.get("TIC_BENCH_SHARE_GPU", "0") == "1"
     ctx = T.Context(0 if share_gpu else local_rank)  # raises loudly if the HIP library / an MI355X is missing
-    h, w, q = args.height, args.width, args.quality
-    variant = N.KERNEL_HYBRID if args.variant == "hybrid" else N.KERNEL_EXACT
+    comm = None
+    if world > 1:
+        if os.environ.get("TIC_BENCH_BACKEND", "rccl") == "gloo":
+            import torch.distributed as dist
 
-    # synthetic frame of this rank (seed 1234 + rank), uploaded once: the timed region starts with data in HBM
-    img = np.random.default_rng(1234 + rank).integers(0, 256, (h, w), dtype=np.uint8)
+            dist.init_process_group(backend="gloo")
+            comm = TorchComm()
+        else:
+            comm = RcclComm(ctx, rank, world)
+    q = args.quality
+    variant = N.KERNEL_HYBRID if args.variant == "hybrid" else N.KERNEL_EXACT
+    multi = world > 1
+    if args.steps is None:
+        args.steps = 200 if multi else 5000
+    if args.warmup is None:
+        args.warmup = 20 if multi else 2000
+
+    def barrier():
+        ctx.check(L.tic_sync(ctx.handle))
+        if comm is not None:
+            comm.barrier()
+
+    ms = C.c_float(0.0)
+    out = None
+    if not multi:
+        out = bench_config2(args, ctx, L, N, q, variant, barrier, ms)
+        if not args.no_config4:
+            out["config4"] = shard_measurements(args, ctx, L, N, T, q, variant, 0, args.shard_frames, ms, steps=50)[0]
+        if not args.no_cpu_baseline:
+            img = rand_frame(1234, args.height, args.width)
+            out["cpu_baseline"] = cpu_baseline(img, q, args.cpu_seconds, 1)
+            out["cpu_baseline_all_cores"] = cpu_baseline(img, q, args.cpu_seconds, 0)
+    else:
+        n_total = args.shard_frames * world
+        lo, hi = shard_range(n_total, rank, world)
+        info, t_wall, kernel_ms, sizes_mine = shard_measurements(args, ctx, L, N, T, q, variant, lo, hi - lo, ms, steps=args.steps,
+                                                                 warmup=args.warmup, barrier=barrier, timed=True)
+        red = comm.allreduce_max([t_wall, kernel_ms, info["host_to_host_s"]])  # max over ranks
+        sizes, offsets = gather_sizes(sizes_mine, n_total, comm)              # RCCL all-gather of the actual stream sizes
+        if rank == 0:
+            h, w = 1080, 1920
+            pixels = float(h) * w * (hi - lo)
+            value = pixels * world * args.steps / float(red[0]) / 1e6
+            achieved = BYTES_PER_PIXEL * pixels / (float(red[1]) * 1e-3) / 1e9
+            out = {
+                "metric": "Mpixels/s encode (DCT+quant kernel)",
+                "value": round(value, 1),
+                "unit": "Mpix/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(float(red[0]) * 1e3 / args.steps, 6),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "f32+f64" if args.variant == "hybrid" else "f64",
+                "data": "synthetic",
+                "config": {
+                    "workload": "batch of %d random 1920x1080 uint8 frames (seeds 1234+i), quality=%d, contiguous shards of %d frames "
+                    "per GPU resident in HBM, one batched launch per step (BASELINE config 4)" % (n_total, q, hi - lo),
+                    "kernel": args.variant,
+                    "frames_per_step_per_gpu": hi - lo,
+                    "sharding": "independent frames, contiguous shards; no data-path collective; RCCL all-gather of per-frame stream sizes",
+                    "settle_ms": args.settle_ms,
+                    "untimed_launches": info["untimed_launches"],
+                    "host_to_host_mpix_s": round(pixels * world / float(red[2]) / 1e6, 1),
+                    "host_to_host_note": "whole pipeline per rank (pinned staging, H2D || kernels || D2H, device entropy stage), PCIe "
+                    "included, max over ranks; never `value`",
+                    "rccl_gathered_sizes": {"frames": int(len(sizes)), "total_bytes": int(offsets[-1]), "first": [int(v) for v in sizes[:8]],
+                                            "sha256": hashlib.sha256(sizes.astype("<i8").tobytes()).hexdigest()},
+                    "device": ctx.arch,
+                },
+                "roofline": {
+                    "bound": "hbm",
+                    "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None,
+                    "kernel_us": round(float(red[1]) * 1e3, 3),
+                    "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels,
+                },
+            }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    ctx.close()
+
+
+def settle(args, ctx, L, fn):
+    """Clock settling (untimed, before the W warm-up steps): the chip needs a few ms of back-to-back launches to reach its
+    sustained clocks (200 launches after 20 read 15.4 us where 5000 after 2000 read 12.1 us).  Returns the count."""
+    n, t0 = 0, time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < args.settle_ms:
+        n += fn()
+    return n
+
+
+def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
+    h, w = args.height, args.width
+    img = rand_frame(1234, h, w)
     pitch = (w + 255) // 256 * 256
     host = np.zeros((h, pitch), dtype=np.uint8)
     host[:, :w] = img
     nblk = L.tic_num_blocks(h, w)
-    d_img, d_out = C.c_void_p(), C.c_void_p()
-    ctx.check(L.tic_dev_alloc(ctx.handle, host.size, C.byref(d_img)))
-    ctx.check(L.tic_dev_alloc(ctx.handle, nblk * 128, C.byref(d_out)))
-    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, host.ctypes.data, host.size))
+    pairs = 1 if args.no_cold else COLD_PAIRS
+    d_imgs, d_outs = (C.c_void_p * pairs)(), (C.c_void_p * pairs)()
+    for k in range(pairs):
+        a, b = C.c_void_p(), C.c_void_p()
+        ctx.check(L.tic_dev_alloc(ctx.handle, host.size, C.byref(a)))
+        ctx.check(L.tic_dev_alloc(ctx.handle, nblk * 128, C.byref(b)))
+        ctx.check(L.tic_memcpy_h2d(ctx.handle, a, host.ctypes.data, host.size))  # (the same pixels in every pair: only the addresses differ)
+        d_imgs[k], d_outs[k] = a, b
+    d_img, d_out = d_imgs[0], d_outs[0]
 
-    def barrier():
-        ctx.check(L.tic_sync(ctx.handle))
-        if dist is not None:
-            dist.barrier()
-            if tdev == "cuda":
-                torch.cuda.synchronize()
-
-    ms = C.c_float(0.0)
     # one untimed launch with the diagnostic counter on: how many blocks leave the fast path on this frame
     fb = C.c_ulonglong(0)
     ctx.check(L.tic_set_stats(ctx.handle, 1))
@@ -107,11 +214,12 @@ def main():
     ctx.check(L.tic_dctq_dev(ctx.handle, d_img, h, w, pitch, q, d_out, variant))
     ctx.check(L.tic_last_fallback_blocks(ctx.handle, C.byref(fb)))
     ctx.check(L.tic_set_stats(ctx.handle, 0))
-    # clock settling (untimed, before the W warm-up steps): the chip needs a few ms of back-to-back launches to reach its
-    # sustained clocks - 200 launches after 20 read 15.4 us where 5000 after 2000 read 12.1 us
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+
+    def burst():
         ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, h, w, pitch, q, d_out, variant, 256, C.byref(ms)))
+        return 256
+
+    untimed = settle(args, ctx, L, burst)
     if args.warmup > 0:
         ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, h, w, pitch, q, d_out, variant, args.warmup, C.byref(ms)))
     barrier()
@@ -119,114 +227,175 @@ def main():
     # exactly K launches, bracketed by HIP events on the launch stream; returns after the stream has drained
     ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, h, w, pitch, q, d_out, variant, args.steps, C.byref(ms)))
     barrier()
-    t1 = time.perf_counter()
-    wall_s = t1 - t0
+    wall_s = time.perf_counter() - t0
     kernel_ms = ms.value / args.steps
 
-    sizes = None
-    if dist is not None:
-        tmax = torch.tensor([wall_s, kernel_ms], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall_s, kernel_ms_max = float(tmax[0]), float(tmax[1])
-        # the north star's only collective (RCCL all-gather of per-frame compressed sizes), outside the timed
-        # region: each rank entropy-codes a 512x512 crop of its frame on the host and the sizes are gathered
-        from tinyimgcodec_amd.distributed import gather_sizes
+    cold = None
+    if not args.no_cold:
+        for _ in range(3):  # settle + warm-up of the rotating variant
+            ctx.check(L.tic_dctq_dev_timed_rotating(ctx.handle, d_imgs, d_outs, pairs, h, w, pitch, q, variant, 600, C.byref(ms)))
+        kcold = max(600, min(args.steps, 3000))
+        ctx.check(L.tic_dctq_dev_timed_rotating(ctx.handle, d_imgs, d_outs, pairs, h, w, pitch, q, variant, kcold, C.byref(ms)))
+        cold_ms = ms.value / kcold
+        cold_gbs = BYTES_PER_PIXEL * h * w / (cold_ms * 1e-3) / 1e9
+        cold = {"achieved": round(cold_gbs, 1), "frac": round(cold_gbs / HBM_PEAK_GBS, 4), "kernel_us": round(cold_ms * 1e3, 3), "launches": kcold,
+                "pairs": pairs, "rotating_bytes": int(pairs * (host.size + nblk * 128)),
+                "note": "launch i uses frame/coefficient buffer pair i %% %d: every line has left the 256 MiB Infinity Cache before its next use" % pairs}
 
-        mine = [len(T.compress(img[:512, :512], q, ctx=ctx))]
-        allsz, _ = gather_sizes(mine, world, device=tdev)
-        sizes = [int(v) for v in allsz]
-    else:
-        kernel_ms_max = kernel_ms
+    pixels = float(h) * float(w)
+    achieved = BYTES_PER_PIXEL * pixels / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath) and (h, w, q) == (4096, 4096, 50):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    out = {
+        "metric": "Mpixels/s encode (DCT+quant kernel)",
+        "value": round(pixels * args.steps / wall_s / 1e6, 1),
+        "unit": "Mpix/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall_s * 1e3 / args.steps, 6),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32+f64" if args.variant == "hybrid" else "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "single %dx%d random uint8 grayscale frame, quality=%d (BASELINE config 2), input resident in HBM" % (h, w, q),
+            "kernel": args.variant,
+            "frames_per_step_per_gpu": 1,
+            "settle_ms": args.settle_ms,
+            "untimed_launches": untimed + 1,
+            "untimed_note": "back-to-back launches of the same kernel before the W warm-up steps (clock settling) + 1 statistics launch",
+            "fallback_blocks_per_launch": fb.value,
+            "device": ctx.arch,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "kernel_us": round(kernel_ms * 1e3, 3),
+            "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels,
+            "note": "one frame and one coefficient buffer replayed: the 50 MB working set stays in the 256 MiB Infinity Cache (see cold)",
+        },
+    }
+    if cold is not None:
+        out["roofline"]["cold"] = cold
+    for k in range(pairs):
+        ctx.check(L.tic_dev_free(ctx.handle, d_imgs[k]))
+        ctx.check(L.tic_dev_free(ctx.handle, d_outs[k]))
+    return out
 
-    if rank == 0:
-        pixels = float(h) * float(w)
-        value = pixels * world * args.steps / wall_s / 1e6  # Mpixel/s, whole job
-        achieved = BYTES_PER_PIXEL * pixels / (kernel_ms_max * 1e-3) / 1e9  # GB/s of one kernel launch
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and (h, w, q) == (4096, 4096, 50):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        out = {
-            "metric": "Mpixels/s encode (DCT+quant kernel)",
-            "value": round(value, 1),
-            "unit": "Mpix/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(wall_s * 1e3 / args.steps, 6),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32+f64" if args.variant == "hybrid" else "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": "single %dx%d random uint8 grayscale frame per GPU, quality=%d (BASELINE config 2), "
-                "input resident in HBM" % (h, w, q),
-                "kernel": args.variant,
-                "frames_per_step_per_gpu": 1,
-                "sharding": "independent frames, one per rank; no data-path collective",
-                "fallback_blocks_per_launch": fb.value,
-                "device": ctx.arch,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "kernel_us": round(kernel_ms_max * 1e3, 3),
-                "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels,
-            },
-        }
-        if sizes is not None:
-            out["config"]["rccl_gathered_sizes"] = sizes
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(img, q, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
 
-    ctx.check(L.tic_dev_free(ctx.handle, d_img))
+def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, warmup=10, barrier=None, timed=False):
+    """BASELINE config 4, this rank's shard: frames first .. first+count-1 (1080x1920, seed 1234 + i).
+    Kernel-only: the shard resident in HBM, one batched launch per step.  Host -> host: tic_compress_batch on the same frames."""
+    h, w = 1080, 1920
+    frames = [rand_frame(1234 + first + i, h, w) for i in range(count)]
+    nblk = L.tic_num_blocks(h, w)
+    img_bytes, coef_bytes = h * w, nblk * 128
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, img_bytes * count, C.byref(d_in)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, coef_bytes * count, C.byref(d_out)))
+    for i, f in enumerate(frames):
+        ctx.check(L.tic_memcpy_h2d(ctx.handle, C.c_void_p(d_in.value + i * img_bytes), f.ctypes.data, img_bytes))
+
+    def launch(k):
+        ctx.check(L.tic_dctq_dev_frames_timed(ctx.handle, d_in, count, h, w, w, img_bytes, q, d_out, coef_bytes, variant, k, C.byref(ms)))
+        return k
+
+    untimed = settle(args, ctx, L, lambda: launch(8))
+    if warmup > 0:
+        launch(warmup)
+    if barrier is not None:
+        barrier()
+    t0 = time.perf_counter()
+    launch(steps)
+    if barrier is not None:
+        barrier()
+    t_wall = time.perf_counter() - t0
+    kernel_ms = ms.value / steps
+    ctx.check(L.tic_dev_free(ctx.handle, d_in))
     ctx.check(L.tic_dev_free(ctx.handle, d_out))
-    ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    # whole pipeline host -> host through the C-ABI (caller-owned worst-case sized output buffers, as a C caller would hold
+    # them; the second pass finds its staging and landing buffers faulted in)
+    cap = L.tic_compress_bound(h, w)
+    pool = np.empty((count, cap), dtype=np.uint8)
+    inp = (C.c_void_p * count)(*[f.ctypes.data for f in frames])
+    outp = (C.c_void_p * count)(*[pool[i].ctypes.data for i in range(count)])
+    caps = (C.c_size_t * count)(*([cap] * count))
+    lens = (C.c_size_t * count)()
+    for _ in range(2):
+        t1 = time.perf_counter()
+        ctx.check(L.tic_compress_batch(ctx.handle, inp, count, h, w, w, q, outp, caps, lens, 0))
+        t_h2h = time.perf_counter() - t1
+    sizes = [int(lens[i]) for i in range(count)]
+    pixels = float(h) * w * count
+    info = {
+        "workload": "%d random 1920x1080 frames (seeds %d..%d), quality=%d" % (count, 1234 + first, 1234 + first + count - 1, q),
+        "kernel_only_mpix_s": round(pixels / (kernel_ms * 1e-3) / 1e6, 1),
+        "kernel_only_us_per_launch": round(kernel_ms * 1e3, 2),
+        "kernel_only_frac_of_8TBs": round(BYTES_PER_PIXEL * pixels / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "host_to_host_mpix_s": round(pixels / t_h2h / 1e6, 1),
+        "host_to_host_s": round(t_h2h, 5),
+        "host_to_host_frames_per_s": round(count / t_h2h, 1),
+        "stream_bytes_total": int(sum(sizes)),
+        "untimed_launches": untimed + warmup,
+    }
+    if timed:
+        return info, t_wall, kernel_ms, sizes
+    return info, sizes
 
 
-def cpu_baseline(img, q, budget_s):
-    """The oracle (C restatement of the reference's CPU path for this stage; bit-identical output, single thread)
-    timed on this host.  Sample: whole passes over the same frame until ~budget_s seconds are spent."""
+def cpu_baseline(img, q, budget_s, threads):
+    """The oracle (C restatement of the reference's CPU path for this stage; bit-identical output) timed on this host.
+    threads = 1: whole passes over the frame on one thread.  threads = 0: all of this process's CPU share (at most 16 threads,
+    the GPU box's share per GPU), the frame cut into bands of block rows, one band per thread (ctypes releases the GIL)."""
     from oracle import pyoracle
 
     pyoracle.build()
     h, w = img.shape
     pyoracle.encode_zz16(img[:64], q)  # warm up
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    T = 1 if threads == 1 else max(1, min(avail, 16))
+    rows = (h + 7) // 8
+    bands = [(rows * t // T * 8, min(h, rows * (t + 1) // T * 8)) for t in range(T)]
+
+    def one_pass():
+        if T == 1:
+            pyoracle.encode_zz16(img, q)
+            return
+        th = [threading.Thread(target=pyoracle.encode_zz16, args=(img[a:b], q)) for a, b in bands if b > a]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
     n, t0 = 0, time.perf_counter()
     while True:
-        pyoracle.encode_zz16(img, q)
+        one_pass()
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 64:
+        if dt >= budget_s or n >= 256:
             break
-    cpu_model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu_model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
     return {
         "value": round(n * h * w / dt / 1e6, 2),
         "unit": "Mpix/s",
-        "cores": 1,
+        "cores": T,
         "kind": "port",
-        "sample": "%d full passes of the same %dx%d frame, q=%d, transform stage only (oracle tico_encode_zz16), "
-        "%.1f s on 1 of %d host threads (%s); the reference's own numpy/scipy encode() measured 21.4 Mpix/s in the "
-        "build container (BASELINE.md)" % (n, h, w, q, dt, os.cpu_count() or 0, cpu_model),
+        "sample": "%d full passes of the same %dx%d frame, q=%d, transform stage only (oracle tico_encode_zz16%s), %.1f s on %d of %d host "
+        "threads (%s); the reference's own numpy/scipy encode() measured 21.4 Mpix/s on one thread in the build container (BASELINE.md)"
+        % (n, h, w, q, "" if T == 1 else ", bands of block rows", dt, T, os.cpu_count() or 0, cpu_model()),
     }
 
 

@@ -69,6 +69,12 @@ int tic_dctq(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_str
 int tic_encode(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, int32_t *dc,
                int32_t *ac);
 
+/* The same for integer images whose values lie outside 0..255 (the reference casts with astype(int32), codec.py:29, and
+ * transforms any integers): int32 pixels (row stride in ELEMENTS), float64 exact operation order on the device, int32
+ * coefficients.  A drop-in edge, not a hot path. */
+int tic_encode_wide(tic_ctx *ctx, const int32_t *image, int h, int w, ptrdiff_t row_stride_elems, int quality, int32_t *dc,
+                    int32_t *ac);
+
 /* Device-resident form (what bench.py times): d_image / d_coeffs are device pointers from tic_dev_alloc.
  * Asynchronous on the context's stream; `variant` is one of TIC_KERNEL_*. */
 int tic_dev_alloc(tic_ctx *ctx, size_t bytes, void **dptr);
@@ -90,6 +96,14 @@ int tic_dctq_dev_frames(tic_ctx *ctx, const void *d_images, int nframes, int h, 
  * (the stream the kernel is launched on).  *ms_total = elapsed milliseconds for all `iters` launches. */
 int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
                        void *d_coeffs_zz, int variant, int iters, float *ms_total);
+/* The same for the batch form (nframes frames per launch). */
+int tic_dctq_dev_frames_timed(tic_ctx *ctx, const void *d_images, int nframes, int h, int w, ptrdiff_t row_stride,
+                              ptrdiff_t frame_stride, int quality, void *d_coeffs_zz, ptrdiff_t coeff_frame_stride,
+                              int variant, int iters, float *ms_total);
+/* Cold-cache timing: launch i works on pair i % npairs of (d_images[k], d_coeffs_zz[k]); with pairs totalling well over
+ * the 256 MiB Infinity Cache every launch streams from and to HBM (bench.py's roofline.cold). */
+int tic_dctq_dev_timed_rotating(tic_ctx *ctx, const void *const *d_images, void *const *d_coeffs_zz, int npairs, int h,
+                                int w, ptrdiff_t row_stride, int quality, int variant, int iters, float *ms_total);
 /* Diagnostics: with stats enabled the HYBRID kernel counts (with a global atomic, which costs time - keep it off
  * when measuring) the blocks it had to redo on the exact path; tic_last_fallback_blocks returns the count
  * accumulated since the previous call and resets it. */
@@ -141,6 +155,23 @@ int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality,
  * (huffman.py:36-38,66-98), GPU dequantise + inverse DCT (utils.py:40-45,52) + clip + truncating uint8 cast.
  * out: uint8[h*w]. */
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap);
+
+/* ---- multi-GPU (the reference has no counterpart: it is single-process, codec.py:133-164 runs one image
+ *      at a time).  One process per GPU; a batch shards by independent frames (frame i -> rank i / ceil(B/G)) with no
+ *      data-path collective.  The one exchange is an all-gather of per-frame compressed sizes, so that every rank knows every
+ *      frame's offset in the concatenated output: RCCL over xGMI, opened lazily (world == 1 never loads librccl).
+ *      Rendezvous: rank 0 publishes the RCCL unique id as the file `rendezvous_path`, the others poll for it; pass a name
+ *      unique to the launch (e.g. /tmp/tic_rdv_<MASTER_PORT>_<launcher pid>). ------------------------------------------ */
+typedef struct tic_comm tic_comm;
+int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_path, tic_comm **out);
+int tic_comm_destroy(tic_comm *comm);
+int tic_comm_rank(const tic_comm *comm);
+int tic_comm_world(const tic_comm *comm);
+const char *tic_comm_last_error(const tic_comm *comm);
+/* all[r * n_mine + k] = size k of rank r (every rank passes the same n_mine; pad short shards). */
+int tic_gather_sizes(tic_comm *comm, const uint64_t *mine, int n_mine, uint64_t *all);
+/* In-place element-wise maximum over the ranks (also serves as a barrier: bench.py's max-over-ranks timing). */
+int tic_comm_allreduce_max(tic_comm *comm, double *vals, int n);
 
 /* ---- diagnostics (not part of the drop-in surface) ------------------------------------------------------------- */
 /* Runs the in-register 8x8 byte transpose used by the kernels (DPP + v_perm) and a shuffle-based formulation of

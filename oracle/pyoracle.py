@@ -34,6 +34,7 @@ def lib():
         L.tico_block_idct.argtypes = [f64p, f64p]
         L.tico_divisors.argtypes = [C.c_int, f64p]
         L.tico_encode.argtypes = [u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, i32p, i32p]
+        L.tico_encode_i32.argtypes = [i32p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, i32p, i32p]
         L.tico_encode_zz16.argtypes = [u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, i16p]
         L.tico_rle_block.argtypes = [i32p, i32p, i32p]
         L.tico_entropy_encode.argtypes = [i32p, i32p, C.c_int, C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -111,6 +112,21 @@ def encode(image, quality=50):
     dc = np.zeros(max(n, 1), dtype=np.int32)
     ac = np.zeros((max(n, 1), 63), dtype=np.int32)
     rc = lib().tico_encode(_p(a, C.c_uint8), h, w, a.strides[0] if a.size else w, int(quality), _p(dc, C.c_int32), _p(ac, C.c_int32))
+    if rc:
+        raise OracleError(rc)
+    return dc[:n], ac[:n]
+
+
+def encode_wide(image, quality=50):
+    """encode() for integer images with values outside 0..255 (codec.py:29: astype(int32) - 128) -> (dc, ac)."""
+    a = np.ascontiguousarray(np.asarray(image).astype(np.int32))
+    if a.ndim != 2:
+        raise ValueError("2-D image expected")
+    h, w = a.shape
+    n = nblocks(h, w)
+    dc = np.zeros(max(n, 1), dtype=np.int32)
+    ac = np.zeros((max(n, 1), 63), dtype=np.int32)
+    rc = lib().tico_encode_i32(_p(a, C.c_int32), h, w, (a.strides[0] // 4) if a.size else w, int(quality), _p(dc, C.c_int32), _p(ac, C.c_int32))
     if rc:
         raise OracleError(rc)
     return dc[:n], ac[:n]

@@ -262,8 +262,10 @@ static int reflect_index(int i, int n) {
     return j < n ? j : p - j;
 }
 
-/* Transform stage up to and including zig-zag; zz: int32 [N][64], zz[.][0] = un-differenced DC. */
-static int transform_zz(const uint8_t *image, int h, int w, ptrdiff_t stride, int quality, int32_t *zz) {
+/* Transform stage up to and including zig-zag; zz: int32 [N][64], zz[.][0] = un-differenced DC.
+ * Pixels come as uint8 (image) or, for integer images outside 0..255, as int32 (image32; codec.py:29 casts with astype(int32)
+ * and transforms whatever it finds); stride in elements. */
+static int transform_zz_any(const uint8_t *image, const int32_t *image32, int h, int w, ptrdiff_t stride, int quality, int32_t *zz) {
     double div[64];
     int rc = tico_divisors(quality, div);
     if (rc) return rc;
@@ -277,7 +279,7 @@ static int transform_zz(const uint8_t *image, int h, int w, ptrdiff_t stride, in
                 int y = reflect_index(by * 8 + i, h);
                 for (int j = 0; j < 8; j++) {
                     int x = reflect_index(bx * 8 + j, w);
-                    px[i * 8 + j] = (int32_t)image[(ptrdiff_t)y * stride + x] - 128; /* codec.py:29 */
+                    px[i * 8 + j] = (image ? (int32_t)image[(ptrdiff_t)y * stride + x] : image32[(ptrdiff_t)y * stride + x]) - 128; /* codec.py:29 */
                 }
             }
             tico_block_dct(px, X);
@@ -293,12 +295,16 @@ static int transform_zz(const uint8_t *image, int h, int w, ptrdiff_t stride, in
     return TICO_OK;
 }
 
-int tico_encode(const uint8_t *image, int h, int w, ptrdiff_t stride, int quality, int32_t *dc, int32_t *ac) {
+static int transform_zz(const uint8_t *image, int h, int w, ptrdiff_t stride, int quality, int32_t *zz) {
+    return transform_zz_any(image, NULL, h, w, stride, quality, zz);
+}
+
+static int encode_any(const uint8_t *image, const int32_t *image32, int h, int w, ptrdiff_t stride, int quality, int32_t *dc, int32_t *ac) {
     size_t n = (size_t)((h + 7) / 8) * (size_t)((w + 7) / 8);
     if (h == 0 || w == 0) n = 0;
     int32_t *zz = (int32_t *)malloc((n ? n : 1) * 64 * sizeof(int32_t));
     if (!zz) return TICO_E_SPACE;
-    int rc = transform_zz(image, h, w, stride, quality, zz);
+    int rc = transform_zz_any(image, image32, h, w, stride, quality, zz);
     if (rc == TICO_OK) {
         int32_t prev = 0;
         for (size_t b = 0; b < n; b++) { /* codec.py:34-36: DPCM over all blocks in raster order */
@@ -310,6 +316,15 @@ int tico_encode(const uint8_t *image, int h, int w, ptrdiff_t stride, int qualit
     }
     free(zz);
     return rc;
+}
+
+int tico_encode(const uint8_t *image, int h, int w, ptrdiff_t stride, int quality, int32_t *dc, int32_t *ac) {
+    return encode_any(image, NULL, h, w, stride, quality, dc, ac);
+}
+
+/* encode() for integer images outside 0..255: int32 pixels, stride in elements (codec.py:29: astype(int32) - 128). */
+int tico_encode_i32(const int32_t *image, int h, int w, ptrdiff_t stride, int quality, int32_t *dc, int32_t *ac) {
+    return encode_any(NULL, image, h, w, stride, quality, dc, ac);
 }
 
 int tico_encode_zz16(const uint8_t *image, int h, int w, ptrdiff_t stride, int quality, int16_t *out) {
@@ -559,7 +574,7 @@ int tico_decompress(const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
         if (!read_int(&r, sym, &v)) continue;
         dc[i] = v;
         int32_t blk[1200];
-        int m = 0, ok = 1;
+        int m = 0, ok = 1, too_long = 0;
         for (;;) { /* huffman.py:87-96 then decode_run_length (huffman.py:36-38) */
             if (!read_code(&r, &HT_AC, &sym)) {
                 ok = 0;
@@ -570,15 +585,16 @@ int tico_decompress(const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
                 ok = 0;
                 break;
             }
-            if (m + run + 1 > 1100) {
-                ok = 0;
-                break;
+            /* the reference keeps reading symbols until EOB or a decode error however long the list grows, and only then
+             * rejects a list longer than 63: keep consuming, stop storing */
+            if (m + run + 1 > 1100) too_long = 1;
+            if (!too_long) {
+                for (int z = 0; z < run; z++) blk[m++] = 0;
+                blk[m++] = v;
             }
-            for (int z = 0; z < run; z++) blk[m++] = 0;
-            blk[m++] = v;
             if (sym == 0) break; /* EOB */
         }
-        if (!ok) continue;
+        if (!ok || too_long) continue;
         m -= 1;            /* [:-1] */
         if (m > 63) continue; /* ac[i, :len] = ... raises on a too-long block -> swallowed, ac stays zero */
         memcpy(ac + i * 63, blk, (size_t)m * sizeof(int32_t));

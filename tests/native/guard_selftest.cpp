@@ -1,0 +1,149 @@
+// guard_selftest.cpp - the guard band of the float32 fast path (kGuard in tic_math.h), checked on the CPU.
+//
+// tic_math.h is host-compilable: this program runs the kernel's own dct8_aan<float> (rows, then columns: the pass order of
+// the strip kernel) and the kernel's quantiser arithmetic against dct8_exact (columns, then rows: the reference's order,
+// float64) and asserts, for every coefficient of every block,
+//     |Z_fast * scale - X_exact| < kGuard[u][v]                      (coefficient units)
+//     |t_fast - X_exact / div|   < kGuard[u][v] / div                (quantised units, q = 10, 50, 90; t = z * mul in float32,
+//                                                                     the larger of the rounded and the fused product's error)
+// on: blocks read from a file (the adversarial blocks of tools/fastpath_error_search.py, tests/golden/adversarial_blocks.npz
+// exported as raw bytes by the test), extreme patterns, and N random blocks (argv[2], default 2,000,000).
+// It also prints kGuard so that the test can compare it with the rigorous bound of tools/fastpath_error_bound.py.
+// Build: g++ -O2 -std=c++17 -ffp-contract=off (tests/test_host_cpu.py).
+#include <initializer_list>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../tinyimgcodec_amd/csrc/tic_math.h"
+
+using namespace tic;
+
+static uint64_t rng_state = 0x2545F4914F6CDD1Dull;
+static uint32_t rnd() {
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return (uint32_t)(rng_state >> 32);
+}
+
+static DctqConsts C10, C50, C90;
+static double aan[8];
+static double worst_ratio[64];  // max over blocks of error / kGuard, coefficient units
+static double worst_ratio_q[64]; // the same in quantised units (worst of the three qualities)
+static long n_blocks = 0, n_viol = 0;
+
+static void check_block(const uint8_t px[64]) {
+    // fast path: pass 1 along the pixel rows, level shift folded into output 0, pass 2 down the columns
+    float y[8][8];
+    for (int r = 0; r < 8; r++) {
+        float d[8];
+        for (int c = 0; c < 8; c++) d[c] = (float)px[r * 8 + c];
+        dct8_aan(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        d[0] -= 1024.0f;
+        for (int v = 0; v < 8; v++) y[r][v] = d[v];
+    }
+    float z[8][8]; // z[u][v]
+    for (int v = 0; v < 8; v++) {
+        float e[8];
+        for (int r = 0; r < 8; r++) e[r] = y[r][v];
+        dct8_aan(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+        for (int u = 0; u < 8; u++) z[u][v] = e[u];
+    }
+    // reference order in float64: axis -2 (down the columns) first, then axis -1
+    double x[8][8];
+    for (int c = 0; c < 8; c++) {
+        double d[8];
+        for (int r = 0; r < 8; r++) d[r] = (double)((int)px[r * 8 + c] - 128);
+        dct8_exact(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        for (int u = 0; u < 8; u++) x[u][c] = d[u];
+    }
+    for (int u = 0; u < 8; u++) dct8_exact(x[u][0], x[u][1], x[u][2], x[u][3], x[u][4], x[u][5], x[u][6], x[u][7]);
+    n_blocks++;
+    for (int u = 0; u < 8; u++)
+        for (int v = 0; v < 8; v++) {
+            const int i = u * 8 + v;
+            const double fast = (double)z[u][v] / (aan[u] * aan[v] * 8.0);
+            const double r1 = fabs(fast - x[u][v]) / kGuard[i];
+            if (r1 > worst_ratio[i]) worst_ratio[i] = r1;
+            double rq = 0;
+            for (const DctqConsts *C : {&C10, &C50, &C90}) {
+                const float mul = C->mulT[v * 8 + u];
+                const float t_rounded = z[u][v] * mul;                     // round-1 quantiser: float32 product
+                const double t_fused = (double)z[u][v] * (double)mul;       // round-2 quantiser: the exact product inside the fma
+                const double want = x[u][v] / C->div[i];
+                const double e = fmax(fabs((double)t_rounded - want), fabs(t_fused - want));
+                const double r = e / (kGuard[i] / C->div[i]);
+                if (r > rq) rq = r;
+            }
+            if (rq > worst_ratio_q[i]) worst_ratio_q[i] = rq;
+            if (r1 >= 1.0 || rq >= 1.0) n_viol++;
+        }
+}
+
+int main(int argc, char **argv) {
+    const char *file = argc > 1 ? argv[1] : "";
+    const long n_random = argc > 2 ? atol(argv[2]) : 2000000;
+    build_consts(10, &C10);
+    build_consts(50, &C50);
+    build_consts(90, &C90);
+    aan[0] = 1.0;
+    for (int k = 1; k < 8; k++) aan[k] = sqrt(2.0) * cos(k * 3.14159265358979323846 / 16.0);
+    printf("kGuard");
+    for (int i = 0; i < 64; i++) printf(" %.6e", kGuard[i]);
+    printf("\n");
+    uint8_t px[64];
+    long n_file = 0;
+    if (file[0]) {
+        FILE *f = fopen(file, "rb");
+        if (!f) { fprintf(stderr, "cannot open %s\n", file); return 2; }
+        while (fread(px, 1, 64, f) == 64) { check_block(px); n_file++; }
+        fclose(f);
+    }
+    // extreme patterns: constants, checkerboards, stripes, single pixels, half planes
+    for (int pat = 0; pat < 64; pat++) {
+        for (int r = 0; r < 8; r++)
+            for (int c = 0; c < 8; c++) {
+                int v;
+                switch (pat & 7) {
+                case 0: v = (pat >> 3) * 36; break;
+                case 1: v = ((r + c) & 1) ? 255 : 0; break;
+                case 2: v = (c & 1) ? 255 : 0; break;
+                case 3: v = (r & 1) ? 255 : 0; break;
+                case 4: v = (r * 8 + c == (pat >> 3) * 9) ? 255 : 0; break;
+                case 5: v = (c < (pat >> 3) + 1) ? 255 : 0; break;
+                case 6: v = (r < (pat >> 3) + 1) ? 0 : 255; break;
+                default: v = ((r / 2 + c / 2) & 1) ? 255 : 0; break;
+                }
+                px[r * 8 + c] = (uint8_t)(v > 255 ? 255 : v);
+            }
+        check_block(px);
+    }
+    for (long k = 0; k < n_random; k++) {
+        const uint32_t mode = k & 3; // uniform bytes / binary 0,255 / near-saturated / low-contrast
+        for (int j = 0; j < 64; j += 4) {
+            uint32_t w = rnd();
+            for (int t = 0; t < 4; t++) {
+                uint32_t b = (w >> (8 * t)) & 0xff;
+                if (mode == 1) b = (b & 1) ? 255 : 0;
+                else if (mode == 2) b = (b & 1) ? 255 - (b >> 5) : (b >> 5);
+                else if (mode == 3) b = 120 + (b & 15);
+                px[j + t] = (uint8_t)b;
+            }
+        }
+        check_block(px);
+    }
+    double w1 = 0, wq = 0;
+    for (int i = 0; i < 64; i++) {
+        if (worst_ratio[i] > w1) w1 = worst_ratio[i];
+        if (worst_ratio_q[i] > wq) wq = worst_ratio_q[i];
+    }
+    printf("blocks %ld (file %ld) worst error/guard: coefficient units %.4f, quantised units %.4f, violations %ld\n", n_blocks, n_file, w1, wq, n_viol);
+    if (n_viol != 0 || w1 >= 1.0 || wq >= 1.0) {
+        printf("guard_selftest FAILED\n");
+        return 1;
+    }
+    printf("guard_selftest ok\n");
+    return 0;
+}

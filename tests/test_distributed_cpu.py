@@ -41,7 +41,7 @@ def _worker(rank, world, port, n_frames, q, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import pyoracle
-    from tinyimgcodec_amd.distributed import compress_sharded
+    from tinyimgcodec_amd.distributed import TorchComm, compress_sharded
 
     called = []
 
@@ -52,7 +52,10 @@ def _worker(rank, world, port, n_frames, q, out_dir):
     def cpu_batch(frames, quality):
         return [pyoracle.compress(f, quality) for f in frames]
 
-    lo, hi, streams, sizes, offsets = compress_sharded(get_frame, n_frames, q, compress_batch_fn=cpu_batch)
+    comm = TorchComm()
+    assert (comm.rank, comm.world) == (rank, world)
+    lo, hi, streams, sizes, offsets = compress_sharded(get_frame, n_frames, q, comm=comm, compress_batch_fn=cpu_batch)
+    assert float(comm.allreduce_max([float(rank)])[0]) == world - 1  # bench.py's max-over-ranks
     assert called == list(range(lo, hi))
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), lo=lo, hi=hi, sizes=sizes, offsets=offsets,
              digest=np.frombuffer(hashlib.sha256(b"".join(streams)).digest(), dtype=np.uint8))

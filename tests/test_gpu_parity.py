@@ -3,6 +3,7 @@
 Bar: bit-exact (integer coefficients, byte streams, decoded pixels).  Run with `-m gpu` on an MI355X."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -500,3 +501,104 @@ def test_coefficient_without_huffman_code_raises_keyerror(ctx, golden):
                 T.compress(d[key + "_img"], q, ctx=ctx)
             hit += 1
     assert hit >= 1
+
+
+def _config4_worker(rank, world, port, n_frames, out_dir):
+    """One rank of the BASELINE config 4 rehearsal: its shard of 1080p frames through the real pipeline on device 0."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tinyimgcodec_amd as TT
+    from tinyimgcodec_amd.distributed import TorchComm, compress_sharded
+
+    c = TT.Context(0)  # both ranks share the one GPU of the box (RCCL wants a GPU per rank: the sizes travel over gloo here)
+    comm = TorchComm()
+    lo, hi, streams, sizes, offsets = compress_sharded(lambda i: rand_frame(1234 + i, 1080, 1920), n_frames, 50, comm=comm,
+                                                       compress_batch_fn=lambda fr, q: TT.compress_batch(fr, q, threads=0, ctx=c))
+    enc = [TT.encode(rand_frame(1234 + i, 1080, 1920), 50, ctx=c) for i in range(lo, hi)]
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), lo=lo, hi=hi, sizes=sizes, offsets=offsets,
+             stream_sha=np.array([sha(s) for s in streams]), mine=np.array([len(s) for s in streams], dtype=np.int64),
+             dc_sha=np.array([sha(e["dc"].astype("<i4").tobytes()) for e in enc]),
+             ac_sha=np.array([sha(e["ac"].astype("<i4").tobytes()) for e in enc]))
+    dist.barrier()
+    dist.destroy_process_group()
+    c.close()
+
+
+def test_config4_rehearsal_two_ranks_on_one_gpu(tmp_path, manifest):
+    """BASELINE config 4 on the hardware that exists: 2 ranks (gloo) share device 0, each sends its contiguous shard of
+    1920x1080 frames (seed 1234 + i) through the real compress_batch; the gathered sizes and offsets agree on both ranks,
+    frame 0's stream and the coefficients of frames 0-3 carry the reference's digests."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world, n_frames = 2, 8
+    mp.spawn(_config4_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
+    d = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+    assert [(int(x["lo"]), int(x["hi"])) for x in d] == [(0, 4), (4, 8)]
+    sizes = np.concatenate([x["mine"] for x in d])
+    for x in d:  # every rank knows every frame's size and offset
+        assert np.array_equal(x["sizes"], sizes)
+        assert np.array_equal(x["offsets"], np.concatenate([[0], np.cumsum(sizes)]))
+    m0 = manifest["rand1234_1080x1920_q50"]
+    assert int(sizes[0]) == m0["bytes"] and str(d[0]["stream_sha"][0]) == m0["sha256"]
+    for i in range(4):
+        m = manifest["rand%d_1080x1920_q50_coeffs" % (1234 + i)]
+        assert str(d[0]["dc_sha"][i]) == m["dc_i4_sha256"] and str(d[0]["ac_sha"][i]) == m["ac_i4_sha256"], i
+
+
+@pytest.mark.parametrize("variant", [N.KERNEL_EXACT, N.KERNEL_HYBRID])
+def test_near_ties_round2(ctx, golden, variant):
+    """Reference-generated fixture: exact ties of the irrational coefficients (2,2) (2,6) (6,2) (6,6), of the rational four, and
+    random blocks with an irrational coefficient within 1e-6 of a tie - decided by the reference's float64, never by a band."""
+    d = golden("near_ties")
+    f = DevFrame(ctx, d["img"])
+    for q in (50, 90, 10, 37):
+        dc, ac = zz_to_dc_ac(f.run(q, variant))
+        assert np.array_equal(dc, d[f"q{q}_dc"]), q
+        assert np.array_equal(ac, d[f"q{q}_ac"]), q
+    f.free()
+
+
+def test_wide_pixels_round2(ctx, golden):
+    """encode() on integer images outside 0..255 (codec.py:29 transforms any integers): the exact float64 device path equals the
+    reference; compress() of such content raises KeyError where the reference's Huffman table has no code."""
+    d = golden("wide_pixels")
+    for name in d["names"]:
+        key, q = str(name).rsplit("_q", 1)
+        e = T.encode(d[key + "_img"], int(q), ctx=ctx)
+        assert np.array_equal(e["dc"], d[f"{name}_dc"]), name
+        assert np.array_equal(e["ac"], d[f"{name}_ac"]), name
+    with pytest.raises(KeyError):
+        T.compress(d["int16_full_img"], 50, ctx=ctx)
+    small = np.array(d["int16_mixed_img"]) // 8  # |coefficients| stay codable
+    e = T.encode(small, 50, ctx=ctx)
+    bs = T.compress(small, 50, ctx=ctx)
+    assert bs == T.entropy_encode(np.concatenate([np.cumsum(e["dc"])[:, None], e["ac"]], axis=1).astype(np.int16), *small.shape, 50)
+    # float qualities: encode() accepts integral floats as the reference does, compress() fails in the header pack
+    img = rand_frame(3, 16, 16)
+    assert np.array_equal(T.encode(img, 50.0, ctx=ctx)["ac"], T.encode(img, 50, ctx=ctx)["ac"])
+    import struct
+    with pytest.raises(struct.error):
+        T.compress(img, 50.0, ctx=ctx)
+    with pytest.raises(ValueError):
+        T.encode(img, 37.5, ctx=ctx)
+
+
+def test_truncated_streams_round2(ctx, golden):
+    """decompress() on truncated / corrupted streams returns what the reference returns (it swallows a block's exception,
+    codec.py:178-186), including blocks that run to more than a thousand symbols without an end-of-block."""
+    d = golden("truncated_streams")
+    for name in d["names"]:
+        name = str(name)
+        got = T.decompress(d[name + "_bs"].tobytes(), ctx=ctx)
+        assert np.array_equal(got, d[name + "_out"]), name

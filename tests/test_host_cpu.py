@@ -158,3 +158,37 @@ def test_host_entropy_coder_under_sanitizers(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host_selftest ok" in r.stdout
+
+
+def test_guard_band_of_the_fast_path_is_a_bound(tmp_path):
+    """kGuard (tic_math.h) is what makes the float32 fast path of the strip kernel 'identical for every input'.  Pinned here:
+    (1) the table is at least the rigorous forward-error bound of tools/fastpath_error_bound.py plus the quantiser multiply's
+        rounding, times the documented 5 % margin, for every coefficient;
+    (2) the kernel's own arithmetic (tic_math.h compiled for the host: dct8_aan<float> rows then columns, both quantiser
+        forms) stays inside kGuard against the exact-order float64 DCT on the adversarial blocks of
+        tools/fastpath_error_search.py (tests/golden/adversarial_blocks.npz), extreme patterns and 2,000,000 random blocks
+        of four kinds, in coefficient units and in quantised units at q = 10, 50, 90."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    exe = tmp_path / "guard_selftest"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", str(exe), os.path.join(root, "tests", "native", "guard_selftest.cpp")],
+                   check=True)
+    adv = np.load(os.path.join(root, "tests", "golden", "adversarial_blocks.npz"))["blocks"]
+    assert adv.shape[1:] == (8, 8) and adv.dtype == np.uint8 and len(adv) >= 64
+    raw = tmp_path / "adv.bin"
+    raw.write_bytes(adv.tobytes())
+    r = subprocess.run([str(exe), str(raw), "2000000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "guard_selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    guard = np.array([float(x) for x in r.stdout.splitlines()[0].split()[1:]]).reshape(8, 8)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import fastpath_error_bound as feb
+    finally:
+        sys.path.pop(0)
+    need = (feb.bound_matrix() + feb.QUANT_MUL) * 1.05
+    assert (guard >= need * (1 - 2e-4)).all(), (guard / need).min()  # (the table is written with five significant digits)
+    assert (guard <= need * 1.02).all()                                # ... and is not needlessly wide: the trip rate scales with it

@@ -157,3 +157,51 @@ def test_error_behaviour(oracle, manifest):
             oracle.compress(img, q)
     assert e["empty_0x8"]["bytes"] == 16
     assert oracle.compress(np.zeros((0, 8), np.uint8), 50).hex() == e["empty_0x8"]["hex"]
+
+
+def test_near_ties_round2(oracle, golden):
+    """Round-2 fixture from the reference: exact ties of the irrational coefficients (2,2) (2,6) (6,2) (6,6), exact ties of the
+    rational four, and random blocks with an irrational coefficient within 1e-6 of a tie (q=50) - the oracle follows the
+    reference's float64 through all of them, at four qualities."""
+    d = golden("near_ties")
+    assert (d["kinds"] == "irrational_true_tie").sum() == 24 and (d["kinds"] == "near_tie_1e-6").sum() >= 64
+    for q in (50, 90, 10, 37):
+        dc, ac = oracle.encode(d["img"], q)
+        assert np.array_equal(dc, d[f"q{q}_dc"]), q
+        assert np.array_equal(ac, d[f"q{q}_ac"]), q
+
+
+def test_wide_pixels_round2(oracle, golden):
+    """Integer images outside 0..255 (the reference transforms any integers, codec.py:29): int16 with negatives, full-range
+    int16, 12-bit uint16, float64 (truncated by astype(int32))."""
+    d = golden("wide_pixels")
+    for name in d["names"]:
+        key, q = str(name).rsplit("_q", 1)
+        dc, ac = oracle.encode_wide(d[key + "_img"], int(q))
+        assert np.array_equal(dc, d[f"{name}_dc"]), name
+        assert np.array_equal(ac, d[f"{name}_ac"]), name
+
+
+def test_truncated_streams_round2(oracle, golden):
+    """What the reference's decompress() returns for truncated / corrupted streams (it swallows the exception of a block,
+    codec.py:178-186; reads past the end follow the bit container's slicing semantics): the oracle decodes the same pixels."""
+    d = golden("truncated_streams")
+    for name in d["names"]:
+        name = str(name)
+        assert int(d[name + "_ok"]) == 1, name  # the reference raised for none of them
+        got = oracle.decompress(d[name + "_bs"].tobytes())
+        assert np.array_equal(got, d[name + "_out"]), name
+
+
+def test_config4_stream_digests_round2(oracle):
+    """BASELINE config 4, frames 1234..1237 (1920x1080): stream sizes and digests recorded from the reference."""
+    import json
+    import os
+
+    from conftest import GOLDEN, rand_frame
+
+    m = json.load(open(os.path.join(GOLDEN, "manifest_r2.json")))["entries"]
+    f = rand_frame(1235, 1080, 1920)
+    bs = oracle.compress(f, 50)
+    e = m["rand1235_1080x1920_q50_stream"]
+    assert len(bs) == e["bytes"] and hashlib.sha256(bs).hexdigest() == e["sha256"]

@@ -40,6 +40,7 @@ SIGNATURES = {
     "tic_compress_bound": (C.c_size_t, [C.c_int, C.c_int]),
     "tic_dctq": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p]),
     "tic_encode": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "tic_encode_wide": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_void_p]),
     "tic_dev_alloc": (C.c_int, [_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),
     "tic_dev_free": (C.c_int, [_ctxp, C.c_void_p]),
     "tic_host_alloc_pinned": (C.c_int, [_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -56,6 +57,16 @@ SIGNATURES = {
     "tic_dctq_dev_timed": (
         C.c_int,
         [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
+    ),
+    "tic_dctq_dev_frames_timed": (
+        C.c_int,
+        [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int,
+         C.POINTER(C.c_float)],
+    ),
+    "tic_dctq_dev_timed_rotating": (
+        C.c_int,
+        [_ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, C.c_int,
+         C.POINTER(C.c_float)],
     ),
     "tic_set_stats": (C.c_int, [_ctxp, C.c_int]),
     "tic_last_fallback_blocks": (C.c_int, [_ctxp, C.POINTER(C.c_ulonglong)]),
@@ -85,6 +96,13 @@ SIGNATURES = {
     "tic_idctq": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "tic_decompress": (C.c_int, [_ctxp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "tic_selftest_transpose": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "tic_comm_create": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "tic_comm_destroy": (C.c_int, [C.c_void_p]),
+    "tic_comm_rank": (C.c_int, [C.c_void_p]),
+    "tic_comm_world": (C.c_int, [C.c_void_p]),
+    "tic_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "tic_gather_sizes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tic_comm_allreduce_max": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
 }
 
 _lib = None

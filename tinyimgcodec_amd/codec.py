@@ -12,7 +12,10 @@ stage runs in C on the host.  There is no Python or CPU fallback: without the HI
 functions raise tinyimgcodec_amd.NativeUnavailable.
 
 Documented differences from the reference (all outside its working domain):
-  * pixel values must lie in 0..255 (the device path is 8-bit; the reference would transform any integers);
+  * integer pixel values outside 0..255 are transformed as the reference does (exact float64 path on the device) by
+    encode() and compress(); the batch and device-layout helpers (compress_batch, dctq) are 8-bit only;
+  * encode()/decode() accept integral float qualities like the reference; non-integral or negative qualities (for which the
+    reference computes with fractional or negative divisors) raise ValueError;
   * auto_generate_huffman_table=True raises NotImplementedError (that path is broken in the reference:
     the table flag is written big-endian and read little-endian, codec.py:111/119);
   * quality > 100 raises ValueError (the reference produces streams with negative divisors);
@@ -30,46 +33,76 @@ def _ctx(ctx):
     return ctx if ctx is not None else N.default_context()
 
 
-def _check_quality(quality, packed_first):
-    """Reproduces the exception types of the reference for an invalid quality.
+def _check_quality(quality, packs_header):
+    """Validates `quality` the way the reference would fail and returns it as an int.
 
-    The reference evaluates `5000 / quality` inside encode() and only later packs the header, so the order of
-    checks depends on the entry point: encode() never packs."""
+    packs_header=True  (compress): the reference evaluates `5000 / quality` in encode() and then struct.pack("III", ...) in
+                       make_header (codec.py:103-108): floats and negatives end in struct.error.
+    packs_header=False (encode, dctq, decode): nothing is packed; the reference computes with whatever number it gets.
+                       Integral floats give the same divisors as the int and are accepted; what the per-quality device
+                       tables cannot express (non-integral or negative values) raises ValueError - a documented difference."""
     if isinstance(quality, (bool, np.bool_)):
         quality = int(quality)
-    if not isinstance(quality, (int, np.integer)):
-        if isinstance(quality, (float, np.floating)) and not packed_first:
-            if quality == 0:
-                raise ZeroDivisionError("float division by zero")
+    if isinstance(quality, (float, np.floating)):
+        if quality == 0:
+            raise ZeroDivisionError("float division by zero")  # utils.py:50
+        if packs_header:
             struct.pack("I", quality)  # raises struct.error: required argument is not an integer
-        raise TypeError("quality must be an int")
+        if quality != int(quality):
+            raise ValueError("non-integral quality %r is not supported by the MI355X path" % (quality,))
+        quality = int(quality)
+    elif not isinstance(quality, (int, np.integer)):
+        raise TypeError("quality must be a number")
     quality = int(quality)
     if quality == 0:
         raise ZeroDivisionError("division by zero")  # utils.py:50
     if quality < 0:
-        struct.pack("I", quality)  # struct.error, codec.py:103-108
+        if packs_header:
+            struct.pack("I", quality)  # struct.error, codec.py:103-108
+        raise ValueError("negative quality is not supported by the MI355X path")
     if quality == 100:
-        raise KeyError((0, 0))  # factor 0 -> inf/NaN coefficients -> no Huffman code (huffman.py:62)
+        if packs_header:
+            raise KeyError((0, 0))  # factor 0 -> inf/NaN coefficients -> no Huffman code (huffman.py:62)
+        raise ValueError("quality 100 makes every divisor zero (the reference returns inf/NaN garbage)")
     if quality > 100:
         raise ValueError("quality must be in 1..99")
     return quality
 
 
-def _as_u8_image(image):
+def _as_image(image):
+    """-> (array, height, width, wide).  uint8-representable images go to the 8-bit device path as uint8; integer images with
+    values outside 0..255 (the reference transforms any integers after astype(int32), codec.py:29) as int32 (`wide`)."""
     image = np.asarray(image)
     height, width = image.shape  # ValueError for non 2-D input, as codec.py:27
     if image.dtype == np.uint8:  # the common case needs no conversion pass
-        return np.ascontiguousarray(image), int(height), int(width)
+        return np.ascontiguousarray(image), int(height), int(width), False
     a = image.astype(np.int32)  # codec.py:29 (truncation of floats, as the reference)
     if a.size and (a.min() < 0 or a.max() > 255):
-        raise ValueError("pixel values must lie in 0..255 (the MI355X path is 8-bit)")
-    return np.ascontiguousarray(a.astype(np.uint8)), int(height), int(width)
+        return np.ascontiguousarray(a), int(height), int(width), True
+    return np.ascontiguousarray(a.astype(np.uint8)), int(height), int(width), False
+
+
+def _as_u8_image(image):
+    img, h, w, wide = _as_image(image)
+    if wide:
+        raise ValueError("pixel values outside 0..255: use encode()/compress() (the int16 device layout of dctq()/compress_batch() is 8-bit only)")
+    return img, h, w
+
+
+def _encode_wide(img, h, w, q, ctx):
+    L = N.load()
+    n = L.tic_num_blocks(h, w)
+    dc = np.zeros(n, dtype=np.int32)
+    ac = np.zeros((n, 63), dtype=np.int32)
+    if n:
+        ctx.check(L.tic_encode_wide(ctx.handle, img.ctypes.data, h, w, img.strides[0] // 4, q, dc.ctypes.data, ac.ctypes.data))
+    return dc, ac
 
 
 def dctq(image, quality=50, ctx=None):
     """Transform stage in the device layout: int16 [N, 64], zig-zag order, DC not differenced."""
     img, h, w = _as_u8_image(image)
-    quality = _check_quality(quality, packed_first=True)
+    quality = _check_quality(quality, packs_header=False)
     ctx = _ctx(ctx)
     n = N.load().tic_num_blocks(h, w)
     zz = np.zeros((n, 64), dtype=np.int16)
@@ -79,9 +112,12 @@ def dctq(image, quality=50, ctx=None):
 
 
 def encode(image, quality=50, ctx=None):
-    img, h, w = _as_u8_image(image)
-    q = _check_quality(quality, packed_first=True)
+    img, h, w, wide = _as_image(image)
+    q = _check_quality(quality, packs_header=False)
     ctx = _ctx(ctx)
+    if wide:
+        dc, ac = _encode_wide(img, h, w, q, ctx)
+        return {"height": h, "width": w, "quality": quality, "dc": dc, "ac": ac}
     n = N.load().tic_num_blocks(h, w)
     dc = np.zeros(n, dtype=np.int32)
     ac = np.zeros((n, 63), dtype=np.int32)
@@ -91,12 +127,20 @@ def encode(image, quality=50, ctx=None):
 
 
 def compress(image, quality=50, auto_generate_huffman_table=False, ctx=None):
-    img, h, w = _as_u8_image(image)
-    q = _check_quality(quality, packed_first=False)
+    img, h, w, wide = _as_image(image)
+    q = _check_quality(quality, packs_header=True)
     if auto_generate_huffman_table:
         raise NotImplementedError("auto_generate_huffman_table=True is not supported (broken in the reference)")
     ctx = _ctx(ctx)
     L = N.load()
+    if wide:  # integer pixels outside 0..255: exact float64 transform on the device, host entropy coder
+        dc, ac = _encode_wide(img, h, w, q, ctx)
+        zz = np.empty((dc.shape[0], 64), dtype=np.int64)
+        zz[:, 0] = np.cumsum(dc.astype(np.int64))
+        zz[:, 1:] = ac
+        if zz.size and np.abs(zz).max() > 32767:
+            raise KeyError("coefficient magnitude has no Huffman code")  # (>= 1024 already has none in the reference)
+        return entropy_encode(zz.astype(np.int16), h, w, q)
     cap = L.tic_compress_bound(h, w)
     # worst-case sized landing buffer kept on the context: a fresh 50 MB mapping per call would be faulted in page by page
     # under the device-to-host copy (20+ ms for a 4096x4096 frame whose whole C-level round trip takes 0.6 ms)
@@ -115,7 +159,7 @@ def compress_batch(images, quality=50, threads=0, ctx=None):
     """Batch of equally sized frames through the stream-overlapped pipeline -> list of bytes.
 
     threads=0: entropy stage on the GPU; threads>0: host entropy coder on that many worker threads."""
-    q = _check_quality(quality, packed_first=False)
+    q = _check_quality(quality, packs_header=True)
     frames = [_as_u8_image(im) for im in images]
     if not frames:
         return []
@@ -194,7 +238,7 @@ def decode(data, ctx=None):
     zz[:, 0] = dc
     zz[:, 1:] = ac
     out = np.zeros((int(height), int(width)), dtype=np.uint8)
-    q = _check_quality(quality, packed_first=True)
+    q = _check_quality(quality, packs_header=False)
     if n:
         ctx.check(N.load().tic_idctq(ctx.handle, zz.ctypes.data, int(height), int(width), q, out.ctypes.data, out.size))
     return out

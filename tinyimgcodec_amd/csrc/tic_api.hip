@@ -117,6 +117,9 @@ int tic_device_count(void) {
 }
 
 const char *tic_last_error(const tic_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+// (internal, for tic_comm.hip)
+__attribute__((visibility("hidden"))) int tic_ctx_device(const tic_ctx *ctx) { return ctx ? ctx->device : -1; }
+__attribute__((visibility("hidden"))) void *tic_ctx_stream(const tic_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 const char *tic_device_arch(const tic_ctx *ctx) { return ctx ? ctx->arch : ""; }
 
 size_t tic_num_blocks(int h, int w) { return num_blocks(h, w); }
@@ -353,6 +356,57 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
     return TIC_OK;
 }
 
+// Batch form of the timed entry: `iters` back-to-back launches of the batched transform (nframes frames per launch).
+int tic_dctq_dev_frames_timed(tic_ctx *ctx, const void *d_images, int nframes, int h, int w, ptrdiff_t row_stride,
+                              ptrdiff_t frame_stride, int quality, void *d_coeffs_zz, ptrdiff_t coeff_frame_stride, int variant,
+                              int iters, float *ms_total) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (!ms_total || iters < 1 || nframes < 1 || nframes > 65535 || !d_images || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
+    if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
+        return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+    if (frame_stride < (ptrdiff_t)h * row_stride || coeff_frame_stride < (ptrdiff_t)(num_blocks(h, w) * 128))
+        return set_err(ctx, TIC_E_ARG, "frame strides smaller than one frame");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DctqArgs a = make_args(ctx, d_images, h, w, row_stride, quality, d_coeffs_zz);
+    a.aligned8 = a.aligned8 && ((frame_stride & 7) == 0);
+    a.nframes = nframes;
+    a.frame_stride_in = (long)frame_stride;
+    a.frame_stride_out = (long)coeff_frame_stride;
+    const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; i++) HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return TIC_OK;
+}
+
+// Cold-cache form of the timed entry: launch i works on pair i % npairs of (image, coefficient buffer).  With enough
+// distinct pairs (their total size well beyond the 256 MiB Infinity Cache) every launch reads and writes lines that have
+// left the cache since their last use: the number is an HBM number, not an on-die one.
+int tic_dctq_dev_timed_rotating(tic_ctx *ctx, const void *const *d_images, void *const *d_coeffs_zz, int npairs, int h, int w,
+                                ptrdiff_t row_stride, int quality, int variant, int iters, float *ms_total) {
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (!ms_total || iters < 1 || npairs < 1 || !d_images || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
+    if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
+        return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+    for (int k = 0; k < npairs; k++)
+        if (!d_images[k] || !d_coeffs_zz[k]) return set_err(ctx, TIC_E_ARG, "null device pointer in pair %d", k);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; i++) {
+        DctqArgs a = make_args(ctx, d_images[i % npairs], h, w, row_stride, quality, d_coeffs_zz[i % npairs]);
+        HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return TIC_OK;
+}
+
 #ifdef TIC_ABLATION
 // Experiment library only (tools/): one launch of a stamp build (variant 17 or 52), per-wave s_memtime stamps to host_out.
 int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
@@ -437,6 +491,44 @@ int tic_encode(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_s
     for (size_t b = 0; b < n; b++) { // codec.py:34-36
         const int16_t *c = ctx->h_coef.data() + b * 64;
         dc[b] = b ? c[0] - prev : c[0];
+        prev = c[0];
+        for (int k = 1; k < 64; k++) ac[b * 63 + (k - 1)] = c[k];
+    }
+    return TIC_OK;
+}
+
+// encode() for integer images outside 0..255 (codec.py:29 casts with astype(int32) and transforms whatever it finds):
+// int32 pixels, float64 exact order on the device, int32 dc (DPCM applied) / ac as the reference returns them.
+int tic_encode_wide(tic_ctx *ctx, const int32_t *image, int h, int w, ptrdiff_t row_stride_elems, int quality, int32_t *dc,
+                    int32_t *ac) {
+    int rc = check_geometry(ctx, h, w, row_stride_elems, quality);
+    if (rc) return rc;
+    const size_t n = num_blocks(h, w);
+    if (n == 0) return TIC_OK;
+    if (!image || !dc || !ac) return set_err(ctx, TIC_E_ARG, "null pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rc = ensure_scratch(ctx, (size_t)h * (size_t)w * 4, n * 256);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_img, (size_t)w * 4, image, (size_t)row_stride_elems * 4, (size_t)w * 4, (size_t)h,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    WideArgs a;
+    a.img = (const int32_t *)ctx->d_img;
+    a.out = (int32_t *)ctx->d_coef;
+    a.h = h;
+    a.w = w;
+    a.stride = w;
+    a.bw = (w + 7) / 8;
+    a.tiles_x = (a.bw + 7) / 8;
+    a.ntiles = ((h + 7) / 8) * a.tiles_x;
+    a.consts = ctx->d_consts + quality;
+    HIPCHK(ctx, launch_dctq_wide(a, ctx->stream));
+    std::vector<int32_t> zz(n * 64);
+    HIPCHK(ctx, hipMemcpyAsync(zz.data(), ctx->d_coef, n * 256, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t prev = 0;
+    for (size_t b = 0; b < n; b++) { // codec.py:34-36 (np.diff wraps in int32 like the reference's arrays)
+        const int32_t *c = zz.data() + b * 64;
+        dc[b] = b ? (int32_t)((uint32_t)c[0] - (uint32_t)prev) : c[0];
         prev = c[0];
         for (int k = 1; k < 64; k++) ac[b * 63 + (k - 1)] = c[k];
     }

@@ -402,22 +402,23 @@ int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
         if (!have_dc) continue; // exception before the AC loop: block stays zero (codec.py:185-186)
         int16_t tmp[1100];
         int m = 0;
-        bool ok = true;
+        bool ok = true, too_long = false;
         for (;;) {
             if (!read_symbol(r, T.acd, sym, v)) {
                 ok = false;
                 break;
             }
             const int run = sym >> 4;
-            if (m + run + 1 > 1090) {
-                ok = false;
-                break;
+            // the reference (huffman.py:77-98) reads symbols until EOB or a decode error however long the list grows and
+            // rejects a list longer than 63 only afterwards: keep consuming (the read position matters), stop storing
+            if (m + run + 1 > 1090) too_long = true;
+            if (!too_long) {
+                for (int z = 0; z < run; z++) tmp[m++] = 0;
+                tmp[m++] = sat16(v);
             }
-            for (int z = 0; z < run; z++) tmp[m++] = 0;
-            tmp[m++] = sat16(v);
             if (sym == 0) break;
         }
-        if (!ok) continue;
+        if (!ok || too_long) continue;
         m -= 1; // decode_run_length drops the element produced by EOB (huffman.py:36-38)
         if (m > 63) continue;
         memcpy(c + 1, tmp, (size_t)m * sizeof(int16_t));

@@ -56,6 +56,15 @@ struct DctqArgs {
     int q_teams, q_waves, q_run_shift, q_ppw;
 };
 
+struct WideArgs {          // dctq_exact_wide_kernel: integer images outside 0..255
+    const int32_t *img;    // device, int32 [h][stride]
+    int32_t *out;          // device, int32 [N][64] zig-zag
+    int h, w;
+    long stride;           // elements between rows
+    int bw, tiles_x, ntiles;
+    const DctqConsts *consts;
+};
+
 struct IdctArgs {
     const int16_t *coeffs; // device, int16 [N][64] zig-zag, DC integrated
     uint8_t *out;          // device, uint8 [h][stride]
@@ -67,6 +76,7 @@ struct IdctArgs {
 };
 
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream);
+hipError_t launch_dctq_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_idct(const IdctArgs &a, hipStream_t stream);
 hipError_t launch_selftest_transpose(const void *in, void *out_dpp, void *out_ref, int nthreads, hipStream_t stream);
 

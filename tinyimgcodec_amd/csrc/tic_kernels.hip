@@ -1935,6 +1935,51 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 4) void dctq_lane_kernel(DctqArgs
 #endif // TIC_ABLATION
 
 // ---------------------------------------------------------------------------------------------------------
+// Kernel 1b: exact path for integer images outside 0..255 (the reference transforms any integers: codec.py:29 is
+// `astype(int32) - 128`).  int32 pixels in, int32 coefficients out (zig-zag order), float64 in pocketfft's order throughout.
+// A drop-in edge, not a hot path: lane 8*b + i gathers pixel column i of block b itself (reflect padding as pad_image).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_wide_kernel(WideArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerWG][kLdsWaveBytes / 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = lane >> 3, i = lane & 7;
+    uint32_t *lds = lds_all[wave];
+    const int tile = blockIdx.x * kWavesPerWG + wave;
+    Strip s = make_strip(tile, a.ntiles, a.tiles_x, a.bw, b);
+    double c[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) c[r] = 0.0;
+    if (s.valid) {
+        const int x = reflect_index(s.bx * 8 + i, a.w);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int y = reflect_index(s.by * 8 + r, a.h);
+            c[r] = (double)a.img[(long)y * a.stride + x] - 128.0; // (int32 - 128 is exact in float64)
+        }
+    }
+    dct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -2: down the column
+    uint32_t w[8], wh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = (uint32_t)__double2loint(c[k]);
+    transpose8x8_dwords(lds, b, i, w);
+#pragma unroll
+    for (int k = 0; k < 8; k++) wh[k] = (uint32_t)__double2hiint(c[k]);
+    transpose8x8_dwords(lds, b, i, wh);
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = __hiloint2double((int)wh[k], (int)w[k]);
+    dct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -1: along frequency row u = i
+    if (!s.valid) return;
+    const double *div = a.consts->div + i * 8;
+    const uint16_t *zz = a.consts->zzofs + i * 8; // byte offset of (u = i, v) in an int16 zig-zag block = 2 * scan position
+    int32_t *ob = a.out + s.oblk * 64;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        ob[zz[v] >> 1] = (int32_t)rint(c[v] / div[v]); // np.round(X / div).astype(int32)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Kernel 3: decode side - dequantise (utils.py:52), inverse DCT (utils.py:40-45, exact order), +128, clip,
 // truncating cast (codec.py:68-70), crop.  Input: int16 [N][64] zig-zag, DC already integrated (np.cumsum).
 // ---------------------------------------------------------------------------------------------------------
@@ -2321,6 +2366,12 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.rem_mode = 1;
         hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(nrem), nf), block, 0, stream, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_dctq_wide(const WideArgs &a, hipStream_t stream) {
+    if (a.ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dctq_exact_wide_kernel, dim3(grid_for(a.ntiles)), dim3(kWavesPerWG * 64), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -25,7 +25,7 @@ def load_gray(path, shape=None):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description=__doc__.split("\\n")[0])
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
     ap.add_argument("input")
     ap.add_argument("output")
     ap.add_argument("--quality", type=int, default=50)

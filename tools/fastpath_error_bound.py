@@ -53,7 +53,8 @@ def aan(d):
     return [o0, z11 + z4, o2, z13 - z2, o4, z13 + z2, o6, z11 - z4]
 
 
-def main():
+def bound_matrix():
+    """Rigorous bound per coefficient [u][v] (orthonormal-DCT units) of the float32 AAN fast path, rows then columns."""
     eye = np.eye(8)
     row = aan([Node(eye[k], 0.0, np.zeros(8), np.full(8, 255.0)) for k in range(8)])  # pass 1: one pixel row
     k = np.arange(8)
@@ -68,10 +69,18 @@ def main():
         col = aan([Node(eye[r], e1, np.full(8, lo), np.full(8, hi)) for r in range(8)])
         for u in range(8):
             bound[u, v] = col[u].err / (aansc[u] * aansc[v] * 8.0)
+    return bound
+
+
+QUANT_MUL = 1024 * 2.0 ** -23  # rounding of the float32 quantiser multiply, in coefficient units (|X| <= 1024)
+
+
+def main():
+    bound = bound_matrix()
     np.set_printoptions(linewidth=140)
     print("rigorous bound per coefficient (x1e-4, orthonormal units; rows u, columns v):")
     print(np.round(bound * 1e4, 2))
-    q = 1024 * 2.0 ** -23
+    q = QUANT_MUL
     print("max bound %.3e + quantiser multiply %.3e = %.3e  (kGuardX = 1.0e-3)" % (bound.max(), q, bound.max() + q))
 
 

@@ -50,14 +50,24 @@ def errors(blocks):  # blocks uint8-valued float arrays [n,8,8]
 
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    save = sys.argv[2] if len(sys.argv) > 2 else None  # .npz: the worst block found for every coefficient (+ runners-up)
     rng = np.random.default_rng(1)
     best = np.zeros((8, 8))
+    worst_blocks = np.zeros((64, 4, 8, 8), np.uint8)  # per coefficient: the 4 blocks with the largest error so far
+    worst_err = np.zeros((64, 4))
     t_end = time.time() + budget
     pop = rng.choice([0.0, 255.0], (4096, 8, 8))
     it = 0
     while time.time() < t_end:
         e = errors(pop)
         best = np.maximum(best, e.max(0))
+        ef = e.reshape(len(pop), 64)
+        for c in range(64):
+            k = int(np.argmax(ef[:, c]))
+            j = int(np.argmin(worst_err[c]))
+            if ef[k, c] > worst_err[c, j] and not any(np.array_equal(pop[k].astype(np.uint8), wb) for wb in worst_blocks[c]):
+                worst_err[c, j] = ef[k, c]
+                worst_blocks[c, j] = pop[k].astype(np.uint8)
         # keep the blocks that are best for any coefficient, mutate them (flip to extremes / random values)
         keep_idx = np.unique(np.argsort(-e.reshape(len(pop), 64), axis=0)[:24].ravel())
         keep = pop[keep_idx]
@@ -72,6 +82,9 @@ def main():
     print(np.round(best * 1e4, 2))
     print("with the quantiser multiply (1024*2^-23 = 1.22e-4): %.3e  -> guard band 1.0e-3 margin x%.2f" % (
         best.max() + 1.22e-4, 1e-3 / (best.max() + 1.22e-4)))
+    if save:
+        np.savez_compressed(save, blocks=worst_blocks.reshape(-1, 8, 8), err=worst_err.reshape(-1))
+        print("saved", worst_blocks.reshape(-1, 8, 8).shape, "blocks to", save)
 
 
 if __name__ == "__main__":
