@@ -804,9 +804,73 @@ constexpr int kMaxStripsPerWave2 = 64;                 // one bit per strip of a
 constexpr int kBatch = 8;                              // entries of the wave's batch
 constexpr int kBatchWaveBytes = kBatch * (128 + 64) + 64; // images, pixel rows, ids
 
+// ---- the batch pass of the strip kernel, round-2 form ("slim"): lower latency, it runs on the launch's tail -------------------
+// A double through DPP: lane i reads the value of the lane the control word names.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// Exact float64 sub-path of the four rational coefficients, 8 lanes per block, no LDS: rowLo/rowHi = pixel row i of the lane's
+// block.  The row's bytes are first reordered (0,7,3,4,1,2,5,6) so that, after the byte transpose, neighbouring lanes hold the
+// columns pocketfft adds first: the 8-point sums of SURVEY Appendix A become three DPP butterflies (xor 1, xor 2, +4).
+// Column sums come from v_sad_u8.  Lanes 0..3 of the block return (0,0), (0,4), (4,0), (4,4) - one coefficient, one division at
+// most, per lane.  Same arithmetic, same order as special_block().
+__device__ __forceinline__ int rational_slim(uint32_t rowLo, uint32_t rowHi, int i, const double *cst_rat) {
+#pragma clang fp contract(off)
+    uint32_t lo = perm_b32(rowHi, rowLo, 0x04030700u); // x0 x7 x3 x4
+    uint32_t hi = perm_b32(rowHi, rowLo, 0x06050201u); // x1 x2 x5 x6
+    transpose8x8_bytes(lo, hi, i);                     // lane i: column (0,7,3,4,1,2,5,6)[i], bytes = rows 0..7
+    const uint32_t tot = __builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+    const uint32_t sa = __builtin_amdgcn_sad_u8(lo & 0xff0000ffu, 0u, __builtin_amdgcn_sad_u8(hi & 0xff0000ffu, 0u, 0u)); // rows 0,3,4,7
+    const int e0 = (int)tot - 1024, e4 = 2 * (int)sa - (int)tot;
+    double y0 = (double)e0 * (kSq2h * 0.5);
+    double y4 = (double)e4 * (kTW3 * 0.5);
+    y0 = y0 + dpp_f64<TIC_DPP_QP_XOR1>(y0); // a0+a7 | a3+a4 | a1+a2 | a5+a6
+    y4 = y4 + dpp_f64<TIC_DPP_QP_XOR1>(y4);
+    y0 = y0 + dpp_f64<TIC_DPP_QP_XOR2>(y0); // A = p07 + p34 (lanes 0..3) | B = p12 + p56 (lanes 4..7)
+    y4 = y4 + dpp_f64<TIC_DPP_QP_XOR2>(y4);
+    const double b0 = dpp_f64<TIC_DPP_ROW_SHL4>(y0), b4 = dpp_f64<TIC_DPP_ROW_SHL4>(y4); // lanes 0..3 read B
+    const double A = (i & 2) ? y4 : y0, B = (i & 2) ? b4 : b0;       // lanes 0,1: frequency row u = 0; lanes 2,3: u = 4
+    const double E = (i & 1) ? A - B : A + B;                         // v = 0 | v = 4
+    const double X = E * ((i & 1) ? (kTW3 * 0.5) : (kSq2h * 0.5));
+    const double div = cst_rat[i & 3], rdiv = cst_rat[4 + (i & 3)];
+    const double t = X * rdiv;
+    double r = rint(t);
+    // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
+    if (fabs(fabs(t - r) - 0.5) < 1e-9) r = rint(X / div);
+    return (int)r;
+}
+// A block redone by the whole wave in float64 straight from the definition (lane 8*u + c: t[u][c] = sum_r M[u][r] x[r][c], then
+// X[u][v = c] = sum_k M[v][k] t[u][k]; error ~1e-13, the reference's own is ~1e-12).  A rounding is decided when no .5 tie lies
+// within 1e-9 of X * (1/div); decided values go to their place in the block's 128-byte zig-zag image.  Returns through the
+// masks which lanes stayed undecided.  ~450 cycles for one block, against ~1,500 for the 8-blocks-at-once second level: the
+// batch of a wave seldom holds more than one such entry.
+__device__ __forceinline__ void wave_redo_block(const uint8_t *px /* 64 pixels, LDS */, double *tbuf /* 64 doubles, LDS */,
+                                                const double *cosm, const double *rdiv, const uint16_t *zzofs, int16_t *img16,
+                                                int lane, unsigned long long &und_rational, unsigned long long &und_other) {
+    const int u = lane >> 3, c = lane & 7;
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) t = fma(cosm[u * 8 + r], (double)((int)px[r * 8 + c] - 128), t);
+    tbuf[u * 8 + c] = t;
+    wave_lds_fence();
+    double X = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) X = fma(cosm[c * 8 + kk], tbuf[u * 8 + kk], X);
+    const double tq = X * rdiv[lane], rq = rint(tq);
+    const bool decided = fabs(tq - rq) < 0.5 - 1e-9;
+    if (decided) img16[zzofs[lane] >> 1] = (int16_t)(int)rq;
+    const bool rational = (lane & 0x1b) == 0; // (u,v) in {0,4} x {0,4}
+    und_rational = __ballot(!decided && rational);
+    und_other = __ballot(!decided && !rational);
+    wave_lds_fence();
+}
+
 // OPT: A/B switches of the experiment library (bit 0: fused quantiser, bit 1: tripped blocks sit out the strip's store);
 // the product is built with all of them on.
-template <int ABL, int ST = 0, int LD = 0, int OPT = 3>
+template <int ABL, int ST = 0, int LD = 0, int OPT = 15>
 __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
@@ -850,13 +914,15 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
         f32x4 m0, m1;
         f32x2 thr;
         u32x4 zzv;
-        // Constants: the workgroup copies the quality's 1152-byte block into LDS, 18 lanes of every wave one 16-byte piece
+        // Constants: the workgroup copies the quality's 2176-byte block into LDS, 34 lanes of every wave one 16-byte piece
         // each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
         // loads per wave in front of the first pixel load: four such loads more cost 0.67 us on a 4096^2 launch).
         // Every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_WAIT).
         u32x4 c_fill;
         {
-            const uint32_t piece = lane < 18 ? (uint32_t)(wave * 18 + lane) : 71u;
+            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 34 pieces of 16 bytes per wave
+            static_assert(kPpw * kWavesPerWG == kStripBlkPieces && kPpw <= 64, "constant block must split evenly over the waves");
+            const uint32_t piece = lane < kPpw ? (uint32_t)(wave * kPpw + lane) : (uint32_t)kStripBlkPieces - 1u;
             const uint32_t fo = piece * 16u;
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c_fill) : "v"(fo), "s"(C->strip_blk) : "memory");
         }
@@ -936,12 +1002,17 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
         unsigned long long p0, p1, p2;
         uint32_t ob0, ob1, ob2;
         TIC_LOAD(p0, ob0);
-        TIC_LOAD(p1, ob1);
+        if (!(OPT & 16)) TIC_LOAD(p1, ob1);
         // the constant piece is older than the pixel loads: it has landed when only those are in flight
-        asm volatile("s_waitcnt vmcnt(2)" : "+v"(c_fill) : : "memory");
-        if (lane < 18) *reinterpret_cast<u32x4 *>(cst_blk + (wave * 18 + lane) * 16) = c_fill;
+        if (OPT & 16) asm volatile("s_waitcnt vmcnt(1)" : "+v"(c_fill) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(c_fill) : : "memory");
+        if (lane < kStripBlkPieces / kWavesPerWG) *reinterpret_cast<u32x4 *>(cst_blk + (wave * (kStripBlkPieces / kWavesPerWG) + lane) * 16) = c_fill;
         // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+        // The second strip's load goes out behind the barrier: the CU's memory pipeline returns data in request order, and
+        // with both loads up front the first strip of the CU's last wave queued behind 39 others (first data 1,400 cycles
+        // after entry for the first workgroup of a CU, 5,000 for the fifth).
+        if (OPT & 16) TIC_LOAD(p1, ob1);
         m0 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32);
         m1 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32 + 16);
         thr = *reinterpret_cast<const f32x2 *>(cst_blk + 256 + i * 8);
@@ -1024,7 +1095,18 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
             if (kRare && kLdsT && kLdsZ && kMem && __builtin_expect((cA | cB) != 0ull, 0)) {
                 const unsigned long long kRat = 0x1111111111111111ull; // lanes v in {0,4}: rational coefficients at u in {0,4}
                 const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
-                const uint32_t gm = byte_any(mG), fm = gm | byte_any(mS); // blocks with an irrational trip / with any trip
+                // per block: an irrational trip / any trip.  Lane l answers for block l & 7 (byte l & 7 of the lane masks); the
+                // low byte of the ballot is the 8-bit block mask (6 vector instructions; folding the bytes on the scalar unit
+                // took ~40 dependent scalar instructions per tripped strip)
+                uint32_t gm, fm;
+                if (OPT & 8) {
+                    const uint32_t sh = 8u * (uint32_t)i;
+                    gm = (uint32_t)__ballot(((mG >> sh) & 0xffull) != 0ull) & 0xffu;
+                    fm = (uint32_t)__ballot((((mG | mS) >> sh) & 0xffull) != 0ull) & 0xffu;
+                } else {
+                    gm = byte_any(mG);
+                    fm = gm | byte_any(mS);
+                }
                 const int nnew = __builtin_popcount(fm);
                 if (nE + nnew <= kBatch && (fm != 0xffu || !(OPT & 2))) {
                     // the blocks join the batch: id + kind, pixel rows (this lane holds row lr of block lb), staged image
@@ -1103,10 +1185,58 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
 #undef TIC_LOAD
 #undef TIC_WAIT
     }
+    // ---- the batch pass ("slim" form; OPT bit 2 off: the round-2a form kept for A/B) ----------------------------------------------
+    if ((OPT & 4) && kBatchPass && nE != 0) {
+        const double *cst_cos = reinterpret_cast<const double *>(cst_blk + 1152); // orthonormal DCT-II matrix, index k*8+n
+        const double *cst_rdiv = reinterpret_cast<const double *>(cst_blk + 1664); // 1/div, index u*8+v
+        // (1) entries that tripped on an irrational coefficient: whole-wave float64 recompute, one block at a time
+        uint32_t m_rat = 0, m_exact = 0; // entries that need the rational sub-path / the exact operation order
+        for (int e = 0; e < nE; e++) {
+            const uint32_t id = bat_id[e];
+            if ((id >> 31) == 0u || ABL == 24) {
+                m_rat |= 1u << e; // a tie entry
+                continue;
+            }
+            unsigned long long ur, uo;
+            wave_redo_block(reinterpret_cast<const uint8_t *>(bat_pix + e * 8), reinterpret_cast<double *>(ldsT), cst_cos, cst_rdiv, cst_zz,
+                            reinterpret_cast<int16_t *>(bat_img + e * 8), lane, ur, uo);
+            if (ur != 0ull) m_rat |= 1u << e;
+            if (uo != 0ull) m_exact |= 1u << e;
+        }
+        // (2) 8 lanes per entry: exact order where even float64 from the definition could not decide (a true tie of an
+        // irrational coefficient - practically never), then the rational sub-path
+        const bool have = b < nE;
+        const int e = have ? b : 0;
+        const uint32_t blk = bat_id[e] & 0x7fffffffu;
+        const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
+        int16_t *img16 = reinterpret_cast<int16_t *>(bat_img + e * 8);
+        if (m_exact != 0u) {
+            uint32_t lo = rowv.x, hi = rowv.y;
+            transpose8x8_bytes(lo, hi, i); // -> pixel column i
+            const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8); // byte offsets in the image of (u = i, v = 0..7)
+            const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+            int qx[8];
+            exact_block(lo, hi, ldsT, b, i, C, qx);
+            if (have && ((m_exact >> e) & 1u)) {
+#pragma unroll
+                for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qx[v];
+            }
+            m_rat &= ~m_exact;
+        }
+        if (m_rat != 0u) {
+            const int r = rational_slim(rowv.x, rowv.y, i, cst_rat);
+            // lanes 0..3: (0,0) (0,4) (4,0) (4,4) at scan positions 0, 14, 10, 39
+            if (have && i < 4 && ((m_rat >> e) & 1u)) img16[i == 0 ? 0 : (i == 1 ? 14 : (i == 2 ? 10 : 39))] = (int16_t)r;
+        }
+        wave_lds_fence();
+        const uint4 val = bat_img[e * 8 + i];
+        if (!(OPT & 2)) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        if (have) store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)blk << 7) + (uint32_t)i * 16u, val);
+    }
     // ---- the batch pass: lane 8*b + i serves entry b ---------------------------------------------------------------------
     if (ABL == 22 && mask_exact == 0x123456789ull) a.out[lane] = 1; // (keeps the accumulated value alive)
     if (ABL == 22) mask_exact = 0;
-    if (kBatchPass && nE != 0) {
+    if (!(OPT & 4) && kBatchPass && nE != 0) {
         const bool have = b < nE;
         const int e = have ? b : 0;
         const uint32_t id = bat_id[e];
@@ -1256,8 +1386,8 @@ __global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs
     u32x4 c_fill;
     const uint32_t ppw = (uint32_t)a.q_ppw; // pieces per wave = ceil(72 / W)
     {
-        const uint32_t piece = (uint32_t)lane < ppw ? (uint32_t)wave * ppw + (uint32_t)lane : 71u;
-        const uint32_t fo = (piece < 72u ? piece : 71u) * 16u;
+        const uint32_t piece = (uint32_t)lane < ppw ? (uint32_t)wave * ppw + (uint32_t)lane : (uint32_t)kStripBlkPieces - 1u;
+        const uint32_t fo = (piece < (uint32_t)kStripBlkPieces ? piece : (uint32_t)kStripBlkPieces - 1u) * 16u;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c_fill) : "v"(fo), "s"(C->strip_blk) : "memory");
     }
     // ticket -> strip: index inside the fast rectangle, byte offset of its first pixel, raster index of its first block
@@ -1347,7 +1477,7 @@ __global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs
             }
             // the constant piece is older than the pixel loads: it has landed when only those are in flight
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(c_fill) : : "memory");
-            if ((uint32_t)lane < ppw && (uint32_t)wave * ppw + (uint32_t)lane < 72u)
+            if ((uint32_t)lane < ppw && (uint32_t)wave * ppw + (uint32_t)lane < (uint32_t)kStripBlkPieces)
                 *reinterpret_cast<u32x4 *>(cst_blk + ((uint32_t)wave * ppw + (uint32_t)lane) * 16u) = c_fill;
             // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about);
             // it also publishes the ticket counter
@@ -2165,7 +2295,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             a.q_waves = W;
             a.q_teams = G;
             a.q_run_shift = tune.q_run >= 0 ? tune.q_run : 2;
-            a.q_ppw = (72 + W - 1) / W;
+            a.q_ppw = (kStripBlkPieces + W - 1) / W;
             a.magic_fast_tx = a.fast_tx <= 1 ? 0u : (uint32_t)((1ull << 32) / (unsigned long long)a.fast_tx + 1ull);
             const size_t lds = (size_t)kQHeadBytes + (size_t)W * kQWaveBytes;
             const dim3 qgrid(G, 1, nf), qblock(W * 64);
@@ -2204,7 +2334,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             int dev = 0, per_cu = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0, 2, 0, 3>, kWavesPerWG * 64, 0) != hipSuccess ||
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0, 2, 0, 15>, kWavesPerWG * 64, 0) != hipSuccess ||
                 per_cu < 1)
                 per_cu = 4;
             return cus * per_cu;
@@ -2343,6 +2473,9 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         case 501: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 1>), grid2, block, tune.lds_pad, stream, a); break;
         case 502: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 2>), grid2, block, tune.lds_pad, stream, a); break;
         case 503: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 3>), grid2, block, tune.lds_pad, stream, a); break;
+        case 507: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 7>), grid2, block, tune.lds_pad, stream, a); break;
+        case 515: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 15>), grid2, block, tune.lds_pad, stream, a); break;
+        case 531: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 31>), grid2, block, tune.lds_pad, stream, a); break;
 #define TIC_POL(S, L)                                                                                                  \
     case 100 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<0, S, L>), grid, block, tune.lds_pad, stream, a); break; \
     case 200 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<6, S, L>), grid, block, tune.lds_pad, stream, a); break; \
@@ -2353,7 +2486,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
 #undef TIC_POL
         case 9: TIC_LAUNCH(0); break; // the round-1 kernel (plain stores)
 #endif
-        default: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 3>), grid2, block, 0, stream, a); break; // the production kernel
+        default: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 15>), grid2, block, 0, stream, a); break; // the production kernel
         }
 #undef TIC_LAUNCH
 #undef TIC_LAUNCH2

@@ -182,11 +182,12 @@ struct DctqConsts {
     uint16_t zzofsT[64]; // index v*8+u: same offsets, transposed (lane v holds u = 0..7)
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
     // Everything the strip kernel needs, packed as the image its workgroups copy into LDS with one 16-byte load per lane
-    // (72 lanes): [0,256) mulT, [256,320) thrT, [320,448) zzofsT, [448,960) mul64, [960,1088) zzofs, [1088,1152) div then rdiv
-    // of the rational coefficients (0,0) (0,4) (4,0) (4,4).
-    alignas(16) unsigned char strip_blk[1152];
+    // (136 lanes): [0,256) mulT, [256,320) thrT, [320,448) zzofsT, [448,960) mul64, [960,1088) zzofs, [1088,1152) div then rdiv
+    // of the rational coefficients (0,0) (0,4) (4,0) (4,4), [1152,1664) cosm, [1664,2176) rdiv.
+    alignas(16) unsigned char strip_blk[2176];
 };
-constexpr int kStripBlkBytes = 1152;
+constexpr int kStripBlkBytes = 2176;
+constexpr int kStripBlkPieces = kStripBlkBytes / 16;
 
 // utils.py:50-53 divisor recipe.  Returns false when quality is outside 1..99.
 inline bool build_consts(int quality, DctqConsts *c) {
@@ -253,6 +254,8 @@ inline bool build_consts(int quality, DctqConsts *c) {
             memcpy(p + 1088 + 8 * k, &c->div[rat[k]], 8);
             memcpy(p + 1120 + 8 * k, &c->rdiv[rat[k]], 8);
         }
+        memcpy(p + 1152, c->cosm, 512);
+        memcpy(p + 1664, c->rdiv, 512);
     }
     return true;
 }

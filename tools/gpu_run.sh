@@ -23,7 +23,7 @@ for step in "$@"; do
     microbench3) run microbench3 240 ./tools/bin/microbench3 ;;
     microbench4) run microbench4 300 ./tools/bin/microbench4 ;;
     parity)     run parity 600 python tools/parity_variant.py ${TIC_PARITY_VARIANTS:-50} ;;
-    ab_pol)     run ab_pol 600 python tools/ab.py --dims 4096 --rounds 5 --iters 400 --variants ${TIC_AB_VARIANTS:-2,50} "" ;;
+    ab_pol)     run ab_pol 600 python tools/ab.py --dims 4096 --rounds ${TIC_AB_ROUNDS:-5} --iters 400 --variants ${TIC_AB_VARIANTS:-2,50} "" ;;
     ab_pol16k)  run ab_pol16k 600 python tools/ab.py --dims 16384 --rounds 4 --iters 20 --variants ${TIC_AB_VARIANTS16:-2,50} "" ;;
     stamps2)    run stamps2 200 python tools/stamps2.py ;;
     stamps3)    run stamps3 200 python tools/stamps3.py ;;
@@ -35,14 +35,16 @@ for step in "$@"; do
     tests_all)  run pytest_gpu_all 900 python -m pytest tests -m gpu -q ;;
     smoke)      run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)      run bench 300 python bench.py ;;
+    bench_cold) run bench_cold 300 python bench.py --steps 50 --warmup 10 --settle-ms 1 --no-cpu-baseline --no-config4 ;;
     bench_exact) run bench_exact 300 python bench.py --variant exact --no-cpu-baseline ;;
     bench16k)   run bench16k 300 python bench.py --height 16384 --width 16384 --steps 20 --warmup 3 --no-cpu-baseline ;;
     sweep)      run sweep 600 python tools/sweep.py ;;
-    prof)       rm -rf gpurun_out/prof; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --no-cpu-baseline ;;
-    pmc_rd)     rm -rf gpurun_out/pmc_rd; run pmc_rd 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_rd -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline ;;
-    pmc_wr)     rm -rf gpurun_out/pmc_wr; run pmc_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_wr -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline ;;
-    pmc_sq)     rm -rf gpurun_out/pmc_sq; run pmc_sq 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_sq -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline ;;
-    pmc_sq2)    rm -rf gpurun_out/pmc_sq2; run pmc_sq2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc_sq2 -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline ;;
+    prof)       rm -rf gpurun_out/prof; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --no-cpu-baseline --no-cold --no-config4 ;;
+    prof_cold)  rm -rf gpurun_out/prof_cold; run prof_cold 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cold -- python bench.py --steps 50 --warmup 10 --settle-ms 1 --no-cpu-baseline --no-config4 ;;
+    pmc_rd)     rm -rf gpurun_out/pmc_rd; run pmc_rd 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_rd -- python bench.py --steps 5 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-cold --no-config4 ;;
+    pmc_wr)     rm -rf gpurun_out/pmc_wr; run pmc_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_wr -- python bench.py --steps 5 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-cold --no-config4 ;;
+    pmc_sq)     rm -rf gpurun_out/pmc_sq; run pmc_sq 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_sq -- python bench.py --steps 5 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-cold --no-config4 ;;
+    pmc_sq2)    rm -rf gpurun_out/pmc_sq2; run pmc_sq2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc_sq2 -- python bench.py --steps 5 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-cold --no-config4 ;;
     pmc_cal)    rm -rf gpurun_out/pmc_cal; run pmc_cal 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_cal -- ./tools/bin/microbench ;;
     pmc_cal_wr) rm -rf gpurun_out/pmc_cal_wr; run pmc_cal_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_cal_wr -- ./tools/bin/microbench ;;
     *) echo "unknown step $step" ;;
