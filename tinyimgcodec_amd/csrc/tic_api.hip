@@ -31,11 +31,9 @@ struct Slot {
     void *d_coef = nullptr;
     hipEvent_t done = nullptr;
     // device entropy stage of the chunk
-    uint32_t *d_nbits = nullptr; // nb_cap block counts, then nb_cap x 8 per-lane counts (bytes)
-    size_t nb_cap = 0;
-    unsigned long long *d_bitoff = nullptr;
-    void *d_tmp = nullptr;
-    size_t tmp_bytes = 0;
+    void *d_work = nullptr;  // workspace of the fused entropy pass
+    size_t work_bytes = 0;
+    int parity = 0;          // which of the two descriptor arrays / error flags the next call uses
     unsigned long long *d_lens = nullptr, *h_lens = nullptr; // stream length per frame (device / pinned host)
     int *d_err = nullptr, *h_err = nullptr;
     void *d_streams = nullptr;                                // finished streams, one compress_bound() apart
@@ -61,12 +59,12 @@ struct tic_ctx {
     std::vector<int16_t> h_coef;
     // device entropy stage workspace
     HuffDev *d_huff = nullptr;
-    uint32_t *d_nbits = nullptr;
-    unsigned long long *d_bitoff = nullptr;
-    void *d_scan_tmp = nullptr;
-    size_t ent_blocks_cap = 0, scan_tmp_cap = 0;
     int *d_err = nullptr;
-    unsigned long long *d_total_bits = nullptr; // payload size of the last device entropy stage
+    unsigned long long *d_total_bits = nullptr; // status block of the device entropy stage: payload bits [2], error flags [2] (used in turn)
+    unsigned long long *h_stat = nullptr, *d_stat = nullptr; // host-mapped status block of the device entropy stage (bits, error)
+    void *d_ent_work = nullptr;                 // workspace of the device entropy stage (tile sums, bit counts, staging slots)
+    size_t ent_work_bytes = 0;
+    int ent_parity = 0;
     void *d_stream_buf = nullptr;
     size_t d_stream_cap = 0;
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
@@ -140,9 +138,7 @@ void tic_destroy(tic_ctx *ctx) {
         if (sl.d_img) (void)hipFree(sl.d_img);
         if (sl.d_coef) (void)hipFree(sl.d_coef);
         if (sl.done) (void)hipEventDestroy(sl.done);
-        if (sl.d_nbits) (void)hipFree(sl.d_nbits);
-        if (sl.d_bitoff) (void)hipFree(sl.d_bitoff);
-        if (sl.d_tmp) (void)hipFree(sl.d_tmp);
+        if (sl.d_work) (void)hipFree(sl.d_work);
         if (sl.d_lens) (void)hipFree(sl.d_lens);
         if (sl.h_lens) (void)hipHostFree(sl.h_lens);
         if (sl.d_err) (void)hipFree(sl.d_err);
@@ -156,10 +152,9 @@ void tic_destroy(tic_ctx *ctx) {
     if (ctx->d_consts) (void)hipFree(ctx->d_consts);
     if (ctx->d_fallback) (void)hipFree(ctx->d_fallback);
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
-    if (ctx->d_nbits) (void)hipFree(ctx->d_nbits);
-    if (ctx->d_bitoff) (void)hipFree(ctx->d_bitoff);
-    if (ctx->d_scan_tmp) (void)hipFree(ctx->d_scan_tmp);
     if (ctx->d_total_bits) (void)hipFree(ctx->d_total_bits); // d_err lives in the same block
+    if (ctx->d_ent_work) (void)hipFree(ctx->d_ent_work);
+    if (ctx->h_stat) (void)hipHostFree(ctx->h_stat);
     if (ctx->d_stream_buf) (void)hipFree(ctx->d_stream_buf);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -198,9 +193,13 @@ static int create_impl(tic_ctx *ctx, int device) {
         build_huff_dev(&hd);
         CK(hipMalloc((void **)&ctx->d_huff, sizeof(HuffDev)));
         CK(hipMemcpy(ctx->d_huff, &hd, sizeof(HuffDev), hipMemcpyHostToDevice));
-        // one 16-byte status block: payload bits of the last device entropy stage, then its error flag
-        CK(hipMalloc((void **)&ctx->d_total_bits, 16));
-        ctx->d_err = reinterpret_cast<int *>(ctx->d_total_bits + 1);
+        // one 32-byte status block: payload bits [2] of the device entropy stage, then its error flags [2]
+        CK(hipMalloc((void **)&ctx->d_total_bits, 32));
+        CK(hipMemset(ctx->d_total_bits, 0, 32));
+        ctx->d_err = reinterpret_cast<int *>(ctx->d_total_bits + 2);
+        // the stage's last kernel writes {payload bits, error} straight into pinned host memory: no copy behind it
+        CK(hipHostMalloc((void **)&ctx->h_stat, 64, hipHostMallocMapped));
+        CK(hipHostGetDevicePointer((void **)&ctx->d_stat, ctx->h_stat, 0));
     }
     CK(hipMalloc((void **)&ctx->d_fallback, sizeof(unsigned long long)));
     CK(hipMemset(ctx->d_fallback, 0, sizeof(unsigned long long)));
@@ -564,40 +563,24 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
         return TIC_OK;
     }
     if (!d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "null coefficient pointer");
-    if (n + 1 > ctx->ent_blocks_cap) {
-        if (ctx->d_nbits) HIPCHK(ctx, hipFree(ctx->d_nbits));
-        if (ctx->d_bitoff) HIPCHK(ctx, hipFree(ctx->d_bitoff));
-        ctx->d_nbits = nullptr;
-        ctx->d_bitoff = nullptr;
-        ctx->ent_blocks_cap = 0;
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_nbits, (n + 1) * sizeof(uint32_t) + n * 8)); // + bits per lane (8 per block)
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_bitoff, (n + 1) * sizeof(unsigned long long)));
-        ctx->ent_blocks_cap = n + 1;
+    const size_t wb = entropy_fused_work_bytes(n);
+    if (wb > ctx->ent_work_bytes) {
+        if (ctx->d_ent_work) HIPCHK(ctx, hipFree(ctx->d_ent_work));
+        ctx->d_ent_work = nullptr;
+        ctx->ent_work_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_ent_work, wb));
+                ctx->ent_work_bytes = wb;
     }
-    const size_t tmp = entropy_gpu_scan_temp_bytes(n + 1);
-    if (tmp > ctx->scan_tmp_cap) {
-        if (ctx->d_scan_tmp) HIPCHK(ctx, hipFree(ctx->d_scan_tmp));
-        ctx->d_scan_tmp = nullptr;
-        ctx->scan_tmp_cap = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_scan_tmp, tmp ? tmp : 16));
-        ctx->scan_tmp_cap = tmp;
-    }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_total_bits, 0, 16, ctx->stream)); // status block: size and error flag
-    // step 1+2: bits per block, exclusive scan
-    uint8_t *d_lanebits = reinterpret_cast<uint8_t *>(ctx->d_nbits + (n + 1));
-    HIPCHK(ctx, entropy_gpu_count((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_nbits, d_lanebits, ctx->d_bitoff,
-                                  ctx->d_scan_tmp, tmp, ctx->d_err, ctx->stream));
-    // step 3: pack, without a host round trip in between: a small kernel publishes the payload size and zeroes exactly
-    // those words (shared words are OR-ed into zeros; the zero fill also is the stream's final padding), the emit kernel
-    // refuses to write past the caller's buffer
+    // three launches, no host round trip and no copy: pack (one walk over the symbols), tile sums, place; the placing kernel
+    // writes the header and puts {payload bits, error} into the host-mapped status block; nothing is written past the
+    // caller's buffer
     const size_t cap_words = ((cap - 16) / 16) * 4; // whole 16-byte units behind the header
-    HIPCHK(ctx, entropy_gpu_zero_payload(ctx->d_nbits, ctx->d_bitoff, n, (uint32_t *)((char *)d_out + 16), cap_words,
-                                         ctx->d_total_bits, ctx->d_err, h, w, quality, ctx->stream));
-    HIPCHK(ctx, entropy_gpu_emit((const int16_t *)d_coeffs_zz, n, n, ctx->d_huff, ctx->d_bitoff, d_lanebits,
-                                 (uint32_t *)((char *)d_out + 16), 0, cap_words, ctx->d_err, ctx->stream));
-    unsigned long long status[2] = {0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_total_bits, 16, hipMemcpyDeviceToHost, ctx->stream));
+    const int par = ctx->ent_parity;
+    ctx->ent_parity ^= 1;
+    HIPCHK(ctx, entropy_gpu_fused((const int16_t *)d_coeffs_zz, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, par, d_out, 0,
+                                  cap_words, h, w, quality, nullptr, ctx->d_stat, ctx->d_err + par, ctx->d_err + (par ^ 1), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long status[2] = {((volatile unsigned long long *)ctx->h_stat)[0], ((volatile unsigned long long *)ctx->h_stat)[1]};
     const unsigned long long total_bits = status[0];
     const int err = (int)(status[1] & 0xffffffffull);
     if (err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
@@ -704,9 +687,7 @@ static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
             if (sl.d_img) (void)hipFree(sl.d_img);
             if (sl.d_coef) (void)hipFree(sl.d_coef);
             if (sl.done) (void)hipEventDestroy(sl.done);
-            if (sl.d_nbits) (void)hipFree(sl.d_nbits);
-            if (sl.d_bitoff) (void)hipFree(sl.d_bitoff);
-            if (sl.d_tmp) (void)hipFree(sl.d_tmp);
+            if (sl.d_work) (void)hipFree(sl.d_work);
             if (sl.d_lens) (void)hipFree(sl.d_lens);
             if (sl.h_lens) (void)hipHostFree(sl.h_lens);
             if (sl.d_err) (void)hipFree(sl.d_err);
@@ -724,15 +705,12 @@ static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
                 (e = hipMalloc(&sl.d_img, need_img)) != hipSuccess || (e = hipMalloc(&sl.d_coef, need_coef)) != hipSuccess ||
                 (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
                 return set_err(ctx, TIC_E_HIP, "batch buffer allocation failed: %s", hipGetErrorString(e));
-            const size_t nb = nblk * (size_t)chunk;
-            sl.nb_cap = nb;
-            sl.tmp_bytes = entropy_gpu_scan_temp_bytes(nb);
-            if ((e = hipMalloc((void **)&sl.d_nbits, nb * sizeof(uint32_t) + nb * 8)) != hipSuccess || // + bits per lane
-                (e = hipMalloc((void **)&sl.d_bitoff, nb * sizeof(unsigned long long))) != hipSuccess ||
-                (e = hipMalloc(&sl.d_tmp, sl.tmp_bytes ? sl.tmp_bytes : 16)) != hipSuccess ||
+            sl.work_bytes = entropy_fused_work_bytes((nblk + 8) * (size_t)chunk); // (every frame's partitions are rounded up)
+            sl.parity = 0;
+            if ((e = hipMalloc(&sl.d_work, sl.work_bytes)) != hipSuccess ||
                 (e = hipMalloc((void **)&sl.d_lens, chunk * sizeof(unsigned long long))) != hipSuccess ||
                 (e = hipHostMalloc((void **)&sl.h_lens, chunk * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&sl.d_err, sizeof(int))) != hipSuccess ||
+                (e = hipMalloc((void **)&sl.d_err, 2 * sizeof(int))) != hipSuccess || (e = hipMemset(sl.d_err, 0, 2 * sizeof(int))) != hipSuccess ||
                 (e = hipHostMalloc((void **)&sl.h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
                 (e = hipMalloc(&sl.d_streams, align_up(compress_bound(h, w), 16) * (size_t)chunk)) != hipSuccess)
                 return set_err(ctx, TIC_E_HIP, "batch entropy workspace allocation failed: %s", hipGetErrorString(e));
@@ -895,6 +873,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         if (s.count == 0) return TIC_OK;
         if (hipEventSynchronize(s.done) != hipSuccess) return set_err(ctx, TIC_E_HIP, "batch chunk failed");
         if (*s.h_err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
+        if (*s.h_err == 3) return set_err(ctx, TIC_E_HIP, "device entropy stage: look-back gave up (internal error)");
         if (*s.h_err) return set_err(ctx, TIC_E_SPACE, "device entropy stage: stream buffer too small");
         // The streams come back packed into the slot's pinned buffer (asynchronous DMA; a copy straight into the caller's
         // pageable buffers is staged by the runtime, ~0.15 ms each) and are handed out by a few threads.
@@ -952,7 +931,6 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         s.first = first;
         s.count = cnt;
         stage_chunk(s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w); // into pinned memory
-        const size_t nb = nblk * (size_t)cnt;
         hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
@@ -962,18 +940,13 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
             a.frame_stride_out = (long)coef_bytes;
             e = launch_dctq(a, 2, st);
         }
-        if (e == hipSuccess) e = hipMemsetAsync(s.d_err, 0, sizeof(int), st);
-        if (e == hipSuccess)
-            e = entropy_gpu_count((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_nbits, (uint8_t *)(s.d_nbits + s.nb_cap),
-                                  s.d_bitoff, s.d_tmp, s.tmp_bytes, s.d_err, st);
-        if (e == hipSuccess) e = hipMemsetAsync(s.d_streams, 0, bound * cnt, st); // shared words are OR-ed into zeros
-        if (e == hipSuccess)
-            e = entropy_gpu_finish_frames(s.d_nbits, s.d_bitoff, nblk, cnt, h, w, quality, s.d_streams, bound, s.d_lens, st);
-        if (e == hipSuccess)
-            e = entropy_gpu_emit((const int16_t *)s.d_coef, nb, nblk, ctx->d_huff, s.d_bitoff, (const uint8_t *)(s.d_nbits + s.nb_cap),
-                                 (uint32_t *)((char *)s.d_streams + 16), bound, (bound - 16) / 4, s.d_err, st);
+        const int par = s.parity;
+        s.parity ^= 1;
+        if (e == hipSuccess) // entropy stage of the whole chunk: one pass + a finishing kernel (headers, lengths); no zero fill
+            e = entropy_gpu_fused((const int16_t *)s.d_coef, nblk, cnt, ctx->d_huff, s.d_work, s.work_bytes, par, s.d_streams, bound,
+                                  (bound - 16) / 4, h, w, quality, s.d_lens, nullptr, s.d_err + par, s.d_err + (par ^ 1), st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_lens, s.d_lens, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err + par, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(s.done, st);
         if (e != hipSuccess) {
             result = set_err(ctx, TIC_E_HIP, "batch enqueue failed at frame %d: %s", first, hipGetErrorString(e));

@@ -37,4 +37,17 @@ hipError_t entropy_gpu_finish_frames(const uint32_t *d_nbits, const unsigned lon
                                      int nframes, int h, int w, int quality, void *d_out, size_t out_frame_stride,
                                      unsigned long long *d_lens, hipStream_t stream);
 
+// Round 2: the whole stage in one pass + a finishing kernel (tic_entropy_gpu.hip).  d_work: entropy_fused_work_bytes() bytes,
+// zeroed once when allocated; `parity` must alternate between consecutive calls on the same workspace (the finishing kernel
+// re-arms the descriptor array the next call uses).  Frame f's stream (16-byte header + payload) starts at d_out +
+// f * out_frame_stride and may hold cap_words payload words; d_lens[f] (may be null) receives its length in bytes;
+// d_status[0] (may be null) the payload bits of frame 0.  *d_err: 1 = a coefficient without a Huffman code, 2 = a stream does
+// not fit, 3 = internal (look-back gave up); it must be zero on entry, and the finishing kernel zeroes *d_err_next (the flag of the
+// next call: two flags used in turn need no memset between calls).  The stream area need not be zeroed.
+size_t entropy_fused_work_bytes(size_t nblocks_total);
+hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int nframes, const HuffDev *d_tab, void *d_work,
+                             size_t work_bytes, int parity, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w,
+                             int quality, unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next,
+                             hipStream_t stream);
+
 } // namespace tic

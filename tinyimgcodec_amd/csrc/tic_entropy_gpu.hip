@@ -328,11 +328,354 @@ __global__ __launch_bounds__(256) void entropy_emit_kernel(const int16_t *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 2: the entropy stage as pack -> offsets -> place: one walk over the symbols, no zero fill, no atomics on the stream.
+//
+// Round 1 ran five launches per frame - count (walks the symbols), a rocPRIM scan (two kernels), a zero fill, emit (walks
+// the symbols again, ORs into the zeroed stream) - 109-129 us for a 4096^2 frame against a 10 us transform.  Now:
+//   entropy_pack_kernel     a wave walks the symbols of its 8 blocks ONCE, every lane packing its bits into a private string
+//                           in LDS (at most 245 bits) and counting them; a prefix over the lanes places the strings in the
+//                           wave's LDS image of its bit range, which leaves as coalesced words into the wave's slot of a
+//                           staging buffer - every partition starts at bit 0 of its own slot, nothing is shared - and the
+//                           bit count goes to nbits[partition].
+//   entropy_offsets_kernel  one workgroup per frame: exclusive scan of the partitions' bit counts (bit offsets in the
+//                           frame's stream), header, length, capacity check.
+//   entropy_place_kernel    a workgroup per 16 partitions: every OUTPUT word is assembled from the one to three
+//                           partitions that meet in it (funnel shifts of staged words) and written once, complete.
+// Explored and dropped: a single-pass version with a decoupled look-back over the waves (byte-exact, 127 us: 5,120 resident
+// 8-block partitions start together and each sums up to 5,000 predecessor descriptors, 64 per memory round trip), and
+// group sums by device-scope atomics from the packing waves (pack 68 us: 64 same-address atomics from 8 XCDs per group).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kLaneWords = 8;                    // a lane emits at most 3 ZRL + 8 x 26 + EOB = 245 bits
+constexpr int kStageWords = kWaveImageWords + 2; // staging slot of a partition (8 blocks), 32-bit words
+constexpr int kGroup = 16;                       // partitions per workgroup of the placing kernel
+
+// Bit sink into the lane's private string (bit 0 = MSB of word 0): plain LDS stores, nothing shared.
+struct LaneSink {
+    uint32_t *str; // word i of the lane's string is str[i * 64]: the 64 lanes of a wave hit 64 different LDS banks
+    uint32_t pos;  // bits so far
+    uint32_t cur;  // word under construction (MSB = first bit)
+    __device__ __forceinline__ void put(uint32_t v, int n) { // 1 <= n <= 27, v < 2^n
+        const int sh = (int)(pos & 31u), avail = 32 - sh;
+        if (n < avail) {
+            cur |= v << (avail - n);
+            pos += n;
+        } else {
+            const int rest = n - avail;
+            cur |= v >> rest;
+            str[(pos >> 5) * 64u] = cur;
+            pos += n;
+            cur = rest ? (v << (32 - rest)) : 0u;
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if (pos & 31u) str[(pos >> 5) * 64u] = cur;
+    }
+};
+
+template <int ABL> // ABL != 0: timing-only builds (tools/), wrong output
+__global__ __launch_bounds__(256) void entropy_pack_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
+                                                           unsigned long long blocks_per_frame, int nframes,
+                                                           unsigned long long parts_per_frame, uint32_t *__restrict__ stage,
+                                                           uint32_t *__restrict__ nbits, int *__restrict__ err_flag) {
+    __shared__ uint32_t ac_tab[256];
+    __shared__ uint32_t dc_tab[16];
+    __shared__ uint32_t image_all[4][kStageWords];
+    __shared__ uint32_t str_all[4][64 * kLaneWords];
+    ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
+    if (threadIdx.x < 16) dc_tab[threadIdx.x] = tab->dc[threadIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *image = image_all[wave];
+    uint32_t *str = str_all[wave] + lane;
+#pragma unroll
+    for (int i = 0; i < (kStageWords + 63) / 64; i++)
+        if (i * 64 + lane < kStageWords) image[i * 64 + lane] = 0u;
+    __syncthreads();
+    const unsigned long long part = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)wave; // partition = 8 blocks
+    const unsigned long long frame = part / parts_per_frame, pif = part - frame * parts_per_frame;
+    if (frame >= (unsigned long long)nframes) return;
+    const unsigned long long first_in_frame = pif * 8ull;
+    const unsigned long long bif = first_in_frame + (unsigned long long)(lane >> 3); // block index inside the frame
+    const int k = lane & 7;
+    const bool valid = bif < blocks_per_frame;
+    const unsigned long long frame_first = frame * blocks_per_frame;
+    const unsigned long long blk = frame_first + (valid ? bif : blocks_per_frame - 1);
+    int16_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int dc_diff = 0;
+    if (valid) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(zz + blk * 64 + k * 8);
+        c[0] = (int16_t)(v.x & 0xffff); c[1] = (int16_t)(v.x >> 16); c[2] = (int16_t)(v.y & 0xffff); c[3] = (int16_t)(v.y >> 16);
+        c[4] = (int16_t)(v.z & 0xffff); c[5] = (int16_t)(v.z >> 16); c[6] = (int16_t)(v.w & 0xffff); c[7] = (int16_t)(v.w >> 16);
+    }
+    {
+        // codec.py:34-35: DPCM over the blocks of one frame in raster order, the first block raw.  The previous block's DC
+        // sits in lane - 8 of this wave, except for the wave's first block (one 2-byte load per wave).
+        const int prev_in_wave = __shfl_up((int)c[0], 8, 64);
+        if (k == 0 && valid) {
+            int prev = prev_in_wave;
+            if (lane == 0) prev = bif ? (int)zz[(blk - 1) * 64] : 0;
+            dc_diff = bif ? (int)c[0] - prev : (int)c[0];
+        }
+    }
+    int nz_mask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) nz_mask |= (c[j] != 0 && !(k == 0 && j == 0)) ? (1 << j) : 0;
+    const int cnt = (k == 0) ? 7 : 8;
+    int az = nz_mask == 0;
+    int tz = az ? cnt : (__clz(nz_mask) - 24);
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const int pa = __shfl_up(az, d, 8), pt = __shfl_up(tz, d, 8);
+        if (k >= d) {
+            tz = az ? pt + tz : tz;
+            az = az & pa;
+        }
+    }
+    int carry = __shfl_up(tz, 1, 8);
+    if (k == 0) carry = 0;
+    // ---- the one walk: symbols -> the lane's private bit string ---------------------------------------------------------
+    uint32_t my_bits = 0;
+    if (valid) {
+        LaneSink sink;
+        sink.str = str;
+        sink.pos = 0u;
+        sink.cur = 0u;
+        int err = 0;
+        if (ABL & 4) {
+            my_bits = (uint32_t)walk_lane<false>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
+        } else {
+            walk_lane<true>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
+            sink.finish();
+            my_bits = sink.pos;
+        }
+        if (err) atomicMax(err_flag, 1);
+    }
+    // prefix of the lanes' bit counts over the wave (lanes are in stream order: block, then scan position)
+    uint32_t incl = my_bits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t pv = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += pv;
+    }
+    const uint32_t wave_bits = (uint32_t)__shfl((int)incl, 63, 64);
+    // ---- lane strings -> the wave's image (bit 0 of the partition = MSB of word 0) ---------------------------------------
+    if (!(ABL & 2)) {
+        const uint32_t lane_pos = incl - my_bits;
+        const uint32_t w0 = lane_pos >> 5, sh = lane_pos & 31u;
+        const int nw = (int)((my_bits + 31u) >> 5);
+        for (int w = 0; w < nw; w++) {
+            const uint32_t v = str[w * 64];
+            atomicOr(image + w0 + w, v >> sh);
+            if (sh) atomicOr(image + w0 + w + 1, v << (32u - sh));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t nwords = (wave_bits + 31u) >> 5;
+    uint32_t *slot = stage + part * (unsigned long long)kStageWords;
+    if (!(ABL & 1))
+        for (uint32_t i = (uint32_t)lane; i < nwords; i += 64u) slot[i] = image[i];
+    if (lane == 0) nbits[part] = wave_bits;
+}
+
+constexpr int kTile = 1024; // partitions per tile sum (a multiple of kGroup)
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (unsigned long long)__shfl_xor((long long)v, d, 64);
+    return v;
+}
+
+// Bits per tile of kTile partitions: the coarse level of the offsets (the placing kernel finishes them).
+__global__ __launch_bounds__(256) void entropy_tilesum_kernel(const uint32_t *__restrict__ nbits, unsigned long long parts_per_frame,
+                                                              unsigned long long tiles_per_frame, unsigned long long *__restrict__ tile_sum) {
+    __shared__ unsigned long long ws[4];
+    const unsigned long long frame = blockIdx.x / tiles_per_frame, tile = blockIdx.x - frame * tiles_per_frame;
+    const uint32_t *fn = nbits + frame * parts_per_frame;
+    const unsigned long long p = tile * (unsigned long long)kTile + threadIdx.x;
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int r = 0; r < kTile / 256; r++)
+        if (p + 256ull * r < parts_per_frame) sum += fn[p + 256ull * r];
+    sum = wave_sum_u64(sum);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// Places kGroup partitions in the frame's stream.  One workgroup per (frame, group); it owns the output words whose first
+// bit lies in its partitions' bit range and assembles each from the partitions that meet in it.
+__global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__restrict__ stage, const uint32_t *__restrict__ nbits,
+                                                            const unsigned long long *__restrict__ tile_sum,
+                                                            unsigned long long parts_per_frame, unsigned long long groups_per_frame,
+                                                            unsigned long long tiles_per_frame, int nframes, unsigned char *__restrict__ out,
+                                                            unsigned long long out_frame_stride, unsigned long long cap_words, int h, int w,
+                                                            int quality, unsigned long long *__restrict__ lens, int *__restrict__ err_flag,
+                                                            int *__restrict__ err_next, unsigned long long *__restrict__ status) {
+    __shared__ unsigned long long off[kGroup + 6]; // off[i] = first bit of partition p0 - 2 + i (empty outside the frame)
+    __shared__ unsigned long long ws[2][4];
+    const unsigned long long gid = blockIdx.x;
+    const unsigned long long frame = gid / groups_per_frame, g = gid - frame * groups_per_frame;
+    if (frame >= (unsigned long long)nframes) return;
+    const long long p0 = (long long)(g * (unsigned long long)kGroup);
+    const uint32_t *fn = nbits + frame * parts_per_frame;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {   // first bit of partition p0: the tiles before its tile + the partitions of its tile before it
+        const unsigned long long tile = (unsigned long long)p0 / (unsigned long long)kTile;
+        const unsigned long long *fts = tile_sum + frame * tiles_per_frame;
+        unsigned long long before = 0, total = 0;
+        for (unsigned long long j = threadIdx.x; j < tiles_per_frame; j += 256ull) {
+            const unsigned long long v = fts[j];
+            total += v;
+            if (j < tile) before += v;
+        }
+#pragma unroll
+        for (int r = 0; r < kTile / 256; r++) {
+            const unsigned long long p = tile * (unsigned long long)kTile + threadIdx.x + 256ull * r;
+            if (p < (unsigned long long)p0) before += fn[p];
+        }
+        before = wave_sum_u64(before);
+        total = wave_sum_u64(total);
+        if (lane == 0) {
+            ws[0][wave] = before;
+            ws[1][wave] = total;
+        }
+    }
+    __syncthreads();
+    const unsigned long long frame_bits = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+    if (wave == 0) {
+        const unsigned long long base = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
+        const long long p = p0 - 2 + (long long)lane;
+        const unsigned long long nb = (lane < kGroup + 5 && p >= 0 && p < (long long)parts_per_frame) ? (unsigned long long)fn[p] : 0ull;
+        unsigned long long incl = nb;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const unsigned long long pv = (unsigned long long)__shfl_up((long long)incl, d, 64);
+            if (lane >= d) incl += pv;
+        }
+        const unsigned long long nb0 = (unsigned long long)__shfl((long long)nb, 0, 64), nb1 = (unsigned long long)__shfl((long long)nb, 1, 64);
+        const unsigned long long off0 = base - nb0 - nb1;
+        if (lane < kGroup + 5) off[lane] = off0 + incl - nb;
+        if (lane == kGroup + 4) off[kGroup + 5] = off0 + incl;
+    }
+    __syncthreads();
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + frame * out_frame_stride + 16);
+    const unsigned long long lo_bit = off[2], hi_bit = off[2 + kGroup]; // the group's bit range
+    // the group owns the words whose first bit lies in its range
+    const unsigned long long w_lo = (lo_bit + 31ull) >> 5, w_hi = (hi_bit + 31ull) >> 5; // [w_lo, w_hi)
+    const uint32_t *fstage = stage + frame * parts_per_frame * (unsigned long long)kStageWords;
+    for (unsigned long long wd = w_lo + threadIdx.x; wd < w_hi; wd += 256ull) {
+        const unsigned long long b0 = wd << 5;
+        // partition holding bit b0: the last i with off[i] <= b0 (i in 2 .. kGroup+1)
+        int i = 2, n = kGroup;
+        while (n > 1) {
+            const int half = n >> 1;
+            if (off[i + half] <= b0) { i += half; n -= half; } else n = half;
+        }
+        uint32_t word = 0u;
+        int filled = 0;
+        while (filled < 32 && i < kGroup + 5) {
+            const unsigned long long pbeg = off[i], pend = off[i + 1];
+            const unsigned long long pos = b0 + (unsigned long long)filled;
+            if (pend > pos) {
+                const uint32_t lb = (uint32_t)(pos - pbeg);
+                const unsigned long long room = pend - pos;
+                const int take = room < (unsigned long long)(32 - filled) ? (int)room : 32 - filled;
+                const uint32_t *sp = fstage + (unsigned long long)(p0 - 2 + i) * (unsigned long long)kStageWords;
+                const uint32_t w0 = lb >> 5, sh = lb & 31u;
+                uint32_t v = sp[w0] << sh;
+                if (sh && (int)(32u - sh) < take) v |= sp[w0 + 1] >> (32u - sh);
+                v = take == 32 ? v : (v >> (32 - take)) << (32 - take); // keep the top `take` bits
+                word |= v >> filled;
+                filled += take;
+            }
+            i++;
+        }
+        if (wd < cap_words) dst[wd] = __builtin_bswap32(word); // the stream is MSB-first bytes
+    }
+    if (g == 0 && threadIdx.x == 0) { // make_header (codec.py:102-114), the frame's length, the caller's status
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(out + frame * out_frame_stride);
+        hdr[0] = (uint32_t)h; // struct.pack("III") little-endian == native order here
+        hdr[1] = (uint32_t)w;
+        hdr[2] = (uint32_t)quality;
+        hdr[3] = 0u;
+        if (lens) lens[frame] = 16ull + (frame_bits + 7ull) / 8ull;
+        const bool over = ((frame_bits + 31ull) >> 5) > cap_words;
+        if (over) atomicMax(err_flag, 2);
+        if (frame == 0ull) {
+            *err_next = 0; // the flag the NEXT call uses (two flags in turn: no memset between calls)
+            if (status) { // single-frame calls: total and error straight into the caller's (host-mapped) status block
+                status[0] = frame_bits;
+                const int e = *err_flag; // set by the packing kernel, complete before this launch
+                status[1] = (unsigned long long)(over ? (e > 2 ? e : 2) : e);
+            }
+        }
+    }
+}
+
 struct U32ToU64 {
     __host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
 };
 
 } // namespace
+
+// Workspace layout: [tile sums u64 x cap | bits per partition u32 x cap | staging slots x cap]; both functions below derive
+// cap from the same formula, so a workspace sized by the first always passes the check of the second.  (A batch never has
+// more tiles than partitions.)
+static constexpr size_t kPerPart = 8 + 4 + (size_t)kStageWords * 4;
+
+size_t entropy_fused_work_bytes(size_t nblocks_total) {
+    const size_t npart = (nblocks_total + 7) / 8 + 8;
+    return npart * kPerPart + 256;
+}
+
+hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int nframes, const HuffDev *d_tab, void *d_work,
+                             size_t work_bytes, int parity, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w,
+                             int quality, unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next,
+                             hipStream_t stream) {
+    (void)parity;
+    if (blocks_per_frame == 0 || nframes <= 0) return hipSuccess;
+    const size_t parts_per_frame = (blocks_per_frame + 7) / 8;
+    const size_t groups_per_frame = (parts_per_frame + kGroup - 1) / kGroup;
+    const size_t npart = parts_per_frame * (size_t)nframes, ngroup = groups_per_frame * (size_t)nframes;
+    if (work_bytes < 256 + kPerPart) return hipErrorInvalidValue;
+    const size_t cap_parts = (work_bytes - 256) / kPerPart;
+    const size_t tiles_per_frame = (parts_per_frame + kTile - 1) / kTile, ntiles = tiles_per_frame * (size_t)nframes;
+    if (npart > cap_parts || ntiles > cap_parts || ngroup > 0x7fffffffull || (npart + 3) / 4 > 0x7fffffffull) return hipErrorInvalidValue;
+    unsigned long long *tile_sum = (unsigned long long *)d_work;
+    uint32_t *nbits = (uint32_t *)(tile_sum + cap_parts);
+    uint32_t *stage = nbits + cap_parts;
+    const dim3 pack_grid((unsigned)((npart + 3) / 4));
+#ifdef TIC_ABLATION
+    static const int abl = getenv("TIC_ENT_ABL") ? atoi(getenv("TIC_ENT_ABL")) : 0;
+#define TIC_PACK(A)                                                                                                                    \
+    hipLaunchKernelGGL(entropy_pack_kernel<A>, pack_grid, dim3(256), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, nframes, \
+                       (unsigned long long)parts_per_frame, stage, nbits, d_err)
+    switch (abl) {
+    case 1: TIC_PACK(1); break;
+    case 2: TIC_PACK(2); break;
+    case 3: TIC_PACK(3); break;
+    case 4: TIC_PACK(4); break;
+    case 7: TIC_PACK(7); break;
+    default: TIC_PACK(0); break;
+    }
+#undef TIC_PACK
+#else
+    hipLaunchKernelGGL(entropy_pack_kernel<0>, pack_grid, dim3(256), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, nframes,
+                       (unsigned long long)parts_per_frame, stage, nbits, d_err);
+#endif
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(entropy_tilesum_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, nbits, (unsigned long long)parts_per_frame,
+                       (unsigned long long)tiles_per_frame, tile_sum);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(entropy_place_kernel, dim3((unsigned)ngroup), dim3(256), 0, stream, stage, nbits, tile_sum,
+                       (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, (unsigned long long)tiles_per_frame, nframes,
+                       (unsigned char *)d_out, (unsigned long long)out_frame_stride, (unsigned long long)cap_words, h, w, quality, d_lens, d_err,
+                       d_err_next, d_status);
+    return hipGetLastError();
+}
 
 size_t entropy_gpu_scan_temp_bytes(size_t nblocks) {
     size_t bytes = 0;

@@ -308,8 +308,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
 constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
 constexpr int kMaxStripsPerWave = 16;             // strips per wave are capped so that the trip list cannot overflow
+#ifdef TIC_ABLATION
 constexpr int kListEntries = 8 * kMaxStripsPerWave; // one entry per block in the worst case (512 B per wave)
 constexpr int kStash = 8;                          // pixels of the first 8 entries of each kind are kept in LDS (1 KiB)
+#endif
 
 // Quantiser of the fast path.  t = z*mul; adding kMagic rounds t to an integer (half-even) whose two's complement
 // sits in the low mantissa bits (no v_rndne / v_cvt); d = t - rint(t) feeds the guard-band test.

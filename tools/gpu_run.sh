@@ -25,6 +25,9 @@ for step in "$@"; do
     parity)     run parity 600 python tools/parity_variant.py ${TIC_PARITY_VARIANTS:-50} ;;
     ab_pol)     run ab_pol 600 python tools/ab.py --dims 4096 --rounds ${TIC_AB_ROUNDS:-5} --iters 400 --variants ${TIC_AB_VARIANTS:-2,50} "" ;;
     ab_pol16k)  run ab_pol16k 600 python tools/ab.py --dims 16384 --rounds 4 --iters 20 --variants ${TIC_AB_VARIANTS16:-2,50} "" ;;
+    compress_dev) run compress_dev 200 python tools/prof_compress_dev.py 4096 200 ;;
+    prof_cdev)  rm -rf gpurun_out/prof_cdev; run prof_cdev 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cdev -- python tools/prof_compress_dev.py 4096 200 ;;
+    ent_abl)    for a in ${TIC_ENT_ABLS:-0 1 2 3 4 7}; do rm -rf gpurun_out/ent_abl$a; export TIC_USE_ABLATE=1 TIC_ENT_ABL=$a; run ent_abl$a 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ent_abl$a -- python tools/prof_compress_dev.py 4096 100; unset TIC_USE_ABLATE TIC_ENT_ABL; done ;;
     stamps2)    run stamps2 200 python tools/stamps2.py ;;
     stamps3)    run stamps3 200 python tools/stamps3.py ;;
     ablate)     run ablate 300 python tools/ablate.py ;;

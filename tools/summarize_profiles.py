@@ -69,7 +69,7 @@ if rd and wr:
     json.dump({"hbm_bytes_per_launch": rb + wb, "source": f"profiles/{tag}_pmc_traffic.json"},
               open(os.path.join(P, "traffic_latest.json"), "w"))
 json.dump(out, open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-for name in ("microbench.txt", "sweep.txt", "bench.txt", "bench_cold.txt"):
+for name in ("bench.txt", "bench_cold.txt"):
     src = os.path.join(G, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
