@@ -465,6 +465,34 @@ def test_compress_dev_resident(ctx, manifest):
     assert n.value == m["bytes"] and sha(out.tobytes()) == m["sha256"]
 
 
+def test_device_entropy_two_level_offsets(ctx, monkeypatch):
+    """Frames of very many partitions take their stream offsets through tile sums (a third small launch); the switch is moved
+    down here so that a 2048x3000 frame (750 groups, 3 tiles) walks that path.  Quality 90 makes the partitions long
+    enough that the placing kernel reads the staging slots directly instead of through LDS.  Checked against the host
+    entropy coder."""
+    L = N.load()
+    img = rand_frame(77, 2048, 3000)
+    cap = L.tic_compress_bound(2048, 3000)
+    d_img, d_out = C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, cap, C.byref(d_out)))
+    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
+    for q in (50, 90):
+        want = T.entropy_encode(T.dctq(img, q), 2048, 3000, q)
+        for direct in ("3", None):
+            if direct is None:
+                monkeypatch.delenv("TIC_ENT_DIRECT_GROUPS", raising=False)
+            else:
+                monkeypatch.setenv("TIC_ENT_DIRECT_GROUPS", direct)
+            n = C.c_size_t()
+            ctx.check(L.tic_compress_dev(ctx.handle, d_img, 2048, 3000, 3000, q, d_out, cap, C.byref(n)))
+            out = np.empty(n.value, np.uint8)
+            ctx.check(L.tic_memcpy_d2h(ctx.handle, out.ctypes.data, d_out, n.value))
+            assert out.tobytes() == want, (q, direct)
+    L.tic_dev_free(ctx.handle, d_img)
+    L.tic_dev_free(ctx.handle, d_out)
+
+
 def test_error_paths(ctx):
     L = N.load()
     img = rand_frame(1, 16, 16)

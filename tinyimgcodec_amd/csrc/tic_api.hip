@@ -2,6 +2,7 @@
 // launches of the transform kernels on the context's own HIP stream, the stream-overlapped batch pipeline, and
 // the glue to the host entropy stage.  No CPU fallback exists for the transform stage.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <atomic>
 #include <condition_variable>
@@ -269,6 +270,18 @@ int tic_sync(tic_ctx *ctx) {
 }
 
 // ---- transform stage -----------------------------------------------------------------------------------
+// Waits for the context's stream.  A blocking hipStreamSynchronize wakes the thread some microseconds after the last kernel
+// retired - a sixth of a 60 us device-resident compress - so short waits poll the stream first and only long ones block.
+static hipError_t wait_stream(tic_ctx *ctx) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(250)) break;
+    }
+    return hipStreamSynchronize(ctx->stream);
+}
+
 static int check_geometry(tic_ctx *ctx, int h, int w, ptrdiff_t stride, int quality) {
     if (!ctx) return TIC_E_ARG;
     if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size %dx%d", h, w);
@@ -579,7 +592,7 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     ctx->ent_parity ^= 1;
     HIPCHK(ctx, entropy_gpu_fused((const int16_t *)d_coeffs_zz, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, par, d_out, 0,
                                   cap_words, h, w, quality, nullptr, ctx->d_stat, ctx->d_err + par, ctx->d_err + (par ^ 1), ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_stream(ctx));
     const unsigned long long status[2] = {((volatile unsigned long long *)ctx->h_stat)[0], ((volatile unsigned long long *)ctx->h_stat)[1]};
     const unsigned long long total_bits = status[0];
     const int err = (int)(status[1] & 0xffffffffull);

@@ -350,39 +350,98 @@ constexpr int kLaneWords = 8;                    // a lane emits at most 3 ZRL +
 constexpr int kStageWords = kWaveImageWords + 2; // staging slot of a partition (8 blocks), 32-bit words
 constexpr int kGroup = 16;                       // partitions per workgroup of the placing kernel
 
-// Bit sink into the lane's private string (bit 0 = MSB of word 0): plain LDS stores, nothing shared.
+// Bit sink into the lane's private string (bit 0 = MSB of word 0), branch-free: every symbol rewrites the word under
+// construction in LDS (word i of the lane's string is str[i * 64], so the 64 lanes of a wave hit 64 different banks), a
+// symbol of 0 bits is a no-op.  The last, partial word stays in `cur`.
 struct LaneSink {
-    uint32_t *str; // word i of the lane's string is str[i * 64]: the 64 lanes of a wave hit 64 different LDS banks
-    uint32_t pos;  // bits so far
+    uint32_t *str;
     uint32_t cur;  // word under construction (MSB = first bit)
-    __device__ __forceinline__ void put(uint32_t v, int n) { // 1 <= n <= 27, v < 2^n
-        const int sh = (int)(pos & 31u), avail = 32 - sh;
-        if (n < avail) {
-            cur |= v << (avail - n);
-            pos += n;
-        } else {
-            const int rest = n - avail;
-            cur |= v >> rest;
-            str[(pos >> 5) * 64u] = cur;
-            pos += n;
-            cur = rest ? (v << (32 - rest)) : 0u;
-        }
+    uint32_t sh;   // bits used in it, 0..31
+    uint32_t full; // complete words behind it
+    __device__ __forceinline__ void put(uint32_t v, uint32_t n) { // n <= 27, v < 2^n
+        const unsigned long long w64 = ((((unsigned long long)v) << 32) << (32u - n)) >> sh; // the symbol at bit `sh` of 64
+        const uint32_t hi = cur | (uint32_t)(w64 >> 32), lo = (uint32_t)w64;
+        const uint32_t nsh = sh + n;
+        const bool done = nsh >= 32u;
+        str[full * 64u] = hi;
+        cur = done ? lo : hi;
+        sh = nsh & 31u;
+        full += done ? 1u : 0u;
     }
-    __device__ __forceinline__ void finish() {
-        if (pos & 31u) str[(pos >> 5) * 64u] = cur;
-    }
+    __device__ __forceinline__ uint32_t bits() const { return full * 32u + sh; }
 };
 
+// The same sink with a branch: the word under construction reaches LDS only when it is complete.
+struct LaneSinkB {
+    uint32_t *str;
+    uint32_t cur, sh, full;
+    __device__ __forceinline__ void put(uint32_t v, uint32_t n) { // 1 <= n <= 27, v < 2^n
+        const uint32_t avail = 32u - sh;
+        if (n < avail) {
+            cur |= v << (avail - n);
+            sh += n;
+        } else {
+            const uint32_t rest = n - avail;
+            cur |= v >> rest;
+            str[full * 64u] = cur;
+            full++;
+            sh = rest;
+            cur = rest ? (v << (32u - rest)) : 0u;
+        }
+    }
+    __device__ __forceinline__ uint32_t bits() const { return full * 32u + sh; }
+};
+
+// The symbols of one lane (8 consecutive scan positions of one block) into its sink, in uniform control flow: a zero
+// coefficient is a symbol of 0 bits.  Follows huffman.py:21-63 (run/size symbols, ZRL, EOB) like walk_lane above.
+__device__ __forceinline__ void walk_pack(const int16_t c[8], int k, int carry_run, int dc_diff, const uint32_t *ac_tab,
+                                          const uint32_t *dc_tab, LaneSink &sink, int &err) {
+    int run = carry_run;
+    {   // DC (lane 0 of the block): category code + value bits
+        const int v = dc_diff;
+        const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+        const int sz = 32 - __clz((int)a); // bit length; 0 for a == 0
+        const uint32_t e = dc_tab[sz & 15];
+        const bool ok = k == 0 && sz <= 11;
+        err |= (k == 0 && sz > 11) ? 1 : 0;
+        const uint32_t sym = ((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u));
+        sink.put(ok ? sym : 0u, ok ? (e & 0xffu) + (uint32_t)sz : 0u);
+    }
+    const uint32_t zrl = ac_tab[0xF0], eob = ac_tab[0];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int v = c[j];
+        const bool dcpos = k == 0 && j == 0;
+        const bool nz = v != 0 && !dcpos;
+        while (__any(nz && run >= 16)) { // ZRL = (15,0), huffman.py:26-28 (rare: the whole wave steps through it)
+            const bool z = nz && run >= 16;
+            sink.put(z ? (zrl >> 8) : 0u, z ? (zrl & 0xffu) : 0u);
+            run -= z ? 16 : 0;
+        }
+        const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+        const int sz = 32 - __clz((int)a);
+        const uint32_t e = ac_tab[((run << 4) | (sz & 15)) & 255];
+        const bool ok = nz && sz <= 10;
+        err |= (nz && sz > 10) ? 1 : 0;
+        const uint32_t sym = ((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u));
+        sink.put(ok ? sym : 0u, ok ? (e & 0xffu) + (uint32_t)sz : 0u);
+        run = nz ? 0 : run + (dcpos ? 0 : 1);
+    }
+    sink.put(k == 7 ? (eob >> 8) : 0u, k == 7 ? (eob & 0xffu) : 0u); // EOB = (0,0) always closes the block (huffman.py:33)
+}
+
 template <int ABL> // ABL != 0: timing-only builds (tools/), wrong output
-__global__ __launch_bounds__(256) void entropy_pack_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
-                                                           unsigned long long blocks_per_frame, int nframes,
-                                                           unsigned long long parts_per_frame, uint32_t *__restrict__ stage,
-                                                           uint32_t *__restrict__ nbits, int *__restrict__ err_flag) {
+__global__ __launch_bounds__(1024) void entropy_pack_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
+                                                            unsigned long long blocks_per_frame, unsigned long long parts_per_frame,
+                                                            unsigned long long groups_per_frame, uint32_t *__restrict__ stage,
+                                                            uint32_t *__restrict__ nbits, uint32_t *__restrict__ gsum,
+                                                            int *__restrict__ err_flag) {
     __shared__ uint32_t ac_tab[256];
     __shared__ uint32_t dc_tab[16];
-    __shared__ uint32_t image_all[4][kStageWords];
-    __shared__ uint32_t str_all[4][64 * kLaneWords];
-    ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
+    __shared__ uint32_t wbits[kGroup];
+    __shared__ uint32_t image_all[kGroup][kStageWords];
+    __shared__ uint32_t str_all[kGroup][64 * kLaneWords];
+    if (threadIdx.x < 256) ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
     if (threadIdx.x < 16) dc_tab[threadIdx.x] = tab->dc[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *image = image_all[wave];
@@ -391,9 +450,12 @@ __global__ __launch_bounds__(256) void entropy_pack_kernel(const int16_t *__rest
     for (int i = 0; i < (kStageWords + 63) / 64; i++)
         if (i * 64 + lane < kStageWords) image[i * 64 + lane] = 0u;
     __syncthreads();
-    const unsigned long long part = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)wave; // partition = 8 blocks
-    const unsigned long long frame = part / parts_per_frame, pif = part - frame * parts_per_frame;
-    if (frame >= (unsigned long long)nframes) return;
+    // one workgroup per (frame, group of kGroup partitions); a wave per partition = 8 blocks
+    const unsigned long long frame = blockIdx.x / groups_per_frame, g = blockIdx.x - frame * groups_per_frame;
+    const unsigned long long pif = g * (unsigned long long)kGroup + (unsigned long long)wave;
+    const unsigned long long part = frame * parts_per_frame + pif;
+    uint32_t wave_bits = 0;
+    if (pif < parts_per_frame) {
     const unsigned long long first_in_frame = pif * 8ull;
     const unsigned long long bif = first_in_frame + (unsigned long long)(lane >> 3); // block index inside the frame
     const int k = lane & 7;
@@ -434,21 +496,43 @@ __global__ __launch_bounds__(256) void entropy_pack_kernel(const int16_t *__rest
     int carry = __shfl_up(tz, 1, 8);
     if (k == 0) carry = 0;
     // ---- the one walk: symbols -> the lane's private bit string ---------------------------------------------------------
-    uint32_t my_bits = 0;
-    if (valid) {
+    uint32_t my_bits = 0, last_word = 0;
+    if (ABL & 4) {
+        int err = 0;
+        if (valid) my_bits = (uint32_t)walk_lane<false>(c, k, carry, dc_diff, ac_tab, dc_tab, (LaneSink *)nullptr, &err);
+    } else if (!(ABL & 24)) { // the product: branching walk, branching sink (fastest of the three measured, profiles/r02_entropy_ablate.txt)
+        LaneSinkB sink;
+        sink.str = str;
+        sink.cur = 0u;
+        sink.sh = 0u;
+        sink.full = 0u;
+        int err = 0;
+        if (valid) walk_lane<true>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
+        my_bits = valid ? sink.bits() : 0u;
+        last_word = sink.cur;
+        if (err && valid) atomicMax(err_flag, 1);
+    } else if (ABL & 8) { // branching walk, branch-free sink
         LaneSink sink;
         sink.str = str;
-        sink.pos = 0u;
         sink.cur = 0u;
+        sink.sh = 0u;
+        sink.full = 0u;
         int err = 0;
-        if (ABL & 4) {
-            my_bits = (uint32_t)walk_lane<false>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
-        } else {
-            walk_lane<true>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
-            sink.finish();
-            my_bits = sink.pos;
-        }
-        if (err) atomicMax(err_flag, 1);
+        if (valid) walk_lane<true>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
+        my_bits = valid ? sink.bits() : 0u;
+        last_word = sink.cur;
+        if (err && valid) atomicMax(err_flag, 1);
+    } else { // uniform control flow throughout
+        LaneSink sink;
+        sink.str = str;
+        sink.cur = 0u;
+        sink.sh = 0u;
+        sink.full = 0u;
+        int err = 0;
+        walk_pack(c, k, carry, dc_diff, ac_tab, dc_tab, sink, err); // (lanes past the frame's last block walk zeros)
+        my_bits = valid ? sink.bits() : 0u;
+        last_word = sink.cur;
+        if (err && valid) atomicMax(err_flag, 1);
     }
     // prefix of the lanes' bit counts over the wave (lanes are in stream order: block, then scan position)
     uint32_t incl = my_bits;
@@ -457,14 +541,14 @@ __global__ __launch_bounds__(256) void entropy_pack_kernel(const int16_t *__rest
         const uint32_t pv = (uint32_t)__shfl_up((int)incl, d, 64);
         if (lane >= d) incl += pv;
     }
-    const uint32_t wave_bits = (uint32_t)__shfl((int)incl, 63, 64);
+    wave_bits = (uint32_t)__shfl((int)incl, 63, 64);
     // ---- lane strings -> the wave's image (bit 0 of the partition = MSB of word 0) ---------------------------------------
     if (!(ABL & 2)) {
         const uint32_t lane_pos = incl - my_bits;
         const uint32_t w0 = lane_pos >> 5, sh = lane_pos & 31u;
         const int nw = (int)((my_bits + 31u) >> 5);
         for (int w = 0; w < nw; w++) {
-            const uint32_t v = str[w * 64];
+            const uint32_t v = (w == nw - 1 && (my_bits & 31u)) ? last_word : str[w * 64]; // the partial word never left the lane
             atomicOr(image + w0 + w, v >> sh);
             if (sh) atomicOr(image + w0 + w + 1, v << (32u - sh));
         }
@@ -477,9 +561,18 @@ __global__ __launch_bounds__(256) void entropy_pack_kernel(const int16_t *__rest
     if (!(ABL & 1))
         for (uint32_t i = (uint32_t)lane; i < nwords; i += 64u) slot[i] = image[i];
     if (lane == 0) nbits[part] = wave_bits;
+    }
+    if (lane == 0) wbits[wave] = wave_bits;
+    __syncthreads();
+    if (threadIdx.x == 0) { // bits of the group: the coarse level of the stream offsets, one plain store
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < kGroup; i++) t += wbits[i];
+        gsum[blockIdx.x] = t;
+    }
 }
 
-constexpr int kTile = 1024; // partitions per tile sum (a multiple of kGroup)
+constexpr int kTileGroups = 256; // groups per tile sum: the second level of the offsets, only for frames of many groups
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
@@ -487,114 +580,175 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-// Bits per tile of kTile partitions: the coarse level of the offsets (the placing kernel finishes them).
-__global__ __launch_bounds__(256) void entropy_tilesum_kernel(const uint32_t *__restrict__ nbits, unsigned long long parts_per_frame,
+// Bits per tile of kTileGroups groups.  Only launched for frames of more than `direct` groups (beyond 8192^2 pixels), where a
+// placing workgroup summing every group sum before it would re-read too much.
+__global__ __launch_bounds__(256) void entropy_tilesum_kernel(const uint32_t *__restrict__ gsum, unsigned long long groups_per_frame,
                                                               unsigned long long tiles_per_frame, unsigned long long *__restrict__ tile_sum) {
     __shared__ unsigned long long ws[4];
     const unsigned long long frame = blockIdx.x / tiles_per_frame, tile = blockIdx.x - frame * tiles_per_frame;
-    const uint32_t *fn = nbits + frame * parts_per_frame;
-    const unsigned long long p = tile * (unsigned long long)kTile + threadIdx.x;
-    unsigned long long sum = 0;
-#pragma unroll
-    for (int r = 0; r < kTile / 256; r++)
-        if (p + 256ull * r < parts_per_frame) sum += fn[p + 256ull * r];
+    const unsigned long long j = tile * (unsigned long long)kTileGroups + threadIdx.x;
+    unsigned long long sum = (threadIdx.x < kTileGroups && j < groups_per_frame) ? (unsigned long long)gsum[frame * groups_per_frame + j] : 0ull;
     sum = wave_sum_u64(sum);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// Places kGroup partitions in the frame's stream.  One workgroup per (frame, group); it owns the output words whose first
-// bit lies in its partitions' bit range and assembles each from the partitions that meet in it.
+constexpr int kPlace = 32;   // partitions per workgroup of the placing kernel (a multiple of kGroup)
+constexpr int kSlotLds = 64; // words of every partition's slot that workgroup fetches into LDS up front (typically 55 are used)
+
+// Places kPlace partitions in the frame's stream.  One workgroup per (frame, kPlace partitions); it owns the output words
+// whose first bit lies in its partitions' bit range and assembles each from the partitions that meet in it.  The kernel is
+// latency-bound (4 waves per workgroup, a few words per thread), so everything it needs from memory - group sums, bit
+// counts, the head of every slot - is requested at once, before the first dependent step.
+template <int ABL> // ABL != 0: timing-only builds (tools/), wrong output
 __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__restrict__ stage, const uint32_t *__restrict__ nbits,
-                                                            const unsigned long long *__restrict__ tile_sum,
+                                                            const uint32_t *__restrict__ gsum, const unsigned long long *__restrict__ tile_sum,
                                                             unsigned long long parts_per_frame, unsigned long long groups_per_frame,
-                                                            unsigned long long tiles_per_frame, int nframes, unsigned char *__restrict__ out,
-                                                            unsigned long long out_frame_stride, unsigned long long cap_words, int h, int w,
-                                                            int quality, unsigned long long *__restrict__ lens, int *__restrict__ err_flag,
+                                                            unsigned long long places_per_frame, unsigned long long tiles_per_frame,
+                                                            unsigned char *__restrict__ out, unsigned long long out_frame_stride,
+                                                            unsigned long long cap_words, int h, int w, int quality,
+                                                            unsigned long long *__restrict__ lens, int *__restrict__ err_flag,
                                                             int *__restrict__ err_next, unsigned long long *__restrict__ status) {
-    __shared__ unsigned long long off[kGroup + 6]; // off[i] = first bit of partition p0 - 2 + i (empty outside the frame)
+    constexpr int kN = kPlace + 3;             // its own partitions and the three behind them (the last word may run into those)
+    constexpr int kPer = (kN + 3) / 4;         // slots a wave fetches
+    __shared__ uint32_t roff[kN + 1]; // first bit of partition p0 + i, counted from bit 0 of word base_word (empty past the frame's end)
+    __shared__ unsigned long long base_word; // stream word that holds the workgroup's first bit
     __shared__ unsigned long long ws[2][4];
-    const unsigned long long gid = blockIdx.x;
-    const unsigned long long frame = gid / groups_per_frame, g = gid - frame * groups_per_frame;
-    if (frame >= (unsigned long long)nframes) return;
-    const long long p0 = (long long)(g * (unsigned long long)kGroup);
+    __shared__ int long_slot;
+    __shared__ uint32_t lds[kN * kSlotLds];
+    const unsigned long long frame = blockIdx.x / places_per_frame, gp = blockIdx.x - frame * places_per_frame;
+    const unsigned long long p0 = gp * (unsigned long long)kPlace;
+    const unsigned long long g = gp * (unsigned long long)(kPlace / kGroup); // first packing group of this workgroup
     const uint32_t *fn = nbits + frame * parts_per_frame;
+    const uint32_t *fstage = stage + (frame * parts_per_frame + p0) * (unsigned long long)kStageWords;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {   // first bit of partition p0: the tiles before its tile + the partitions of its tile before it
-        const unsigned long long tile = (unsigned long long)p0 / (unsigned long long)kTile;
-        const unsigned long long *fts = tile_sum + frame * tiles_per_frame;
-        unsigned long long before = 0, total = 0;
-        for (unsigned long long j = threadIdx.x; j < tiles_per_frame; j += 256ull) {
-            const unsigned long long v = fts[j];
-            total += v;
-            if (j < tile) before += v;
+    // ---- every load of the prologue, back to back --------------------------------------------------------------------------
+    const unsigned long long pl = p0 + (unsigned long long)lane;
+    const unsigned long long nb = (wave == 0 && lane < kN && pl < parts_per_frame) ? (unsigned long long)fn[pl] : 0ull;
+    unsigned long long before = 0, total = 0;
+    {   // first bit of partition p0 = the group sums before group g (through the tile sums when the frame has them); the
+        // frame's first workgroup also needs the frame's total
+        const uint32_t *fg = gsum + frame * groups_per_frame;
+        unsigned long long first = 0; // first group summed directly
+        if (tiles_per_frame) {
+            const unsigned long long *fts = tile_sum + frame * tiles_per_frame;
+            const unsigned long long tile = g / (unsigned long long)kTileGroups;
+            first = tile * (unsigned long long)kTileGroups;
+            const unsigned long long upto = gp == 0 ? tiles_per_frame : tile;
+            for (unsigned long long j = threadIdx.x; j < upto; j += 256ull) {
+                const unsigned long long v = fts[j];
+                total += v;
+                if (j < tile) before += v;
+            }
         }
+        const unsigned long long upto = (ABL & 4) ? 0ull : ((gp == 0 && !tiles_per_frame) ? groups_per_frame : g);
+        for (unsigned long long j0 = first; j0 < upto; j0 += 8ull * 256ull) { // 8 independent loads in flight per thread
+            uint32_t v[8];
 #pragma unroll
-        for (int r = 0; r < kTile / 256; r++) {
-            const unsigned long long p = tile * (unsigned long long)kTile + threadIdx.x + 256ull * r;
-            if (p < (unsigned long long)p0) before += fn[p];
+            for (int r = 0; r < 8; r++) {
+                const unsigned long long j = j0 + (unsigned long long)(r * 256) + threadIdx.x;
+                v[r] = j < upto ? fg[j] : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const unsigned long long j = j0 + (unsigned long long)(r * 256) + threadIdx.x;
+                if (!tiles_per_frame) total += v[r];
+                if (j < g) before += v[r];
+            }
         }
-        before = wave_sum_u64(before);
-        total = wave_sum_u64(total);
-        if (lane == 0) {
-            ws[0][wave] = before;
-            ws[1][wave] = total;
-        }
+    }
+    uint32_t head[kPer];
+#pragma unroll
+    for (int r = 0; r < kPer; r++) {
+        const int i = wave + 4 * r;
+        head[r] = (!(ABL & 2) && i < kN && p0 + (unsigned long long)i < parts_per_frame) ? fstage[(unsigned long long)i * (unsigned long long)kStageWords + lane] : 0u;
+    }
+    // ---- offsets ---------------------------------------------------------------------------------------------------------------
+    before = wave_sum_u64(before);
+    total = wave_sum_u64(total);
+    if (lane == 0) {
+        ws[0][wave] = before;
+        ws[1][wave] = total;
+    }
+#pragma unroll
+    for (int r = 0; r < kPer; r++) {
+        const int i = wave + 4 * r;
+        if (i < kN) lds[i * kSlotLds + lane] = head[r];
     }
     __syncthreads();
     const unsigned long long frame_bits = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
-    if (wave == 0) {
+    if (wave == 0) { // bit offsets of the kN partitions: a prefix sum over the lanes
         const unsigned long long base = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
-        const long long p = p0 - 2 + (long long)lane;
-        const unsigned long long nb = (lane < kGroup + 5 && p >= 0 && p < (long long)parts_per_frame) ? (unsigned long long)fn[p] : 0ull;
         unsigned long long incl = nb;
 #pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
+        for (int d = 1; d < 64; d <<= 1) {
             const unsigned long long pv = (unsigned long long)__shfl_up((long long)incl, d, 64);
             if (lane >= d) incl += pv;
         }
-        const unsigned long long nb0 = (unsigned long long)__shfl((long long)nb, 0, 64), nb1 = (unsigned long long)__shfl((long long)nb, 1, 64);
-        const unsigned long long off0 = base - nb0 - nb1;
-        if (lane < kGroup + 5) off[lane] = off0 + incl - nb;
-        if (lane == kGroup + 4) off[kGroup + 5] = off0 + incl;
+        // positions relative to the word that holds the workgroup's first bit: 35 partitions of at most 13.9 Kbit fit 32 bits
+        const uint32_t a = (uint32_t)(base & 31ull);
+        if (lane < kN) roff[lane] = a + (uint32_t)(incl - nb);
+        if (lane == kN - 1) roff[kN] = a + (uint32_t)incl;
+        const int any_long = __any(nb > (unsigned long long)(kSlotLds * 32)); // a slot longer than its LDS copy: read the slots directly
+        if (lane == 0) {
+            long_slot = any_long;
+            base_word = base >> 5;
+        }
     }
     __syncthreads();
-    uint32_t *dst = reinterpret_cast<uint32_t *>(out + frame * out_frame_stride + 16);
-    const unsigned long long lo_bit = off[2], hi_bit = off[2 + kGroup]; // the group's bit range
-    // the group owns the words whose first bit lies in its range
-    const unsigned long long w_lo = (lo_bit + 31ull) >> 5, w_hi = (hi_bit + 31ull) >> 5; // [w_lo, w_hi)
-    const uint32_t *fstage = stage + frame * parts_per_frame * (unsigned long long)kStageWords;
-    for (unsigned long long wd = w_lo + threadIdx.x; wd < w_hi; wd += 256ull) {
-        const unsigned long long b0 = wd << 5;
-        // partition holding bit b0: the last i with off[i] <= b0 (i in 2 .. kGroup+1)
-        int i = 2, n = kGroup;
-        while (n > 1) {
-            const int half = n >> 1;
-            if (off[i + half] <= b0) { i += half; n -= half; } else n = half;
-        }
-        uint32_t word = 0u;
-        int filled = 0;
-        while (filled < 32 && i < kGroup + 5) {
-            const unsigned long long pbeg = off[i], pend = off[i + 1];
-            const unsigned long long pos = b0 + (unsigned long long)filled;
-            if (pend > pos) {
-                const uint32_t lb = (uint32_t)(pos - pbeg);
-                const unsigned long long room = pend - pos;
-                const int take = room < (unsigned long long)(32 - filled) ? (int)room : 32 - filled;
-                const uint32_t *sp = fstage + (unsigned long long)(p0 - 2 + i) * (unsigned long long)kStageWords;
-                const uint32_t w0 = lb >> 5, sh = lb & 31u;
-                uint32_t v = sp[w0] << sh;
-                if (sh && (int)(32u - sh) < take) v |= sp[w0 + 1] >> (32u - sh);
-                v = take == 32 ? v : (v >> (32 - take)) << (32 - take); // keep the top `take` bits
-                word |= v >> filled;
-                filled += take;
+    const bool in_lds = long_slot == 0;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + frame * out_frame_stride + 16) + base_word;
+    const unsigned long long room_words = cap_words > base_word ? cap_words - base_word : 0ull; // words of the caller's buffer from base_word on
+    auto assemble = [&](auto fetch) {
+        // words that lie inside one partition: a funnel shift of two staged words, the shift the same for the whole partition
+        for (int i = wave; i < kPlace; i += 4) {
+            const uint32_t b = roff[i], e = roff[i + 1];
+            const uint32_t wfirst = (b + 31u) >> 5, wend = e >> 5;
+            const uint32_t s = (32u - (b & 31u)) & 31u; // position of the first such word inside the partition
+            for (uint32_t wr = wfirst + (uint32_t)lane; wr < wend; wr += 64u) {
+                const uint32_t x = ((wr << 5) - b) >> 5;
+                uint32_t v = fetch(i, x);
+                if (s) v = (v << s) | (fetch(i, x + 1u) >> (32u - s));
+                if (wr < room_words) dst[wr] = __builtin_bswap32(v); // the stream is MSB-first bytes
             }
-            i++;
         }
-        if (wd < cap_words) dst[wd] = __builtin_bswap32(word); // the stream is MSB-first bytes
-    }
-    if (g == 0 && threadIdx.x == 0) { // make_header (codec.py:102-114), the frame's length, the caller's status
+        // words in which partitions meet: one per partition end that is not word-aligned, assembled piece by piece.  The
+        // workgroup owns a word if its first bit lies in the workgroup's range (the others belong to the workgroup before).
+        if (threadIdx.x < kPlace) {
+            int i = (int)threadIdx.x;
+            const uint32_t e = roff[i + 1];
+            if ((e & 31u) && e > roff[i]) {
+                const uint32_t wr = e >> 5, b0 = wr << 5;
+                while (i > 0 && roff[i] > b0) i--;
+                if (roff[i] <= b0) {
+                    uint32_t word = 0u;
+                    uint32_t filled = 0u;
+                    while (filled < 32u && i < kN) {
+                        const uint32_t pbeg = roff[i], pend = roff[i + 1], pos = b0 + filled;
+                        if (pend > pos) {
+                            const uint32_t lb = pos - pbeg, room = pend - pos;
+                            const uint32_t take = room < 32u - filled ? room : 32u - filled;
+                            const uint32_t w0 = lb >> 5, sh = lb & 31u;
+                            uint32_t v = fetch(i, w0) << sh;
+                            if (sh && 32u - sh < take) v |= fetch(i, w0 + 1u) >> (32u - sh);
+                            v = take == 32u ? v : (v >> (32u - take)) << (32u - take); // keep the top `take` bits
+                            word |= v >> filled;
+                            filled += take;
+                        }
+                        i++;
+                    }
+                    if (wr < room_words) dst[wr] = __builtin_bswap32(word);
+                }
+            }
+        }
+    };
+    if (ABL & 1) {
+    } else if (in_lds)
+        assemble([&](int i, uint32_t w0) { return lds[i * kSlotLds + (int)w0]; });
+    else
+        assemble([&](int i, uint32_t w0) { return fstage[(unsigned long long)i * (unsigned long long)kStageWords + w0]; });
+    if (gp == 0 && threadIdx.x == 0) { // make_header (codec.py:102-114), the frame's length, the caller's status
         uint32_t *hdr = reinterpret_cast<uint32_t *>(out + frame * out_frame_stride);
         hdr[0] = (uint32_t)h; // struct.pack("III") little-endian == native order here
         hdr[1] = (uint32_t)w;
@@ -620,10 +774,9 @@ struct U32ToU64 {
 
 } // namespace
 
-// Workspace layout: [tile sums u64 x cap | bits per partition u32 x cap | staging slots x cap]; both functions below derive
-// cap from the same formula, so a workspace sized by the first always passes the check of the second.  (A batch never has
-// more tiles than partitions.)
-static constexpr size_t kPerPart = 8 + 4 + (size_t)kStageWords * 4;
+// Workspace layout: [tile sums u64 x cap | group sums u32 x cap | bits per partition u32 x cap | staging slots x cap]; both
+// functions below derive cap from the same formula, so a workspace sized by the first always passes the check of the second.
+static constexpr size_t kPerPart = 8 + 4 + 4 + (size_t)kStageWords * 4;
 
 size_t entropy_fused_work_bytes(size_t nblocks_total) {
     const size_t npart = (nblocks_total + 7) / 8 + 8;
@@ -641,39 +794,64 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
     const size_t npart = parts_per_frame * (size_t)nframes, ngroup = groups_per_frame * (size_t)nframes;
     if (work_bytes < 256 + kPerPart) return hipErrorInvalidValue;
     const size_t cap_parts = (work_bytes - 256) / kPerPart;
-    const size_t tiles_per_frame = (parts_per_frame + kTile - 1) / kTile, ntiles = tiles_per_frame * (size_t)nframes;
-    if (npart > cap_parts || ntiles > cap_parts || ngroup > 0x7fffffffull || (npart + 3) / 4 > 0x7fffffffull) return hipErrorInvalidValue;
-    unsigned long long *tile_sum = (unsigned long long *)d_work;
-    uint32_t *nbits = (uint32_t *)(tile_sum + cap_parts);
+    // frames of more than `direct` groups take the offsets in two levels (tile sums); TIC_ENT_DIRECT_GROUPS moves the switch
+    size_t direct = 8192;
+    if (const char *e = getenv("TIC_ENT_DIRECT_GROUPS")) direct = (size_t)strtoull(e, nullptr, 10);
+    const size_t tiles_per_frame = groups_per_frame > direct ? (groups_per_frame + kTileGroups - 1) / kTileGroups : 0;
+    const size_t ntiles = tiles_per_frame * (size_t)nframes;
+    if (npart > cap_parts || ngroup > cap_parts || ngroup > 0x7fffffffull) return hipErrorInvalidValue;
+    unsigned long long *tile_sum = (unsigned long long *)d_work; // (never more tiles than groups, never more groups than partitions)
+    uint32_t *gsum = (uint32_t *)(tile_sum + cap_parts);
+    uint32_t *nbits = gsum + cap_parts;
     uint32_t *stage = nbits + cap_parts;
-    const dim3 pack_grid((unsigned)((npart + 3) / 4));
+    const dim3 pack_grid((unsigned)ngroup);
 #ifdef TIC_ABLATION
     static const int abl = getenv("TIC_ENT_ABL") ? atoi(getenv("TIC_ENT_ABL")) : 0;
-#define TIC_PACK(A)                                                                                                                    \
-    hipLaunchKernelGGL(entropy_pack_kernel<A>, pack_grid, dim3(256), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, nframes, \
-                       (unsigned long long)parts_per_frame, stage, nbits, d_err)
+#define TIC_PACK(A)                                                                                                            \
+    hipLaunchKernelGGL(entropy_pack_kernel<A>, pack_grid, dim3(1024), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, \
+                       (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err)
     switch (abl) {
     case 1: TIC_PACK(1); break;
     case 2: TIC_PACK(2); break;
     case 3: TIC_PACK(3); break;
     case 4: TIC_PACK(4); break;
     case 7: TIC_PACK(7); break;
+    case 8: TIC_PACK(8); break;
+    case 16: TIC_PACK(16); break;
     default: TIC_PACK(0); break;
     }
 #undef TIC_PACK
 #else
-    hipLaunchKernelGGL(entropy_pack_kernel<0>, pack_grid, dim3(256), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, nframes,
-                       (unsigned long long)parts_per_frame, stage, nbits, d_err);
+    hipLaunchKernelGGL(entropy_pack_kernel<0>, pack_grid, dim3(1024), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame,
+                       (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err);
 #endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(entropy_tilesum_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, nbits, (unsigned long long)parts_per_frame,
-                       (unsigned long long)tiles_per_frame, tile_sum);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(entropy_place_kernel, dim3((unsigned)ngroup), dim3(256), 0, stream, stage, nbits, tile_sum,
-                       (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, (unsigned long long)tiles_per_frame, nframes,
-                       (unsigned char *)d_out, (unsigned long long)out_frame_stride, (unsigned long long)cap_words, h, w, quality, d_lens, d_err,
-                       d_err_next, d_status);
+    if (ntiles) {
+        hipLaunchKernelGGL(entropy_tilesum_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, gsum, (unsigned long long)groups_per_frame,
+                           (unsigned long long)tiles_per_frame, tile_sum);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    const size_t places_per_frame = (parts_per_frame + kPlace - 1) / kPlace;
+#define TIC_PLACE(A)                                                                                                                      \
+    hipLaunchKernelGGL(entropy_place_kernel<A>, dim3((unsigned)(places_per_frame * (size_t)nframes)), dim3(256), 0, stream, stage, nbits, gsum, \
+                       tile_sum, (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame,                               \
+                       (unsigned long long)places_per_frame, (unsigned long long)tiles_per_frame, (unsigned char *)d_out,                  \
+                       (unsigned long long)out_frame_stride, (unsigned long long)cap_words, h, w, quality, d_lens, d_err, d_err_next, d_status)
+#ifdef TIC_ABLATION
+    static const int pabl = getenv("TIC_PLACE_ABL") ? atoi(getenv("TIC_PLACE_ABL")) : 0;
+    switch (pabl) {
+    case 1: TIC_PLACE(1); break;
+    case 2: TIC_PLACE(2); break;
+    case 3: TIC_PLACE(3); break;
+    case 4: TIC_PLACE(4); break;
+    case 7: TIC_PLACE(7); break;
+    default: TIC_PLACE(0); break;
+    }
+#else
+    TIC_PLACE(0);
+#endif
+#undef TIC_PLACE
     return hipGetLastError();
 }
 
