@@ -590,7 +590,7 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     const size_t cap_words = ((cap - 16) / 16) * 4; // whole 16-byte units behind the header
     const int par = ctx->ent_parity;
     ctx->ent_parity ^= 1;
-    HIPCHK(ctx, entropy_gpu_fused((const int16_t *)d_coeffs_zz, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, par, d_out, 0,
+    HIPCHK(ctx, entropy_gpu_fused((const int16_t *)d_coeffs_zz, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, d_out, 0,
                                   cap_words, h, w, quality, nullptr, ctx->d_stat, ctx->d_err + par, ctx->d_err + (par ^ 1), ctx->stream));
     HIPCHK(ctx, wait_stream(ctx));
     const unsigned long long status[2] = {((volatile unsigned long long *)ctx->h_stat)[0], ((volatile unsigned long long *)ctx->h_stat)[1]};
@@ -956,7 +956,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         const int par = s.parity;
         s.parity ^= 1;
         if (e == hipSuccess) // entropy stage of the whole chunk: one pass + a finishing kernel (headers, lengths); no zero fill
-            e = entropy_gpu_fused((const int16_t *)s.d_coef, nblk, cnt, ctx->d_huff, s.d_work, s.work_bytes, par, s.d_streams, bound,
+            e = entropy_gpu_fused((const int16_t *)s.d_coef, nblk, cnt, ctx->d_huff, s.d_work, s.work_bytes, s.d_streams, bound,
                                   (bound - 16) / 4, h, w, quality, s.d_lens, nullptr, s.d_err + par, s.d_err + (par ^ 1), st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_lens, s.d_lens, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err + par, sizeof(int), hipMemcpyDeviceToHost, st);

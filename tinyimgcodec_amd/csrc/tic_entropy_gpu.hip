@@ -1,5 +1,5 @@
-// tic_entropy_gpu.hip - entropy stage on the GPU: run-length + Huffman symbol generation,
-// bit counting, offset scan and parallel bit packing, producing the reference's stream byte for byte.
+// tic_entropy_gpu.hip - entropy stage on the GPU: run-length + Huffman symbol generation and
+// parallel bit packing, producing the reference's stream byte for byte.
 //
 // Replaces, on the device, the per-block Python loops of compress() (codec.py:142-162 of the reference):
 // DC DPCM (codec.py:34-35), encode_run_length (huffman.py:12-33), encode_huffman (huffman.py:41-63) and the
@@ -9,20 +9,32 @@
 //
 // Decomposition: 8 lanes per block, lane k owns zig-zag entries 8k..8k+7 (one 16-byte load).  The only cross-lane
 // dependency of the symbol stream is the run of zeros carried into a lane, an associative "carry-through" scan over
-// the 8 lanes.  Three steps:
-//   1. entropy_bits_kernel<false>: bits per block -> nbits[N]
-//   2. rocPRIM exclusive scan (64-bit) -> bit offset of every block; the last offset + count is the payload size
-//   3. entropy_emit_kernel: a wave owns 8 consecutive blocks of one frame, i.e. one contiguous bit range of the
-//      stream.  Every lane re-derives its symbols and ORs them into the wave's LDS image of that range (LDS atomics);
-//      the wave then writes the image out with coalesced 32-bit stores - plain stores for the words it covers alone,
-//      atomicOr into the zeroed buffer only for its first and last word (shared with the neighbouring waves).
-//      (The first version had every lane write its own words to global memory: 2 global atomics per lane, 78 us for a
-//      4096^2 frame where this one takes a third.)
+// the 8 lanes.  A wave owns a PARTITION of 8 consecutive blocks of one frame, i.e. one contiguous bit range of the stream.
+//
+// Two launches (three for frames beyond 8192^2), one walk over the symbols, no zero fill, no atomics on the stream:
+//   entropy_pack_kernel     a wave walks the symbols of its 8 blocks ONCE, every lane packing its bits into a private string
+//                           in LDS (at most 245 bits) and counting them; a prefix over the lanes places the strings in the
+//                           wave's LDS image of its bit range, which leaves as coalesced words into the wave's slot of a
+//                           staging buffer - every partition starts at bit 0 of its own slot, nothing is shared.  The
+//                           bit count goes to nbits[partition], the workgroup's 16 counts summed to gsum[group].
+//   entropy_tilesum_kernel  only for frames of more than 8192 groups: sums of 256 group sums, a second level of offsets.
+//   entropy_place_kernel    a workgroup per 32 partitions: its stream offset is the sum of the group sums before it (one
+//                           batch of independent loads), its partitions' offsets a prefix over 35 bit counts; every
+//                           OUTPUT word is then written once, complete - words inside one partition by a funnel shift
+//                           of two staged words, the words in which partitions meet piece by piece.  It also writes
+//                           header, length and the caller's status.
+// History (profiles/r02_entropy_*.txt).  Round 1 ran five launches per frame - count (walks the symbols), a rocPRIM scan
+// (two kernels), a zero fill, emit (walks the symbols again and ORs into the zeroed stream; edge words by global atomics):
+// 109-129 us for a 4096^2 frame against a 10 us transform.  Explored and dropped this round: a single pass with a decoupled
+// look-back over the waves (byte-exact, 127 us: 5,120 resident 8-block partitions start together and each sums up to 5,000
+// predecessor descriptors, 64 per memory round trip); group sums by device-scope atomics from the packing waves (pack
+// 68 us instead of 29: 64 same-address atomics from 8 XCDs per group); a one-workgroup scan kernel between pack and place
+// (59 us of serial load latency); a branch-free symbol walk (32 us against 29: for noise every wave walks every position
+// anyway, and the uniform bit sink costs more than the branch it saves).
 #include <hip/hip_runtime.h>
-#include <cstring> // rocPRIM's texture_cache_iterator.hpp uses memset without including it
-#include <string.h>
-#include <rocprim/rocprim.hpp>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "tic_entropy_gpu.h"
 #include "tic_tables.h"
@@ -30,76 +42,60 @@
 namespace tic {
 
 void build_huff_dev(HuffDev *t) {
-    for (int i = 0; i < 256; i++) t->ac[i] = 0;
-    for (int i = 0; i < 16; i++) t->dc[i] = 0;
+    memset(t, 0, sizeof(*t));
     unsigned code = 0;
     int k = 0;
     for (int l = 1; l <= 16; l++) {
-        for (int i = 0; i < kDcBits[l - 1]; i++) t->dc[kDcVals[k++]] = (code++ << 8) | (unsigned)l;
+        for (int i = 0; i < kDcBits[l - 1]; i++) {
+            const int sz = kDcVals[k++]; // the symbol is the size category
+            t->dc_sym[sz] = code++ << sz;
+            t->dc_bits[sz] = (unsigned)(l + sz);
+        }
         code <<= 1;
     }
     code = 0;
     k = 0;
     for (int l = 1; l <= 16; l++) {
-        for (int i = 0; i < kAcBits[l - 1]; i++) t->ac[kAcVals[k++]] = (code++ << 8) | (unsigned)l;
+        for (int i = 0; i < kAcBits[l - 1]; i++) {
+            const int rs = kAcVals[k++], sz = rs & 15; // (run << 4) | size
+            t->ac_sym[rs] = code++ << sz;
+            t->ac_bits[rs] = (unsigned)(l + sz);
+        }
         code <<= 1;
     }
 }
 
 namespace {
 
-// MSB-first bit sink aligned to the 32-bit words of the output stream.
-struct BitSink {
-    uint32_t *words;        // stream payload as big-endian words
-    unsigned long long pos; // next bit position
-    uint32_t cur;           // bits of the word under construction (host order, MSB = first bit)
-    bool first;             // the word under construction may be shared with the previous lane
-    __device__ __forceinline__ void store_word(unsigned long long index, bool shared) {
-        const uint32_t be = __builtin_bswap32(cur); // the stream is MSB-first bytes
-        if (shared)
-            atomicOr(words + index, be);
-        else
-            words[index] = be;
-    }
-    __device__ __forceinline__ void put(uint32_t v, int n) { // 1 <= n <= 27, v < 2^n
-        const int sh = (int)(pos & 31), avail = 32 - sh;
-        if (n < avail) {
-            cur |= v << (avail - n);
-            pos += n;
-        } else { // completes the word under construction
-            const int rest = n - avail;
-            cur |= v >> rest;
-            // shared with the previous lane only if it is the first word this lane touches; every later word
-            // completed here is covered by this lane's bits alone
-            store_word(pos >> 5, first);
-            first = false;
-            pos += n;
-            cur = rest ? (v << (32 - rest)) : 0u;
-        }
-    }
-    __device__ __forceinline__ void finish() { // leftover bits of the last word: always possibly shared
-        if ((pos & 31) && cur) atomicOr(words + (pos >> 5), __builtin_bswap32(cur));
-    }
-};
+// Size category of a coefficient: its bit length, 0 for 0.  The exponent of the float is exact for |v| <= 32768.
+__device__ __forceinline__ int size_category(int v) {
+    int e;
+    (void)frexpf((float)v, &e); // v_cvt_f32_i32 + v_frexp_exp_i32_f32; frexp(0) gives exponent 0
+    return e;
+}
 
+// Value bits of a coefficient of size category sz: v for v > 0, v - 1 for v < 0, low sz bits (huffman.py:51-56).
+__device__ __forceinline__ uint32_t value_bits(int v, int sz) { return __builtin_amdgcn_ubfe((uint32_t)(v + (v >> 31)), 0u, (uint32_t)sz); }
+
+// The symbols of one lane (8 consecutive scan positions of one block) into its sink; returns their total bits.
+// huffman.py:12-33 (run/size symbols, ZRL, EOB) and :41-63 (codeword + value bits).
 template <bool EMIT, typename Sink>
-__device__ __forceinline__ int walk_lane(const int16_t c[8], int k, int carry_run, int dc_diff, const uint32_t *ac_tab,
-                                         const uint32_t *dc_tab, Sink *sink, int *err) {
+__device__ __forceinline__ int walk_lane(const int16_t c[8], int k, int carry_run, int dc_diff, const uint2 *ac_tab,
+                                         const uint2 *dc_tab, Sink *sink, int *err) {
     int bits = 0;
     int run = carry_run;
     if (k == 0) { // DC: category code + value bits (huffman.py:41-63 with dc_ac = DC)
         const int v = dc_diff;
-        const uint32_t a = (uint32_t)(v < 0 ? -v : v);
-        const int sz = 32 - __clz((int)a); // bit length; 0 for a == 0
-        if (sz > 11) {
+        const int sz = size_category(v);
+        const uint2 e = dc_tab[sz & 15]; // |difference| <= 65535: sz <= 16, and 16 wraps to the (valid) entry 0 ...
+        if (e.y == 0u || sz > 11) {      // ... hence the explicit bound
             *err = 1;
         } else {
-            const uint32_t e = dc_tab[sz];
-            const int len = (int)(e & 0xff);
-            bits += len + sz;
-            if (EMIT) sink->put(((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u)), len + sz);
+            bits += (int)e.y;
+            if (EMIT) sink->put(e.x | value_bits(v, sz), e.y);
         }
     }
+    const uint2 zrl = ac_tab[0xF0];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         if (k == 0 && j == 0) continue;
@@ -109,243 +105,29 @@ __device__ __forceinline__ int walk_lane(const int16_t c[8], int k, int carry_ru
             continue;
         }
         while (run >= 16) { // ZRL = (15,0), huffman.py:26-28
-            const uint32_t e = ac_tab[0xF0];
-            bits += (int)(e & 0xff);
-            if (EMIT) sink->put(e >> 8, (int)(e & 0xff));
+            bits += (int)zrl.y;
+            if (EMIT) sink->put(zrl.x, zrl.y);
             run -= 16;
         }
-        const uint32_t a = (uint32_t)(v < 0 ? -v : v);
-        const int sz = 32 - __clz((int)a);
-        if (sz > 10) {
+        const int sz = size_category(v); // 1..16 for an int16
+        const uint2 e = ac_tab[(run << 4) | (sz > 15 ? 15 : sz)];
+        if (e.y == 0u) { // sizes above 10 have no code (the reference raises KeyError)
             *err = 1;
         } else {
-            const uint32_t e = ac_tab[(run << 4) | sz];
-            const int len = (int)(e & 0xff);
-            bits += len + sz;
-            if (EMIT) sink->put(((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u)), len + sz);
+            bits += (int)e.y;
+            if (EMIT) sink->put(e.x | value_bits(v, sz), e.y);
         }
         run = 0;
     }
     if (k == 7) { // EOB = (0,0) always closes the block (huffman.py:33)
-        const uint32_t e = ac_tab[0];
-        bits += (int)(e & 0xff);
-        if (EMIT) sink->put(e >> 8, (int)(e & 0xff));
+        const uint2 e = ac_tab[0];
+        bits += (int)e.y;
+        if (EMIT) sink->put(e.x, e.y);
     }
     return bits;
 }
 
-template <bool EMIT>
-__global__ __launch_bounds__(256) void entropy_bits_kernel(const int16_t *__restrict__ zz, unsigned long long nblocks,
-                                                           const HuffDev *__restrict__ tab, uint32_t *__restrict__ nbits,
-                                                           const unsigned long long *__restrict__ bitoff,
-                                                           uint32_t *__restrict__ out_words, int *__restrict__ err_flag,
-                                                           unsigned long long blocks_per_frame, unsigned long long out_frame_stride,
-                                                           uint8_t *__restrict__ lanebits) {
-    __shared__ uint32_t ac_tab[256];
-    __shared__ uint32_t dc_tab[16];
-    ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
-    if (threadIdx.x < 16) dc_tab[threadIdx.x] = tab->dc[threadIdx.x];
-    __syncthreads();
-    const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
-    const unsigned long long blk = t >> 3;
-    const int k = (int)(t & 7);
-    const bool valid = blk < nblocks;
-    int16_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int dc_diff = 0;
-    if (valid) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(zz + blk * 64 + k * 8);
-        c[0] = (int16_t)(v.x & 0xffff); c[1] = (int16_t)(v.x >> 16); c[2] = (int16_t)(v.y & 0xffff); c[3] = (int16_t)(v.y >> 16);
-        c[4] = (int16_t)(v.z & 0xffff); c[5] = (int16_t)(v.z >> 16); c[6] = (int16_t)(v.w & 0xffff); c[7] = (int16_t)(v.w >> 16);
-        // codec.py:34-35: DPCM over the blocks of one frame in raster order, the first block raw
-        if (k == 0) dc_diff = (blk % blocks_per_frame) ? (int)c[0] - (int)zz[(blk - 1) * 64] : (int)c[0];
-    }
-    // zeros carried into this lane: carry-through scan over the 8 lanes of the block.
-    // per lane: az = every AC entry is zero; tz = zeros after its last non-zero entry (all of them if az)
-    int nz_mask = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) nz_mask |= (c[j] != 0 && !(k == 0 && j == 0)) ? (1 << j) : 0;
-    const int cnt = (k == 0) ? 7 : 8;
-    int az = nz_mask == 0;
-    int tz = az ? cnt : (__clz(nz_mask) - 24); // bits 7..0: leading zeros of the byte = trailing (later) zero entries
-    // inclusive scan: (A,T) o (a,t) = (A & a, a ? T + t : t)
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        const int pa = __shfl_up(az, d, 8), pt = __shfl_up(tz, d, 8);
-        if (k >= d) {
-            tz = az ? pt + tz : tz;
-            az = az & pa;
-        }
-    }
-    int carry = __shfl_up(tz, 1, 8); // exclusive: state after the previous lane
-    if (k == 0) carry = 0;
-
-    int err = 0;
-    const int my_bits = walk_lane<false>(c, k, carry, dc_diff, ac_tab, dc_tab, (BitSink *)nullptr, &err);
-    // bits of the block = sum over its 8 lanes; lane prefix for the emit pass
-    int incl = my_bits;
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        const int p = __shfl_up(incl, d, 8);
-        if (k >= d) incl += p;
-    }
-    if (!EMIT) {
-        if (valid && lanebits) lanebits[t] = (uint8_t)my_bits; // at most 8 x 27 bits: the emit kernel need not walk twice
-        if (valid && k == 7) nbits[blk] = (uint32_t)incl;
-        if (err && valid) atomicMax(err_flag, 1);
-        return;
-    }
-    if (!valid) return;
-    BitSink sink;
-    // every frame is a stream of its own: its words start at its own buffer, its bits at its own first block
-    const unsigned long long frame = blk / blocks_per_frame;
-    sink.words = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(out_words) + frame * out_frame_stride);
-    sink.pos = bitoff[blk] - bitoff[frame * blocks_per_frame] + (unsigned long long)(incl - my_bits);
-    sink.cur = 0;
-    sink.first = true;
-    int e2 = 0;
-    walk_lane<true>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &e2);
-    sink.finish();
-}
-
-// Bit sink into the wave's LDS image of its bit range (bit 0 = MSB of word 0).  All words are OR-ed (LDS atomics are
-// as cheap as LDS stores); the image is zeroed beforehand.
-struct LdsSink {
-    uint32_t *buf;
-    uint32_t pos; // next bit, relative to the image
-    uint32_t cur; // bits of the word under construction (MSB = first bit)
-    __device__ __forceinline__ void put(uint32_t v, int n) { // 1 <= n <= 27, v < 2^n
-        const int sh = (int)(pos & 31u), avail = 32 - sh;
-        if (n < avail) {
-            cur |= v << (avail - n);
-            pos += n;
-        } else {
-            const int rest = n - avail;
-            cur |= v >> rest;
-            atomicOr(buf + (pos >> 5), cur);
-            pos += n;
-            cur = rest ? (v << (32 - rest)) : 0u;
-        }
-    }
-    __device__ __forceinline__ void finish() {
-        if ((pos & 31u) && cur) atomicOr(buf + (pos >> 5), cur);
-    }
-};
-
 constexpr int kWaveImageWords = 432; // 8 blocks x at most 64 x 27 bits, plus word alignment: 13,855 bits
-
-__global__ __launch_bounds__(256) void entropy_emit_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
-                                                           const unsigned long long *__restrict__ bitoff,
-                                                           uint32_t *__restrict__ out_words, int *__restrict__ err_flag,
-                                                           unsigned long long blocks_per_frame, int nframes,
-                                                           unsigned long long waves_per_frame, unsigned long long out_frame_stride,
-                                                           unsigned long long cap_words, const uint8_t *__restrict__ lanebits) {
-    __shared__ uint32_t ac_tab[256];
-    __shared__ uint32_t dc_tab[16];
-    __shared__ uint32_t image_all[4][kWaveImageWords];
-    ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
-    if (threadIdx.x < 16) dc_tab[threadIdx.x] = tab->dc[threadIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *image = image_all[wave];
-#pragma unroll
-    for (int i = 0; i < (kWaveImageWords + 63) / 64; i++)
-        if (i * 64 + lane < kWaveImageWords) image[i * 64 + lane] = 0u;
-    __syncthreads();
-    const unsigned long long wg = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)wave;
-    const unsigned long long frame = wg / waves_per_frame, wif = wg - frame * waves_per_frame;
-    if (frame >= (unsigned long long)nframes) return;
-    const unsigned long long first_in_frame = wif * 8ull;
-    const unsigned long long bif = first_in_frame + (unsigned long long)(lane >> 3); // block index inside the frame
-    const int k = lane & 7;
-    const bool valid = bif < blocks_per_frame;
-    const unsigned long long frame_first = frame * blocks_per_frame;
-    const unsigned long long blk = frame_first + (valid ? bif : blocks_per_frame - 1);
-    int16_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int dc_diff = 0;
-    if (valid) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(zz + blk * 64 + k * 8);
-        c[0] = (int16_t)(v.x & 0xffff); c[1] = (int16_t)(v.x >> 16); c[2] = (int16_t)(v.y & 0xffff); c[3] = (int16_t)(v.y >> 16);
-        c[4] = (int16_t)(v.z & 0xffff); c[5] = (int16_t)(v.z >> 16); c[6] = (int16_t)(v.w & 0xffff); c[7] = (int16_t)(v.w >> 16);
-        if (k == 0) dc_diff = bif ? (int)c[0] - (int)zz[(blk - 1) * 64] : (int)c[0]; // DPCM restarts at every frame
-    }
-    int nz_mask = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) nz_mask |= (c[j] != 0 && !(k == 0 && j == 0)) ? (1 << j) : 0;
-    const int cnt = (k == 0) ? 7 : 8;
-    int az = nz_mask == 0;
-    int tz = az ? cnt : (__clz(nz_mask) - 24);
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        const int pa = __shfl_up(az, d, 8), pt = __shfl_up(tz, d, 8);
-        if (k >= d) {
-            tz = az ? pt + tz : tz;
-            az = az & pa;
-        }
-    }
-    int carry = __shfl_up(tz, 1, 8);
-    if (k == 0) carry = 0;
-    const int my_bits = valid ? (int)lanebits[blk * 8ull + (unsigned long long)k] : 0; // counted by entropy_bits_kernel
-    int incl = my_bits;
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        const int p = __shfl_up(incl, d, 8);
-        if (k >= d) incl += p;
-    }
-    // frame-relative bit position of this lane's first bit; the wave's image starts at the word holding its first bit
-    const unsigned long long frame_bit0 = bitoff[frame_first];
-    const unsigned long long my_pos = bitoff[blk] - frame_bit0 + (unsigned long long)(incl - my_bits);
-    const unsigned long long wave_pos = (unsigned long long)__shfl((long long)my_pos, 0, 64);
-    const unsigned long long word0 = wave_pos >> 5;
-    const uint32_t rel = (uint32_t)(my_pos - (word0 << 5));
-    if (valid) {
-        LdsSink sink;
-        sink.buf = image;
-        sink.pos = rel;
-        sink.cur = 0u;
-        int e2 = 0;
-        walk_lane<true>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &e2);
-        sink.finish();
-    }
-    // end of the wave's range = end of its last valid lane
-    const unsigned long long nvalid_blocks = blocks_per_frame - first_in_frame < 8ull ? blocks_per_frame - first_in_frame : 8ull;
-    const uint32_t my_end = rel + (uint32_t)my_bits;
-    const uint32_t wave_end = (uint32_t)__shfl((int)my_end, (int)(nvalid_blocks * 8ull - 1ull), 64);
-    const uint32_t nwords = (wave_end + 31u) >> 5;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t *dst = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(out_words) + frame * out_frame_stride);
-    if (word0 + nwords > cap_words) { // would run past the caller's buffer: report, write nothing
-        if (lane == 0) atomicMax(err_flag, 2);
-        return;
-    }
-    for (uint32_t i = (uint32_t)lane; i < nwords; i += 64u) {
-        const uint32_t be = __builtin_bswap32(image[i]); // the stream is MSB-first bytes
-        if (i == 0u || i == nwords - 1u) {
-            if (be) atomicOr(dst + word0 + i, be); // shared with the neighbouring wave
-        } else {
-            dst[word0 + i] = be;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Round 2: the entropy stage as pack -> offsets -> place: one walk over the symbols, no zero fill, no atomics on the stream.
-//
-// Round 1 ran five launches per frame - count (walks the symbols), a rocPRIM scan (two kernels), a zero fill, emit (walks
-// the symbols again, ORs into the zeroed stream) - 109-129 us for a 4096^2 frame against a 10 us transform.  Now:
-//   entropy_pack_kernel     a wave walks the symbols of its 8 blocks ONCE, every lane packing its bits into a private string
-//                           in LDS (at most 245 bits) and counting them; a prefix over the lanes places the strings in the
-//                           wave's LDS image of its bit range, which leaves as coalesced words into the wave's slot of a
-//                           staging buffer - every partition starts at bit 0 of its own slot, nothing is shared - and the
-//                           bit count goes to nbits[partition].
-//   entropy_offsets_kernel  one workgroup per frame: exclusive scan of the partitions' bit counts (bit offsets in the
-//                           frame's stream), header, length, capacity check.
-//   entropy_place_kernel    a workgroup per 16 partitions: every OUTPUT word is assembled from the one to three
-//                           partitions that meet in it (funnel shifts of staged words) and written once, complete.
-// Explored and dropped: a single-pass version with a decoupled look-back over the waves (byte-exact, 127 us: 5,120 resident
-// 8-block partitions start together and each sums up to 5,000 predecessor descriptors, 64 per memory round trip), and
-// group sums by device-scope atomics from the packing waves (pack 68 us: 64 same-address atomics from 8 XCDs per group).
-// ---------------------------------------------------------------------------------------------------------
 constexpr int kLaneWords = 8;                    // a lane emits at most 3 ZRL + 8 x 26 + EOB = 245 bits
 constexpr int kStageWords = kWaveImageWords + 2; // staging slot of a partition (8 blocks), 32-bit words
 constexpr int kGroup = 16;                       // partitions per workgroup of the placing kernel
@@ -392,42 +174,37 @@ struct LaneSinkB {
     __device__ __forceinline__ uint32_t bits() const { return full * 32u + sh; }
 };
 
-// The symbols of one lane (8 consecutive scan positions of one block) into its sink, in uniform control flow: a zero
-// coefficient is a symbol of 0 bits.  Follows huffman.py:21-63 (run/size symbols, ZRL, EOB) like walk_lane above.
-__device__ __forceinline__ void walk_pack(const int16_t c[8], int k, int carry_run, int dc_diff, const uint32_t *ac_tab,
-                                          const uint32_t *dc_tab, LaneSink &sink, int &err) {
+// The same walk in uniform control flow (a zero coefficient is a symbol of 0 bits): timing-only builds, see the history above.
+__device__ __forceinline__ void walk_pack(const int16_t c[8], int k, int carry_run, int dc_diff, const uint2 *ac_tab,
+                                          const uint2 *dc_tab, LaneSink &sink, int &err) {
     int run = carry_run;
-    {   // DC (lane 0 of the block): category code + value bits
+    {
         const int v = dc_diff;
-        const uint32_t a = (uint32_t)(v < 0 ? -v : v);
-        const int sz = 32 - __clz((int)a); // bit length; 0 for a == 0
-        const uint32_t e = dc_tab[sz & 15];
+        const int sz = size_category(v);
+        const uint2 e = dc_tab[sz & 15];
         const bool ok = k == 0 && sz <= 11;
         err |= (k == 0 && sz > 11) ? 1 : 0;
-        const uint32_t sym = ((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u));
-        sink.put(ok ? sym : 0u, ok ? (e & 0xffu) + (uint32_t)sz : 0u);
+        sink.put(ok ? (e.x | value_bits(v, sz)) : 0u, ok ? e.y : 0u);
     }
-    const uint32_t zrl = ac_tab[0xF0], eob = ac_tab[0];
+    const uint2 zrl = ac_tab[0xF0], eob = ac_tab[0];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int v = c[j];
         const bool dcpos = k == 0 && j == 0;
         const bool nz = v != 0 && !dcpos;
-        while (__any(nz && run >= 16)) { // ZRL = (15,0), huffman.py:26-28 (rare: the whole wave steps through it)
+        while (__any(nz && run >= 16)) {
             const bool z = nz && run >= 16;
-            sink.put(z ? (zrl >> 8) : 0u, z ? (zrl & 0xffu) : 0u);
+            sink.put(z ? zrl.x : 0u, z ? zrl.y : 0u);
             run -= z ? 16 : 0;
         }
-        const uint32_t a = (uint32_t)(v < 0 ? -v : v);
-        const int sz = 32 - __clz((int)a);
-        const uint32_t e = ac_tab[((run << 4) | (sz & 15)) & 255];
-        const bool ok = nz && sz <= 10;
-        err |= (nz && sz > 10) ? 1 : 0;
-        const uint32_t sym = ((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u));
-        sink.put(ok ? sym : 0u, ok ? (e & 0xffu) + (uint32_t)sz : 0u);
+        const int sz = size_category(v);
+        const uint2 e = ac_tab[((run << 4) | (sz > 15 ? 15 : sz)) & 255];
+        const bool ok = nz && e.y != 0u;
+        err |= (nz && e.y == 0u) ? 1 : 0;
+        sink.put(ok ? (e.x | value_bits(v, sz)) : 0u, ok ? e.y : 0u);
         run = nz ? 0 : run + (dcpos ? 0 : 1);
     }
-    sink.put(k == 7 ? (eob >> 8) : 0u, k == 7 ? (eob & 0xffu) : 0u); // EOB = (0,0) always closes the block (huffman.py:33)
+    sink.put(k == 7 ? eob.x : 0u, k == 7 ? eob.y : 0u);
 }
 
 template <int ABL> // ABL != 0: timing-only builds (tools/), wrong output
@@ -436,13 +213,13 @@ __global__ __launch_bounds__(1024) void entropy_pack_kernel(const int16_t *__res
                                                             unsigned long long groups_per_frame, uint32_t *__restrict__ stage,
                                                             uint32_t *__restrict__ nbits, uint32_t *__restrict__ gsum,
                                                             int *__restrict__ err_flag) {
-    __shared__ uint32_t ac_tab[256];
-    __shared__ uint32_t dc_tab[16];
+    __shared__ uint2 ac_tab[256];
+    __shared__ uint2 dc_tab[16];
     __shared__ uint32_t wbits[kGroup];
     __shared__ uint32_t image_all[kGroup][kStageWords];
     __shared__ uint32_t str_all[kGroup][64 * kLaneWords];
-    if (threadIdx.x < 256) ac_tab[threadIdx.x] = tab->ac[threadIdx.x];
-    if (threadIdx.x < 16) dc_tab[threadIdx.x] = tab->dc[threadIdx.x];
+    if (threadIdx.x < 256) ac_tab[threadIdx.x] = make_uint2(tab->ac_sym[threadIdx.x], tab->ac_bits[threadIdx.x]);
+    if (threadIdx.x < 16) dc_tab[threadIdx.x] = make_uint2(tab->dc_sym[threadIdx.x], tab->dc_bits[threadIdx.x]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *image = image_all[wave];
     uint32_t *str = str_all[wave] + lane;
@@ -768,10 +545,6 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
     }
 }
 
-struct U32ToU64 {
-    __host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
-};
-
 } // namespace
 
 // Workspace layout: [tile sums u64 x cap | group sums u32 x cap | bits per partition u32 x cap | staging slots x cap]; both
@@ -784,10 +557,8 @@ size_t entropy_fused_work_bytes(size_t nblocks_total) {
 }
 
 hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int nframes, const HuffDev *d_tab, void *d_work,
-                             size_t work_bytes, int parity, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w,
-                             int quality, unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next,
-                             hipStream_t stream) {
-    (void)parity;
+                             size_t work_bytes, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w, int quality,
+                             unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next, hipStream_t stream) {
     if (blocks_per_frame == 0 || nframes <= 0) return hipSuccess;
     const size_t parts_per_frame = (blocks_per_frame + 7) / 8;
     const size_t groups_per_frame = (parts_per_frame + kGroup - 1) / kGroup;
@@ -852,100 +623,6 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
     TIC_PLACE(0);
 #endif
 #undef TIC_PLACE
-    return hipGetLastError();
-}
-
-size_t entropy_gpu_scan_temp_bytes(size_t nblocks) {
-    size_t bytes = 0;
-    auto in = rocprim::make_transform_iterator((const uint32_t *)nullptr, U32ToU64());
-    (void)rocprim::exclusive_scan(nullptr, bytes, in, (unsigned long long *)nullptr, 0ull, nblocks,
-                                  rocprim::plus<unsigned long long>(), (hipStream_t)0);
-    return bytes;
-}
-
-hipError_t entropy_gpu_count(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
-                             uint32_t *d_nbits, uint8_t *d_lanebits, unsigned long long *d_bitoff, void *d_temp,
-                             size_t temp_bytes, int *d_err, hipStream_t stream) {
-    if (nblocks == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((nblocks * 8 + 255) / 256);
-    hipLaunchKernelGGL(entropy_bits_kernel<false>, dim3(grid), dim3(256), 0, stream, d_zz, (unsigned long long)nblocks, d_tab,
-                       d_nbits, (const unsigned long long *)nullptr, (uint32_t *)nullptr, d_err,
-                       (unsigned long long)blocks_per_frame, 0ull, d_lanebits);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    auto in = rocprim::make_transform_iterator((const uint32_t *)d_nbits, U32ToU64());
-    return rocprim::exclusive_scan(d_temp, temp_bytes, in, d_bitoff, 0ull, nblocks, rocprim::plus<unsigned long long>(), stream);
-}
-
-hipError_t entropy_gpu_emit(const int16_t *d_zz, size_t nblocks, size_t blocks_per_frame, const HuffDev *d_tab,
-                            const unsigned long long *d_bitoff, const uint8_t *d_lanebits, uint32_t *d_payload_words,
-                            size_t out_frame_stride, size_t cap_words, int *d_err, hipStream_t stream) {
-    if (nblocks == 0 || blocks_per_frame == 0) return hipSuccess;
-    const size_t nframes = nblocks / blocks_per_frame;
-    const size_t waves_per_frame = (blocks_per_frame + 7) / 8;
-    const unsigned grid = (unsigned)((nframes * waves_per_frame + 3) / 4);
-    hipLaunchKernelGGL(entropy_emit_kernel, dim3(grid), dim3(256), 0, stream, d_zz, d_tab, d_bitoff, d_payload_words, d_err,
-                       (unsigned long long)blocks_per_frame, (int)nframes, (unsigned long long)waves_per_frame,
-                       (unsigned long long)out_frame_stride, (unsigned long long)cap_words, d_lanebits);
-    return hipGetLastError();
-}
-
-// Single-frame form without a host round trip between the steps: reads the payload size the scan produced, publishes
-// it (bits) and zeroes exactly the payload words the emit kernel will OR into (grid-stride, 16 bytes per store).
-__global__ __launch_bounds__(256) void zero_payload_kernel(const uint32_t *__restrict__ nbits,
-                                                           const unsigned long long *__restrict__ bitoff,
-                                                           unsigned long long last_block, uint32_t *__restrict__ payload,
-                                                           unsigned long long cap_words, unsigned long long *__restrict__ total_bits,
-                                                           int *__restrict__ err_flag, int h, int w, int quality) {
-    const unsigned long long bits = bitoff[last_block] + nbits[last_block];
-    unsigned long long words = (bits + 31ull) >> 5;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *total_bits = bits;
-        if (words > cap_words) atomicMax(err_flag, 2);
-        uint32_t *hdr = payload - 4; // make_header (codec.py:102-114): struct.pack("III") + a zero flag word
-        hdr[0] = (uint32_t)h;
-        hdr[1] = (uint32_t)w;
-        hdr[2] = (uint32_t)quality;
-        hdr[3] = 0u;
-    }
-    if (words > cap_words) words = cap_words;
-    const unsigned long long quads = (words + 3ull) >> 2; // the buffer behind the payload is 16-byte granular (compress bound)
-    uint4 *p = reinterpret_cast<uint4 *>(payload);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < quads; i += (unsigned long long)gridDim.x * 256ull)
-        p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-hipError_t entropy_gpu_zero_payload(const uint32_t *d_nbits, const unsigned long long *d_bitoff, size_t nblocks,
-                                    uint32_t *d_payload_words, size_t cap_words, unsigned long long *d_total_bits, int *d_err,
-                                    int h, int w, int quality, hipStream_t stream) {
-    hipLaunchKernelGGL(zero_payload_kernel, dim3(1024), dim3(256), 0, stream, d_nbits, d_bitoff, (unsigned long long)(nblocks - 1),
-                       d_payload_words, (unsigned long long)cap_words, d_total_bits, d_err, h, w, quality);
-    return hipGetLastError();
-}
-
-// Per-frame epilogue of a batch: stream length in bytes and the 16-byte header (make_header, codec.py:102-114).
-__global__ void frame_finish_kernel(const uint32_t *__restrict__ nbits, const unsigned long long *__restrict__ bitoff,
-                                    unsigned long long blocks_per_frame, int nframes, int h, int w, int quality,
-                                    unsigned char *__restrict__ out, unsigned long long out_frame_stride,
-                                    unsigned long long *__restrict__ lens) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
-    const unsigned long long first = (unsigned long long)f * blocks_per_frame, last = first + blocks_per_frame - 1;
-    const unsigned long long bits = bitoff[last] + nbits[last] - bitoff[first];
-    lens[f] = 16ull + (bits + 7ull) / 8ull;
-    uint32_t *hdr = reinterpret_cast<uint32_t *>(out + (unsigned long long)f * out_frame_stride);
-    hdr[0] = (uint32_t)h; // struct.pack("III") little-endian == native order here
-    hdr[1] = (uint32_t)w;
-    hdr[2] = (uint32_t)quality;
-    hdr[3] = 0u;
-}
-
-hipError_t entropy_gpu_finish_frames(const uint32_t *d_nbits, const unsigned long long *d_bitoff, size_t blocks_per_frame,
-                                     int nframes, int h, int w, int quality, void *d_out, size_t out_frame_stride,
-                                     unsigned long long *d_lens, hipStream_t stream) {
-    hipLaunchKernelGGL(frame_finish_kernel, dim3((nframes + 63) / 64), dim3(64), 0, stream, d_nbits, d_bitoff,
-                       (unsigned long long)blocks_per_frame, nframes, h, w, quality, (unsigned char *)d_out,
-                       (unsigned long long)out_frame_stride, d_lens);
     return hipGetLastError();
 }
 
