@@ -872,8 +872,8 @@ __device__ __forceinline__ void wave_redo_block(const uint8_t *px /* 64 pixels, 
 
 // OPT: A/B switches of the experiment library (bit 0: fused quantiser, bit 1: tripped blocks sit out the strip's store);
 // the product is built with all of them on.
-template <int ABL, int ST = 0, int LD = 0, int OPT = 15>
-__global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArgs a) {
+template <int ABL, int ST = 0, int LD = 0, int OPT = 15, int OCC = 6>
+__global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) unsigned char cst_blk[kStripBlkBytes]; // constants, shared by the workgroup
@@ -1135,19 +1135,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_strip_kernel(DctqArg
                     wave_lds_fence();
                     const uint2 rowv = pb[lane]; // row i of block b
                     wave_lds_fence();
-                    uint32_t lo = rowv.x, hi = rowv.y;
-                    transpose8x8_bytes(lo, hi, i); // -> pixel column i
-                    RationalConsts KR;
-                    KR.div0 = cst_rat[(i >> 2) * 2];
-                    KR.div4 = cst_rat[(i >> 2) * 2 + 1];
-                    KR.rdiv0 = cst_rat[4 + (i >> 2) * 2];
-                    KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
-                    int r0, r4;
-                    special_block(lo, hi, ldsT, b, i, KR, r0, r4);
-                    if ((i & 3) == 0) { // lane i = 0: (0,0) and (0,4) at scan positions 0, 14; lane i = 4: (4,0), (4,4) at 10, 39
-                        *zz_ptr(i ? 20u : 0u) = (int16_t)r0;
-                        *zz_ptr(i ? 78u : 28u) = (int16_t)r4;
-                    }
+                    // lanes 0..3 of a block: (0,0), (0,4), (4,0), (4,4) at scan positions 0, 14, 10, 39 (no LDS, few registers:
+                    // this branch sits in the loop and must not raise its register count)
+                    const int rq = rational_slim(rowv.x, rowv.y, i, cst_rat);
+                    if (i < 4) *zz_ptr(i == 0 ? 0u : (i == 1 ? 28u : (i == 2 ? 20u : 78u))) = (int16_t)rq;
                     wave_lds_fence();
                     val = *zr;
                     wave_lds_fence();
@@ -2213,7 +2204,7 @@ static Tunables read_tunables() {
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
     t.chunk = geti("TIC_CHUNK", kMaxStripsPerWave); // strips per wave of schedules 1 and 2
     // per-round row weights of the team schedule ("0" disables it)
-    const char *sp = getenv("TIC_SPLIT") ? getenv("TIC_SPLIT") : "10,9,7,4,2";
+    const char *sp = getenv("TIC_SPLIT") ? getenv("TIC_SPLIT") : "16,13,10,7,4,2";
     for (int k = 0; k < 8; k++) t.split[k] = 0;
     for (int k = 0; k < 8 && sp && *sp; k++) {
         t.split[k] = atoi(sp);
@@ -2339,6 +2330,9 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0, 2, 0, 15>, kWavesPerWG * 64, 0) != hipSuccess ||
                 per_cu < 1)
                 per_cu = 4;
+            // 72 VGPRs and 21.4 KiB of LDS allow 7 workgroups per CU; 6 measured best (a seventh lengthens the start ramp by
+            // as much as it hides: profiles/r02_ab_occupancy.txt)
+            if (per_cu > 6) per_cu = 6;
             return cus * per_cu;
         }();
 #ifdef TIC_ABLATION
