@@ -281,29 +281,25 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Kernel 2: hybrid path (the production kernel).
+// Kernel 2: the hybrid path.  The production kernel is dctq_strip_kernel further down; its round-1 predecessor
+// dctq_hybrid_kernel (workgroup-shared post-pass behind a barrier) is kept in the experiment library as the A/B baseline.
 //
 // Persistent waves, each walking its strips (strip = 8 horizontally adjacent blocks) in the order the launcher chose:
 // team schedule when the grid fits the chip at once, chunked schedule for larger grids (launch_dctq).
-// Main loop, per strip (unrolled x3, pixel registers rotate by name; 96 VGPRs, 5 waves per SIMD):
+// Main loop, per strip (unrolled x3, pixel registers rotate by name):
 //   load   : lane 8*r + b reads the 8 bytes of pixel row r of block b -> every 8 lanes read 64 contiguous bytes; inline
 //            assembly + hand-counted vmcnt keep two strips in flight.
 //   pass 1 : float32 AAN along the pixel row held by the lane (no cross-lane traffic); the level shift is folded
 //            into output 0 (row sum - 1024, an exact integer).
 //   xpose  : 8x8 dword transpose per block through wave-private LDS (conflict-free slot layout); lane 8*b + v then
 //            holds column v.
-//   pass 2 : float32 AAN down that column; quantise by t = Z*mul with the magic-number rounding trick; the guard test is
-//            max |t - rint(t)| per lane against two per-column thresholds.
+//   pass 2 : float32 AAN down that column; quantise with the magic-number rounding trick; the guard test is the largest
+//            distance to the rounded value per lane against two per-column thresholds.
 //   store  : int16 results scattered to zig-zag order in LDS, read back 16 B per lane, 1 KiB contiguous per wave.
-//   trips  : blocks of a strip in which a lane tripped its guard band are recorded in a wave-private LDS list, their
-//            pixels stashed.
-// After the loop the workgroup shares the recorded blocks: blocks whose only trips are exact ties of the four rational
-// coefficients (~2 % of blocks) get those four values from the exact float64 sub-path; blocks with any other trip
-// (~0.3 % at q=50) are redone on the float64 second level / exact path.  Keeping this out of the loop keeps the loop's
-// register footprint small.
+//   trips  : blocks of a strip in which a lane tripped its guard band are settled after the loop (round 1: by the
+//            workgroup, from LDS lists; round 2: by the wave itself, from its batch - see dctq_strip_kernel).
 // Template parameter ABL: 0 = production; every other value is a timing-only build whose output is wrong by
-// construction (tools/ablate.py): 1 no arithmetic, 2 no LDS, 6 neither, 3 no post-pass, 4/5/7 parts of the post-pass,
-// 8 in-kernel stamps, 9/10/11 no memory traffic (all / without LDS / without arithmetic).
+// construction (experiment library only).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
 constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
@@ -796,11 +792,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
 //     for what the second level cannot decide; results patch the 128-byte images in LDS, which then leave with 16-byte
 //     stores.  Constants of the pass sit in wave-private LDS (filled behind the same counted wait as the loop's own).
 //   * a batch that would overflow (tie-dense content): if the strip's trips are rational ties only, the wave runs the
-//     exact sub-path for the whole strip right there, before its store; otherwise the strip's bit is set in a per-wave
-//     mask and the strip is redone in the exact operation order after the loop.
-// Measured against the alternatives on a 4096^2 frame (profiles/r02_*): workgroup-shared post-pass behind a barrier
-// (round 1) +2.0 us over the loop; settling every tripped strip inside the loop +2.9 us (a wave with four tripped
-// strips ends 2 us after its neighbours: static schedule, dependent float64 chains); this batch pass +0.x us.
+//     exact sub-path for the whole strip right there, before its store (rational_slim: this branch sits in the loop and
+//     set the kernel's register count - 88 VGPRs - while it used special_block); otherwise the strip's bit is set in a
+//     per-wave mask and the strip is redone in the exact operation order after the loop.
+// Measured against the alternatives on a 4096^2 frame (profiles/r02_ablate.txt): workgroup-shared
+// post-pass behind a barrier (round 1) +2.0 us over the loop; settling every tripped strip inside the loop +2.9 us (a wave
+// with four tripped strips ends 2 us after its neighbours: static schedule, dependent float64 chains); this batch pass
+// +0.9 us.  Resources: 72 VGPRs, 21.4 KiB of LDS per workgroup, six workgroups per CU (OCC).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxStripsPerWave2 = 64;                 // one bit per strip of a wave's walk in the exact-redo mask
 constexpr int kBatch = 8;                              // entries of the wave's batch
