@@ -226,17 +226,17 @@ __global__ __launch_bounds__(1024) void entropy_pack_kernel(const int16_t *__res
 #pragma unroll
     for (int i = 0; i < (kStageWords + 63) / 64; i++)
         if (i * 64 + lane < kStageWords) image[i * 64 + lane] = 0u;
-    __syncthreads();
-    // one workgroup per (frame, group of kGroup partitions); a wave per partition = 8 blocks
+    // one workgroup per (frame, group of kGroup partitions); a wave per partition = 8 blocks.  The coefficient load and the
+    // zero-run scan need no table: they run in front of the barrier that publishes the tables, not behind it.
     const unsigned long long frame = blockIdx.x / groups_per_frame, g = blockIdx.x - frame * groups_per_frame;
     const unsigned long long pif = g * (unsigned long long)kGroup + (unsigned long long)wave;
     const unsigned long long part = frame * parts_per_frame + pif;
+    const bool active = pif < parts_per_frame;
     uint32_t wave_bits = 0;
-    if (pif < parts_per_frame) {
     const unsigned long long first_in_frame = pif * 8ull;
     const unsigned long long bif = first_in_frame + (unsigned long long)(lane >> 3); // block index inside the frame
     const int k = lane & 7;
-    const bool valid = bif < blocks_per_frame;
+    const bool valid = active && bif < blocks_per_frame;
     const unsigned long long frame_first = frame * blocks_per_frame;
     const unsigned long long blk = frame_first + (valid ? bif : blocks_per_frame - 1);
     int16_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -272,6 +272,8 @@ __global__ __launch_bounds__(1024) void entropy_pack_kernel(const int16_t *__res
     }
     int carry = __shfl_up(tz, 1, 8);
     if (k == 0) carry = 0;
+    __syncthreads();
+    if (active) {
     // ---- the one walk: symbols -> the lane's private bit string ---------------------------------------------------------
     uint32_t my_bits = 0, last_word = 0;
     if (ABL & 4) {
