@@ -24,6 +24,28 @@
 using namespace tic;
 
 namespace {
+#ifdef TIC_ABLATION // phase times of the batch pipeline's host thread (tools/prof_batch.py)
+struct BatchTrace { // (phases 0,1,5 belong to the submitting thread, 2,3,4 to the finishing thread)
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static std::chrono::steady_clock::time_point &t0() {
+        static thread_local std::chrono::steady_clock::time_point v;
+        return v;
+    }
+    void start() { t0() = std::chrono::steady_clock::now(); }
+    void stop(int k) { t[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0()).count(); }
+};
+static BatchTrace g_bt;
+#define BT_START() g_bt.start()
+#define BT_STOP(K) g_bt.stop(K)
+extern "C" void tic_debug_batch_trace(double *out8, int reset) {
+    for (int k = 0; k < 8; k++) out8[k] = g_bt.t[k];
+    if (reset) g_bt = BatchTrace();
+}
+#else
+#define BT_START() ((void)0)
+#define BT_STOP(K) ((void)0)
+#endif
+
 constexpr int kChunk = 16;
 struct Slot {
     uint8_t *pin_in = nullptr;
@@ -40,6 +62,7 @@ struct Slot {
     void *d_streams = nullptr;                                // finished streams, one compress_bound() apart
     int first = 0, count = 0; // frames [first, first+count) are in flight in this slot
     int remaining = 0;        // frames of the chunk not yet consumed; 0 = slot free
+    size_t rb_row = 0;        // row pitch of the streams read back into pin_out (0: they went straight to the caller)
 };
 } // namespace
 
@@ -47,6 +70,7 @@ struct tic_ctx {
     int device = -1;
     hipStream_t stream = nullptr;     // all single-frame work
     hipStream_t bstream[2] = {nullptr, nullptr}; // batch pipeline streams
+    hipStream_t rstream = nullptr;               // read-back of finished streams: never queued behind a later chunk's work
     DctqConsts *d_consts = nullptr;   // [100], index = quality
     unsigned long long *d_fallback = nullptr;
     void *d_dbg = nullptr; // diagnostic stamp buffer (tic_debug_stamps)
@@ -128,6 +152,7 @@ void tic_destroy(tic_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
     for (auto &s : ctx->bstream)
         if (s) {
             (void)hipStreamSynchronize(s);
@@ -182,6 +207,7 @@ static int create_impl(tic_ctx *ctx, int device) {
     CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&ctx->bstream[0], hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&ctx->bstream[1], hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&ctx->rstream, hipStreamNonBlocking));
     CK(hipEventCreate(&ctx->ev0));
     CK(hipEventCreate(&ctx->ev1));
     std::vector<DctqConsts> all(100);
@@ -688,7 +714,7 @@ static void stage_chunk(uint8_t *pin, size_t img_bytes, size_t pitch, const uint
 }
 
 static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
-    const int S = 3;
+    const int S = 4; // staging, device, read-back, hand-out: one chunk each
     const size_t nblk = num_blocks(h, w);
     const size_t pitch = batch_pitch(w);
     const size_t img_bytes = pitch * (size_t)h, coef_bytes = nblk * 128;
@@ -818,7 +844,10 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
             s.remaining = cnt;
         }
         hipStream_t st = ctx->bstream[c & 1];
+        BT_START();
         stage_chunk(s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w); // into pinned memory
+        BT_STOP(0);
+        BT_START();
         hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
@@ -830,6 +859,7 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
         }
         if (e == hipSuccess && need_d2h) e = hipMemcpyAsync(s.pin_out, s.d_coef, coef_bytes * cnt, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(s.done, st);
+        BT_STOP(1);
         if (e != hipSuccess) {
             result = set_err(ctx, TIC_E_HIP, "batch enqueue failed at frame %d: %s", first, hipGetErrorString(e));
             std::lock_guard<std::mutex> lk(mu);
@@ -881,45 +911,61 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     std::vector<Slot> &slots = ctx->bslots;
     const int S = (int)slots.size();
     int result = TIC_OK;
-    // finishing a chunk: wait for its lengths, then read back exactly the bytes of each stream
-    auto finish = [&](Slot &s, hipStream_t st) -> int {
+    // finishing a chunk, part 1: wait for its lengths, then read its streams back into pinned memory
+    auto read_back = [&](Slot &s, hipStream_t st) -> int {
         if (s.count == 0) return TIC_OK;
-        if (hipEventSynchronize(s.done) != hipSuccess) return set_err(ctx, TIC_E_HIP, "batch chunk failed");
+        BT_START();
+        const hipError_t ev = hipEventSynchronize(s.done);
+        BT_STOP(2);
+        if (ev != hipSuccess) return set_err(ctx, TIC_E_HIP, "batch chunk failed");
         if (*s.h_err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
         if (*s.h_err == 3) return set_err(ctx, TIC_E_HIP, "device entropy stage: look-back gave up (internal error)");
         if (*s.h_err) return set_err(ctx, TIC_E_SPACE, "device entropy stage: stream buffer too small");
-        // The streams come back packed into the slot's pinned buffer (asynchronous DMA; a copy straight into the caller's
-        // pageable buffers is staged by the runtime, ~0.15 ms each) and are handed out by a few threads.
-        size_t total = 0;
+        // The streams come back into the slot's pinned buffer (asynchronous DMA; a copy straight into the caller's pageable
+        // buffers is staged by the runtime, ~0.15 ms each) and are handed out by a few threads.
+        size_t maxlen = 0;
         for (int k = 0; k < s.count; k++) {
             const size_t len = (size_t)s.h_lens[k];
             const int f = s.first + k;
             if (len > caps[f]) return set_err(ctx, TIC_E_SPACE, "output buffer of frame %d too small (%zu bytes needed)", f, len);
             out_lens[f] = len;
-            total += align_up(len, 16);
+            if (len > maxlen) maxlen = len;
         }
+        // ONE strided copy brings the head of every frame's stream buffer - as many bytes as the longest stream has - into
+        // the slot's pinned buffer (16 separate copies of ~0.9 MB cost ~45 us each, 2.5 x their transfer time); frames of one
+        // batch compress to similar sizes, so little more than the streams themselves crosses PCIe.
         const size_t pin_cap = coef_bytes * (size_t)chunk; // size of pin_out (ensure_batch_slots)
-        const bool packed = total <= pin_cap;
-        size_t off = 0;
-        for (int k = 0; k < s.count; k++) {
-            const size_t len = (size_t)s.h_lens[k];
-            void *dst = packed ? (void *)((char *)s.pin_out + off) : (void *)outs[s.first + k];
-            hipError_t e = hipMemcpyAsync(dst, (char *)s.d_streams + (size_t)k * bound, len, hipMemcpyDeviceToHost, st);
+        const size_t row = align_up(maxlen, 256);
+        const bool packed = row * (size_t)s.count <= pin_cap;
+        BT_START();
+        if (packed) {
+            hipError_t e = hipMemcpy2DAsync(s.pin_out, row, s.d_streams, bound, maxlen, (size_t)s.count, hipMemcpyDeviceToHost, st);
             if (e != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed: %s", hipGetErrorString(e));
-            off += align_up(len, 16);
+        } else {
+            for (int k = 0; k < s.count; k++) {
+                hipError_t e = hipMemcpyAsync(outs[s.first + k], (char *)s.d_streams + (size_t)k * bound, (size_t)s.h_lens[k],
+                                              hipMemcpyDeviceToHost, st);
+                if (e != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed: %s", hipGetErrorString(e));
+            }
         }
-        if (hipStreamSynchronize(st) != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed");
+        const hipError_t rb = hipStreamSynchronize(st);
+        BT_STOP(3);
+        if (rb != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed");
+        s.rb_row = packed ? row : 0;
+        return TIC_OK;
+    };
+    // part 2: out of pinned memory into the caller's buffers, by a few threads
+    auto hand_out_chunk = [&](Slot &s) -> int {
+        if (s.count == 0) return TIC_OK;
+        const size_t row = s.rb_row;
+        const bool packed = row != 0;
+        BT_START();
         if (packed) {
             const int cnt = s.count, first = s.first;
             const char *src = (const char *)s.pin_out;
             const unsigned long long *lens = s.h_lens;
             auto hand_out = [=](int t, int T) {
-                size_t o = 0;
-                for (int k = 0; k < cnt; k++) {
-                    const size_t len = (size_t)lens[k];
-                    if (k % T == t) memcpy(outs[first + k], src + o, len);
-                    o += align_up(len, 16);
-                }
+                for (int k = t; k < cnt; k += T) memcpy(outs[first + k], src + (size_t)k * row, (size_t)lens[k]);
             };
             const int T = cnt < 4 ? 1 : 4;
             if (T == 1) {
@@ -930,20 +976,92 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
                 for (auto &x : th) x.join();
             }
         }
+        BT_STOP(4);
         s.count = 0;
         return TIC_OK;
     };
     for (auto &sl : slots) sl.count = 0;
+    // Three host threads, four slots: this thread stages chunk c into pinned memory and enqueues it (H2D, kernels, lengths),
+    // a second waits for each chunk in turn and reads its streams back into pinned memory, a third hands them out to the
+    // caller's buffers.  The device always has work queued while the threads copy, and a slot is staged into again only after
+    // the third thread has released it.
+    // (History, 256 x 1080p host -> host: one thread that finished chunk c - 3 on the stream already holding chunk c - 1,
+    // then staged chunk c: 28 ms, the device idle during the host copies; read-back on its own stream after enqueueing
+    // chunk c: 23.5 ms; one strided read-back copy per chunk instead of 16: 21.5 ms; read-back + hand-out on a second
+    // thread: 15 ms; this: see DESIGN.md section 6.)
+    std::mutex mu;
+    std::condition_variable cv_read, cv_hand, cv_free;
+    std::deque<int> q_read, q_hand; // slots to read back / to hand out, in submission order
+    std::vector<char> busy(S, 0);   // slot submitted and not yet released by the hand-out thread
+    bool stop_read = false, stop_hand = false;
+    int fin_result = TIC_OK;
+    std::thread reader([&]() {
+        (void)hipSetDevice(ctx->device);
+        for (;;) {
+            int k;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv_read.wait(l, [&] { return stop_read || !q_read.empty(); });
+                if (q_read.empty()) break;
+                k = q_read.front();
+                q_read.pop_front();
+            }
+            const int r = read_back(slots[k], ctx->rstream);
+            {
+                std::lock_guard<std::mutex> l(mu);
+                if (r != TIC_OK) {
+                    if (fin_result == TIC_OK) fin_result = r;
+                    slots[k].count = 0; // nothing to hand out
+                }
+                q_hand.push_back(k);
+            }
+            cv_hand.notify_one();
+        }
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop_hand = true;
+        }
+        cv_hand.notify_one();
+    });
+    std::thread hander([&]() {
+        for (;;) {
+            int k;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv_hand.wait(l, [&] { return stop_hand || !q_hand.empty(); });
+                if (q_hand.empty()) return;
+                k = q_hand.front();
+                q_hand.pop_front();
+            }
+            const int r = hand_out_chunk(slots[k]);
+            {
+                std::lock_guard<std::mutex> l(mu);
+                if (r != TIC_OK && fin_result == TIC_OK) fin_result = r;
+                slots[k].count = 0;
+                busy[k] = 0;
+            }
+            cv_free.notify_all();
+        }
+    });
     int c = 0;
     for (int first = 0; first < n && result == TIC_OK; first += chunk, c++) {
         const int cnt = n - first < chunk ? n - first : chunk;
-        Slot &s = slots[c % S];
+        const int si = c % S;
+        Slot &s = slots[si];
         hipStream_t st = ctx->bstream[c & 1];
-        if (s.count) result = finish(s, ctx->bstream[(c - S) & 1]); // slot still holds chunk c - S
-        if (result != TIC_OK) break;
+        {
+            BT_START();
+            std::unique_lock<std::mutex> l(mu);
+            cv_free.wait(l, [&] { return !busy[si]; });
+            BT_STOP(5);
+            if (fin_result != TIC_OK) break;
+        }
         s.first = first;
         s.count = cnt;
+        BT_START();
         stage_chunk(s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w); // into pinned memory
+        BT_STOP(0);
+        BT_START();
         hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
@@ -955,25 +1073,36 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         }
         const int par = s.parity;
         s.parity ^= 1;
-        if (e == hipSuccess) // entropy stage of the whole chunk: one pass + a finishing kernel (headers, lengths); no zero fill
+        if (e == hipSuccess) // entropy stage of the whole chunk: pack + place (headers, lengths); no zero fill
             e = entropy_gpu_fused((const int16_t *)s.d_coef, nblk, cnt, ctx->d_huff, s.d_work, s.work_bytes, s.d_streams, bound,
                                   (bound - 16) / 4, h, w, quality, s.d_lens, nullptr, s.d_err + par, s.d_err + (par ^ 1), st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_lens, s.d_lens, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err + par, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(s.done, st);
+        BT_STOP(1);
         if (e != hipSuccess) {
             result = set_err(ctx, TIC_E_HIP, "batch enqueue failed at frame %d: %s", first, hipGetErrorString(e));
             s.count = 0;
+            break;
         }
+        {
+            std::lock_guard<std::mutex> l(mu);
+            busy[si] = 1;
+            q_read.push_back(si);
+        }
+        cv_read.notify_one();
     }
-    // drain in submission order
-    for (int k = c - S < 0 ? 0 : c - S; k < c; k++) {
-        Slot &s = slots[k % S];
-        int r = finish(s, ctx->bstream[k & 1]);
-        if (result == TIC_OK) result = r;
+    {
+        std::lock_guard<std::mutex> l(mu);
+        stop_read = true;
     }
+    cv_read.notify_one();
+    reader.join(); // (each drains its queue first)
+    hander.join();
+    if (result == TIC_OK) result = fin_result;
     (void)hipStreamSynchronize(ctx->bstream[0]);
     (void)hipStreamSynchronize(ctx->bstream[1]);
+    (void)hipStreamSynchronize(ctx->rstream);
     for (auto &sl : slots) sl.count = 0;
     return result;
 }
