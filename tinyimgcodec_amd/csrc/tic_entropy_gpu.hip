@@ -130,7 +130,7 @@ __device__ __forceinline__ int walk_lane(const int16_t c[8], int k, int carry_ru
 constexpr int kWaveImageWords = 432; // 8 blocks x at most 64 x 27 bits, plus word alignment: 13,855 bits
 constexpr int kLaneWords = 8;                    // a lane emits at most 3 ZRL + 8 x 26 + EOB = 245 bits
 constexpr int kStageWords = kWaveImageWords + 2; // staging slot of a partition (8 blocks), 32-bit words
-constexpr int kGroup = 16;                       // partitions per workgroup of the placing kernel
+constexpr int kGroup = 16;                       // partitions (waves) per workgroup of the packing kernel = per group sum
 
 // Bit sink into the lane's private string (bit 0 = MSB of word 0), branch-free: every symbol rewrites the word under
 // construction in LDS (word i of the lane's string is str[i * 64], so the 64 lanes of a wave hit 64 different banks), a
@@ -208,7 +208,7 @@ __device__ __forceinline__ void walk_pack(const int16_t c[8], int k, int carry_r
 }
 
 template <int ABL> // ABL != 0: timing-only builds (tools/), wrong output
-__global__ __launch_bounds__(1024) void entropy_pack_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
+__global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
                                                             unsigned long long blocks_per_frame, unsigned long long parts_per_frame,
                                                             unsigned long long groups_per_frame, uint32_t *__restrict__ stage,
                                                             uint32_t *__restrict__ nbits, uint32_t *__restrict__ gsum,
@@ -581,7 +581,7 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
 #ifdef TIC_ABLATION
     static const int abl = getenv("TIC_ENT_ABL") ? atoi(getenv("TIC_ENT_ABL")) : 0;
 #define TIC_PACK(A)                                                                                                            \
-    hipLaunchKernelGGL(entropy_pack_kernel<A>, pack_grid, dim3(1024), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, \
+    hipLaunchKernelGGL(entropy_pack_kernel<A>, pack_grid, dim3(kGroup * 64), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, \
                        (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err)
     switch (abl) {
     case 1: TIC_PACK(1); break;
@@ -595,7 +595,7 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
     }
 #undef TIC_PACK
 #else
-    hipLaunchKernelGGL(entropy_pack_kernel<0>, pack_grid, dim3(1024), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame,
+    hipLaunchKernelGGL(entropy_pack_kernel<0>, pack_grid, dim3(kGroup * 64), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame,
                        (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err);
 #endif
     hipError_t e = hipGetLastError();
