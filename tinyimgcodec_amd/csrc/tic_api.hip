@@ -428,12 +428,18 @@ int tic_dctq_dev_timed_rotating(tic_ctx *ctx, const void *const *d_images, void 
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!ms_total || iters < 1 || npairs < 1 || !d_images || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
+#ifndef TIC_ABLATION
     if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
         return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+#endif
     for (int k = 0; k < npairs; k++)
         if (!d_images[k] || !d_coeffs_zz[k]) return set_err(ctx, TIC_E_ARG, "null device pointer in pair %d", k);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+#ifdef TIC_ABLATION
+    const int v = variant >= 10 ? variant : (variant == TIC_KERNEL_EXACT ? 1 : 2); // experiment variants pass through
+#else
     const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
+#endif
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++) {
         DctqArgs a = make_args(ctx, d_images[i % npairs], h, w, row_stride, quality, d_coeffs_zz[i % npairs]);

@@ -870,7 +870,7 @@ __device__ __forceinline__ void wave_redo_block(const uint8_t *px /* 64 pixels, 
 
 // OPT: A/B switches of the experiment library (bit 0: fused quantiser, bit 1: tripped blocks sit out the strip's store);
 // the product is built with all of them on.
-template <int ABL, int ST = 0, int LD = 0, int OPT = 15, int OCC = 6>
+template <int ABL, int ST = 0, int LD = 0, int OPT = 15, int OCC = 6, int PF = 2>
 __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
@@ -999,8 +999,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
             if (n_my < 0) a.out[lane] = (int16_t)((float)c_fill.x + (float)in_off + (float)oblk);
             return;
         }
-        unsigned long long p0, p1, p2;
-        uint32_t ob0, ob1, ob2;
+        unsigned long long p0, p1, p2, p3 = 0;
+        uint32_t ob0, ob1, ob2, ob3 = 0;
         TIC_LOAD(p0, ob0);
         if (!(OPT & 16)) TIC_LOAD(p1, ob1);
         // the constant piece is older than the pixel loads: it has landed when only those are in flight
@@ -1013,6 +1013,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         // with both loads up front the first strip of the CU's last wave queued behind 39 others (first data 1,400 cycles
         // after entry for the first workgroup of a CU, 5,000 for the fifth).
         if (OPT & 16) TIC_LOAD(p1, ob1);
+        if (PF == 3) TIC_LOAD(p2, ob2); // experiment: three strips ahead
         m0 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32);
         m1 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32 + 16);
         thr = *reinterpret_cast<const f32x2 *>(cst_blk + 256 + i * 8);
@@ -1150,6 +1151,25 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         // Two strips ahead: strip j is consumed after L(j+2) is issued; in steady state the instructions younger than
         // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.  (A rare branch issues at most
         // the same single store per strip.)
+        if (PF == 3) { // experiment (variant 610): L(j+3) is issued before strip j is consumed; steady state vmcnt(6)
+            do {
+                if (left == 0) break;
+                TIC_LOAD(p3, ob3); TIC_WAIT(p0, 3); process(p0, ob0);
+                if (left == 0) break;
+                TIC_LOAD(p0, ob0); TIC_WAIT(p1, 4); process(p1, ob1);
+                if (left == 0) break;
+                TIC_LOAD(p1, ob1); TIC_WAIT(p2, 5); process(p2, ob2);
+                while (left != 0) {
+                    TIC_LOAD(p2, ob2); TIC_WAIT(p3, 6); process(p3, ob3);
+                    if (left == 0) break;
+                    TIC_LOAD(p3, ob3); TIC_WAIT(p0, 6); process(p0, ob0);
+                    if (left == 0) break;
+                    TIC_LOAD(p0, ob0); TIC_WAIT(p1, 6); process(p1, ob1);
+                    if (left == 0) break;
+                    TIC_LOAD(p1, ob1); TIC_WAIT(p2, 6); process(p2, ob2);
+                }
+            } while (0);
+        } else
         do {
             if (left == 0) break;
             TIC_LOAD(p2, ob2); TIC_WAIT(p0, 2);
@@ -1172,7 +1192,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 3] = __builtin_amdgcn_s_memtime(); // loop left
         // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved until
         // only the wave's last store is outstanding
-        asm volatile("s_waitcnt vmcnt(1)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : : "memory");
 #undef TIC_LOAD
 #undef TIC_WAIT
     }
@@ -2470,6 +2490,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         case 507: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 7>), grid2, block, tune.lds_pad, stream, a); break;
         case 515: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 15>), grid2, block, tune.lds_pad, stream, a); break;
         case 531: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 31>), grid2, block, tune.lds_pad, stream, a); break;
+        case 610: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 15, 6, 3>), grid2, block, tune.lds_pad, stream, a); break; // three strips ahead
 #define TIC_POL(S, L)                                                                                                  \
     case 100 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<0, S, L>), grid, block, tune.lds_pad, stream, a); break; \
     case 200 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<6, S, L>), grid, block, tune.lds_pad, stream, a); break; \
