@@ -151,9 +151,14 @@ int tic_parse_header(const uint8_t *data, size_t len, int *h, int *w, int *quali
  * (utils.py:40-45) + clip + truncating uint8 cast + crop.  out: uint8[h*w], cap >= h*w. */
 int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap);
 
-/* decompress() codec.py:167-189 + decode() codec.py:46-70 for default-table streams: host Huffman/RLE decode
- * (huffman.py:36-38,66-98), GPU dequantise + inverse DCT (utils.py:40-45,52) + clip + truncating uint8 cast.
- * out: uint8[h*w]. */
+/* decode()'s scaled_dct branch, codec.py:59-62 (coefficients of the reference's C encoder, header flag 1<<30, codec.py:127-128):
+ * coeffs / ANNSCALES (constants.py:37-51) * 2**exponent, inverse quantiser of quality 50, then as tic_idctq.  exponent = the
+ * stream's quality field, 0..62. */
+int tic_idctq_scaled(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int exponent, uint8_t *out, size_t cap);
+
+/* decompress() codec.py:167-189 + decode() codec.py:46-70 for default-table streams, including those of the reference's C
+ * encoder (header flag 1<<30 -> scaled_dct branch): host Huffman/RLE decode (huffman.py:36-38,66-98), GPU dequantise +
+ * inverse DCT (utils.py:40-45,52) + clip + truncating uint8 cast.  out: uint8[h*w]. */
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap);
 
 /* ---- multi-GPU (the reference has no counterpart: it is single-process, codec.py:133-164 runs one image

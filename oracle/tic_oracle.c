@@ -22,6 +22,14 @@ static const int32_t QTABLE[64] = {
     69, 56, 14, 17, 22,  29,  51,  87,  80, 62, 18, 22, 37,  56,  68,  109, 103, 77, 24, 35, 55, 64,
     81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
 
+/* constants.py:37-51: ANNSCALES = <this integer table> / 2048, the scale the reference's C encoder leaves in its coefficients
+ * (8 * a_u * a_v of the AAN factorisation in 14-bit fixed point); used by decode()'s scaled_dct branch only. */
+static const int32_t ANNSCALES_INT[64] = {
+    16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
+    21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906,  19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
+    16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  12873, 17855, 16819, 15137, 12873, 10114, 6967,  3552,
+    8867,  12299, 11585, 10426, 8867,  6967,  4799,  2446,  4520,  6270,  5906,  5315,  4520,  3552,  2446,  1247};
+
 /* ZIGZAG[k] = natural index (u*8+v) of the k-th coefficient in scan order. */
 static const uint8_t ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -554,8 +562,10 @@ int tico_decompress(const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
     uint32_t flag;
     int rc = tico_parse_header(data, len, &h, &w, &quality, &flag);
     if (rc) return rc;
-    if (flag & ((1u << 31) | (1u << 30))) return TICO_E_STREAM; /* custom-table / scaled_dct streams: not restated */
-    if (quality < 1 || quality > 99) return TICO_E_QUALITY;
+    if (flag & (1u << 31)) return TICO_E_STREAM; /* custom-table streams: not restated (broken in the reference) */
+    /* codec.py:127-128: flag 1<<30 marks a stream of the reference's C encoder; its quality field is an exponent (codec.py:59-62) */
+    const int scaled = (flag & (1u << 30)) != 0;
+    if (scaled ? (quality < 0 || quality > 62) : (quality < 1 || quality > 99)) return TICO_E_QUALITY;
     if ((size_t)h * (size_t)w > cap) return TICO_E_SPACE;
     int bh = (h + 7) / 8, bw = (w + 7) / 8;
     size_t n = (size_t)bh * (size_t)bw;
@@ -600,8 +610,12 @@ int tico_decompress(const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
         memcpy(ac + i * 63, blk, (size_t)m * sizeof(int32_t));
     }
     /* codec.py:46-70 */
-    double div[64];
-    tico_divisors(quality, div);
+    double div[64], ann[64], pow2 = 1.0;
+    tico_divisors(scaled ? 50 : quality, div); /* codec.py:62: quality = 50 on the scaled branch */
+    if (scaled) {
+        for (int k = 0; k < 64; k++) ann[k] = (double)ANNSCALES_INT[k] / 2048.0; /* exact */
+        pow2 = ldexp(1.0, quality);                                              /* 2 ** quality */
+    }
     /* np.cumsum(dc) over all blocks in raster order (codec.py:53) */
     {
         int32_t run_dc = 0;
@@ -614,10 +628,18 @@ int tico_decompress(const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
         for (int bx = 0; bx < bw; bx++) {
             size_t b = (size_t)by * bw + bx;
             double X[64], Y[64];
-            X[0] = (double)dc[b] * div[0];
-            for (int k = 1; k < 64; k++) {
-                int nat = ZIGZAG[k];
-                X[nat] = (double)ac[b * 63 + (k - 1)] * div[nat]; /* utils.py:52 */
+            if (scaled) { /* codec.py:60-61: coeffs / ANNSCALES, then *= 2 ** quality, then the inverse quantiser at quality 50 */
+                X[0] = (((double)dc[b] / ann[0]) * pow2) * div[0];
+                for (int k = 1; k < 64; k++) {
+                    int nat = ZIGZAG[k];
+                    X[nat] = (((double)ac[b * 63 + (k - 1)] / ann[nat]) * pow2) * div[nat];
+                }
+            } else {
+                X[0] = (double)dc[b] * div[0];
+                for (int k = 1; k < 64; k++) {
+                    int nat = ZIGZAG[k];
+                    X[nat] = (double)ac[b * 63 + (k - 1)] * div[nat]; /* utils.py:52 */
+                }
             }
             tico_block_idct(X, Y);
             for (int i = 0; i < 8; i++) {

@@ -622,6 +622,36 @@ def test_wide_pixels_round2(ctx, golden):
         T.encode(img, 37.5, ctx=ctx)
 
 
+def test_scaled_dct_streams_round2(ctx, golden):
+    """decompress() of streams of the reference's C encoder (header flag 1<<30 -> decode()'s scaled_dct branch, codec.py:59-62)
+    and of re-flagged Python streams: pixel-identical to the reference; decode() with scaled_dct=True takes the same path."""
+    import hashlib
+    import struct
+
+    d = golden("scaled_streams")
+
+    def same(name, img):
+        if name + "_img" in d:
+            return np.array_equal(img, d[name + "_img"])
+        return (np.array_equal(img[:32], d[name + "_rows"])
+                and hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == str(d[name + "_sha"]))
+
+    for name in d["names"]:
+        name = str(name)
+        assert same(name, T.decompress(d[name + "_bs"].tobytes())), name
+    # the dict interface: coefficients of a Python stream, handed to decode() as scaled ones
+    img = rand_frame(5, 37, 53)
+    info = T.encode(img, 75)
+    info["scaled_dct"] = True
+    info["quality"] = 2
+    bs = bytearray(T.compress(img, 75))
+    bs[:16] = struct.pack("IIII", 37, 53, 2, 1 << 30)
+    assert np.array_equal(T.decode(info), T.decompress(bytes(bs)))
+    info["quality"] = 63
+    with pytest.raises(ValueError):
+        T.decode(info)
+
+
 def test_truncated_streams_round2(ctx, golden):
     """decompress() on truncated / corrupted streams returns what the reference returns (it swallows a block's exception,
     codec.py:178-186), including blocks that run to more than a thousand symbols without an end-of-block."""

@@ -193,6 +193,22 @@ def test_truncated_streams_round2(oracle, golden):
         assert np.array_equal(got, d[name + "_out"]), name
 
 
+def _same_as_fixture(d, name, img):
+    if name + "_img" in d:
+        return np.array_equal(img, d[name + "_img"])
+    return (tuple(img.shape) == tuple(d[name + "_shape"]) and np.array_equal(img[:32], d[name + "_rows"])
+            and hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == str(d[name + "_sha"]))
+
+
+def test_scaled_dct_streams_round2(oracle, golden):
+    """decode()'s scaled_dct branch (codec.py:59-62, 127-128): streams of the reference's C encoder at its four qualities and
+    Python streams re-flagged with small exponents, decoded by the reference (tests/golden/gen/make_goldens_scaled.py)."""
+    d = golden("scaled_streams")
+    for name in d["names"]:
+        name = str(name)
+        assert _same_as_fixture(d, name, oracle.decompress(d[name + "_bs"].tobytes())), name
+
+
 def test_config4_stream_digests_round2(oracle):
     """BASELINE config 4, frames 1234..1237 (1920x1080): stream sizes and digests recorded from the reference."""
     import json

@@ -19,7 +19,8 @@ Documented differences from the reference (all outside its working domain):
   * auto_generate_huffman_table=True raises NotImplementedError (that path is broken in the reference:
     the table flag is written big-endian and read little-endian, codec.py:111/119);
   * quality > 100 raises ValueError (the reference produces streams with negative divisors);
-  * streams carrying the custom-table or scaled_dct flag are rejected by decompress().
+  * streams carrying the custom-table flag are rejected by decompress(); scaled_dct streams (the reference's C encoder) are
+    decoded for exponents 0..62 (the C encoder writes 0..3).
 """
 import ctypes as C
 import struct
@@ -225,8 +226,7 @@ def decode(data, ctx=None):
     """decode() of the reference: dict with height, width, quality, scaled_dct, dc (DPCM'd), ac."""
     ctx = _ctx(ctx)
     height, width, quality = data["height"], data["width"], data["quality"]
-    if data["scaled_dct"]:
-        raise NotImplementedError("scaled_dct (C encoder) streams are not supported")
+    scaled = bool(data["scaled_dct"])
     dc = np.cumsum(np.asarray(data["dc"], dtype=np.int64))  # codec.py:53
     ac = np.asarray(data["ac"])
     n = N.load().tic_num_blocks(int(height), int(width))
@@ -238,6 +238,12 @@ def decode(data, ctx=None):
     zz[:, 0] = dc
     zz[:, 1:] = ac
     out = np.zeros((int(height), int(width)), dtype=np.uint8)
+    if scaled:  # codec.py:59-62: the quality field is an exponent, the inverse quantiser runs at quality 50
+        if int(quality) != quality or not (0 <= int(quality) <= 62):
+            raise ValueError("scaled_dct exponent outside 0..62")
+        if n:
+            ctx.check(N.load().tic_idctq_scaled(ctx.handle, zz.ctypes.data, int(height), int(width), int(quality), out.ctypes.data, out.size))
+        return out
     q = _check_quality(quality, packs_header=False)
     if n:
         ctx.check(N.load().tic_idctq(ctx.handle, zz.ctypes.data, int(height), int(width), q, out.ctypes.data, out.size))

@@ -1125,10 +1125,12 @@ int tic_dctq_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int
 }
 
 // ---- decode ---------------------------------------------------------------------------------------------
-int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap) {
+// scaled_exp < 0: decode() proper; >= 0: its scaled_dct branch with 2 ** scaled_exp (codec.py:59-62)
+static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, int scaled_exp, uint8_t *out, size_t cap) {
     if (!ctx) return TIC_E_ARG;
     if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size");
-    if (quality < 1 || quality > 99) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
+    if (scaled_exp < 0 && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
+    if (scaled_exp > 62) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d outside 0..62", scaled_exp);
     const size_t n = num_blocks(h, w);
     if (n == 0) return TIC_OK;
     if (!coeffs_zz) return set_err(ctx, TIC_E_ARG, "null coefficient pointer");
@@ -1148,12 +1150,23 @@ int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality,
     a.tiles_x = (a.bw + 7) / 8;
     a.ntiles = ((h + 7) / 8) * a.tiles_x;
     a.aligned8 = 1;
-    a.consts = ctx->d_consts + quality;
+    a.consts = ctx->d_consts + (scaled_exp >= 0 ? 50 : quality); // codec.py:62: quality = 50 on the scaled branch
+    a.scaled = scaled_exp >= 0;
+    a.pow2 = scaled_exp >= 0 ? ldexp(1.0, scaled_exp) : 1.0;
     HIPCHK(ctx, launch_idct(a, ctx->stream));
     HIPCHK(ctx, hipMemcpy2DAsync(out, (size_t)w, ctx->d_img, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost,
                                  ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return TIC_OK;
+}
+
+int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap) {
+    return idctq_impl(ctx, coeffs_zz, h, w, quality, -1, out, cap);
+}
+
+int tic_idctq_scaled(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int exponent, uint8_t *out, size_t cap) {
+    if (ctx && exponent < 0) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d outside 0..62", exponent);
+    return idctq_impl(ctx, coeffs_zz, h, w, 50, exponent, out, cap);
 }
 
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
@@ -1163,15 +1176,16 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
     if (parse_header(data, len, &h, &w, &quality, &flag) != TIC_OK)
         return set_err(ctx, TIC_E_STREAM, "stream shorter than the 16-byte header");
     if (flag & (1u << 31)) return set_err(ctx, TIC_E_STREAM, "streams with an embedded Huffman table are not supported");
-    if (flag & (1u << 30)) return set_err(ctx, TIC_E_STREAM, "scaled_dct (C encoder) streams are not supported");
+    const bool scaled = (flag & (1u << 30)) != 0; // a stream of the reference's C encoder (codec.py:127-128): quality = exponent
     if (h < 0 || w < 0) return set_err(ctx, TIC_E_STREAM, "bad geometry in header");
-    if (quality < 1 || quality > 99) return set_err(ctx, TIC_E_QUALITY, "quality %d in header outside 1..99", quality);
+    if (scaled && (quality < 0 || quality > 62)) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d in header outside 0..62", quality);
+    if (!scaled && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "quality %d in header outside 1..99", quality);
     const size_t n = num_blocks(h, w);
     if (n == 0) return TIC_OK;
     if (!out || (size_t)h * (size_t)w > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
     std::vector<int16_t> zz(n * 64);
     entropy_decode(data, len, h, w, zz.data());
-    return tic_idctq(ctx, zz.data(), h, w, quality, out, cap);
+    return idctq_impl(ctx, zz.data(), h, w, scaled ? 50 : quality, scaled ? quality : -1, out, cap);
 }
 
 // ---- self test hook (used by tests/ only; not part of the drop-in surface) --------------------------------

@@ -73,6 +73,8 @@ struct IdctArgs {
     int bw, tiles_x, ntiles;
     int aligned8;
     const DctqConsts *consts;
+    int scaled = 0;    // decode()'s scaled_dct branch (codec.py:59-62): coefficients / ANNSCALES * pow2, consts = quality 50
+    double pow2 = 1.0; // 2 ** (quality field of the stream)
 };
 
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream);

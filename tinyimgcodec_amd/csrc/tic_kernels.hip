@@ -2124,6 +2124,14 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_wide_kernel(WideA
 // Kernel 3: decode side - dequantise (utils.py:52), inverse DCT (utils.py:40-45, exact order), +128, clip,
 // truncating cast (codec.py:68-70), crop.  Input: int16 [N][64] zig-zag, DC already integrated (np.cumsum).
 // ---------------------------------------------------------------------------------------------------------
+// constants.py:37-51: ANNSCALES = this integer table / 2048 - the scale the reference's C encoder leaves in its coefficients
+// (8 * a_u * a_v of the AAN factorisation, 14-bit fixed point).  decode()'s scaled_dct branch divides by it.
+__constant__ int kAnnScalesInt[64] = {
+    16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
+    21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906,  19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
+    16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  12873, 17855, 16819, 15137, 12873, 10114, 6967,  3552,
+    8867,  12299, 11585, 10426, 8867,  6967,  4799,  2446,  4520,  6270,  5906,  5315,  4520,  3552,  2446,  1247};
+
 __global__ __launch_bounds__(kWavesPerWG * 64) void idct_kernel(IdctArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerWG][kLdsWaveBytes / 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2152,7 +2160,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void idct_kernel(IdctArgs a) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         int16_t cv = *reinterpret_cast<const int16_t *>(blk + (u * 8 + i) * 2);
-        c[u] = (double)cv * C->div[u * 8 + i]; // coeffs * (Q*factor/100)
+        if (a.scaled) // codec.py:60-62: (coeffs / ANNSCALES) * 2**quality, then the inverse quantiser of quality 50: three roundings
+            c[u] = (((double)cv / ((double)kAnnScalesInt[u * 8 + i] / 2048.0)) * a.pow2) * C->div[u * 8 + i];
+        else
+            c[u] = (double)cv * C->div[u * 8 + i]; // coeffs * (Q*factor/100)
     }
     wave_lds_fence();
     idct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -2
