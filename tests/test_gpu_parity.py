@@ -622,6 +622,27 @@ def test_wide_pixels_round2(ctx, golden):
         T.encode(img, 37.5, ctx=ctx)
 
 
+def test_rccl_single_rank_smoke(ctx, monkeypatch, tmp_path):
+    """The RCCL leg of the C-ABI (tic_comm.hip) with ONE rank forced through the library: dlopen of librccl, unique id through
+    the rendezvous file, ncclCommInitRank on the context's device, all-gather and all-reduce on its stream.  (Two ranks need
+    two GPUs: that run is the driver's; the two-process flow is rehearsed with gloo in test_config4_rehearsal_two_ranks_on_one_gpu.)"""
+    from tinyimgcodec_amd.distributed import RcclComm, gather_sizes
+
+    monkeypatch.setenv("TIC_COMM_FORCE_RCCL", "1")
+    comm = RcclComm(ctx, rank=0, world=1, rendezvous_path=str(tmp_path / "rdv"))
+    try:
+        mine = np.arange(1, 257, dtype=np.uint64) * np.uint64(1000003)
+        got = comm.all_gather_u64(mine)
+        assert got.shape == (1, 256) and np.array_equal(got[0], mine)
+        v = comm.allreduce_max([3.5, -2.0, 1e300])
+        assert list(v) == [3.5, -2.0, 1e300]
+        sizes, offsets = gather_sizes(list(range(10, 20)), 10, comm)
+        assert list(sizes) == list(range(10, 20)) and offsets[-1] == sum(range(10, 20))
+        assert not (tmp_path / "rdv").exists()  # rank 0 removed the rendezvous file after the first collective
+    finally:
+        comm.close()
+
+
 def test_scaled_dct_streams_round2(ctx, golden):
     """decompress() of streams of the reference's C encoder (header flag 1<<30 -> decode()'s scaled_dct branch, codec.py:59-62)
     and of re-flagged Python streams: pixel-identical to the reference; decode() with scaled_dct=True takes the same path."""

@@ -9,6 +9,7 @@
 
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -86,8 +87,11 @@ int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_pa
     c->world = world;
     *out = nullptr;
     if (hipSetDevice(tic_ctx_device(ctx)) != hipSuccess) { delete c; return comm_fail(nullptr, TIC_E_HIP, "hipSetDevice failed", nullptr); }
-    if (world > 1) {
-        if (!rendezvous_path || !*rendezvous_path) { delete c; return comm_fail(nullptr, TIC_E_ARG, "rendezvous path required for world > 1", nullptr); }
+    // TIC_COMM_FORCE_RCCL: a single rank goes through RCCL too (library load, communicator, collectives on the context's stream):
+    // the only way to exercise this file on a one-GPU box (tests/test_gpu_parity.py::test_rccl_single_rank_smoke)
+    const bool forced = world == 1 && getenv("TIC_COMM_FORCE_RCCL") != nullptr;
+    if (world > 1 || forced) {
+        if (world > 1 && (!rendezvous_path || !*rendezvous_path)) { delete c; return comm_fail(nullptr, TIC_E_ARG, "rendezvous path required for world > 1", nullptr); }
         c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!c->lib) c->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!c->lib) { const char *e = dlerror(); delete c; return comm_fail(nullptr, TIC_E_NODEVICE, "cannot load librccl", e); }
@@ -103,8 +107,11 @@ int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_pa
 #undef SYM
         ncclUniqueId id;
         memset(&id, 0, sizeof id);
-        const std::string path(rendezvous_path), tmp = path + ".tmp";
-        if (rank == 0) {
+        const std::string path(rendezvous_path ? rendezvous_path : ""), tmp = path + ".tmp";
+        if (forced && path.empty()) {
+            ncclResult_t r = c->GetUniqueId(&id);
+            if (r != ncclSuccess) { const char *e = c->GetErrorString(r); delete c; return comm_fail(nullptr, TIC_E_HIP, "ncclGetUniqueId failed", e); }
+        } else if (rank == 0) {
             ncclResult_t r = c->GetUniqueId(&id);
             if (r != ncclSuccess) { const char *e = c->GetErrorString(r); delete c; return comm_fail(nullptr, TIC_E_HIP, "ncclGetUniqueId failed", e); }
             FILE *f = fopen(tmp.c_str(), "wb");
@@ -133,10 +140,10 @@ int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_pa
         if (r != ncclSuccess) { const char *e = c->GetErrorString(r); delete c; return comm_fail(nullptr, TIC_E_HIP, "ncclCommInitRank failed", e); }
     }
     *out = c;
-    if (world > 1) { // everybody has read the id once a first collective has completed: rank 0 removes the file
+    if (c->comm) { // everybody has read the id once a first collective has completed: rank 0 removes the file
         double one = 1.0;
         int rc = tic_comm_allreduce_max(c, &one, 1);
-        if (rank == 0) (void)unlink(rendezvous_path);
+        if (rank == 0 && rendezvous_path && *rendezvous_path) (void)unlink(rendezvous_path);
         if (rc != TIC_OK) { *out = nullptr; std::string keep = c->err; tic_comm_destroy(c); return comm_fail(nullptr, rc, "first collective failed", keep.c_str()); }
     }
     return TIC_OK;
@@ -149,7 +156,7 @@ int tic_gather_sizes(tic_comm *c, const uint64_t *mine, int n_mine, uint64_t *al
     if (!c || n_mine < 0 || (n_mine > 0 && (!mine || !all))) return comm_fail(c, TIC_E_ARG, "bad gather arguments", nullptr);
     if (n_mine == 0) return TIC_OK;
     const size_t sb = (size_t)n_mine * sizeof(uint64_t);
-    if (c->world == 1) {
+    if (!c->comm) { // a single rank without RCCL
         memcpy(all, mine, sb);
         return TIC_OK;
     }
@@ -168,7 +175,7 @@ int tic_gather_sizes(tic_comm *c, const uint64_t *mine, int n_mine, uint64_t *al
 
 int tic_comm_allreduce_max(tic_comm *c, double *vals, int n) {
     if (!c || n < 0 || (n > 0 && !vals)) return comm_fail(c, TIC_E_ARG, "bad all-reduce arguments", nullptr);
-    if (n == 0 || c->world == 1) return TIC_OK;
+    if (n == 0 || !c->comm) return TIC_OK;
     if (hipSetDevice(tic_ctx_device(c->ctx)) != hipSuccess) return comm_fail(c, TIC_E_HIP, "hipSetDevice failed", nullptr);
     const size_t sb = (size_t)n * sizeof(double);
     int rc = ensure_bufs(c, sb, sb);
