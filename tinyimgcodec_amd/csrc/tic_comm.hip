@@ -4,6 +4,9 @@
 // librccl.so is opened on first use (it is half a gigabyte; single-GPU users never load it).  Rendezvous: rank 0 creates
 // the RCCL unique id and publishes it as a small file (written under a temporary name, then renamed); the other ranks poll
 // for it.  The caller names the file - something unique to the launch, e.g. /tmp/tic_rdv_<MASTER_PORT>_<launcher pid>.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE // dladdr
+#endif
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -92,7 +95,18 @@ int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_pa
     const bool forced = world == 1 && getenv("TIC_COMM_FORCE_RCCL") != nullptr;
     if (world > 1 || forced) {
         if (world > 1 && (!rendezvous_path || !*rendezvous_path)) { delete c; return comm_fail(nullptr, TIC_E_ARG, "rendezvous path required for world > 1", nullptr); }
-        c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        // The RCCL that belongs to the HIP runtime this library runs on: the one in the same directory.  (A bare soname would
+        // return whatever librccl.so.1 the process loaded first - e.g. the copy bundled with a PyTorch wheel, which brings up a
+        // second HSA runtime and fails with "no ROCm-capable device is detected".)
+        {
+            Dl_info di;
+            if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &di) && di.dli_fname) {
+                std::string dir(di.dli_fname);
+                const size_t slash = dir.rfind('/');
+                if (slash != std::string::npos) c->lib = dlopen((dir.substr(0, slash) + "/librccl.so.1").c_str(), RTLD_NOW | RTLD_LOCAL);
+            }
+        }
+        if (!c->lib) c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!c->lib) c->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!c->lib) { const char *e = dlerror(); delete c; return comm_fail(nullptr, TIC_E_NODEVICE, "cannot load librccl", e); }
 #define SYM(field, name)                                                                                  \
@@ -136,6 +150,7 @@ int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_pa
             }
             if (!got) { delete c; return comm_fail(nullptr, TIC_E_ARG, "rendezvous file did not appear", path.c_str()); }
         }
+        (void)hipGetLastError(); // RCCL reads the thread's last HIP error: a stale one from an earlier, unrelated call would fail it
         ncclResult_t r = c->CommInitRank(&c->comm, world, id, rank);
         if (r != ncclSuccess) { const char *e = c->GetErrorString(r); delete c; return comm_fail(nullptr, TIC_E_HIP, "ncclCommInitRank failed", e); }
     }
@@ -165,6 +180,7 @@ int tic_gather_sizes(tic_comm *c, const uint64_t *mine, int n_mine, uint64_t *al
     if (rc) return rc;
     hipStream_t st = (hipStream_t)tic_ctx_stream(c->ctx);
     if (hipMemcpyAsync(c->d_send, mine, sb, hipMemcpyHostToDevice, st) != hipSuccess) return comm_fail(c, TIC_E_HIP, "upload failed", nullptr);
+    (void)hipGetLastError();
     ncclResult_t r = c->AllGather(c->d_send, c->d_recv, (size_t)n_mine, ncclUint64, c->comm, st);
     if (r != ncclSuccess) return comm_fail(c, TIC_E_HIP, "ncclAllGather failed", c->GetErrorString(r));
     if (hipMemcpyAsync(all, c->d_recv, sb * (size_t)c->world, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -182,6 +198,7 @@ int tic_comm_allreduce_max(tic_comm *c, double *vals, int n) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)tic_ctx_stream(c->ctx);
     if (hipMemcpyAsync(c->d_send, vals, sb, hipMemcpyHostToDevice, st) != hipSuccess) return comm_fail(c, TIC_E_HIP, "upload failed", nullptr);
+    (void)hipGetLastError();
     ncclResult_t r = c->AllReduce(c->d_send, c->d_recv, (size_t)n, ncclFloat64, ncclMax, c->comm, st);
     if (r != ncclSuccess) return comm_fail(c, TIC_E_HIP, "ncclAllReduce failed", c->GetErrorString(r));
     if (hipMemcpyAsync(vals, c->d_recv, sb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
