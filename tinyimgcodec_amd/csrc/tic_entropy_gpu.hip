@@ -252,6 +252,24 @@ __device__ __forceinline__ void walk_pack(const int16_t c[8], int k, int carry_r
     sink.put(k == 7 ? eob.x : 0u, k == 7 ? eob.y : 0u);
 }
 
+// Cross-lane moves by DPP (one VALU instruction, no LDS): row_shr:n shifts inside rows of 16 lanes, row_bcast:15 / :31 hand the
+// last lane of a row / of the lower half-wave to the rows behind it.  Lanes without a source (or outside row_mask) get 0.
+template <int N>
+__device__ __forceinline__ int dpp_row_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, false);
+}
+// Inclusive prefix sum over the 64 lanes of the wave: 4 steps inside the rows, 2 across them.
+__device__ __forceinline__ uint32_t wave_prefix_sum_u32(uint32_t x) {
+    int v = (int)x;
+    v += dpp_row_shr<1>(v);
+    v += dpp_row_shr<2>(v);
+    v += dpp_row_shr<4>(v);
+    v += dpp_row_shr<8>(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false); // rows 1, 3 += total of the row before
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false); // rows 2, 3 += total of rows 0-1
+    return (uint32_t)v;
+}
+
 template <int ABL> // ABL != 0: timing-only builds (tools/), wrong output
 __global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
                                                             unsigned long long blocks_per_frame, unsigned long long parts_per_frame,
@@ -261,16 +279,16 @@ __global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t
     __shared__ uint2 ac_tab[256];
     __shared__ uint2 dc_tab[16];
     __shared__ uint32_t wbits[kGroup];
-    __shared__ uint32_t image_all[kGroup][kStageWords];
+    __shared__ __attribute__((aligned(16))) uint32_t image_all[kGroup][512]; // kStageWords used, 512 so that two 16-byte stores per lane zero it
     __shared__ uint32_t str_all[kGroup][64 * kLaneWords];
     if (threadIdx.x < 256) ac_tab[threadIdx.x] = make_uint2(tab->ac_sym[threadIdx.x], tab->ac_bits[threadIdx.x]);
     if (threadIdx.x < 16) dc_tab[threadIdx.x] = make_uint2(tab->dc_sym[threadIdx.x], tab->dc_bits[threadIdx.x]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *image = image_all[wave];
     uint32_t *str = str_all[wave] + lane;
-#pragma unroll
-    for (int i = 0; i < (kStageWords + 63) / 64; i++)
-        if (i * 64 + lane < kStageWords) image[i * 64 + lane] = 0u;
+    static_assert(kStageWords <= 512, "image rows are 512 words");
+    reinterpret_cast<uint4 *>(image)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4 *>(image)[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
     // one workgroup per (frame, group of kGroup partitions); a wave per partition = 8 blocks.  The coefficient load and the
     // zero-run scan need no table: they run in front of the barrier that publishes the tables, not behind it.
     const unsigned long long frame = blockIdx.x / groups_per_frame, g = blockIdx.x - frame * groups_per_frame;
@@ -307,15 +325,20 @@ __global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t
     const int cnt = (k == 0) ? 7 : 8;
     int az = nz_mask == 0;
     int tz = az ? cnt : (__clz(nz_mask) - 24);
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        const int pa = __shfl_up(az, d, 8), pt = __shfl_up(tz, d, 8);
-        if (k >= d) {
-            tz = az ? pt + tz : tz;
-            az = az & pa;
-        }
+    // (a lane only uses what comes from inside its own group of 8: k >= d, so the 16-lane rows of row_shr are wide enough)
+#define TIC_CARRY_STEP(D)                                          \
+    {                                                              \
+        const int pa = dpp_row_shr<D>(az), pt = dpp_row_shr<D>(tz); \
+        if (k >= D) {                                              \
+            tz = az ? pt + tz : tz;                                \
+            az = az & pa;                                          \
+        }                                                          \
     }
-    int carry = __shfl_up(tz, 1, 8);
+    TIC_CARRY_STEP(1)
+    TIC_CARRY_STEP(2)
+    TIC_CARRY_STEP(4)
+#undef TIC_CARRY_STEP
+    int carry = dpp_row_shr<1>(tz);
     if (k == 0) carry = 0;
     __syncthreads();
     if (active) {
@@ -370,13 +393,8 @@ __global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t
         if (err && valid) atomicMax(err_flag, 1);
     }
     // prefix of the lanes' bit counts over the wave (lanes are in stream order: block, then scan position)
-    uint32_t incl = my_bits;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t pv = (uint32_t)__shfl_up((int)incl, d, 64);
-        if (lane >= d) incl += pv;
-    }
-    wave_bits = (uint32_t)__shfl((int)incl, 63, 64);
+    const uint32_t incl = wave_prefix_sum_u32(my_bits);
+    wave_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     // ---- lane strings -> the wave's image (bit 0 of the partition = MSB of word 0) ---------------------------------------
     if (!(ABL & 64) && !(ABL & 2)) { // every string word ORed into its two image words (LDS atomics into the zeroed image)
         const uint32_t lane_pos = incl - my_bits;
@@ -519,8 +537,13 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
         head[r] = (!(ABL & 2) && i < kN && p0 + (unsigned long long)i < parts_per_frame) ? fstage[(unsigned long long)i * (unsigned long long)kStageWords + lane] : 0u;
     }
     // ---- offsets ---------------------------------------------------------------------------------------------------------------
-    before = wave_sum_u64(before);
-    total = wave_sum_u64(total);
+    if (tiles_per_frame) { // frames beyond 8192^2: 64-bit sums
+        before = wave_sum_u64(before);
+        total = wave_sum_u64(total);
+    } else { // a frame of at most 8,192 groups holds fewer than 2^32 bits: 32-bit sums by DPP (six instructions, no LDS round trips)
+        before = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)wave_prefix_sum_u32((uint32_t)before), 63);
+        total = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)wave_prefix_sum_u32((uint32_t)total), 63);
+    }
     if (lane == 0) {
         ws[0][wave] = before;
         ws[1][wave] = total;
@@ -534,16 +557,11 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
     const unsigned long long frame_bits = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
     if (wave == 0) { // bit offsets of the kN partitions: a prefix sum over the lanes
         const unsigned long long base = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
-        unsigned long long incl = nb;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long pv = (unsigned long long)__shfl_up((long long)incl, d, 64);
-            if (lane >= d) incl += pv;
-        }
         // positions relative to the word that holds the workgroup's first bit: 35 partitions of at most 13.9 Kbit fit 32 bits
+        const uint32_t incl = wave_prefix_sum_u32((uint32_t)nb);
         const uint32_t a = (uint32_t)(base & 31ull);
-        if (lane < kN) roff[lane] = a + (uint32_t)(incl - nb);
-        if (lane == kN - 1) roff[kN] = a + (uint32_t)incl;
+        if (lane < kN) roff[lane] = a + (incl - (uint32_t)nb);
+        if (lane == kN - 1) roff[kN] = a + incl;
         const int any_long = __any(nb > (unsigned long long)(kSlotLds * 32)); // a slot longer than its LDS copy: read the slots directly
         if (lane == 0) {
             long_slot = any_long;
@@ -645,6 +663,7 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
     // frames of more than `direct` groups take the offsets in two levels (tile sums); TIC_ENT_DIRECT_GROUPS moves the switch
     size_t direct = 8192;
     if (const char *e = getenv("TIC_ENT_DIRECT_GROUPS")) direct = (size_t)strtoull(e, nullptr, 10);
+    if (direct > 8192) direct = 8192; // the placing kernel's 32-bit sums rely on it
     const size_t tiles_per_frame = groups_per_frame > direct ? (groups_per_frame + kTileGroups - 1) / kTileGroups : 0;
     const size_t ntiles = tiles_per_frame * (size_t)nframes;
     if (npart > cap_parts || ngroup > cap_parts || ngroup > 0x7fffffffull) return hipErrorInvalidValue;
