@@ -53,6 +53,7 @@ for step in "$@"; do
     pmc_ent)    rm -rf gpurun_out/pmc_ent gpurun_out/pmc_ent2; run pmc_ent 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc_ent -- python tools/prof_compress_dev.py 4096 10
                 run pmc_ent2 300 rocprofv3 --pmc SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc_ent2 -- python tools/prof_compress_dev.py 4096 10 ;;
     pmc_sq2)    rm -rf gpurun_out/pmc_sq2; run pmc_sq2 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc_sq2 -- python bench.py --steps 5 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-cold --no-config4 ;;
+    pmc_lds)    rm -rf gpurun_out/pmc_lds; run pmc_lds 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVES --output-format csv -d gpurun_out/pmc_lds -- ./tools/bin/microbench4 ;;
     pmc_cal)    rm -rf gpurun_out/pmc_cal; run pmc_cal 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_cal -- ./tools/bin/microbench ;;
     pmc_cal_wr) rm -rf gpurun_out/pmc_cal_wr; run pmc_cal_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_cal_wr -- ./tools/bin/microbench ;;
     *) echo "unknown step $step" ;;
