@@ -518,6 +518,33 @@ def test_error_paths(ctx):
     f.free()
 
 
+def test_batch_pipeline_error_paths(ctx):
+    """The three-thread batch pipeline reports a frame whose output buffer is too small (no overrun of that buffer, no hang), keeps
+    working afterwards, and handles batches that are not a multiple of the chunk (40 frames: chunks of 16, 16, 8)."""
+    L = N.load()
+    n, h, w = 40, 128, 192
+    frames = [rand_frame(100 + i, h, w) for i in range(n)]
+    want = [T.compress(f, 50, ctx=ctx) for f in frames[:3]] + [None] * (n - 3)
+    cap = L.tic_compress_bound(h, w)
+    outs = [np.full(cap + 64, 0xA5, np.uint8) for _ in range(n)]
+    caps_list = [cap] * n
+    caps_list[21] = 100  # chunk 1, frame 5 of it
+    imgs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+    outp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    caps = (C.c_size_t * n)(*caps_list)
+    lens = (C.c_size_t * n)()
+    rc = L.tic_compress_batch(ctx.handle, imgs, n, h, w, w, 50, outp, caps, lens, 0)
+    assert rc == N.TIC_E_SPACE and b"frame 21" in L.tic_last_error(ctx.handle)
+    assert (outs[21][100:] == 0xA5).all()  # nothing written past the small buffer
+    caps[21] = cap
+    ctx.check(L.tic_compress_batch(ctx.handle, imgs, n, h, w, w, 50, outp, caps, lens, 0))
+    for i in range(3):
+        assert outs[i][: lens[i]].tobytes() == want[i]
+    for i in range(n):
+        assert (outs[i][cap:] == 0xA5).all() and 16 < lens[i] <= cap
+    assert outs[39][: lens[39]].tobytes() == T.compress(frames[39], 50, ctx=ctx)
+
+
 def test_coefficient_without_huffman_code_raises_keyerror(ctx, golden):
     """|AC| >= 1024 has no Huffman code: the reference raises KeyError (goldens with an empty stream)."""
     d = golden("transform_small")
