@@ -96,7 +96,10 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
     return j < n ? j : p - j;
 }
 
-constexpr int kWavesPerWG = 4;
+#ifndef TIC_WAVES_PER_WG
+#define TIC_WAVES_PER_WG 4 // (8 measured in the experiment library: tools/Makefile ablate8, profiles/r02_ab_wg8.txt)
+#endif
+constexpr int kWavesPerWG = TIC_WAVES_PER_WG;
 constexpr int kLdsStrideDw = 68;    // dwords per block in the transpose buffer (64 + 4 pad; bank analysis in DESIGN.md)
 constexpr int kZzStrideB = 144;     // bytes per block in the zig-zag staging buffer (128 + 16 pad)
 constexpr int kLdsWaveBytes = 8 * kLdsStrideDw * 4; // 2176 B per wave (>= 8*144)
