@@ -252,6 +252,11 @@ __device__ __forceinline__ void walk_pack(const int16_t c[8], int k, int carry_r
     sink.put(k == 7 ? eob.x : 0u, k == 7 ? eob.y : 0u);
 }
 
+// Write-through store (sc1): the launch does not end with a write-back of dirty L2 lines (as in the transform kernel).
+__device__ __forceinline__ void store_u32_wt(uint32_t *p, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 // Cross-lane moves by DPP (one VALU instruction, no LDS): row_shr:n shifts inside rows of 16 lanes, row_bcast:15 / :31 hand the
 // last lane of a row / of the lower half-wave to the rows behind it.  Lanes without a source (or outside row_mask) get 0.
 template <int N>
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t
     const uint32_t nwords = (wave_bits + 31u) >> 5;
     uint32_t *slot = stage + part * (unsigned long long)kStageWords;
     if (!(ABL & 1))
-        for (uint32_t i = (uint32_t)lane; i < nwords; i += 64u) slot[i] = image[i];
+        for (uint32_t i = (uint32_t)lane; i < nwords; i += 64u) store_u32_wt(slot + i, image[i]);
     if (lane == 0) nbits[part] = wave_bits;
     }
     if (lane == 0) wbits[wave] = wave_bits;
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
                 const uint32_t x = ((wr << 5) - b) >> 5;
                 uint32_t v = fetch(i, x);
                 if (s) v = (v << s) | (fetch(i, x + 1u) >> (32u - s));
-                if (wr < room_words) dst[wr] = __builtin_bswap32(v); // the stream is MSB-first bytes
+                if (wr < room_words) store_u32_wt(dst + wr, __builtin_bswap32(v)); // the stream is MSB-first bytes
             }
         }
         // words in which partitions meet: one per partition end that is not word-aligned, assembled piece by piece.  The
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
                         }
                         i++;
                     }
-                    if (wr < room_words) dst[wr] = __builtin_bswap32(word);
+                    if (wr < room_words) store_u32_wt(dst + wr, __builtin_bswap32(word));
                 }
             }
         }
