@@ -338,6 +338,22 @@ static DctqArgs make_args(tic_ctx *ctx, const void *d_image, int h, int w, ptrdi
     return a;
 }
 
+// Frames that follow each other without a gap and end on a block row ARE one tall frame for the transform stage (the DC is not
+// differenced there): one persistent grid walks the whole batch in chunks, as for a 16384^2 frame, instead of a grid plane per
+// frame with its own ramp and tail (256 x 1080p: 0.63-0.67 of the roofline per plane, see DESIGN.md section 5.5 for the merged form).
+static void merge_frames(DctqArgs &a) {
+    if (a.nframes <= 1 || (a.h & 7) != 0) return;
+    const long long nblk = (long long)(a.h / 8) * a.bw;
+    if (a.frame_stride_in != (long)a.h * a.stride || a.frame_stride_out != (long)(nblk * 128)) return;
+    if ((unsigned long long)a.frame_stride_in * (unsigned long long)a.nframes >= (1ull << 32)) return; // the strip walk uses 32-bit offsets
+    if ((long long)a.h * a.nframes > 0x7fffffffll / 8 || nblk * a.nframes > 0x7fffffffll) return;
+    a.h *= a.nframes;
+    a.ntiles = ((a.h + 7) / 8) * a.tiles_x;
+    a.nframes = 1;
+    a.frame_stride_in = 0;
+    a.frame_stride_out = 0;
+}
+
 int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
                  int variant) {
     int rc = check_geometry(ctx, h, w, row_stride, quality);
@@ -368,6 +384,7 @@ int tic_dctq_dev_frames(tic_ctx *ctx, const void *d_images, int nframes, int h, 
     a.nframes = nframes;
     a.frame_stride_in = (long)frame_stride;
     a.frame_stride_out = (long)coeff_frame_stride;
+    merge_frames(a);
     HIPCHK(ctx, launch_dctq(a, variant == TIC_KERNEL_EXACT ? 1 : 2, ctx->stream));
     return TIC_OK;
 }
@@ -411,6 +428,7 @@ int tic_dctq_dev_frames_timed(tic_ctx *ctx, const void *d_images, int nframes, i
     a.nframes = nframes;
     a.frame_stride_in = (long)frame_stride;
     a.frame_stride_out = (long)coeff_frame_stride;
+    merge_frames(a);
     const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++) HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
@@ -861,6 +879,7 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
             a.nframes = cnt;
             a.frame_stride_in = (long)img_bytes;
             a.frame_stride_out = (long)coef_bytes;
+            merge_frames(a);
             e = launch_dctq(a, 2, st);
         }
         if (e == hipSuccess && need_d2h) e = hipMemcpyAsync(s.pin_out, s.d_coef, coef_bytes * cnt, hipMemcpyDeviceToHost, st);
@@ -1075,6 +1094,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
             a.nframes = cnt;
             a.frame_stride_in = (long)img_bytes;
             a.frame_stride_out = (long)coef_bytes;
+            merge_frames(a);
             e = launch_dctq(a, 2, st);
         }
         const int par = s.parity;
