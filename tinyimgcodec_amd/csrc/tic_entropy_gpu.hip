@@ -29,8 +29,10 @@
 // look-back over the waves (byte-exact, 127 us: 5,120 resident 8-block partitions start together and each sums up to 5,000
 // predecessor descriptors, 64 per memory round trip); group sums by device-scope atomics from the packing waves (pack
 // 68 us instead of 29: 64 same-address atomics from 8 XCDs per group); a one-workgroup scan kernel between pack and place
-// (59 us of serial load latency); a branch-free symbol walk (32 us against 29: for noise every wave walks every position
-// anyway, and the uniform bit sink costs more than the branch it saves).
+// (59 us of serial load latency); a branch-free symbol walk (+2 us: for noise every wave walks every position anyway, and
+// the uniform bit sink costs more than the branch it saves).  What helped after the structure stood (pack 29 -> 25 us, place
+// 9.5 -> 8.5): every cross-lane scan and reduction by DPP instead of LDS shuffles, write-through stores, the coefficient
+// load and the zero-run scan in front of the barrier that publishes the tables.  DESIGN.md section 5.4 has the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
