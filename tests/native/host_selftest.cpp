@@ -97,6 +97,55 @@ int main() {
             }
         }
     }
+    // ---- long streams: the parallel decoder (ranges measured speculatively, stitched, decoded in parallel) against the serial one
+    //      (TIC_DECODE_SERIAL), on well-formed streams and on streams damaged in the middle, where the parallel path has to notice
+    //      and hand the whole stream to the serial decoder (the reference's quirks on malformed data live there)
+    for (int mode : {0, 1, 5, 6}) {
+        const int h = 1024, w = 1536; // 24,576 blocks
+        const size_t n = tic::num_blocks(h, w);
+        std::vector<int16_t> zz(n * 64);
+        for (size_t b = 0; b < n; b++)
+            for (int k = 0; k < 64; k++) {
+                const uint32_t r = rnd();
+                int v;
+                switch (mode) {
+                case 0: v = (int)(r % 41) - 20; break;
+                case 1: v = (r % 7 == 0) ? (int)(r >> 8) % 2047 - 1023 : 0; break;
+                case 5: v = (int)(r % 2047) - 1023; break;
+                default: v = (k < 6 + (int)(b % 5)) ? (int)(r % 255) - 127 : 0; break; // natural-image-like: short blocks of varying length
+                }
+                if (k == 0) v = (int)(r % 1500) - 750;
+                zz[b * 64 + k] = (int16_t)v;
+            }
+        const size_t bound = tic::compress_bound(h, w);
+        std::vector<uint8_t> bs(bound);
+        size_t len = 0;
+        if (tic::entropy_encode(zz.data(), h, w, 50, bs.data(), bs.size(), &len) != 0) return fail("long stream: encode", h, w, mode);
+        bs.resize(len);
+        std::vector<int16_t> par(n * 64), ser(n * 64);
+        auto both = [&](const std::vector<uint8_t> &t) {
+            unsetenv("TIC_DECODE_SERIAL");
+            (void)tic::entropy_decode(t.data(), t.size(), h, w, par.data());
+            setenv("TIC_DECODE_SERIAL", "1", 1);
+            (void)tic::entropy_decode(t.data(), t.size(), h, w, ser.data());
+            unsetenv("TIC_DECODE_SERIAL");
+            return memcmp(par.data(), ser.data(), n * 128) == 0;
+        };
+        if (!both(bs)) return fail("long stream: parallel != serial", h, w, mode);
+        if (memcmp(par.data(), zz.data(), n * 128) != 0) return fail("long stream: round trip mismatch", h, w, mode);
+        cases++;
+        for (int k = 0; k < 12; k++) { // one flipped bit somewhere: both decoders must agree on every coefficient
+            std::vector<uint8_t> t(bs);
+            t[16 + rnd() % (t.size() - 16)] ^= (uint8_t)(1u << (rnd() & 7));
+            if (!both(t)) return fail("long stream, flipped bit: parallel != serial", h, w, mode * 100 + k);
+            cases++;
+        }
+        for (int k = 0; k < 4; k++) { // truncated
+            std::vector<uint8_t> t(bs.begin(), bs.begin() + (long)(bs.size() / 5 * (size_t)(k + 1)));
+            if (!both(t)) return fail("long stream, truncated: parallel != serial", h, w, mode * 100 + k);
+            cases++;
+        }
+    }
     printf("host_selftest ok: %d cases\n", cases);
     return 0;
 }

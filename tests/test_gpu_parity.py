@@ -329,6 +329,22 @@ def test_decompress_goldens(ctx, golden, manifest):
         assert np.array_equal(got, L[f"q{q}_dec"])
 
 
+def test_decompress_long_stream_parallel_decoder(ctx, oracle, monkeypatch):
+    """Streams of 16,384 blocks and more take the parallel host Huffman decoder (ranges measured speculatively, stitched on the true
+    chain, decoded by 16 threads): same pixels as the serial decoder and as the oracle, also when the stream is damaged."""
+    img = rand_frame(4321, 1536, 2048)
+    bs = T.compress(img, 50, ctx=ctx)
+    want = oracle.decompress(bs)
+    assert np.array_equal(T.decompress(bs, ctx=ctx), want)
+    monkeypatch.setenv("TIC_DECODE_SERIAL", "1")
+    assert np.array_equal(T.decompress(bs, ctx=ctx), want)
+    monkeypatch.delenv("TIC_DECODE_SERIAL")
+    damaged = bytearray(bs)
+    damaged[len(bs) // 3] ^= 0x10
+    damaged = bytes(damaged[: len(bs) * 9 // 10])
+    assert np.array_equal(T.decompress(damaged, ctx=ctx), oracle.decompress(damaged))
+
+
 def test_decode_dict_roundtrip(ctx, golden):
     """decode(encode(x)) through the reference's dict convention == decompress(compress(x))."""
     img = golden("lenna")["img"][:120, :200]

@@ -154,7 +154,7 @@ def test_host_entropy_coder_under_sanitizers(tmp_path):
     flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
     subprocess.run(["gcc", "-c", *flags, "-o", str(obj), os.path.join(root, "oracle", "tic_oracle.c")], check=True)
     subprocess.run(["g++", "-std=c++17", *flags, "-o", str(exe), os.path.join(root, "tests", "native", "host_selftest.cpp"),
-                    os.path.join(root, "tinyimgcodec_amd", "csrc", "tic_entropy.cpp"), str(obj), "-lm"], check=True)
+                    os.path.join(root, "tinyimgcodec_amd", "csrc", "tic_entropy.cpp"), str(obj), "-lm", "-lpthread"], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host_selftest ok" in r.stdout

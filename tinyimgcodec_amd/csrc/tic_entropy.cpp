@@ -10,11 +10,19 @@
 // Input is the device stage's layout: int16 [N][64], zig-zag order, element 0 = quantised DC before DPCM.
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/tinyimgcodec_hip.h"
 #include "tic_entropy.h"
 #include "tic_tables.h"
+
+#include <algorithm>
+#include <chrono>
+#include <stdio.h>
+#include <atomic>
+#include <thread>
+#include <vector>
 
 namespace tic {
 
@@ -320,13 +328,245 @@ inline bool read_symbol(BitReader &r, const EncTables::Dec &d, int &sym, int &va
 
 } // namespace
 
+namespace {
+
+// One block on the table-driven fast path (the caller guarantees 2048 readable bits from pos0: any valid block is at most 64 x 27
+// bits long).  STORE: coefficients c[1..63] are written (c must be zero on entry); otherwise the block is only measured.  Returns
+// false on anything unusual - a prefix that is no codeword, more than 63 coefficients - with nothing consumed; the caller then
+// takes the bit-serial path, which reproduces the reference's behaviour on malformed streams.
+template <bool STORE>
+inline bool block_fast(const EncTables &T, const uint8_t *p, size_t pos0, int16_t *c, int &dc_diff, size_t &used_out) {
+    // bit buffer in a register: `cnt` valid bits at the top of `buf`; branch-free refill to >= 56 bits before every symbol (a
+    // data-dependent refill branch mispredicts every few symbols and doubles the time)
+    const uint8_t *bp = p + (pos0 >> 3);
+    uint64_t buf;
+    memcpy(&buf, bp, 8);
+    buf = __builtin_bswap64(buf) << (pos0 & 7);
+    int cnt = 64 - (int)(pos0 & 7);
+    bp += 8;
+    size_t used = 0;
+    auto refill = [&]() {
+        uint64_t w8;
+        memcpy(&w8, bp, 8);
+        buf |= cnt < 64 ? __builtin_bswap64(w8) >> cnt : 0;
+        bp += (63 - (cnt > 63 ? 63 : cnt)) >> 3;
+        cnt |= 56;
+    };
+    auto value = [](uint64_t bits, int len, int size) -> int { // value bits follow the codeword
+        // branch-free (the sign bit is a coin flip): x with its top bit clear stands for x - (2^size - 1)
+        const int x = (int)(((bits << len) >> 1) >> (63 - size)); // size = 0 gives 0
+        const int half = (1 << size) >> 1;
+        const int neg_mask = (x - half) >> 31; // all ones when the top bit is clear
+        return x + (neg_mask & (1 - (1 << size)));
+    };
+    uint16_t e = T.dcd.lut11[buf >> 53];
+    if (!e) return false; // DC categories are at most 9 bits long
+    int len = e >> 8, size = e & 15;
+    dc_diff = value(buf, len, size);
+    buf <<= len + size;
+    cnt -= len + size;
+    used += (size_t)(len + size);
+    int k = 1;
+    for (;;) {
+        refill();
+        e = T.acd.lut11[buf >> 53];
+        if (!e) e = T.acd.lut[buf >> 48];
+        if (!e) return false;
+        len = e >> 8;
+        size = e & 15;
+        const uint64_t bits = buf;
+        buf <<= len + size;
+        cnt -= len + size;
+        used += (size_t)(len + size);
+        if ((e & 0xff) == 0) break; // EOB
+        k += (e >> 4) & 15;
+        if (k > 63) return false;
+        if (STORE) c[k] = (int16_t)value(bits, len, size);
+        k++;
+    }
+    used_out = used;
+    return true;
+}
+
+// Parallel decode of a long, well-formed stream (the format has no restart markers: the serial decoder is one dependent chain,
+// 44 ms for a 4096^2 frame).  The stream is cut into T bit ranges.  (A) every thread measures blocks from the start of its range
+// as if a block started there - a guess, except for the first - recording each block's first bit and DC difference; (B) a serial
+// stitch follows the true chain: from the end of a range it measures on until it lands on a block start the next thread also
+// recorded; the two decoders are then in the same state (a block start carries none), so the rest of that thread's list is the
+// truth - Huffman streams re-synchronise within a few blocks; (C) with every block's first bit and the running DC known the
+// threads decode disjoint block ranges straight into the output.  Anything unusual inside the TRUE chain (an invalid prefix,
+// a block of more than 63 coefficients) makes the function give up, and the caller decodes serially as before: malformed
+// streams keep the reference's quirks.  Returns the number of blocks decoded (0: not attempted / given up) and the read
+// position and running DC behind them.
+size_t decode_parallel(const EncTables &T, const uint8_t *data, size_t nbits, size_t n, int16_t *zz, size_t &pos_out, int &dc_out) {
+    const size_t first_bit = 128;
+    if (n < 16384 || nbits < first_bit + (1u << 21) || getenv("TIC_DECODE_SERIAL")) return 0;
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? hw / 2 : 4);
+    nt = nt < 2 ? 2 : (nt > 16 ? 16 : nt);
+    if (const char *e = getenv("TIC_DECODE_THREADS")) nt = atoi(e) < 1 ? 1 : (atoi(e) > 64 ? 64 : atoi(e));
+    const size_t fast_end = nbits - 2048; // a block may START on the fast path up to here
+    const size_t span = (fast_end - first_bit + (size_t)nt - 1) / (size_t)nt;
+    struct Trace {
+        std::vector<uint64_t> start;
+        std::vector<int32_t> dc;
+        std::vector<size_t> breaks; // number of blocks recorded when a measurement failed and the thread moved on by one bit
+        size_t end = 0;             // first bit behind the last measured block
+    };
+    std::vector<Trace> tr((size_t)nt);
+#ifdef TIC_ABLATION // phase times on stderr (tools/native/dec_time.cpp)
+    const bool trace = getenv("TIC_DECODE_TRACE") != nullptr;
+#else
+    const bool trace = false;
+#endif
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    auto t_start = now();
+    auto seg_lo = [&](int t) { return first_bit + span * (size_t)t; };
+    auto seg_hi = [&](int t) { const size_t e = first_bit + span * (size_t)(t + 1); return e < fast_end ? e : fast_end; };
+    {   // (A)
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                Trace &r = tr[(size_t)t];
+                const size_t hi = seg_hi(t);
+                r.start.reserve(n / (size_t)nt + n / 8);
+                r.dc.reserve(n / (size_t)nt + n / 8);
+                size_t pos = seg_lo(t);
+                while (pos < hi) {
+                    int d;
+                    size_t used;
+                    if (block_fast<false>(T, data, pos, nullptr, d, used)) {
+                        r.start.push_back(pos);
+                        r.dc.push_back(d);
+                        pos += used;
+                    } else {
+                        if (t == 0) break; // the true chain: the stitch below sees the short trace and gives up
+                        r.breaks.push_back(r.start.size());
+                        pos++; // a guess that led nowhere (or, behind the point of synchronisation, a malformed stream): next bit
+                    }
+                }
+                r.end = pos;
+            });
+        for (auto &x : th) x.join();
+    }
+    if (trace) {
+        size_t tot = 0, brk = 0;
+        for (auto &r : tr) { tot += r.start.size(); brk += r.breaks.size(); }
+        fprintf(stderr, "decode_parallel: %d threads, phase A %.2f ms, %zu blocks measured, %zu failed guesses\n", nt, ms_since(t_start), tot, brk);
+    }
+    auto t_b = now();
+    size_t by_hand = 0;
+    // (B) the true chain: block starts and DC differences in order
+    std::vector<uint64_t> start;
+    std::vector<int32_t> dcd;
+    start.reserve(n);
+    dcd.reserve(n);
+    size_t pos = first_bit;
+    int t = 0;
+    bool synced = true; // thread 0 starts on a true block start
+    size_t idx = 0;     // next entry of thread t's trace on the true chain
+    while (start.size() < n && pos < fast_end) {
+        if (t < nt && synced) {
+            const Trace &r = tr[(size_t)t];
+            // copy the rest of this thread's trace (it ends at the first block start at or behind the range's end)
+            const size_t take = r.start.size() - idx < n - start.size() ? r.start.size() - idx : n - start.size();
+            start.insert(start.end(), r.start.begin() + (long)idx, r.start.begin() + (long)(idx + take));
+            dcd.insert(dcd.end(), r.dc.begin() + (long)idx, r.dc.begin() + (long)(idx + take));
+            if (idx + take < r.start.size()) break; // n blocks reached
+            pos = r.end;
+            if (t == 0 && pos < seg_hi(0)) return 0; // the first thread stopped at something unusual
+            t++;
+            synced = false;
+            continue;
+        }
+        if (t < nt) { // is `pos` a block start the next thread recorded?  (its trace is sorted)
+            const Trace &r = tr[(size_t)t];
+            if (pos >= seg_hi(t) && !(t == nt - 1)) { // walked through the whole range without meeting its trace: next one
+                t++;
+                continue;
+            }
+            const auto it = std::lower_bound(r.start.begin(), r.start.end(), (uint64_t)pos);
+            if (it != r.start.end() && *it == (uint64_t)pos) {
+                idx = (size_t)(it - r.start.begin());
+                // from here on the thread walked the true chain: a failed measurement behind this point is the stream's fault
+                if (!r.breaks.empty() && r.breaks.back() > idx) return 0;
+                synced = true;
+                continue;
+            }
+        }
+        // measure one block of the true chain by hand
+        int d;
+        size_t used;
+        if (!block_fast<false>(T, data, pos, nullptr, d, used)) return 0; // unusual: the serial decoder takes the whole stream
+        start.push_back(pos);
+        dcd.push_back(d);
+        pos += used;
+        by_hand++;
+    }
+    const size_t m = start.size();
+    if (trace) fprintf(stderr, "decode_parallel: phase B %.2f ms, %zu blocks on the chain, %zu measured by hand\n", ms_since(t_b), m, by_hand);
+    auto t_c = now();
+    if (m == 0) return 0;
+    // running DC (np.cumsum(dc), codec.py:53) in front of every block
+    std::vector<int32_t> run(m);
+    {
+        int acc = 0;
+        for (size_t b = 0; b < m; b++) {
+            acc += dcd[b];
+            run[b] = acc;
+        }
+    }
+    // (C)
+    std::atomic<int> bad{0};
+    size_t last_used = 0;
+    {
+        std::vector<std::thread> th;
+        for (int j = 0; j < nt; j++)
+            th.emplace_back([&, j]() {
+                const size_t b0 = m * (size_t)j / (size_t)nt, b1 = m * (size_t)(j + 1) / (size_t)nt;
+                memset(zz + b0 * 64, 0, (b1 - b0) * 64 * sizeof(int16_t)); // (the caller zeroes only what this function leaves)
+                for (size_t b = b0; b < b1; b++) {
+                    int16_t *c = zz + b * 64;
+                    int d;
+                    size_t used;
+                    if (!block_fast<true>(T, data, (size_t)start[b], c, d, used)) {
+                        bad.store(1);
+                        return;
+                    }
+                    c[0] = sat16(run[b]);
+                    if (b == m - 1) last_used = used;
+                }
+            });
+        for (auto &x : th) x.join();
+    }
+    if (trace) fprintf(stderr, "decode_parallel: phase C %.2f ms\n", ms_since(t_c));
+    if (bad.load()) return 0;
+    pos_out = (size_t)start[m - 1] + last_used;
+    dc_out = run[m - 1];
+    return m;
+}
+
+} // namespace
+
 int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
     const EncTables &T = tables();
     const size_t n = num_blocks(h, w);
-    memset(zz, 0, n * 64 * sizeof(int16_t));
     BitReader r{data, len * 8, 128};
     int running_dc = 0; // np.cumsum(dc), codec.py:53
-    for (size_t b = 0; b < n; b++) {
+    size_t b_first = 0;
+    {
+        size_t pos = 0;
+        int dc = 0;
+        const size_t done = decode_parallel(T, data, len * 8, n, zz, pos, dc); // zeroes and fills blocks [0, done)
+        if (done) {
+            b_first = done;
+            r.pos = pos;
+            running_dc = dc;
+        }
+    }
+    memset(zz + b_first * 64, 0, (n - b_first) * 64 * sizeof(int16_t)); // (everything, if the parallel attempt gave up)
+    for (size_t b = b_first; b < n; b++) {
         int16_t *c = zz + b * 64;
         int sym, v;
         // Fast path for a whole block while the stream is long enough for any valid block (<= 64 x 27 bits): table
@@ -334,67 +574,15 @@ int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
         // coefficients - rewinds to the block's first bit and takes the bit-serial path below, which reproduces the
         // reference's behaviour on malformed streams.
         if (r.pos + 2048 <= r.nbits) {
-            const size_t pos0 = r.pos;
-            // bit buffer in a register: `cnt` valid bits at the top of `buf`; branch-free refill to >= 56 bits before
-            // every symbol (a data-dependent refill branch mispredicts every few symbols and doubles the time)
-            const uint8_t *bp = r.p + (pos0 >> 3);
-            uint64_t buf;
-            memcpy(&buf, bp, 8);
-            buf = __builtin_bswap64(buf) << (pos0 & 7);
-            int cnt = 64 - (int)(pos0 & 7);
-            bp += 8;
-            size_t used = 0;
-            auto refill = [&]() {
-                uint64_t w8;
-                memcpy(&w8, bp, 8);
-                buf |= cnt < 64 ? __builtin_bswap64(w8) >> cnt : 0;
-                bp += (63 - (cnt > 63 ? 63 : cnt)) >> 3;
-                cnt |= 56;
-            };
-            auto value = [](uint64_t bits, int len, int size) -> int { // value bits follow the codeword
-                // branch-free (the sign bit is a coin flip): x with its top bit clear stands for x - (2^size - 1)
-                const int x = (int)(((bits << len) >> 1) >> (63 - size)); // size = 0 gives 0
-                const int half = (1 << size) >> 1;
-                const int neg_mask = (x - half) >> 31; // all ones when the top bit is clear
-                return x + (neg_mask & (1 - (1 << size)));
-            };
-            bool good = false;
-            uint16_t e = T.dcd.lut11[buf >> 53];
-            if (e) { // DC categories are at most 9 bits long
-                int len = e >> 8, size = e & 15;
-                const int dc = running_dc + value(buf, len, size);
-                buf <<= len + size;
-                cnt -= len + size;
-                used += (size_t)(len + size);
-                int k = 1;
-                for (;;) {
-                    refill();
-                    e = T.acd.lut11[buf >> 53];
-                    if (!e) e = T.acd.lut[buf >> 48];
-                    if (!e) break;
-                    len = e >> 8;
-                    size = e & 15;
-                    const uint64_t bits = buf;
-                    buf <<= len + size;
-                    cnt -= len + size;
-                    used += (size_t)(len + size);
-                    if ((e & 0xff) == 0) { // EOB
-                        good = true;
-                        break;
-                    }
-                    k += (e >> 4) & 15;
-                    if (k > 63) break;
-                    c[k++] = (int16_t)value(bits, len, size);
-                }
-                if (good) {
-                    running_dc = dc;
-                    c[0] = sat16(running_dc);
-                    r.pos = pos0 + used;
-                    continue;
-                }
+            int d;
+            size_t used;
+            if (block_fast<true>(T, r.p, r.pos, c, d, used)) {
+                running_dc += d;
+                c[0] = sat16(running_dc);
+                r.pos += used;
+                continue;
             }
             memset(c, 0, 64 * sizeof(int16_t));
-            r.pos = pos0;
         }
         bool have_dc = read_symbol(r, T.dcd, sym, v);
         if (have_dc) running_dc += v;
