@@ -91,14 +91,27 @@ def main():
     share_gpu = os.environ.get("TIC_BENCH_SHARE_GPU", "0") == "1"
     ctx = T.Context(0 if share_gpu else local_rank)  # raises loudly if the HIP library / an MI355X is missing
     comm = None
+    comm_note = "RCCL through the C-ABI (tic_comm_create / tic_gather_sizes / tic_comm_allreduce_max)"
     if world > 1:
         if os.environ.get("TIC_BENCH_BACKEND", "rccl") == "gloo":
+            comm_note = "gloo (TIC_BENCH_BACKEND=gloo rehearsal)"
             import torch.distributed as dist
 
             dist.init_process_group(backend="gloo")
             comm = TorchComm()
         else:
-            comm = RcclComm(ctx, rank, world)
+            try:
+                comm = RcclComm(ctx, rank, world)
+            except Exception as e:  # an RCCL that cannot come up (library, IPC, topology) fails on every rank alike:
+                # keep the measurement and say so in the line - the sizes then travel over gloo (torch is present: it launched us)
+                import datetime
+
+                import torch.distributed as dist
+
+                sys.stderr.write("bench.py rank %d: RCCL communicator failed (%s); falling back to gloo\n" % (rank, e))
+                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+                comm = TorchComm()
+                comm_note = "gloo fallback: RCCL communicator failed: %s" % str(e)[:200]
     q = args.quality
     variant = N.KERNEL_HYBRID if args.variant == "hybrid" else N.KERNEL_EXACT
     multi = world > 1
@@ -152,13 +165,14 @@ def main():
                     "per GPU resident in HBM, one batched launch per step (BASELINE config 4)" % (n_total, q, hi - lo),
                     "kernel": args.variant,
                     "frames_per_step_per_gpu": hi - lo,
-                    "sharding": "independent frames, contiguous shards; no data-path collective; RCCL all-gather of per-frame stream sizes",
+                    "sharding": "independent frames, contiguous shards; no data-path collective; all-gather of per-frame stream sizes",
+                    "comm": comm_note,
                     "settle_ms": args.settle_ms,
                     "untimed_launches": info["untimed_launches"],
                     "host_to_host_mpix_s": round(pixels * world / float(red[2]) / 1e6, 1),
                     "host_to_host_note": "whole pipeline per rank (pinned staging, H2D || kernels || D2H, device entropy stage), PCIe "
                     "included, max over ranks; never `value`",
-                    "rccl_gathered_sizes": {"frames": int(len(sizes)), "total_bytes": int(offsets[-1]), "first": [int(v) for v in sizes[:8]],
+                    "gathered_sizes": {"frames": int(len(sizes)), "total_bytes": int(offsets[-1]), "first": [int(v) for v in sizes[:8]],
                                             "sha256": hashlib.sha256(sizes.astype("<i8").tobytes()).hexdigest()},
                     "device": ctx.arch,
                 },
