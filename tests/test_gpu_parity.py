@@ -409,6 +409,27 @@ def test_batched_launch_matches_per_frame(ctx, oracle):
             assert (raw[k * cstride + nblk * 128 : (k + 1) * cstride] == 0x33).all()  # gap untouched
     L.tic_dev_free(ctx.handle, d_img)
     L.tic_dev_free(ctx.handle, d_out)
+    # frames that follow each other without a gap and end on a block row are walked as ONE tall frame (ragged width: the
+    # remainder strips of every frame come from the exact kernel's tall launch too)
+    n, h, w, pitch = 7, 96, 200, 208
+    frames = [rand_frame(600 + k, h, w) for k in range(n)]
+    host = np.zeros((n, h, pitch), np.uint8)
+    for k, f in enumerate(frames):
+        host[k, :, :w] = f
+    nblk = L.tic_num_blocks(h, w)
+    ctx.check(L.tic_dev_alloc(ctx.handle, host.size, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, n * nblk * 128, C.byref(d_out)))
+    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, host.ctypes.data, host.size))
+    for variant in (N.KERNEL_HYBRID, N.KERNEL_EXACT):
+        ctx.check(L.tic_memset_dev(ctx.handle, d_out, 0x33, n * nblk * 128))
+        ctx.check(L.tic_dctq_dev_frames(ctx.handle, d_img, n, h, w, pitch, h * pitch, 60, d_out, nblk * 128, variant))
+        raw = np.empty(n * nblk * 128, np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, raw.ctypes.data, d_out, raw.size))
+        for k in range(n):
+            got = raw[k * nblk * 128 : (k + 1) * nblk * 128].view(np.int16).reshape(nblk, 64)
+            assert np.array_equal(got, oracle.encode_zz16(frames[k], 60)), (k, variant)
+    L.tic_dev_free(ctx.handle, d_img)
+    L.tic_dev_free(ctx.handle, d_out)
 
 
 def test_device_entropy_stage_matches_reference_streams(ctx, oracle, golden, manifest):
