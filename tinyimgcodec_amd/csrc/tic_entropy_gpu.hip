@@ -129,9 +129,12 @@ __device__ __forceinline__ int walk_lane(const int16_t c[8], int k, int carry_ru
     return bits;
 }
 
-// The same walk written for fewer instructions: the DC position of lane 0 becomes an ordinary zero (its run starts at -1), the
-// zero-run escapes are at most two conditional puts (ZRL ZRL packed into one 22-bit symbol) instead of a loop.
-template <typename Sink>
+// The walk of the packing kernel.  Against walk_lane above: the DC position of lane 0 is an ordinary zero (its run starts at
+// -1); the zero-run escapes are at most two conditional puts (ZRL ZRL packed into one 22-bit symbol), and compiled in only
+// where the WAVE has a lane that needs one (ZRL = false otherwise: the kernel decides per wave, see need_zrl there); a
+// coefficient without a code becomes a symbol of 0 bits and an error flag, without a branch.  (The two tests inside the loop
+// cost 1.6 us of 25 on a 4096^2 noise frame, for paths that noise never takes.)
+template <bool ZRL, typename Sink>
 __device__ __forceinline__ void walk_lane_lean(const int16_t c[8], int k, int carry_run, int dc_diff, const uint2 *ac_tab,
                                                const uint2 *dc_tab, Sink *sink, int *err) {
     int run = carry_run;
@@ -141,8 +144,9 @@ __device__ __forceinline__ void walk_lane_lean(const int16_t c[8], int k, int ca
         const int v = dc_diff;
         const int sz = size_category(v);
         const uint2 e = dc_tab[sz & 15];
-        if (e.y == 0u || sz > 11) *err = 1;
-        else sink->put(e.x | value_bits(v, sz), e.y);
+        const bool bad = e.y == 0u || sz > 11; // (|difference| up to 65535: size 16 wraps to the valid entry 0, hence the bound)
+        *err |= bad ? 1 : 0;
+        sink->put(bad ? 0u : (e.x | value_bits(v, sz)), bad ? 0u : e.y);
         run = -1;
     }
 #pragma unroll
@@ -152,7 +156,7 @@ __device__ __forceinline__ void walk_lane_lean(const int16_t c[8], int k, int ca
             run++;
             continue;
         }
-        if (run >= 16) { // at most three ZRL = (15,0), huffman.py:26-28
+        if (ZRL && run >= 16) { // at most three ZRL = (15,0), huffman.py:26-28
             if (run >= 32) {
                 sink->put(zrl2, zrl2_bits);
                 run -= 32;
@@ -162,13 +166,14 @@ __device__ __forceinline__ void walk_lane_lean(const int16_t c[8], int k, int ca
                 run -= 16;
             }
         }
-        const int sz = size_category(v);
-        const uint2 e = ac_tab[(run << 4) | (sz > 15 ? 15 : sz)];
-        if (e.y == 0u) *err = 1;
-        else sink->put(e.x | value_bits(v, sz), e.y);
+        const int sz = size_category(v); // 1..16 for an int16
+        const uint2 e = ac_tab[((run & 15) << 4) | (sz > 15 ? 15 : sz)];
+        const bool bad = e.y == 0u; // sizes above 10 have no code (the reference raises KeyError)
+        *err |= bad ? 1 : 0;
+        sink->put(bad ? 0u : (e.x | value_bits(v, sz)), e.y);
         run = 0;
     }
-    if (k == 7) {
+    if (k == 7) { // EOB = (0,0) always closes the block (huffman.py:33)
         const uint2 e = ac_tab[0];
         sink->put(e.x, e.y);
     }
@@ -204,10 +209,10 @@ struct LaneSink {
 struct LaneSinkB {
     uint32_t *str;
     uint32_t cur, sh, full;
-    __device__ __forceinline__ void put(uint32_t v, uint32_t n) { // 1 <= n <= 27, v < 2^n
+    __device__ __forceinline__ void put(uint32_t v, uint32_t n) { // n <= 27, v < 2^n (n = 0, v = 0: nothing happens)
         const uint32_t avail = 32u - sh;
         if (n < avail) {
-            cur |= v << (avail - n);
+            cur |= v << ((avail - n) & 31u);
             sh += n;
         } else {
             const uint32_t rest = n - avail;
@@ -354,18 +359,25 @@ __global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t
     if (ABL & 4) {
         int err = 0;
         if (valid) my_bits = (uint32_t)walk_lane<false>(c, k, carry, dc_diff, ac_tab, dc_tab, (LaneSink *)nullptr, &err);
-    } else if (ABL & 32) { // experiment: the lean walk
+    } else if (!(ABL & 56)) { // the product
         LaneSinkB sink;
         sink.str = str;
         sink.cur = 0u;
         sink.sh = 0u;
         sink.full = 0u;
         int err = 0;
-        if (valid) walk_lane_lean(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
+        // a zero run of 16 or more can only reach a lane's first non-zero entry (a lane holds 8): decided per wave
+        const int lead = nz_mask ? __builtin_ctz((unsigned)nz_mask) - (k == 0 ? 1 : 0) : 0;
+        const bool need_zrl = valid && nz_mask != 0 && carry + lead >= 16;
+        if (__any(need_zrl)) {
+            if (valid) walk_lane_lean<true>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
+        } else {
+            if (valid) walk_lane_lean<false>(c, k, carry, dc_diff, ac_tab, dc_tab, &sink, &err);
+        }
         my_bits = valid ? sink.bits() : 0u;
         last_word = sink.cur;
         if (err && valid) atomicMax(err_flag, 1);
-    } else if (!(ABL & 24)) { // the product: branching walk, branching sink (fastest of the three measured, profiles/r02_entropy_ablate.txt)
+    } else if (ABL & 32) { // experiment: the first walk (walk_lane: DC special case, ZRL loop, tests as branches), branching sink
         LaneSinkB sink;
         sink.str = str;
         sink.cur = 0u;
