@@ -1,0 +1,37 @@
+"""Kernel time on natural content: the 512x512 Lenna pixels tiled to 4096^2 (and a smoothed, a flat and a gradient frame) against
+the random frame of the benchmark.  Natural images have flat and smooth blocks, i.e. many exact ties of the rational coefficients."""
+import ctypes as C, sys
+sys.path.insert(0, '.')
+import numpy as np
+import tinyimgcodec_amd as T
+from tinyimgcodec_amd import _native as N
+L = N.load(); ctx = T.Context(0)
+lenna = np.load('tests/golden/lenna.npz')['img']
+dim = 4096
+frames = {
+    "random (benchmark)": np.random.default_rng(1234).integers(0, 256, (dim, dim), dtype=np.uint8),
+    "lenna tiled 8x8": np.tile(lenna, (8, 8)),
+    "lenna upscaled 8x (smooth)": np.kron(lenna, np.ones((8, 8), np.uint8)),
+    "flat 201": np.full((dim, dim), 201, np.uint8),
+    "horizontal gradient": np.tile((np.arange(dim) // 16).astype(np.uint8), (dim, 1)),
+    "lenna tiled, quantised to 32 levels": (np.tile(lenna, (8, 8)) // 8 * 8 + 1).astype(np.uint8),
+}
+for name, img in frames.items():
+    img = np.ascontiguousarray(img)
+    d_img, d_out = C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size * 2, C.byref(d_out)))
+    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
+    ms = C.c_float()
+    for q in (50, 90):
+        ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, dim, dim, dim, q, d_out, 2, 3000, C.byref(ms)))
+        ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, dim, dim, dim, q, d_out, 2, 2000, C.byref(ms)))
+        t = ms.value * 1e3 / 2000
+        L.tic_set_stats(ctx.handle, 1)  # (the statistics launch carries a diagnostic atomic: never timed)
+        ctx.check(L.tic_dctq_dev(ctx.handle, d_img, dim, dim, dim, q, d_out, 2))
+        fb = C.c_ulonglong()
+        L.tic_last_fallback_blocks(ctx.handle, C.byref(fb))
+        L.tic_set_stats(ctx.handle, 0)
+        n = C.c_size_t()
+        print("%-38s q=%d  kernel %6.2f us  (%.1f %% of 8 TB/s)  second-level blocks %d" % (name, q, t, 3.0 * dim * dim / t / 1e3 / 80, fb.value), flush=True)
+    L.tic_dev_free(ctx.handle, d_img); L.tic_dev_free(ctx.handle, d_out)
