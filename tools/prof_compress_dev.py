@@ -14,6 +14,8 @@ dim = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 h = w = dim
 img = np.random.default_rng(1234).integers(0, 256, (h, w), dtype=np.uint8)
+if os.environ.get('TIC_CONTENT') == 'lenna':  # natural content: the 512x512 Lenna pixels tiled
+    img = np.ascontiguousarray(np.tile(np.load('tests/golden/lenna.npz')['img'], (dim // 512, dim // 512)))
 cap = L.tic_compress_bound(h, w)
 d_img, d_out = C.c_void_p(), C.c_void_p()
 ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
