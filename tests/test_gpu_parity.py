@@ -502,6 +502,34 @@ def test_compress_dev_resident(ctx, manifest):
     assert n.value == m["bytes"] and sha(out.tobytes()) == m["sha256"]
 
 
+def test_device_entropy_content_sweep(ctx):
+    """Device entropy stage against the host coder on content that stresses the placing kernel: flat frames (48-bit partitions:
+    a stream word holds the ends of two partitions), gradients, sparse spikes (long zero runs: ZRL decided per wave), noise at
+    the quality extremes, and shapes whose partition count is not a multiple of the kernels' group sizes."""
+    rng = np.random.default_rng(2024)
+    shapes = [(1024, 1536), (8, 8), (8, 72), (136, 200), (1000, 1000), (264, 2056)]
+    for h, w in shapes:
+        spikes = np.full((h, w), 128, np.uint8)
+        spikes[rng.integers(0, h, max(1, h * w // 4000)), rng.integers(0, w, max(1, h * w // 4000))] = 255
+        contents = {
+            "flat": np.full((h, w), 201, np.uint8),
+            "gradient": np.tile((np.arange(w) // 3).astype(np.uint8), (h, 1)),
+            "spikes": spikes,
+            "noise": rng.integers(0, 256, (h, w), dtype=np.uint8),
+            "soft noise": rng.integers(120, 136, (h, w), dtype=np.uint8),
+        }
+        for name, img in contents.items():
+            for q in (1, 50, 97):
+                zz = T.dctq(img, q, ctx=ctx)
+                try:
+                    want = T.entropy_encode(zz, h, w, q)
+                except KeyError:
+                    with pytest.raises(KeyError):
+                        T.compress(img, q, ctx=ctx)
+                    continue
+                assert T.compress(img, q, ctx=ctx) == want, (h, w, name, q)
+
+
 def test_device_entropy_two_level_offsets(ctx, monkeypatch):
     """Frames of very many partitions take their stream offsets through tile sums (a third small launch); the switch is moved
     down here so that a 2048x3000 frame (750 groups, 3 tiles) walks that path.  Quality 90 makes the partitions long
