@@ -4,8 +4,10 @@
 // the strip kernel) and the kernel's quantiser arithmetic against dct8_exact (columns, then rows: the reference's order,
 // float64) and asserts, for every coefficient of every block,
 //     |Z_fast * scale - X_exact| < kGuard[u][v]                      (coefficient units)
-//     |t_fast - X_exact / div|   < kGuard[u][v] / div                (quantised units, q = 10, 50, 90; t = z * mul in float32,
-//                                                                     the larger of the rounded and the fused product's error)
+//     |t_fast - X_exact / div|   < kGuard[u][v] / div                (quantised units, q = 1, 10, 50, 90, 99; t = the exact product
+//                                                                     z * mul that lives inside quant_fma's fused multiply-adds)
+// and, end to end, the kernel's own decision: wherever the accept test of the strip kernel (d = fmaf(z, mul, magic - s) against
+// the float thresholds thrT of build_consts) ACCEPTS a rounding, that rounding is rint(X_exact / div), the reference's.
 // on: blocks read from a file (the adversarial blocks of tools/fastpath_error_search.py, tests/golden/adversarial_blocks.npz
 // exported as raw bytes by the test), extreme patterns, and N random blocks (argv[2], default 2,000,000).
 // It also prints kGuard so that the test can compare it with the rigorous bound of tools/fastpath_error_bound.py.
@@ -28,7 +30,9 @@ static uint32_t rnd() {
     return (uint32_t)(rng_state >> 32);
 }
 
-static DctqConsts C10, C50, C90;
+static DctqConsts C1, C10, C50, C90, C99;
+static long n_accept = 0, n_trip = 0, n_wrong = 0;
+static long n_trip_q[5][2]; // per quality: trips of the 60 irrational / the 4 rational coefficients
 static double aan[8];
 static double worst_ratio[64];  // max over blocks of error / kGuard, coefficient units
 static double worst_ratio_q[64]; // the same in quantised units (worst of the three qualities)
@@ -68,14 +72,28 @@ static void check_block(const uint8_t px[64]) {
             const double r1 = fabs(fast - x[u][v]) / kGuard[i];
             if (r1 > worst_ratio[i]) worst_ratio[i] = r1;
             double rq = 0;
-            for (const DctqConsts *C : {&C10, &C50, &C90}) {
+            for (const DctqConsts *C : {&C1, &C10, &C50, &C90, &C99}) {
                 const float mul = C->mulT[v * 8 + u];
-                const float t_rounded = z[u][v] * mul;                     // round-1 quantiser: float32 product
-                const double t_fused = (double)z[u][v] * (double)mul;       // round-2 quantiser: the exact product inside the fma
+                const double t_fused = (double)z[u][v] * (double)mul;       // the exact product inside the fma
                 const double want = x[u][v] / C->div[i];
-                const double e = fmax(fabs((double)t_rounded - want), fabs(t_fused - want));
-                const double r = e / (kGuard[i] / C->div[i]);
+                const double r = fabs(t_fused - want) / (kGuard[i] / C->div[i]);
                 if (r > rq) rq = r;
+                // the kernel's accept test, operation for operation (quant_fma + the max/compare of the strip kernel)
+                const float s = fmaf(z[u][v], mul, kMagic);
+                const float nr = kMagic - s;
+                const float d = fmaf(z[u][v], mul, nr);
+                const float thr = C->thrT[2 * v + ((u == 0 || u == 4) ? 1 : 0)];
+                if (fabsf(d) > thr) {
+                    n_trip++;
+                    const int qi = C == &C1 ? 0 : C == &C10 ? 1 : C == &C50 ? 2 : C == &C90 ? 3 : 4;
+                    n_trip_q[qi][((u & 3) == 0 && (v & 3) == 0) ? 1 : 0]++;
+                } else {
+                    n_accept++;
+                    uint32_t bits;
+                    memcpy(&bits, &s, 4);
+                    const int got = (int)(int16_t)(bits & 0xffffu);
+                    if (got != (int)rint(want)) n_wrong++;
+                }
             }
             if (rq > worst_ratio_q[i]) worst_ratio_q[i] = rq;
             if (r1 >= 1.0 || rq >= 1.0) n_viol++;
@@ -85,6 +103,8 @@ static void check_block(const uint8_t px[64]) {
 int main(int argc, char **argv) {
     const char *file = argc > 1 ? argv[1] : "";
     const long n_random = argc > 2 ? atol(argv[2]) : 2000000;
+    build_consts(1, &C1);
+    build_consts(99, &C99);
     build_consts(10, &C10);
     build_consts(50, &C50);
     build_consts(90, &C90);
@@ -140,7 +160,11 @@ int main(int argc, char **argv) {
         if (worst_ratio_q[i] > wq) wq = worst_ratio_q[i];
     }
     printf("blocks %ld (file %ld) worst error/guard: coefficient units %.4f, quantised units %.4f, violations %ld\n", n_blocks, n_file, w1, wq, n_viol);
-    if (n_viol != 0 || w1 >= 1.0 || wq >= 1.0) {
+    printf("accept test: %ld accepted, %ld tripped, %ld accepted roundings differ from the reference\n", n_accept, n_trip, n_wrong);
+    printf("trips per million coefficients (irrational / rational), q = 1, 10, 50, 90, 99:");
+    for (int k = 0; k < 5; k++) printf("  %.1f / %.1f", 1e6 * n_trip_q[k][0] / (60.0 * n_blocks), 1e6 * n_trip_q[k][1] / (4.0 * n_blocks));
+    printf("\n");
+    if (n_viol != 0 || w1 >= 1.0 || wq >= 1.0 || n_wrong != 0) {
         printf("guard_selftest FAILED\n");
         return 1;
     }

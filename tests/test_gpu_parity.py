@@ -773,3 +773,50 @@ def test_truncated_streams_round2(ctx, golden):
         name = str(name)
         got = T.decompress(d[name + "_bs"].tobytes(), ctx=ctx)
         assert np.array_equal(got, d[name + "_out"]), name
+
+
+def test_module_level_api_is_reentrant(ctx, oracle):
+    """The reference's compress/decompress/encode are pure functions (codec.py:26-189, no global state).  Here: 8 Python
+    threads x 50 calls of the module-level API on different frames (every thread gets its own default context) equal the
+    single-thread results byte for byte; and 4 threads hammering ONE explicitly shared Context (its calls serialise on the
+    context's lock) do too."""
+    import threading
+
+    shapes = [(64, 64), (200, 328), (136, 520), (72, 1032), (512, 512), (33, 47), (256, 1024), (8, 8)]
+    frames = [rand_frame(9000 + i, *shapes[i % len(shapes)]) for i in range(50)]
+    quals = [10, 50, 90, 35, 75]
+    want = [oracle.compress(f, quals[i % 5]) for i, f in enumerate(frames)]
+    want_px = [oracle.decompress(b) for b in want]
+    errors = []
+
+    def worker(tid, use_ctx):
+        try:
+            order = list(range(50))
+            np.random.default_rng(tid).shuffle(order)
+            for i in order:
+                bs = T.compress(frames[i], quals[i % 5], ctx=use_ctx)
+                if bs != want[i]:
+                    errors.append("thread %d frame %d: stream differs" % (tid, i))
+                if not np.array_equal(T.decompress(bs, ctx=use_ctx), want_px[i]):
+                    errors.append("thread %d frame %d: pixels differ" % (tid, i))
+                e = T.encode(frames[i], quals[i % 5], ctx=use_ctx)
+                if e["dc"].shape[0] != ((frames[i].shape[0] + 7) // 8) * ((frames[i].shape[1] + 7) // 8):
+                    errors.append("thread %d frame %d: encode shape" % (tid, i))
+        except Exception as ex:  # noqa: BLE001
+            errors.append("thread %d: %r" % (tid, ex))
+
+    seen = {}
+    alive = threading.Barrier(3)
+
+    def which_ctx(tid):
+        seen[tid] = N.default_context().handle
+        alive.wait(60)  # (a context freed by a finished thread could hand its address to the next one)
+
+    for target, args_of, nthreads in ((worker, lambda t: (t, None), 8), (worker, lambda t: (t, ctx), 4), (which_ctx, lambda t: (t,), 3)):
+        th = [threading.Thread(target=target, args=args_of(t)) for t in range(nthreads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    assert not errors, errors[:5]
+    assert len(set(seen.values())) == 3, "default_context() must be per thread"

@@ -162,12 +162,17 @@ def test_host_entropy_coder_under_sanitizers(tmp_path):
 
 def test_guard_band_of_the_fast_path_is_a_bound(tmp_path):
     """kGuard (tic_math.h) is what makes the float32 fast path of the strip kernel 'identical for every input'.  Pinned here:
-    (1) the table is at least the rigorous forward-error bound of tools/fastpath_error_bound.py plus the quantiser multiply's
-        rounding, times the documented 5 % margin, for every coefficient;
-    (2) the kernel's own arithmetic (tic_math.h compiled for the host: dct8_aan<float> rows then columns, both quantiser
-        forms) stays inside kGuard against the exact-order float64 DCT on the adversarial blocks of
-        tools/fastpath_error_search.py (tests/golden/adversarial_blocks.npz), extreme patterns and 2,000,000 random blocks
-        of four kinds, in coefficient units and in quantised units at q = 10, 50, 90."""
+    (1) the table is at least the COMPLETE forward-error bound of tools/fastpath_error_bound.py - systematic error of the
+        float32 AAN constants (exact maximum of a linear functional over the pixel box), float32 roundings of both passes,
+        representation error of the quantiser multiplier, the reference's own float64 error - times its margin, for every
+        coefficient, and not needlessly wider (the trip rate scales with it);
+    (2) the systematic term is real: on the block that maximises it, the float-constant algorithm evaluated in float64
+        differs from the true DCT by exactly that much;
+    (3) the kernel's own arithmetic (tic_math.h compiled for the host: dct8_aan<float> rows then columns, quant_fma) stays
+        inside kGuard against the exact-order float64 DCT on the adversarial blocks of tools/fastpath_error_search.py
+        (tests/golden/adversarial_blocks.npz), extreme patterns and 2,000,000 random blocks of four kinds, in coefficient
+        units and in quantised units at q = 1, 10, 50, 90, 99; and wherever the kernel's accept test (float thresholds of
+        build_consts, float distance) accepts a rounding, it is the reference's."""
     import shutil
     import subprocess
     import sys
@@ -179,16 +184,41 @@ def test_guard_band_of_the_fast_path_is_a_bound(tmp_path):
                    check=True)
     adv = np.load(os.path.join(root, "tests", "golden", "adversarial_blocks.npz"))["blocks"]
     assert adv.shape[1:] == (8, 8) and adv.dtype == np.uint8 and len(adv) >= 64
-    raw = tmp_path / "adv.bin"
-    raw.write_bytes(adv.tobytes())
-    r = subprocess.run([str(exe), str(raw), "2000000"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "guard_selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    guard = np.array([float(x) for x in r.stdout.splitlines()[0].split()[1:]]).reshape(8, 8)
     sys.path.insert(0, os.path.join(root, "tools"))
     try:
         import fastpath_error_bound as feb
     finally:
         sys.path.pop(0)
-    need = (feb.bound_matrix() + feb.QUANT_MUL) * 1.05
-    assert (guard >= need * (1 - 2e-4)).all(), (guard / need).min()  # (the table is written with five significant digits)
-    assert (guard <= need * 1.02).all()                                # ... and is not needlessly wide: the trip rate scales with it
+    sysb, worst = feb.systematic_bound(want_blocks=True)
+    raw = tmp_path / "adv.bin"
+    raw.write_bytes(adv.tobytes() + worst.tobytes())  # the maximisers of the systematic term join the adversarial set
+    r = subprocess.run([str(exe), str(raw), "2000000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "guard_selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " 0 accepted roundings differ" in r.stdout
+    guard = np.array([float(x) for x in r.stdout.splitlines()[0].split()[1:]]).reshape(8, 8)
+    # (1)
+    need = feb.guard_matrix()
+    assert (guard >= need).all(), (guard / need).min()
+    assert (guard <= need * 1.001).all(), (guard / need).max()  # (the table is written with five significant digits, rounded up)
+    t = feb.terms()
+    assert (t["systematic"][:, 7] > 1.2e-4).all() and t["systematic"][7, 7] > 2e-4  # the term round 2's bound lacked is not small
+    assert (feb.bound_matrix() >= t["systematic"] + t["rounding"] + t["multiplier"]).all()
+    # (2) float64 evaluation of the float-constant algorithm (rows, then columns) against the true scaled DCT
+    k = np.arange(8)
+    T1 = np.where(k[:, None] == 0, 1.0, np.sqrt(2) * np.cos(k[:, None] * np.pi / 16) * np.sqrt(8) * 0.5 * np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16))
+
+    class V:  # float64 values with dct8_aan's operation set
+        def __init__(self, a): self.a = a
+        def __add__(self, o): return V(self.a + o.a)
+        def __sub__(self, o): return V(self.a - o.a)
+        def mulc(self, c): return V(self.a * c)
+        def fma(self, c, o): return V(self.a * c + o.a)
+
+    for (u, v) in [(7, 7), (0, 7), (7, 0), (1, 1), (3, 5)]:
+        x = worst[u, v].astype(np.float64) - 128.0
+        rows = np.stack([o.a for o in feb.aan([V(x[:, n]) for n in range(8)], feb.C_F32)], 1)     # along the pixel rows
+        z = np.stack([o.a for o in feb.aan([V(rows[r, :]) for r in range(8)], feb.C_F32)], 0)      # down the columns
+        true = T1 @ x @ T1.T
+        assert abs(abs(z[u, v] - true[u, v]) - sysb[u, v]) < 1e-9 * max(1.0, sysb[u, v]) + 1e-9, (u, v, z[u, v] - true[u, v], sysb[u, v])
+
+

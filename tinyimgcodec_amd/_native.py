@@ -107,7 +107,7 @@ SIGNATURES = {
 }
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()  # re-entrant: default_context() creates a Context (which calls load()) under it
 
 
 def load():
@@ -133,10 +133,15 @@ def load():
 
 
 class Context:
-    """One HIP device + stream (tic_ctx).  Not thread-safe: use one per host thread."""
+    """One HIP device + stream + scratch buffers (tic_ctx).
+
+    Thread-safety: every C-ABI call locks its context, so a Context shared between threads is safe - its calls serialise.
+    `lock` (re-entrant) is what the Python mirror holds around a call AND the landing buffers it keeps on the context.
+    Threads that should overlap use one Context each; default_context() hands every thread its own."""
 
     def __init__(self, device=None):
         L = load()
+        self.lock = threading.RLock()
         if device is None:
             device = int(os.environ.get("TINYIMGCODEC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         self._L = L
@@ -170,11 +175,15 @@ class Context:
             pass
 
 
-_default_ctx = None
+_tls = threading.local()
 
 
 def default_context():
-    global _default_ctx
-    if _default_ctx is None:
-        _default_ctx = Context()
-    return _default_ctx
+    """The calling thread's own context (created on first use, closed when the thread ends).  The reference's functions are
+    pure and re-entrant (codec.py:26-189, no global state): with a context per thread so are compress()/decompress()/
+    encode()/decode() here - no stream, scratch buffer or landing buffer is shared between two threads."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None or not ctx.handle:
+        with _lock:  # one tic_create at a time (device open, constant upload)
+            ctx = _tls.ctx = Context()
+    return ctx

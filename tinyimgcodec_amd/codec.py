@@ -96,7 +96,8 @@ def _encode_wide(img, h, w, q, ctx):
     dc = np.zeros(n, dtype=np.int32)
     ac = np.zeros((n, 63), dtype=np.int32)
     if n:
-        ctx.check(L.tic_encode_wide(ctx.handle, img.ctypes.data, h, w, img.strides[0] // 4, q, dc.ctypes.data, ac.ctypes.data))
+        with ctx.lock:
+            ctx.check(L.tic_encode_wide(ctx.handle, img.ctypes.data, h, w, img.strides[0] // 4, q, dc.ctypes.data, ac.ctypes.data))
     return dc, ac
 
 
@@ -108,7 +109,8 @@ def dctq(image, quality=50, ctx=None):
     n = N.load().tic_num_blocks(h, w)
     zz = np.zeros((n, 64), dtype=np.int16)
     if n:
-        ctx.check(N.load().tic_dctq(ctx.handle, img.ctypes.data, h, w, img.strides[0], quality, zz.ctypes.data))
+        with ctx.lock:
+            ctx.check(N.load().tic_dctq(ctx.handle, img.ctypes.data, h, w, img.strides[0], quality, zz.ctypes.data))
     return zz
 
 
@@ -123,7 +125,8 @@ def encode(image, quality=50, ctx=None):
     dc = np.zeros(n, dtype=np.int32)
     ac = np.zeros((n, 63), dtype=np.int32)
     if n:
-        ctx.check(N.load().tic_encode(ctx.handle, img.ctypes.data, h, w, img.strides[0], q, dc.ctypes.data, ac.ctypes.data))
+        with ctx.lock:
+            ctx.check(N.load().tic_encode(ctx.handle, img.ctypes.data, h, w, img.strides[0], q, dc.ctypes.data, ac.ctypes.data))
     return {"height": h, "width": w, "quality": quality, "dc": dc, "ac": ac}
 
 
@@ -145,15 +148,17 @@ def compress(image, quality=50, auto_generate_huffman_table=False, ctx=None):
     cap = L.tic_compress_bound(h, w)
     # worst-case sized landing buffer kept on the context: a fresh 50 MB mapping per call would be faulted in page by page
     # under the device-to-host copy (20+ ms for a 4096x4096 frame whose whole C-level round trip takes 0.6 ms)
-    out = getattr(ctx, "_out_buf", None)
-    if out is None or out.size < cap:
-        out = ctx._out_buf = np.empty(cap, dtype=np.uint8)
-    n = C.c_size_t(0)
-    rc = L.tic_compress(ctx.handle, img.ctypes.data, h, w, img.strides[0] if img.size else max(w, 1), q, out.ctypes.data, cap, C.byref(n))
-    if rc == N.TIC_E_RANGE:
-        raise KeyError("coefficient magnitude has no Huffman code")  # as the reference's dict lookup
-    ctx.check(rc)
-    return out[: n.value].tobytes()
+    # (the buffer belongs to the context: the context's lock is held from the call to the copy into the returned bytes)
+    with ctx.lock:
+        out = getattr(ctx, "_out_buf", None)
+        if out is None or out.size < cap:
+            out = ctx._out_buf = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = L.tic_compress(ctx.handle, img.ctypes.data, h, w, img.strides[0] if img.size else max(w, 1), q, out.ctypes.data, cap, C.byref(n))
+        if rc == N.TIC_E_RANGE:
+            raise KeyError("coefficient magnitude has no Huffman code")  # as the reference's dict lookup
+        ctx.check(rc)
+        return out[: n.value].tobytes()
 
 
 def compress_batch(images, quality=50, threads=0, ctx=None):
@@ -173,19 +178,20 @@ def compress_batch(images, quality=50, threads=0, ctx=None):
     cap = L.tic_compress_bound(h, w)
     # one mapping, kept on the context: only the bytes actually written are ever touched, and a second batch of the same
     # geometry finds them already faulted in (first-touch page faults cost more than the whole GPU pipeline)
-    pool = getattr(ctx, "_batch_pool", None)
-    if pool is None or pool.shape[0] < n or pool.shape[1] != cap:
-        pool = ctx._batch_pool = np.empty((n, cap), dtype=np.uint8)
-    outs = [pool[i] for i in range(n)]
-    inp = (C.c_void_p * n)(*[f[0].ctypes.data for f in frames])
-    outp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
-    caps = (C.c_size_t * n)(*([cap] * n))
-    lens = (C.c_size_t * n)()
-    rc = L.tic_compress_batch(ctx.handle, inp, n, h, w, max(w, 1), q, outp, caps, lens, int(threads))
-    if rc == N.TIC_E_RANGE:
-        raise KeyError("coefficient magnitude has no Huffman code")
-    ctx.check(rc)
-    return [outs[i][: lens[i]].tobytes() for i in range(n)]
+    with ctx.lock:
+        pool = getattr(ctx, "_batch_pool", None)
+        if pool is None or pool.shape[0] < n or pool.shape[1] != cap:
+            pool = ctx._batch_pool = np.empty((n, cap), dtype=np.uint8)
+        outs = [pool[i] for i in range(n)]
+        inp = (C.c_void_p * n)(*[f[0].ctypes.data for f in frames])
+        outp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * n)(*([cap] * n))
+        lens = (C.c_size_t * n)()
+        rc = L.tic_compress_batch(ctx.handle, inp, n, h, w, max(w, 1), q, outp, caps, lens, int(threads))
+        if rc == N.TIC_E_RANGE:
+            raise KeyError("coefficient magnitude has no Huffman code")
+        ctx.check(rc)
+        return [outs[i][: lens[i]].tobytes() for i in range(n)]
 
 
 def entropy_encode(coeffs_zz, height, width, quality):
@@ -203,9 +209,19 @@ def entropy_encode(coeffs_zz, height, width, quality):
     return out[: n.value].tobytes()
 
 
+def _as_bytes_view(data):
+    """uint8 view of a bytes-like object without copying it (bytes, bytearray, memoryview, uint8 arrays)."""
+    if isinstance(data, np.ndarray) and data.dtype == np.uint8 and data.flags.c_contiguous:
+        return data.reshape(-1)
+    try:
+        return np.frombuffer(data, dtype=np.uint8)
+    except (TypeError, ValueError):
+        return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
 def parse_header(data):
     L = N.load()
-    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    buf = _as_bytes_view(data)
     h, w, q, flag = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
     rc = L.tic_parse_header(buf.ctypes.data, buf.size, C.byref(h), C.byref(w), C.byref(q), C.byref(flag))
     if rc != N.TIC_OK:
@@ -215,10 +231,11 @@ def parse_header(data):
 
 def decompress(data, ctx=None):
     ctx = _ctx(ctx)
-    hdr = parse_header(data)
-    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    buf = _as_bytes_view(data)  # one view for the header and the payload: the stream is not copied
+    hdr = parse_header(buf)
     out = np.zeros((hdr["height"], hdr["width"]), dtype=np.uint8)
-    ctx.check(N.load().tic_decompress(ctx.handle, buf.ctypes.data, buf.size, out.ctypes.data, out.size))
+    with ctx.lock:
+        ctx.check(N.load().tic_decompress(ctx.handle, buf.ctypes.data, buf.size, out.ctypes.data, out.size))
     return out
 
 
@@ -242,9 +259,11 @@ def decode(data, ctx=None):
         if int(quality) != quality or not (0 <= int(quality) <= 62):
             raise ValueError("scaled_dct exponent outside 0..62")
         if n:
-            ctx.check(N.load().tic_idctq_scaled(ctx.handle, zz.ctypes.data, int(height), int(width), int(quality), out.ctypes.data, out.size))
+            with ctx.lock:
+                ctx.check(N.load().tic_idctq_scaled(ctx.handle, zz.ctypes.data, int(height), int(width), int(quality), out.ctypes.data, out.size))
         return out
     q = _check_quality(quality, packs_header=False)
     if n:
-        ctx.check(N.load().tic_idctq(ctx.handle, zz.ctypes.data, int(height), int(width), q, out.ctypes.data, out.size))
+        with ctx.lock:
+            ctx.check(N.load().tic_idctq(ctx.handle, zz.ctypes.data, int(height), int(width), q, out.ctypes.data, out.size))
     return out

@@ -67,6 +67,10 @@ struct Slot {
 } // namespace
 
 struct tic_ctx {
+    // Every entry point that takes a context holds this lock for its whole duration: a context shared between host threads is
+    // safe (calls serialise); threads that want to overlap use one context each (the Python mirror's default context is
+    // per thread).  Recursive because the host-buffer entry points call the device-buffer ones.
+    std::recursive_mutex mu;
     int device = -1;
     hipStream_t stream = nullptr;     // all single-frame work
     hipStream_t bstream[2] = {nullptr, nullptr}; // batch pipeline streams
@@ -124,6 +128,10 @@ static int set_err(tic_ctx *ctx, int code, const char *fmt, ...) {
             return set_err(ctx, TIC_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,  \
                            __LINE__);                                                                        \
     } while (0)
+
+#define TIC_LOCK(ctx)                                      \
+    std::unique_lock<std::recursive_mutex> ctx_lock_;      \
+    if (ctx) ctx_lock_ = std::unique_lock<std::recursive_mutex>((ctx)->mu)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -248,30 +256,35 @@ tic_ctx *tic_create(int device) {
 
 // ---- device memory helpers ---------------------------------------------------------------------------
 int tic_dev_alloc(tic_ctx *ctx, size_t bytes, void **dptr) {
+    TIC_LOCK(ctx);
     if (!ctx || !dptr) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 1));
     return TIC_OK;
 }
 int tic_dev_free(tic_ctx *ctx, void *dptr) {
+    TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipFree(dptr));
     return TIC_OK;
 }
 int tic_host_alloc_pinned(tic_ctx *ctx, size_t bytes, void **hptr) {
+    TIC_LOCK(ctx);
     if (!ctx || !hptr) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
     return TIC_OK;
 }
 int tic_host_free_pinned(tic_ctx *ctx, void *hptr) {
+    TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipHostFree(hptr));
     return TIC_OK;
 }
 int tic_memcpy_h2d(tic_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -279,6 +292,7 @@ int tic_memcpy_h2d(tic_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return TIC_OK;
 }
 int tic_memcpy_d2h(tic_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -286,12 +300,14 @@ int tic_memcpy_d2h(tic_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return TIC_OK;
 }
 int tic_memset_dev(tic_ctx *ctx, void *dst, int value, size_t bytes) {
+    TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
     return TIC_OK;
 }
 int tic_sync(tic_ctx *ctx) {
+    TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -359,6 +375,7 @@ static void merge_frames(DctqArgs &a) {
 
 int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
                  int variant) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (h == 0 || w == 0) return TIC_OK;
@@ -373,6 +390,7 @@ int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_
 
 int tic_dctq_dev_frames(tic_ctx *ctx, const void *d_images, int nframes, int h, int w, ptrdiff_t row_stride,
                         ptrdiff_t frame_stride, int quality, void *d_coeffs_zz, ptrdiff_t coeff_frame_stride, int variant) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (nframes < 0) return set_err(ctx, TIC_E_ARG, "negative frame count");
@@ -394,6 +412,7 @@ int tic_dctq_dev_frames(tic_ctx *ctx, const void *d_images, int nframes, int h, 
 
 int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
                        void *d_coeffs_zz, int variant, int iters, float *ms_total) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!ms_total || iters < 1 || !d_image || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
@@ -418,6 +437,7 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
 int tic_dctq_dev_frames_timed(tic_ctx *ctx, const void *d_images, int nframes, int h, int w, ptrdiff_t row_stride,
                               ptrdiff_t frame_stride, int quality, void *d_coeffs_zz, ptrdiff_t coeff_frame_stride, int variant,
                               int iters, float *ms_total) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!ms_total || iters < 1 || nframes < 1 || nframes > 65535 || !d_images || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
@@ -446,6 +466,7 @@ int tic_dctq_dev_frames_timed(tic_ctx *ctx, const void *d_images, int nframes, i
 // left the cache since their last use: the number is an HBM number, not an on-die one.
 int tic_dctq_dev_timed_rotating(tic_ctx *ctx, const void *const *d_images, void *const *d_coeffs_zz, int npairs, int h, int w,
                                 ptrdiff_t row_stride, int quality, int variant, int iters, float *ms_total) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!ms_total || iters < 1 || npairs < 1 || !d_images || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
@@ -476,6 +497,7 @@ int tic_dctq_dev_timed_rotating(tic_ctx *ctx, const void *const *d_images, void 
 // Experiment library only (tools/): one launch of a stamp build (variant 17 or 52), per-wave s_memtime stamps to host_out.
 int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
                      unsigned long long *host_out, size_t n_u64, int variant) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -491,12 +513,14 @@ int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t 
 #endif
 
 int tic_set_stats(tic_ctx *ctx, int enable) {
+    TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     ctx->stats = enable != 0;
     return TIC_OK;
 }
 
 int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count) {
+    TIC_LOCK(ctx);
     if (!ctx || !count) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(count, ctx->d_fallback, sizeof *count, hipMemcpyDeviceToHost, ctx->stream));
@@ -524,6 +548,7 @@ static int ensure_scratch(tic_ctx *ctx, size_t img_bytes, size_t coef_bytes) {
 }
 
 int tic_dctq(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, int16_t *coeffs_zz) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     const size_t n = num_blocks(h, w);
@@ -544,6 +569,7 @@ int tic_dctq(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_str
 
 int tic_encode(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, int32_t *dc,
                int32_t *ac) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     const size_t n = num_blocks(h, w);
@@ -566,6 +592,7 @@ int tic_encode(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_s
 // int32 pixels, float64 exact order on the device, int32 dc (DPCM applied) / ac as the reference returns them.
 int tic_encode_wide(tic_ctx *ctx, const int32_t *image, int h, int w, ptrdiff_t row_stride_elems, int quality, int32_t *dc,
                     int32_t *ac) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride_elems, quality);
     if (rc) return rc;
     const size_t n = num_blocks(h, w);
@@ -613,6 +640,7 @@ int tic_parse_header(const uint8_t *data, size_t len, int *h, int *w, int *quali
 // on the host between the counting and the packing step).
 int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, int quality, void *d_out, size_t cap,
                            size_t *out_len) {
+    TIC_LOCK(ctx);
     if (!ctx || !out_len) return TIC_E_ARG;
     if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size");
     if (quality < 1 || quality > 99) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
@@ -660,6 +688,7 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
 // compress() with every stage on the device: transform kernels + device entropy stage; image and stream in HBM.
 int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out,
                      size_t cap, size_t *out_len) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     const size_t n = num_blocks(h, w);
@@ -672,6 +701,7 @@ int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t 
 
 int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, uint8_t *out,
                  size_t cap, size_t *out_len) {
+    TIC_LOCK(ctx);
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!out || !out_len) return set_err(ctx, TIC_E_ARG, "null output pointer");
@@ -1138,12 +1168,14 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
 
 int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
                        uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads) {
+    TIC_LOCK(ctx);
     if (threads <= 0) return compress_batch_gpu(ctx, images, n, h, w, row_stride, quality, outs, caps, out_lens);
     return batch_impl(ctx, images, n, h, w, row_stride, quality, nullptr, outs, caps, out_lens, threads, true);
 }
 
 int tic_dctq_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
                    int16_t *const *coeffs) {
+    TIC_LOCK(ctx);
     return batch_impl(ctx, images, n, h, w, row_stride, quality, coeffs, nullptr, nullptr, nullptr, 4, false);
 }
 
@@ -1184,15 +1216,18 @@ static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int 
 }
 
 int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap) {
+    TIC_LOCK(ctx);
     return idctq_impl(ctx, coeffs_zz, h, w, quality, -1, out, cap);
 }
 
 int tic_idctq_scaled(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int exponent, uint8_t *out, size_t cap) {
+    TIC_LOCK(ctx);
     if (ctx && exponent < 0) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d outside 0..62", exponent);
     return idctq_impl(ctx, coeffs_zz, h, w, 50, exponent, out, cap);
 }
 
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
+    TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     int h, w, quality;
     uint32_t flag;
@@ -1222,6 +1257,7 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
 
 // ---- self test hook (used by tests/ only; not part of the drop-in surface) --------------------------------
 int tic_selftest_transpose(tic_ctx *ctx, const void *host_in, void *host_dpp, void *host_ref, int nthreads) {
+    TIC_LOCK(ctx);
     if (!ctx || nthreads <= 0 || nthreads % 256) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     void *d_in, *d_a, *d_b;

@@ -130,22 +130,27 @@ TIC_HD void dct8_aan(T &d0, T &d1, T &d2, T &d3, T &d4, T &d5, T &d6, T &d7) {
     d7 = z11 - z4;
 }
 
-// Guard band of the fast path per coefficient (u = vertical, v = horizontal frequency), in coefficient (X) units: a
-// rigorous forward error bound of dct8_aan() in float32, rows then columns, for uint8 pixels (every operation
-// contributes 2^-24 * |result|max, exact integer additions nothing, errors propagate linearly;
-// tools/fastpath_error_bound.py), plus the rounding of the quantiser multiply (1024 * 2^-23), times 1.05.  The largest
-// error an adversarial search found (tools/fastpath_error_search.py) is 4.6e-4, a factor 4-8 below the bounds of
-// the worst positions.  |X_fast - X_reference| < kGuard[u][v] for every input, so a rounding decided outside the
-// band is the reference's rounding.
+// Guard band of the fast path per coefficient (u = vertical, v = horizontal frequency), in coefficient (X) units: a COMPLETE
+// forward error bound of what the strip kernel computes against what the reference computes, for every block of uint8 pixels
+// (tools/fastpath_error_bound.py, which prints this table; tests/test_host_cpu.py asserts table >= bound):
+//   systematic  dct8_aan<float> multiplies by float32(0.7071...) etc., not by the real numbers: the largest value over the pixel
+//               box of the difference between the float-constant algorithm in exact arithmetic and the true DCT, computed exactly;
+//   rounding    half an ulp of the largest magnitude of every float32 result that is not provably exact (integer sums are),
+//               carried through the two passes (rows, then columns);
+//   multiplier  the float32 quantiser multiplier's representation error, 1024 * 2^-24 (the product is not rounded: quant_fma);
+//   reference   the reference's own float64 error (~1e-12);
+// times 1.02.  |X_fast - X_reference| < kGuard[u][v] for every input, so a rounding decided outside the band is the reference's
+// rounding.  The float32 resolution of the accept test itself is taken out of the thresholds by build_consts() (thr_below).
+// The largest error an adversarial search found (tools/fastpath_error_search.py) is 4.6e-4 at (7,7), a factor 6 below.
 static constexpr double kGuard[64] = {
-    1.2817e-04, 4.3501e-04, 3.6408e-04, 4.4856e-04, 1.2817e-04, 4.9276e-04, 3.6408e-04, 7.3890e-04,
-    2.6147e-04, 5.4881e-04, 4.6611e-04, 5.6482e-04, 2.6147e-04, 6.1707e-04, 4.6611e-04, 9.0801e-04,
-    1.8715e-04, 4.4296e-04, 3.7804e-04, 4.5547e-04, 1.8715e-04, 4.9631e-04, 3.7804e-04, 7.2371e-04,
-    2.7502e-04, 5.3390e-04, 4.5962e-04, 5.4838e-04, 2.7502e-04, 5.9563e-04, 4.5962e-04, 8.5871e-04,
-    1.2817e-04, 4.3501e-04, 3.6408e-04, 4.4856e-04, 1.2817e-04, 4.9276e-04, 3.6408e-04, 7.3890e-04,
-    3.1923e-04, 7.0935e-04, 5.9767e-04, 7.3103e-04, 3.1923e-04, 8.0174e-04, 5.9767e-04, 1.1955e-03,
-    1.8715e-04, 8.1255e-04, 6.5436e-04, 8.4277e-04, 1.8715e-04, 9.4136e-04, 6.5436e-04, 1.4904e-03,
-    5.6536e-04, 2.0317e-03, 1.6119e-03, 2.1123e-03, 5.6536e-04, 2.3749e-03, 1.6119e-03, 3.8376e-03,
+    6.2256e-05, 3.2315e-04, 2.6249e-04, 3.4557e-04, 6.2256e-05, 3.3290e-04, 2.0056e-04, 5.9516e-04,
+    1.8850e-04, 3.9880e-04, 3.3279e-04, 4.4030e-04, 1.8850e-04, 4.2003e-04, 2.8730e-04, 7.1855e-04,
+    1.1955e-04, 3.1685e-04, 2.7439e-04, 3.5239e-04, 1.1955e-04, 3.3094e-04, 2.2674e-04, 5.9192e-04,
+    1.8674e-04, 3.7822e-04, 3.2467e-04, 4.1881e-04, 1.8674e-04, 3.9724e-04, 2.9065e-04, 6.9278e-04,
+    6.2256e-05, 3.2315e-04, 2.6249e-04, 3.4557e-04, 6.2256e-05, 3.3290e-04, 2.0056e-04, 5.9516e-04,
+    2.1405e-04, 4.9996e-04, 4.2070e-04, 5.6244e-04, 2.1405e-04, 5.6214e-04, 3.5821e-04, 9.0797e-04,
+    1.1428e-04, 6.1485e-04, 5.1255e-04, 7.0510e-04, 1.1428e-04, 6.6162e-04, 3.4923e-04, 1.0793e-03,
+    5.1054e-04, 1.5901e-03, 1.3262e-03, 1.8402e-03, 5.1054e-04, 1.7563e-03, 1.0117e-03, 2.7581e-03,
 };
 // Guard classes of the one-block-per-lane kernel: every lane quantises all 64 coefficients, so the accept test is a
 // max over the coefficients of a class against one threshold per class (0.5 - largest guard/div of the class).  That
@@ -189,6 +194,16 @@ struct DctqConsts {
 constexpr int kStripBlkBytes = 2176;
 constexpr int kStripBlkPieces = kStripBlkBytes / 16;
 
+// Accept threshold of the fast path as a float: the kernel accepts a rounding when fl32(|t - rint(t)|) <= thr.  The distance
+// is a float32 result in [0, 0.5]: above 0.25 it is rounded by at most 2^-26, i.e. by less than the gap between thr and the next
+// float below 0.5.  Rounding tau DOWN to a float and stepping one float further down therefore guarantees
+// accepted  =>  |t - rint(t)| < tau, whatever tau's and the distance's own roundings were.
+inline float thr_below(double tau) {
+    float f = (float)tau;
+    if ((double)f > tau) f = nextafterf(f, 0.0f);
+    return nextafterf(f, 0.0f);
+}
+
 // utils.py:50-53 divisor recipe.  Returns false when quality is outside 1..99.
 inline bool build_consts(int quality, DctqConsts *c) {
 #pragma clang fp contract(off)
@@ -222,8 +237,8 @@ inline bool build_consts(int quality, DctqConsts *c) {
             else
                 ga = g > ga ? g : ga;
         }
-        c->thrT[2 * v] = (float)(0.5 - ga);
-        c->thrT[2 * v + 1] = (float)(0.5 - gb);
+        c->thrT[2 * v] = thr_below(0.5 - ga);
+        c->thrT[2 * v + 1] = thr_below(0.5 - gb);
     }
     {
         double gmax[4] = {0.0, 0.0, 0.0, 0.0};
@@ -231,7 +246,7 @@ inline bool build_consts(int quality, DctqConsts *c) {
             const double g = kGuard[(i & 7) * 8 + (i >> 3)] / c->div[i]; // columns-first: transposed bound
             if (g > gmax[kLaneClass[i]]) gmax[kLaneClass[i]] = g;
         }
-        for (int k = 0; k < 4; k++) c->thrC[k] = (float)(0.5 - gmax[k]);
+        for (int k = 0; k < 4; k++) c->thrC[k] = thr_below(0.5 - gmax[k]);
     }
     for (int k = 0; k < 8; k++)
         for (int n = 0; n < 8; n++)
