@@ -82,7 +82,7 @@ static void check_block(const uint8_t px[64]) {
                 const float s = fmaf(z[u][v], mul, kMagic);
                 const float nr = kMagic - s;
                 const float d = fmaf(z[u][v], mul, nr);
-                const float thr = C->thrT[2 * v + ((u == 0 || u == 4) ? 1 : 0)];
+                const float thr = C->thrG[4 * v + ((u == 0 || u == 4) ? 2 : (u < 4 ? 0 : 1))]; // the strip kernel's three groups per column
                 if (fabsf(d) > thr) {
                     n_trip++;
                     const int qi = C == &C1 ? 0 : C == &C10 ? 1 : C == &C50 ? 2 : C == &C90 ? 3 : 4;

@@ -874,7 +874,7 @@ __device__ __forceinline__ void wave_redo_block(const uint8_t *px /* 64 pixels, 
 // OPT: A/B switches of the experiment library (bit 0: fused quantiser, bit 1: tripped blocks sit out the strip's store);
 // the product is built with all of them on.
 template <int ABL, int ST = 0, int LD = 0, int OPT = 15, int OCC = 6, int PF = 2>
-__global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqArgs a) {
+__global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vgpr(72))) void dctq_strip_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) unsigned char cst_blk[kStripBlkBytes]; // constants, shared by the workgroup
@@ -908,6 +908,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
     unsigned long long mask_exact = 0;       // strips of this wave's walk to redo in the exact order (wave-uniform)
     uint32_t n_second = 0;                   // blocks sent to the second level (statistics)
     int nE = 0;                              // entries in the batch (wave-uniform)
+    uint32_t kind_mask = 0;                  // bit e: entry e tripped on an irrational coefficient (wave-uniform, scalar register)
     int t_first, n_my;
     const uint32_t st_off = (uint32_t)lane * 16u; // lane offset inside a strip's 1 KiB output
     {
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         f32x4 m0, m1;
-        f32x2 thr;
+        f32x4 thr;
         u32x4 zzv;
         // Constants: the workgroup copies the quality's 2176-byte block into LDS, 34 lanes of every wave one 16-byte piece
         // each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
             static_assert(kPpw * kWavesPerWG == kStripBlkPieces && kPpw <= 64, "constant block must split evenly over the waves");
             const uint32_t piece = lane < kPpw ? (uint32_t)(wave * kPpw + lane) : (uint32_t)kStripBlkPieces - 1u;
             const uint32_t fo = piece * 16u;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c_fill) : "v"(fo), "s"(C->strip_blk) : "memory");
+            asm volatile("global_load_dwordx4 v[76:79], %0, %1" : : "v"(fo), "s"(C->strip_blk) : "memory", "v76", "v77", "v78", "v79"); // (lands in reserved registers: see TIC_LOAD)
         }
         // LDS layouts of the loop: as in the kernel above (conflict-free transpose and zig-zag staging)
         uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // v in {0,1,4,5}: + v*32 dwords
@@ -975,21 +976,37 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         uint32_t src_off = 0; // a load past the end of the walk re-reads the wave's last strip (strip 0 if it has none)
         int n_issued = 0;
         const uint8_t *img_s = a.img;
-#define TIC_LOAD(P, OB)                                                                                      \
+        // Pixel loads land in RESERVED registers v72..v79: the kernel is compiled with amdgpu_num_vgpr(72), so the compiler
+        // allocates v0..v71 only, and the asm statements below name v72.. explicitly (declared as clobbers, which makes the
+        // kernel descriptor cover them: 80 registers, six waves per SIMD).  The compiler never sees a loaded value before the
+        // counted wait that precedes its first use, inside the same asm statement.  (Rounds 1-2 gave the asm load a "=v" output: the
+        // compiler then believes the value exists from that statement on and is free to copy it - a phi move, a coalescing with a
+        // register tuple - before it has landed, and to reuse a register that a load in flight will still write.  It happened not
+        // to; tools/microbench7.hip faulted exactly that way.  Accumulator registers would do too, but the compiler then splits the
+        // 80 registers 40:40 and spills.)  tests/test_host_cpu.py checks in the disassembly that no instruction outside these
+        // statements touches v72..v79.
+#define TIC_RSV_CLOBBER "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
+#define TIC_LOAD(R, OB)                                                                                      \
     do {                                                                                                     \
         src_off = n_issued < n_my ? in_off : src_off;                                                        \
         OB = oblk;                                                                                           \
         const uint8_t *src = img_s + src_off;                                                                \
-        if (!kMem) P = ((unsigned long long)(ld_off * 2654435761u + src_off) << 24) ^ (ld_off + oblk); /* compute-only build */ \
-        else if (LD == 0) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        else if (LD == 1) asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        else if (LD == 2) asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        else if (LD == 3) asm volatile("global_load_dwordx2 %0, %1, %2 sc0 sc1" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        else asm volatile("global_load_dwordx2 %0, %1, %2 sc1 nt" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
+        if (!kMem) { /* compute-only build: TIC_TAKE makes up the pixels */ }                                \
+        else if (LD == 0) asm volatile("global_load_dwordx2 v[" R "], %0, %1" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
+        else if (LD == 1) asm volatile("global_load_dwordx2 v[" R "], %0, %1 nt" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
+        else if (LD == 2) asm volatile("global_load_dwordx2 v[" R "], %0, %1 sc1" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
+        else if (LD == 3) asm volatile("global_load_dwordx2 v[" R "], %0, %1 sc0 sc1" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
+        else asm volatile("global_load_dwordx2 v[" R "], %0, %1 sc1 nt" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
         n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
         if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
     } while (0)
-#define TIC_WAIT(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(P) : : "memory")
+    // waits until all but the N youngest vector-memory operations are done, then copies the strip's pixel words out of v[R0], v[R1]
+    // (two moves per strip; the conversions cannot read the reserved registers directly without pinning the whole of pass 1)
+#define TIC_TAKE(LO, HI, R0, R1, N)                                                                          \
+    do {                                                                                                     \
+        if (kMem) asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 : "=v"(LO), "=v"(HI) : : TIC_RSV_CLOBBER); \
+        else { LO = ld_off * 2654435761u + kstrip * 40503u; HI = LO ^ (oblk << 7); }                         \
+    } while (0)
         if (ABL == 8 && a.dbg != nullptr && lane == 0) {
             unsigned long long *d = a.dbg + (((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8;
             d[0] = t_entry;
@@ -998,28 +1015,32 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
             d[7] = t_desc;
         }
         if (ABL == 13) { // timing-only: prologue (arguments, constants, walk set-up), no strips
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(c_fill) : : "memory");
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v76" : "=v"(c_fill.x) : : "memory", "v76", "v77", "v78", "v79");
             if (n_my < 0) a.out[lane] = (int16_t)((float)c_fill.x + (float)in_off + (float)oblk);
             return;
         }
-        unsigned long long p0, p1, p2, p3 = 0;
         uint32_t ob0, ob1, ob2, ob3 = 0;
-        TIC_LOAD(p0, ob0);
-        if (!(OPT & 16)) TIC_LOAD(p1, ob1);
+        uint32_t kstrip = 0; // ordinal of the strip in this wave's walk
+        TIC_LOAD("72:73", ob0);
+        if (!(OPT & 16)) TIC_LOAD("74:75", ob1);
         // the constant piece is older than the pixel loads: it has landed when only those are in flight
-        if (OPT & 16) asm volatile("s_waitcnt vmcnt(1)" : "+v"(c_fill) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(c_fill) : : "memory");
+#define TIC_TAKE_CONSTS(N)                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_mov_b32 %0, v76\n\tv_mov_b32 %1, v77\n\tv_mov_b32 %2, v78\n\tv_mov_b32 %3, v79" \
+                 : "=v"(c_fill.x), "=v"(c_fill.y), "=v"(c_fill.z), "=v"(c_fill.w) : : "memory", "v76", "v77", "v78", "v79")
+        if (OPT & 16) TIC_TAKE_CONSTS(1);
+        else TIC_TAKE_CONSTS(2);
+#undef TIC_TAKE_CONSTS
         if (lane < kStripBlkPieces / kWavesPerWG) *reinterpret_cast<u32x4 *>(cst_blk + (wave * (kStripBlkPieces / kWavesPerWG) + lane) * 16) = c_fill;
         // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
         // The second strip's load goes out behind the barrier: the CU's memory pipeline returns data in request order, and
         // with both loads up front the first strip of the CU's last wave queued behind 39 others (first data 1,400 cycles
         // after entry for the first workgroup of a CU, 5,000 for the fifth).
-        if (OPT & 16) TIC_LOAD(p1, ob1);
-        if (PF == 3) TIC_LOAD(p2, ob2); // experiment: three strips ahead
+        if (OPT & 16) TIC_LOAD("74:75", ob1);
+        if (PF == 3) TIC_LOAD("76:77", ob2); // experiment: three strips ahead
         m0 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32);
         m1 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32 + 16);
-        thr = *reinterpret_cast<const f32x2 *>(cst_blk + 256 + i * 8);
+        thr = *reinterpret_cast<const f32x4 *>(cst_blk + 2176 + i * 16); // accept thresholds of column v = i: u in {1,2,3} | {5,6,7} | {0,4}
         zzv = *reinterpret_cast<const u32x4 *>(cst_blk + 320 + i * 16);
         auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
             return reinterpret_cast<int16_t *>(ldsZ + (ofs >> 4) * 128 + (ofs & 15) + 16 * (b ^ (4 * ((ofs >> 5) & 1))));
@@ -1031,11 +1052,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         wave_lds_fence();
 
         int left = n_my;
-        uint32_t kstrip = 0; // ordinal of the strip in this wave's walk
         uint4 acc = make_uint4(0, 0, 0, 0);
-        auto process = [&](const unsigned long long px, const uint32_t ob) {
+        auto process = [&](const uint32_t lo0, const uint32_t hi0, const uint32_t ob) {
             // ---- pass 1: along the pixel row ------------------------------------------------------------------
-            const uint32_t lo0 = (uint32_t)px, hi0 = (uint32_t)(px >> 32);
             float d0, d1, d2, d3, d4, d5, d6, d7;
             asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d0) : "v"(lo0));
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d1) : "v"(lo0));
@@ -1073,12 +1092,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
                 if (OPT & 1) quant_fma(e5, m1.y, q5, r5); else quant_magic(e5, m1.y, q5, r5);
                 if (OPT & 1) quant_fma(e6, m1.z, q6, r6); else quant_magic(e6, m1.z, q6, r6);
                 if (OPT & 1) quant_fma(e7, m1.w, q7, r7); else quant_magic(e7, m1.w, q7, r7);
-                float mA = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
-                mA = fmaxf(fmaxf(mA, fabsf(r5)), fabsf(r6));
-                mA = fmaxf(mA, fabsf(r7));
+                const float mA1 = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
+                const float mA2 = fmaxf(fmaxf(fabsf(r5), fabsf(r6)), fabsf(r7));
                 const float mB = fmaxf(fabsf(r0), fabsf(r4));
-                cA = __ballot(mA > thr.x);
-                cB = __ballot(mB > thr.y);
+                cA = __ballot(mA1 > thr.x) | __ballot(mA2 > thr.y);
+                cB = __ballot(mB > thr.z);
             } else {
                 q0 = __float_as_uint(e0); q1 = __float_as_uint(e1); q2 = __float_as_uint(e2); q3 = __float_as_uint(e3);
                 q4 = __float_as_uint(e4); q5 = __float_as_uint(e5); q6 = __float_as_uint(e6); q7 = __float_as_uint(e7);
@@ -1118,7 +1136,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
                     const bool mine = (fm >> b) & 1u;
                     const int e = nE + __builtin_popcount(fm & below);
                     if (mine) bat_img[e * 8 + i] = val;
-                    if (mine && i == 0) bat_id[e] = (ob + (uint32_t)b) | (((gm >> b) & 1u) << 31);
+                    if (mine && i == 0) bat_id[e] = ob + (uint32_t)b;
+                    for (uint32_t f = fm, kk = (uint32_t)nE; f != 0u; f &= f - 1u, kk++) // entry kinds, in entry order (scalar unit)
+                        kind_mask |= ((gm >> __builtin_ctz(f)) & 1u) << kk;
                     if ((fm >> lb) & 1u) bat_pix[(nE + __builtin_popcount(fm & lbelow)) * 8 + lr] = make_uint2(lo0, hi0);
                     // the tripped blocks leave with the batch pass; the others now (at least one lane stores: the strip's one
                     // vector-memory instruction is issued on every path, which the counted waits rely on)
@@ -1154,40 +1174,43 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         // Two strips ahead: strip j is consumed after L(j+2) is issued; in steady state the instructions younger than
         // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.  (A rare branch issues at most
         // the same single store per strip.)
+        uint32_t plo, phi;
+#define TIC_STEP(ALOAD, OBL, A0, A1, OBP, N) TIC_LOAD(ALOAD, OBL); TIC_TAKE(plo, phi, A0, A1, N); process(plo, phi, OBP)
         if (PF == 3) { // experiment (variant 610): L(j+3) is issued before strip j is consumed; steady state vmcnt(6)
             do {
                 if (left == 0) break;
-                TIC_LOAD(p3, ob3); TIC_WAIT(p0, 3); process(p0, ob0);
+                TIC_STEP("78:79", ob3, 72, 73, ob0, 3);
                 if (left == 0) break;
-                TIC_LOAD(p0, ob0); TIC_WAIT(p1, 4); process(p1, ob1);
+                TIC_STEP("72:73", ob0, 74, 75, ob1, 4);
                 if (left == 0) break;
-                TIC_LOAD(p1, ob1); TIC_WAIT(p2, 5); process(p2, ob2);
+                TIC_STEP("74:75", ob1, 76, 77, ob2, 5);
                 while (left != 0) {
-                    TIC_LOAD(p2, ob2); TIC_WAIT(p3, 6); process(p3, ob3);
+                    TIC_STEP("76:77", ob2, 78, 79, ob3, 6);
                     if (left == 0) break;
-                    TIC_LOAD(p3, ob3); TIC_WAIT(p0, 6); process(p0, ob0);
+                    TIC_STEP("78:79", ob3, 72, 73, ob0, 6);
                     if (left == 0) break;
-                    TIC_LOAD(p0, ob0); TIC_WAIT(p1, 6); process(p1, ob1);
+                    TIC_STEP("72:73", ob0, 74, 75, ob1, 6);
                     if (left == 0) break;
-                    TIC_LOAD(p1, ob1); TIC_WAIT(p2, 6); process(p2, ob2);
+                    TIC_STEP("74:75", ob1, 76, 77, ob2, 6);
                 }
             } while (0);
         } else
         do {
             if (left == 0) break;
-            TIC_LOAD(p2, ob2); TIC_WAIT(p0, 2);
+            TIC_LOAD("76:77", ob2); TIC_TAKE(plo, phi, 72, 73, 2);
             if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
-            process(p0, ob0);
+            process(plo, phi, ob0);
             if (left == 0) break;
-            TIC_LOAD(p0, ob0); TIC_WAIT(p1, 3); process(p1, ob1);
+            TIC_STEP("72:73", ob0, 74, 75, ob1, 3);
             while (left != 0) {
-                TIC_LOAD(p1, ob1); TIC_WAIT(p2, 4); process(p2, ob2);
+                TIC_STEP("74:75", ob1, 76, 77, ob2, 4);
                 if (left == 0) break;
-                TIC_LOAD(p2, ob2); TIC_WAIT(p0, 4); process(p0, ob0);
+                TIC_STEP("76:77", ob2, 72, 73, ob0, 4);
                 if (left == 0) break;
-                TIC_LOAD(p0, ob0); TIC_WAIT(p1, 4); process(p1, ob1);
+                TIC_STEP("72:73", ob0, 74, 75, ob1, 4);
             }
         } while (0);
+#undef TIC_STEP
         if (!kMem) { // one store per wave, to its first strip (always inside the frame)
             if (n_my > 0) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob_first << 7) + st_off) = acc;
             return;
@@ -1195,22 +1218,22 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 3] = __builtin_amdgcn_s_memtime(); // loop left
         // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved until
         // only the wave's last store is outstanding
-        asm volatile("s_waitcnt vmcnt(1)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : : "memory");
+        asm volatile("s_waitcnt vmcnt(1)" : : : TIC_RSV_CLOBBER);
 #undef TIC_LOAD
-#undef TIC_WAIT
+#undef TIC_TAKE
+#undef TIC_RSV_CLOBBER
     }
     // ---- the batch pass ("slim" form; OPT bit 2 off: the round-2a form kept for A/B) ----------------------------------------------
     if ((OPT & 4) && kBatchPass && nE != 0) {
         const double *cst_cos = reinterpret_cast<const double *>(cst_blk + 1152); // orthonormal DCT-II matrix, index k*8+n
         const double *cst_rdiv = reinterpret_cast<const double *>(cst_blk + 1664); // 1/div, index u*8+v
         // (1) entries that tripped on an irrational coefficient: whole-wave float64 recompute, one block at a time
-        uint32_t m_rat = 0, m_exact = 0; // entries that need the rational sub-path / the exact operation order
-        for (int e = 0; e < nE; e++) {
-            const uint32_t id = bat_id[e];
-            if ((id >> 31) == 0u || ABL == 24) {
-                m_rat |= 1u << e; // a tie entry
-                continue;
-            }
+        // (the kinds sit in a scalar register: round 2 read every entry's id back from LDS here, ~100 cycles per entry on the
+        // launch's tail, although most entries are tie entries that need nothing in this step)
+        const uint32_t m_all = (1u << nE) - 1u;
+        uint32_t m_rat = ABL == 24 ? m_all : (m_all & ~kind_mask), m_exact = 0; // entries that need the rational sub-path / the exact operation order
+        for (uint32_t todo = ABL == 24 ? 0u : kind_mask; todo != 0u; todo &= todo - 1u) {
+            const int e = __builtin_ctz(todo);
             unsigned long long ur, uo;
             wave_redo_block(reinterpret_cast<const uint8_t *>(bat_pix + e * 8), reinterpret_cast<double *>(ldsT), cst_cos, cst_rdiv, cst_zz,
                             reinterpret_cast<int16_t *>(bat_img + e * 8), lane, ur, uo);
@@ -1221,7 +1244,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         // irrational coefficient - practically never), then the rational sub-path
         const bool have = b < nE;
         const int e = have ? b : 0;
-        const uint32_t blk = bat_id[e] & 0x7fffffffu;
+        const uint32_t blk = bat_id[e];
         const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
         int16_t *img16 = reinterpret_cast<int16_t *>(bat_img + e * 8);
         if (m_exact != 0u) {
@@ -1254,8 +1277,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) void dctq_strip_kernel(DctqA
         const bool have = b < nE;
         const int e = have ? b : 0;
         const uint32_t id = bat_id[e];
-        const bool isG = have && (id >> 31) != 0u && ABL != 24; // (ABL 24, timing only: no second level, every entry is treated as a tie entry)
-        const uint32_t blk = id & 0x7fffffffu;
+        const bool isG = have && ((kind_mask >> e) & 1u) != 0u && ABL != 24; // (ABL 24, timing only: no second level, every entry is treated as a tie entry)
+        const uint32_t blk = id;
         const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
         uint32_t lo = rowv.x, hi = rowv.y;
         transpose8x8_bytes(lo, hi, i); // -> pixel column i
@@ -2359,7 +2382,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             int dev = 0, per_cu = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0, 2, 0, 15>, kWavesPerWG * 64, 0) != hipSuccess ||
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0, 4, 0, 15>, kWavesPerWG * 64, 0) != hipSuccess ||
                 per_cu < 1)
                 per_cu = 4;
             // 72 VGPRs and 21.4 KiB of LDS allow 7 workgroups per CU; 6 measured best (a seventh lengthens the start ramp by
@@ -2463,7 +2486,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             }
 #ifdef TIC_ABLATION
 #define TIC_LAUNCH(ABL) hipLaunchKernelGGL(dctq_hybrid_kernel<ABL>, grid, block, tune.lds_pad, stream, a)
-#define TIC_LAUNCH2(ABL) hipLaunchKernelGGL(dctq_strip_kernel<ABL>, grid2, block, tune.lds_pad, stream, a)
+#define TIC_LAUNCH2(ABL) hipLaunchKernelGGL((dctq_strip_kernel<ABL, 4>), grid2, block, tune.lds_pad, stream, a)
 #endif
         switch (variant) {
 #ifdef TIC_ABLATION
@@ -2488,23 +2511,23 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         case 55: TIC_LAUNCH2(6); break;  // streaming skeleton
         case 56: TIC_LAUNCH2(1); break;  // no arithmetic
         case 57: TIC_LAUNCH2(9); break;  // compute only
-        case 60: hipLaunchKernelGGL((dctq_strip_kernel<20, 2>), grid2, block, tune.lds_pad, stream, a); break; // no zig-zag staging
-        case 61: hipLaunchKernelGGL((dctq_strip_kernel<21, 2>), grid2, block, tune.lds_pad, stream, a); break; // no transpose
-        case 62: hipLaunchKernelGGL((dctq_strip_kernel<2, 2>), grid2, block, tune.lds_pad, stream, a); break;  // no LDS in the loop
-        case 63: hipLaunchKernelGGL((dctq_strip_kernel<3, 2>), grid2, block, tune.lds_pad, stream, a); break;  // tripped blocks ignored
-        case 64: hipLaunchKernelGGL((dctq_strip_kernel<1, 2>), grid2, block, tune.lds_pad, stream, a); break;  // no arithmetic
-        case 65: hipLaunchKernelGGL((dctq_strip_kernel<9, 2>), grid2, block, tune.lds_pad, stream, a); break;  // compute only
-        case 66: hipLaunchKernelGGL((dctq_strip_kernel<22, 2>), grid2, block, tune.lds_pad, stream, a); break; // guard test only
-        case 67: hipLaunchKernelGGL((dctq_strip_kernel<23, 2>), grid2, block, tune.lds_pad, stream, a); break; // no batch pass
-        case 68: hipLaunchKernelGGL((dctq_strip_kernel<24, 2>), grid2, block, tune.lds_pad, stream, a); break; // batch pass without the second level
-        case 500: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 0>), grid2, block, tune.lds_pad, stream, a); break;
-        case 501: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 1>), grid2, block, tune.lds_pad, stream, a); break;
-        case 502: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 2>), grid2, block, tune.lds_pad, stream, a); break;
-        case 503: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 3>), grid2, block, tune.lds_pad, stream, a); break;
-        case 507: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 7>), grid2, block, tune.lds_pad, stream, a); break;
-        case 515: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 15>), grid2, block, tune.lds_pad, stream, a); break;
-        case 531: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 31>), grid2, block, tune.lds_pad, stream, a); break;
-        case 610: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 15, 6, 3>), grid2, block, tune.lds_pad, stream, a); break; // three strips ahead
+        case 60: hipLaunchKernelGGL((dctq_strip_kernel<20, 4>), grid2, block, tune.lds_pad, stream, a); break; // no zig-zag staging
+        case 61: hipLaunchKernelGGL((dctq_strip_kernel<21, 4>), grid2, block, tune.lds_pad, stream, a); break; // no transpose
+        case 62: hipLaunchKernelGGL((dctq_strip_kernel<2, 4>), grid2, block, tune.lds_pad, stream, a); break;  // no LDS in the loop
+        case 63: hipLaunchKernelGGL((dctq_strip_kernel<3, 4>), grid2, block, tune.lds_pad, stream, a); break;  // tripped blocks ignored
+        case 64: hipLaunchKernelGGL((dctq_strip_kernel<1, 4>), grid2, block, tune.lds_pad, stream, a); break;  // no arithmetic
+        case 65: hipLaunchKernelGGL((dctq_strip_kernel<9, 4>), grid2, block, tune.lds_pad, stream, a); break;  // compute only
+        case 66: hipLaunchKernelGGL((dctq_strip_kernel<22, 4>), grid2, block, tune.lds_pad, stream, a); break; // guard test only
+        case 67: hipLaunchKernelGGL((dctq_strip_kernel<23, 4>), grid2, block, tune.lds_pad, stream, a); break; // no batch pass
+        case 68: hipLaunchKernelGGL((dctq_strip_kernel<24, 4>), grid2, block, tune.lds_pad, stream, a); break; // batch pass without the second level
+        case 500: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 0>), grid2, block, tune.lds_pad, stream, a); break;
+        case 501: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 1>), grid2, block, tune.lds_pad, stream, a); break;
+        case 502: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 2>), grid2, block, tune.lds_pad, stream, a); break;
+        case 503: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 3>), grid2, block, tune.lds_pad, stream, a); break;
+        case 507: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 7>), grid2, block, tune.lds_pad, stream, a); break;
+        case 515: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 15>), grid2, block, tune.lds_pad, stream, a); break;
+        case 531: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 31>), grid2, block, tune.lds_pad, stream, a); break;
+        case 610: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 15, 6, 3>), grid2, block, tune.lds_pad, stream, a); break; // three strips ahead
 #define TIC_POL(S, L)                                                                                                  \
     case 100 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<0, S, L>), grid, block, tune.lds_pad, stream, a); break; \
     case 200 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<6, S, L>), grid, block, tune.lds_pad, stream, a); break; \
@@ -2515,7 +2538,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
 #undef TIC_POL
         case 9: TIC_LAUNCH(0); break; // the round-1 kernel (plain stores)
 #endif
-        default: hipLaunchKernelGGL((dctq_strip_kernel<0, 2, 0, 15>), grid2, block, 0, stream, a); break; // the production kernel
+        default: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 15>), grid2, block, 0, stream, a); break; // the production kernel (stores: sc1 nt)
         }
 #undef TIC_LAUNCH
 #undef TIC_LAUNCH2
