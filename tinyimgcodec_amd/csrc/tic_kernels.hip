@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "tic_kernels.h"
 #include "tic_math.h"
@@ -1000,12 +1001,20 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
         n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
         if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
     } while (0)
-    // waits until all but the N youngest vector-memory operations are done, then copies the strip's pixel words out of v[R0], v[R1]
-    // (two moves per strip; the conversions cannot read the reserved registers directly without pinning the whole of pass 1)
-#define TIC_TAKE(LO, HI, R0, R1, N)                                                                          \
+    // waits until all but the N youngest vector-memory operations are done, then converts the strip's eight pixels straight out
+    // of the landing registers v[R0], v[R1] (which keep the strip's bytes until the pair is loaded again, two strips later: the
+    // rare paths fetch the raw words from there, TIC_RAW)
+#define TIC_TAKE(D, R0, R1, N)                                                                               \
     do {                                                                                                     \
-        if (kMem) asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 : "=v"(LO), "=v"(HI) : : TIC_RSV_CLOBBER); \
-        else { LO = ld_off * 2654435761u + kstrip * 40503u; HI = LO ^ (oblk << 7); }                         \
+        if (kMem)                                                                                            \
+            asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_cvt_f32_ubyte0 %0, v" #R0 "\n\tv_cvt_f32_ubyte1 %1, v" #R0 "\n\tv_cvt_f32_ubyte2 %2, v" #R0 \
+                         "\n\tv_cvt_f32_ubyte3 %3, v" #R0 "\n\tv_cvt_f32_ubyte0 %4, v" #R1 "\n\tv_cvt_f32_ubyte1 %5, v" #R1                       \
+                         "\n\tv_cvt_f32_ubyte2 %6, v" #R1 "\n\tv_cvt_f32_ubyte3 %7, v" #R1                                                       \
+                         : "=v"(D[0]), "=v"(D[1]), "=v"(D[2]), "=v"(D[3]), "=v"(D[4]), "=v"(D[5]), "=v"(D[6]), "=v"(D[7]) : : TIC_RSV_CLOBBER); \
+        else {                                                                                               \
+            const uint32_t slo = ld_off * 2654435761u + kstrip * 40503u, shi = slo ^ (oblk << 7);            \
+            for (int q_ = 0; q_ < 4; q_++) { D[q_] = (float)((slo >> (8 * q_)) & 0xffu); D[4 + q_] = (float)((shi >> (8 * q_)) & 0xffu); } \
+        }                                                                                                    \
     } while (0)
         if (ABL == 8 && a.dbg != nullptr && lane == 0) {
             unsigned long long *d = a.dbg + (((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8;
@@ -1053,17 +1062,18 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
 
         int left = n_my;
         uint4 acc = make_uint4(0, 0, 0, 0);
-        auto process = [&](const uint32_t lo0, const uint32_t hi0, const uint32_t ob) {
-            // ---- pass 1: along the pixel row ------------------------------------------------------------------
-            float d0, d1, d2, d3, d4, d5, d6, d7;
-            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d0) : "v"(lo0));
-            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d1) : "v"(lo0));
-            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d2) : "v"(lo0));
-            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d3) : "v"(lo0));
-            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d4) : "v"(hi0));
-            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d5) : "v"(hi0));
-            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d6) : "v"(hi0));
-            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d7) : "v"(hi0));
+        // raw pixel words of the strip in work, out of its landing registers (rare paths only)
+        auto raw_words = [&](auto tag, uint32_t &lo, uint32_t &hi) {
+            constexpr int R = decltype(tag)::value;
+            if (!kMem) { lo = ld_off * 2654435761u + kstrip * 40503u; hi = lo ^ (oblk << 7); }
+            else if constexpr (R == 72) asm volatile("v_mov_b32 %0, v72\n\tv_mov_b32 %1, v73" : "=v"(lo), "=v"(hi) : : "memory");
+            else if constexpr (R == 74) asm volatile("v_mov_b32 %0, v74\n\tv_mov_b32 %1, v75" : "=v"(lo), "=v"(hi) : : "memory");
+            else if constexpr (R == 76) asm volatile("v_mov_b32 %0, v76\n\tv_mov_b32 %1, v77" : "=v"(lo), "=v"(hi) : : "memory");
+            else asm volatile("v_mov_b32 %0, v78\n\tv_mov_b32 %1, v79" : "=v"(lo), "=v"(hi) : : "memory");
+        };
+        auto process = [&](auto tag, const float (&px)[8], const uint32_t ob) {
+            // ---- pass 1: along the pixel row (the pixels arrive converted: TIC_TAKE) -----------------------------
+            float d0 = px[0], d1 = px[1], d2 = px[2], d3 = px[3], d4 = px[4], d5 = px[5], d6 = px[6], d7 = px[7];
             if (kArith) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
             d0 -= 1024.0f;
             float e0 = d0, e1 = d1, e2 = d2, e3 = d3, e4 = d4, e5 = d5, e6 = d6, e7 = d7;
@@ -1130,6 +1140,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
                     fm = gm | byte_any(mS);
                 }
                 const int nnew = __builtin_popcount(fm);
+                uint32_t lo0, hi0;
+                raw_words(tag, lo0, hi0);
                 if (nE + nnew <= kBatch && (fm != 0xffu || !(OPT & 2))) {
                     // the blocks join the batch: id + kind, pixel rows (this lane holds row lr of block lb), staged image
                     const uint32_t below = (1u << b) - 1u, lbelow = (1u << lb) - 1u;
@@ -1174,8 +1186,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
         // Two strips ahead: strip j is consumed after L(j+2) is issued; in steady state the instructions younger than
         // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.  (A rare branch issues at most
         // the same single store per strip.)
-        uint32_t plo, phi;
-#define TIC_STEP(ALOAD, OBL, A0, A1, OBP, N) TIC_LOAD(ALOAD, OBL); TIC_TAKE(plo, phi, A0, A1, N); process(plo, phi, OBP)
+        float pxf[8];
+#define TIC_STEP(ALOAD, OBL, A0, A1, OBP, N) TIC_LOAD(ALOAD, OBL); TIC_TAKE(pxf, A0, A1, N); process(std::integral_constant<int, A0>(), pxf, OBP)
         if (PF == 3) { // experiment (variant 610): L(j+3) is issued before strip j is consumed; steady state vmcnt(6)
             do {
                 if (left == 0) break;
@@ -1197,9 +1209,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
         } else
         do {
             if (left == 0) break;
-            TIC_LOAD("76:77", ob2); TIC_TAKE(plo, phi, 72, 73, 2);
+            TIC_LOAD("76:77", ob2); TIC_TAKE(pxf, 72, 73, 2);
             if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
-            process(plo, phi, ob0);
+            process(std::integral_constant<int, 72>(), pxf, ob0);
             if (left == 0) break;
             TIC_STEP("72:73", ob0, 74, 75, ob1, 3);
             while (left != 0) {
