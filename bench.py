@@ -13,14 +13,25 @@ encode(), codec.py:26-43) over this rank's input, already resident in HBM.
           rank (shard_range), one batched launch of the rank's 256 resident frames per step; afterwards every rank sends its
           shard through the whole pipeline host -> host (tic_compress_batch: pinned staging, H2D || kernels || D2H, entropy
           stage on the device) and the ACTUAL 256 stream sizes of every rank are all-gathered with RCCL (tic_gather_sizes).
-          No torch anywhere: torch.distributed.run only spawns the ranks; barrier and max-over-ranks use RCCL too.
+          Barrier and max-over-ranks use RCCL too (torch.distributed.run spawns the ranks; gloo only carries the one-word
+          agreement on whether every rank's RCCL communicator came up, and the whole exchange if one did not).
+  --workload config4 runs the N > 1 workload on ONE GPU too (the N = 1 point of a config-4 scaling curve).
+
+SCALING: N = 1 and N > 1 measure DIFFERENT workloads by default (config 2: one 50 MB launch per step, launch gaps included;
+config 4: 1.6 GB per launch).  A curve must compare like with like: every N > 1 line names its baseline
+(`scaling_baseline`): the N = 1 line's `config4.kernel_only_mpix_s` for `value`, `config4.host_to_host_mpix_s` for
+`config.host_to_host_mpix_s` - or the `value` of a `--gpus 1 --workload config4` run.  `value` at N > 1 is kernel-only weak
+scaling with no data-path collective (N x by construction, up to clock and power differences between GPUs); the figure that
+can fail to scale is host -> host (PCIe, host DRAM, NUMA), reported beside it.
 
 Rank 0 prints ONE JSON line.  `value` = whole-job Mpixel/s = pixels of all ranks x K / max-over-ranks wall time of the K
 steps.  `roofline.achieved` = algorithmic bytes per launch (3 B/pixel: 1 B read + 2 B written) / average launch duration
 measured with HIP events recorded on the library's own stream around the same K launches; `roofline.cold` = the same with
 12 distinct frame/coefficient buffer pairs in rotation (604 MB > the 256 MiB Infinity Cache: every launch streams from and
-to HBM).  `cpu_baseline` / `cpu_baseline_all_cores` = the oracle (C restatement of the reference's CPU path) on this host,
-1 thread / row bands on several threads.  `config4` = the 256-frame shard of this rank, kernel-only and host -> host.
+to HBM).  `cpu_baseline` / `cpu_baseline_threads` = the oracle (C restatement of the reference's CPU path) on this host, 1 thread /
+row bands on this process's CPU share (at most 16 threads: a GPU box gives one GPU 16 of its cores; `cores` says how many);
+`cpu_baseline_numpy_scipy` = oracle/np_encode.py, a numpy/scipy restatement of encode() on the reference's own library stack,
+where scipy is importable.  `config4` = the 256-frame shard of this rank, kernel-only and host -> host.
 """
 import argparse
 import ctypes as C
@@ -70,6 +81,8 @@ def main():
     ap.add_argument("--no-cold", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="N=1 only: skip the 256-frame shard measurements")
     ap.add_argument("--shard-frames", type=int, default=256, help="frames per rank of BASELINE config 4")
+    ap.add_argument("--workload", choices=["auto", "config2", "config4"], default="auto",
+                    help="auto: config 2 at N = 1 (the headline), config 4 at N > 1; config4 at N = 1 = the baseline of a config-4 scaling curve")
     ap.add_argument("--settle-ms", type=float, default=60.0, help="untimed back-to-back launches before the warm-up steps (clock settling)")
     args = ap.parse_args()
 
@@ -93,28 +106,39 @@ def main():
     comm = None
     comm_note = "RCCL through the C-ABI (tic_comm_create / tic_gather_sizes / tic_comm_allreduce_max)"
     if world > 1:
-        if os.environ.get("TIC_BENCH_BACKEND", "rccl") == "gloo":
-            comm_note = "gloo (TIC_BENCH_BACKEND=gloo rehearsal)"
-            import torch.distributed as dist
+        import datetime
 
-            dist.init_process_group(backend="gloo")
-            comm = TorchComm()
-        else:
+        import torch.distributed as dist
+
+        # gloo is the control channel: EVERY rank joins it, whatever became of its RCCL communicator, and the ranks agree on
+        # one backend.  (Round 2 fell back per rank: had RCCL failed on some ranks only, the others would have sat in
+        # ncclCommInitRank or in the first all-reduce without a timeout.)  A rank that hangs inside RCCL never reaches the
+        # agreement: the others time out here and exit non-zero, which makes torchrun tear the job down.
+        rccl, rccl_err = None, ""
+        if os.environ.get("TIC_BENCH_BACKEND", "rccl") != "gloo":
             try:
-                comm = RcclComm(ctx, rank, world)
-            except Exception as e:  # an RCCL that cannot come up (library, IPC, topology) fails on every rank alike:
-                # keep the measurement and say so in the line - the sizes then travel over gloo (torch is present: it launched us)
-                import datetime
-
-                import torch.distributed as dist
-
-                sys.stderr.write("bench.py rank %d: RCCL communicator failed (%s); falling back to gloo\n" % (rank, e))
-                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
-                comm = TorchComm()
-                comm_note = "gloo fallback: RCCL communicator failed: %s" % str(e)[:200]
+                rccl = RcclComm(ctx, rank, world)
+            except Exception as e:  # noqa: BLE001
+                rccl_err = str(e)[:200]
+                sys.stderr.write("bench.py rank %d: RCCL communicator failed (%s)\n" % (rank, e))
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+        gl = TorchComm()
+        ok_everywhere = float(gl.allreduce_max([0.0 if rccl is not None else 1.0])[0]) == 0.0
+        if ok_everywhere:
+            comm = rccl
+        else:
+            if rccl is not None:
+                rccl.close()
+            comm = gl
+            if os.environ.get("TIC_BENCH_BACKEND", "rccl") == "gloo":
+                comm_note = "gloo (TIC_BENCH_BACKEND=gloo rehearsal)"
+            else:
+                comm_note = "gloo fallback: the RCCL communicator did not come up on every rank (this rank: %s)" % (rccl_err or "ok")
     q = args.quality
     variant = N.KERNEL_HYBRID if args.variant == "hybrid" else N.KERNEL_EXACT
-    multi = world > 1
+    multi = world > 1 or args.workload == "config4"
+    if args.workload == "config2" and world > 1:
+        sys.exit("--workload config2 is a single-GPU workload")
     if args.steps is None:
         args.steps = 200 if multi else 5000
     if args.warmup is None:
@@ -131,17 +155,26 @@ def main():
         out = bench_config2(args, ctx, L, N, q, variant, barrier, ms)
         if not args.no_config4:
             out["config4"] = shard_measurements(args, ctx, L, N, T, q, variant, 0, args.shard_frames, ms, steps=50)[0]
+            out["config4"]["note"] = "the N = 1 baseline of every N > 1 line (scaling_baseline): same 256-frame shard, one GPU"
         if not args.no_cpu_baseline:
             img = rand_frame(1234, args.height, args.width)
             out["cpu_baseline"] = cpu_baseline(img, q, args.cpu_seconds, 1)
-            out["cpu_baseline_all_cores"] = cpu_baseline(img, q, args.cpu_seconds, 0)
+            out["cpu_baseline_threads"] = cpu_baseline(img, q, args.cpu_seconds, 0)
+            py = cpu_baseline_numpy_scipy(img, q, args.cpu_seconds)
+            if py is not None:
+                out["cpu_baseline_numpy_scipy"] = py
     else:
         n_total = args.shard_frames * world
         lo, hi = shard_range(n_total, rank, world)
         info, t_wall, kernel_ms, sizes_mine = shard_measurements(args, ctx, L, N, T, q, variant, lo, hi - lo, ms, steps=args.steps,
                                                                  warmup=args.warmup, barrier=barrier, timed=True)
-        red = comm.allreduce_max([t_wall, kernel_ms, info["host_to_host_s"]])  # max over ranks
-        sizes, offsets = gather_sizes(sizes_mine, n_total, comm)              # RCCL all-gather of the actual stream sizes
+        if comm is not None:
+            red = comm.allreduce_max([t_wall, kernel_ms, info["host_to_host_s"], info["host_to_host_registered_s"]])  # max over ranks
+            sizes, offsets = gather_sizes(sizes_mine, n_total, comm)          # RCCL all-gather of the actual stream sizes
+        else:  # --gpus 1 --workload config4
+            red = [t_wall, kernel_ms, info["host_to_host_s"], info["host_to_host_registered_s"]]
+            sizes = np.asarray(sizes_mine, dtype=np.int64)
+            offsets = np.concatenate([[0], np.cumsum(sizes)])
         if rank == 0:
             h, w = 1080, 1920
             pixels = float(h) * w * (hi - lo)
@@ -170,11 +203,23 @@ def main():
                     "settle_ms": args.settle_ms,
                     "untimed_launches": info["untimed_launches"],
                     "host_to_host_mpix_s": round(pixels * world / float(red[2]) / 1e6, 1),
-                    "host_to_host_note": "whole pipeline per rank (pinned staging, H2D || kernels || D2H, device entropy stage), PCIe "
-                    "included, max over ranks; never `value`",
+                    "host_to_host_registered_mpix_s": round(pixels * world / float(red[3]) / 1e6, 1),
+                    "host_to_host_note": "whole pipeline per rank (H2D || kernels || D2H, device entropy stage), PCIe included, max over "
+                    "ranks; never `value`.  Plain: pageable caller frames staged into pinned memory; registered: the caller's frames "
+                    "pinned with tic_host_register and copied from where they lie",
+                    "per_rank": {"kernel_only_mpix_s": round(value / world, 1), "host_to_host_mpix_s": round(pixels / float(red[2]) / 1e6, 1),
+                                 "host_to_host_registered_mpix_s": round(pixels / float(red[3]) / 1e6, 1)},
+                    "numa": info.get("numa"),
                     "gathered_sizes": {"frames": int(len(sizes)), "total_bytes": int(offsets[-1]), "first": [int(v) for v in sizes[:8]],
                                             "sha256": hashlib.sha256(sizes.astype("<i8").tobytes()).hexdigest()},
                     "device": ctx.arch,
+                },
+                "scaling_baseline": {
+                    "value": "`config4.kernel_only_mpix_s` of the N = 1 line (or `value` of --gpus 1 --workload config4): the same "
+                    "256-frame shard on one GPU.  NOT the N = 1 line's `value`, which is config 2 (one 4096x4096 launch per step)",
+                    "host_to_host": "`config4.host_to_host_mpix_s` / `config4.host_to_host_registered_mpix_s` of the N = 1 line",
+                    "note": "`value` is kernel-only weak scaling without a data-path collective: N x by construction; host -> host is the "
+                    "figure that can fail to scale.  No curve had been measured when this was written (no multi-GPU box was available)",
                 },
                 "roofline": {
                     "bound": "hbm",
@@ -258,11 +303,13 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
 
     pixels = float(h) * float(w)
     achieved = BYTES_PER_PIXEL * pixels / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath) and (h, w, q) == (4096, 4096, 50):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = "%s (carried: PMC passes of an earlier rocprofv3 run of this command, tools/gpu_run.sh pmc_rd pmc_wr; not measured in this run)" % tj.get("source")
         except Exception:  # noqa: BLE001
             traffic = None
     out = {
@@ -295,6 +342,7 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel_us": round(kernel_ms * 1e3, 3),
             "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels,
             "note": "one frame and one coefficient buffer replayed: the 50 MB working set stays in the 256 MiB Infinity Cache (see cold)",
@@ -351,6 +399,24 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
         ctx.check(L.tic_compress_batch(ctx.handle, inp, count, h, w, w, q, outp, caps, lens, 0))
         t_h2h = time.perf_counter() - t1
     sizes = [int(lens[i]) for i in range(count)]
+    # the same with the caller's frames pinned (tic_host_register): no staging copy on the host, the H2D engine reads the frames
+    # where they lie.  One registered block holding the shard, as a capture or decode buffer would be.
+    block = np.empty((count, h, w), dtype=np.uint8)
+    for i, f in enumerate(frames):
+        block[i] = f
+    ctx.check(L.tic_host_register(ctx.handle, block.ctypes.data, block.nbytes))
+    inp_r = (C.c_void_p * count)(*[block[i].ctypes.data for i in range(count)])
+    lens_r = (C.c_size_t * count)()
+    for _ in range(2):
+        t1 = time.perf_counter()
+        ctx.check(L.tic_compress_batch(ctx.handle, inp_r, count, h, w, w, q, outp, caps, lens_r, 0))
+        t_h2h_reg = time.perf_counter() - t1
+    n_direct, n_staged = C.c_int(), C.c_int()
+    ctx.check(L.tic_last_batch_input_path(ctx.handle, C.byref(n_direct), C.byref(n_staged)))
+    ctx.check(L.tic_host_unregister(ctx.handle, block.ctypes.data))
+    assert [int(lens_r[i]) for i in range(count)] == sizes, "registered-input pass produced different streams"
+    node, ncpus = C.c_int(), C.c_int()
+    ctx.check(L.tic_numa_info(ctx.handle, C.byref(node), C.byref(ncpus)))
     pixels = float(h) * w * count
     info = {
         "workload": "%d random 1920x1080 frames (seeds %d..%d), quality=%d" % (count, 1234 + first, 1234 + first + count - 1, q),
@@ -360,6 +426,12 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
         "host_to_host_mpix_s": round(pixels / t_h2h / 1e6, 1),
         "host_to_host_s": round(t_h2h, 5),
         "host_to_host_frames_per_s": round(count / t_h2h, 1),
+        "host_to_host_registered_mpix_s": round(pixels / t_h2h_reg / 1e6, 1),
+        "host_to_host_registered_s": round(t_h2h_reg, 5),
+        "host_to_host_registered_frames_per_s": round(count / t_h2h_reg, 1),
+        "registered_frames_copied_in_place": int(n_direct.value),
+        "numa": {"device_node": int(node.value), "cpus_of_that_node_in_this_process": int(ncpus.value),
+                 "note": "the pipeline's own threads bind to those CPUs; pinned slots are placed on the device's node by hipHostMalloc"},
         "stream_bytes_total": int(sum(sizes)),
         "untimed_launches": untimed + warmup,
     }
@@ -411,6 +483,30 @@ def cpu_baseline(img, q, budget_s, threads):
         "threads (%s); the reference's own numpy/scipy encode() measured 21.4 Mpix/s on one thread in the build container (BASELINE.md)"
         % (n, h, w, q, "" if T == 1 else ", bands of block rows", dt, T, os.cpu_count() or 0, cpu_model()),
     }
+
+
+def cpu_baseline_numpy_scipy(img, q, budget_s):
+    """the like-for-like "pure-Python-stack" figure - encode() restated on numpy + scipy.fftpack (oracle/np_encode.py,
+    equal to the C oracle coefficient for coefficient), single thread as the reference runs it.  None where scipy is missing."""
+    try:
+        import scipy  # noqa: F401
+
+        from oracle import np_encode
+    except ImportError:
+        return None
+    h, w = img.shape
+    np_encode.encode(img[:64], q)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        np_encode.encode(img, q)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 64:
+            break
+    return {"value": round(n * h * w / dt / 1e6, 2), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": "%d full passes of the same %dx%d frame, q=%d, oracle/np_encode.py (numpy %s + scipy %s: pad, level shift, "
+            "scipy.fftpack.dct twice, np.round(X / div), zig-zag gather, DC difference), %.1f s on one thread (%s); the reference's own "
+            "encode() measured 21.4 Mpix/s in the build container (BASELINE.md)" % (n, h, w, q, np.__version__, scipy.__version__, dt, cpu_model())}
 
 
 if __name__ == "__main__":

@@ -81,6 +81,19 @@ int tic_dev_alloc(tic_ctx *ctx, size_t bytes, void **dptr);
 int tic_dev_free(tic_ctx *ctx, void *dptr);
 int tic_host_alloc_pinned(tic_ctx *ctx, size_t bytes, void **hptr);
 int tic_host_free_pinned(tic_ctx *ctx, void *hptr);
+/* Pins memory the caller already holds (hipHostRegister / hipHostUnregister).  tic_compress_batch and tic_dctq_batch copy frames
+ * that lie in pinned or registered memory with rows back to back (row_stride == w, w a multiple of 8) to the device from where
+ * they are; other frames are staged through the pipeline's own pinned slots (one extra host copy). */
+int tic_host_register(tic_ctx *ctx, void *hptr, size_t bytes);
+int tic_host_unregister(tic_ctx *ctx, void *hptr);
+/* Host side of the batch pipeline and NUMA ("own pinned buffers / NUMA node" per GPU): *node = NUMA node of
+ * the context's device (-1: unknown), *ncpus = CPUs of that node the process may run on.  The threads the pipeline creates
+ * (staging, read-back, hand-out) bind themselves to those CPUs - never the caller's thread - unless tic_set_numa_binding(ctx, 0);
+ * the pinned staging slots are placed on the device's node by hipHostMalloc itself. */
+int tic_numa_info(tic_ctx *ctx, int *node, int *ncpus);
+int tic_set_numa_binding(tic_ctx *ctx, int enable);
+/* How the last batch call took its input: frames copied from the caller's pinned/registered memory / frames staged. */
+int tic_last_batch_input_path(tic_ctx *ctx, int *direct_frames, int *staged_frames);
 int tic_memcpy_h2d(tic_ctx *ctx, void *dst, const void *src, size_t bytes);
 int tic_memcpy_d2h(tic_ctx *ctx, void *dst, const void *src, size_t bytes);
 int tic_memset_dev(tic_ctx *ctx, void *dst, int value, size_t bytes);
@@ -166,7 +179,9 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
  *      data-path collective.  The one exchange is an all-gather of per-frame compressed sizes, so that every rank knows every
  *      frame's offset in the concatenated output: RCCL over xGMI, opened lazily (world == 1 never loads librccl).
  *      Rendezvous: rank 0 publishes the RCCL unique id as the file `rendezvous_path`, the others poll for it; pass a name
- *      unique to the launch (e.g. /tmp/tic_rdv_<MASTER_PORT>_<launcher pid>). ------------------------------------------ */
+ *      unique to the launch and to the communicator (e.g. /tmp/tic_rdv_<MASTER_PORT>_<launcher pid>_<launcher start>_<seq>).
+ *      RCCL with more than one rank needs one GPU per rank: it has run with a single rank only so far (no multi-GPU box
+ *      was available to the build); the multi-rank flow is covered by world_size-2 tests over gloo. ---------------------- */
 typedef struct tic_comm tic_comm;
 int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_path, tic_comm **out);
 int tic_comm_destroy(tic_comm *comm);
@@ -177,6 +192,12 @@ const char *tic_comm_last_error(const tic_comm *comm);
 int tic_gather_sizes(tic_comm *comm, const uint64_t *mine, int n_mine, uint64_t *all);
 /* In-place element-wise maximum over the ranks (also serves as a barrier: bench.py's max-over-ranks timing). */
 int tic_comm_allreduce_max(tic_comm *comm, double *vals, int n);
+/* The rendezvous file of tic_comm_create, usable on its own (no GPU involved): publish = exclusive creation (O_EXCL|O_NOFOLLOW,
+ * 0600) under a temporary name + rename, after removing leftovers of the same name; wait = poll (timeout_ms) for a complete
+ * file with `bytes` of payload published no earlier than not_before_ns (CLOCK_REALTIME; 0 = the calling process's start:
+ * a file an earlier launch left behind is ignored). */
+int tic_rdv_publish(const char *path, const void *payload, size_t bytes);
+int tic_rdv_wait(const char *path, void *payload, size_t bytes, int timeout_ms, uint64_t not_before_ns);
 
 /* ---- diagnostics (not part of the drop-in surface) ------------------------------------------------------------- */
 /* Runs the in-register 8x8 byte transpose used by the kernels (DPP + v_perm) and a shuffle-based formulation of

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the library honours its test hooks (tinyimgcodec_amd/csrc/tic_hooks.h) only if this is set when it is first used
+os.environ.setdefault("TIC_TEST_HOOKS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -820,3 +820,76 @@ def test_module_level_api_is_reentrant(ctx, oracle):
             t.join()
     assert not errors, errors[:5]
     assert len(set(seen.values())) == 3, "default_context() must be per thread"
+
+
+def test_batch_takes_registered_frames_in_place(ctx, oracle):
+    """tic_compress_batch copies frames that lie in registered (pinned) memory to the device from where they are - no staging copy
+    on the host - and stages pageable frames as before; the streams are the same either way and equal the oracle's.  The
+    context reports its device's NUMA node (pinned buffers / NUMA node per GPU)."""
+    L = N.load()
+    n, h, w, q = 20, 136, 520, 50  # more than one chunk of 16
+    block = np.stack([rand_frame(4000 + i, h, w) for i in range(n)])
+    want = [oracle.compress(block[i], q) for i in range(n)]
+    cap = L.tic_compress_bound(h, w)
+    pool = np.empty((n, cap), dtype=np.uint8)
+    outp = (C.c_void_p * n)(*[pool[i].ctypes.data for i in range(n)])
+    caps = (C.c_size_t * n)(*([cap] * n))
+
+    def run(ptrs):
+        lens = (C.c_size_t * n)()
+        inp = (C.c_void_p * n)(*ptrs)
+        ctx.check(L.tic_compress_batch(ctx.handle, inp, n, h, w, w, q, outp, caps, lens, 0))
+        d, s = C.c_int(), C.c_int()
+        ctx.check(L.tic_last_batch_input_path(ctx.handle, C.byref(d), C.byref(s)))
+        return [pool[i, : lens[i]].tobytes() for i in range(n)], d.value, s.value
+
+    got, direct, staged = run([block[i].ctypes.data for i in range(n)])
+    assert got == want and (direct, staged) == (0, n)
+    ctx.check(L.tic_host_register(ctx.handle, block.ctypes.data, block.nbytes))
+    try:
+        got, direct, staged = run([block[i].ctypes.data for i in range(n)])          # contiguous frames: one copy per chunk
+        assert got == want and (direct, staged) == (n, 0)
+        order = list(range(n - 1, -1, -1))
+        got, direct, staged = run([block[i].ctypes.data for i in order])               # scattered frames: one copy per frame
+        assert got == [want[i] for i in order] and (direct, staged) == (n, 0)
+    finally:
+        ctx.check(L.tic_host_unregister(ctx.handle, block.ctypes.data))
+    node, ncpus = C.c_int(-5), C.c_int(-5)
+    ctx.check(L.tic_numa_info(ctx.handle, C.byref(node), C.byref(ncpus)))
+    assert node.value >= -1 and ncpus.value >= 0
+    ctx.check(L.tic_set_numa_binding(ctx.handle, 0))
+    got, _, _ = run([block[i].ctypes.data for i in range(n)])
+    ctx.check(L.tic_set_numa_binding(ctx.handle, 1))
+    assert got == want
+
+
+def test_bench_lines_name_their_scaling_baseline(tmp_path):
+    """bench.py: --workload config4 on one GPU (the N = 1 point of a config-4 curve) and the two-rank rehearsal on the one GPU
+    of the box (gloo for the exchange: RCCL needs a GPU per rank).  Both lines carry the same workload, per-rank rates and the
+    name of the field an N > 1 value must be compared with; the gathered sizes of the two ranks are the first 16 of the one."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--shard-frames", "8", "--steps", "2", "--warmup", "1", "--settle-ms", "1"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "config4"] + small, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = json.loads(r.stdout.strip().splitlines()[-1])
+    assert one["n_gpus"] == 1 and "config 4" in one["config"]["workload"] and one["scaling_baseline"]["value"].startswith("`config4.kernel_only_mpix_s`")
+    assert one["config"]["per_rank"]["kernel_only_mpix_s"] == one["value"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TIC_BENCH_BACKEND="gloo", TIC_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + small,
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["config"]["gathered_sizes"]["frames"] == 16 and "gloo" in two["config"]["comm"]
+    assert two["config"]["gathered_sizes"]["first"] == one["config"]["gathered_sizes"]["first"]
+    assert abs(two["config"]["per_rank"]["kernel_only_mpix_s"] * 2 - two["value"]) < 1.0
+    assert "NOT the N = 1 line's `value`" in two["scaling_baseline"]["value"]

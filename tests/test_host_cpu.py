@@ -301,3 +301,46 @@ def test_strip_kernel_binary_keeps_its_landing_registers_private(tmp_path):
         blk = ".agpr_count:" + blk
         assert re.search(r"\.vgpr_count:\s+80\b", blk) and re.search(r"\.private_segment_fixed_size:\s+0\b", blk) and re.search(r"\.agpr_count:\s+0\b", blk), blk
     assert found, "dctq_strip_kernel not found in the library"
+
+
+def test_rendezvous_file_is_created_exclusively_and_stale_files_are_ignored(tmp_path):
+    """tic_comm_create's rendezvous (tic_rdv_publish / tic_rdv_wait, no GPU involved): rank 0 replaces whatever an earlier launch
+    left under the name and never writes through a symlink; a reader ignores a complete file that is older than its own
+    process (a crashed launch with the same MASTER_PORT / launcher pid) and takes the fresh one once it appears."""
+    import ctypes as C
+    import struct
+    import threading
+    import time
+    from tinyimgcodec_amd import _native as N
+    L = N.load()
+    path = str(tmp_path / "rdv")
+    ident = bytes(range(128))
+    # a leftover of an earlier launch: complete, right size, right magic, but published long ago
+    old = struct.pack("<8sQQ", b"TICRDV1\0", int((time.time() - 3600) * 1e9), 128) + bytes(128)
+    with open(path, "wb") as f:
+        f.write(old)
+    buf = C.create_string_buffer(128)
+    assert L.tic_rdv_wait(path.encode(), buf, 128, 300, 0) == N.TIC_E_ARG
+    assert b"stale" in L.tic_comm_last_error(None)
+    # rank 0 publishes 0.3 s after the reader started to poll: the reader must return the new payload, not the leftover
+    t = threading.Timer(0.3, lambda: L.tic_rdv_publish(path.encode(), ident, 128))
+    t.start()
+    assert L.tic_rdv_wait(path.encode(), buf, 128, 5000, 0) == N.TIC_OK
+    t.join()
+    assert buf.raw == ident
+    assert oct(os.stat(path).st_mode & 0o777) == "0o600"
+    # never through a symlink: the temporary name is removed first, then created with O_EXCL|O_NOFOLLOW
+    victim = tmp_path / "victim"
+    victim.write_bytes(b"precious")
+    os.unlink(path)
+    os.symlink(str(victim), path + ".tmp")
+    assert L.tic_rdv_publish(path.encode(), ident, 128) == N.TIC_OK
+    assert victim.read_bytes() == b"precious" and not os.path.islink(path)
+    # a file of the wrong size or magic is not a rendezvous file
+    with open(path, "wb") as f:
+        f.write(b"x" * 152)
+    assert L.tic_rdv_wait(path.encode(), buf, 128, 100, 0) == N.TIC_E_ARG
+    assert L.tic_rdv_wait(path.encode(), buf, 128, 100, 1) == N.TIC_E_ARG  # (an explicit not-before time does not help a bad file)
+    # communicators of one job get distinct names
+    from tinyimgcodec_amd import distributed as D
+    assert D.default_rendezvous_path() != D.default_rendezvous_path()

@@ -221,3 +221,17 @@ def test_config4_stream_digests_round2(oracle):
     bs = oracle.compress(f, 50)
     e = m["rand1235_1080x1920_q50_stream"]
     assert len(bs) == e["bytes"] and hashlib.sha256(bs).hexdigest() == e["sha256"]
+
+
+def test_numpy_scipy_restatement_equals_the_c_oracle(oracle):
+    """oracle/np_encode.py (bench.py's "pure-Python-stack" CPU figure) runs on scipy's pocketfft - the reference's
+    own arithmetic - and must equal the C restatement coefficient for coefficient, ragged shapes and the whole quality range included."""
+    scipy = pytest.importorskip("scipy")  # noqa: F841
+    from oracle import np_encode
+    rng = np.random.default_rng(77)
+    for h, w, q in ((1, 1, 50), (5, 13, 10), (64, 72, 50), (33, 47, 90), (200, 328, 1), (136, 520, 99), (256, 256, 37)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = np_encode.encode(img, q)
+        dc, ac = oracle.encode(img, q)
+        assert np.array_equal(got["dc"], dc) and np.array_equal(got["ac"], ac), (h, w, q)
+    assert list(np_encode.ZIGZAG[:10]) == [0, 1, 8, 16, 9, 2, 3, 10, 17, 24]

@@ -45,6 +45,11 @@ SIGNATURES = {
     "tic_dev_free": (C.c_int, [_ctxp, C.c_void_p]),
     "tic_host_alloc_pinned": (C.c_int, [_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),
     "tic_host_free_pinned": (C.c_int, [_ctxp, C.c_void_p]),
+    "tic_host_register": (C.c_int, [_ctxp, C.c_void_p, C.c_size_t]),
+    "tic_host_unregister": (C.c_int, [_ctxp, C.c_void_p]),
+    "tic_numa_info": (C.c_int, [_ctxp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tic_set_numa_binding": (C.c_int, [_ctxp, C.c_int]),
+    "tic_last_batch_input_path": (C.c_int, [_ctxp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tic_memcpy_h2d": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tic_memcpy_d2h": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tic_memset_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_size_t]),
@@ -104,6 +109,8 @@ SIGNATURES = {
     "tic_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "tic_gather_sizes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tic_comm_allreduce_max": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "tic_rdv_publish": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
+    "tic_rdv_wait": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64]),
 }
 
 _lib = None

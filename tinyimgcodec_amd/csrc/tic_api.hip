@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 
+#include <sched.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
@@ -102,9 +104,56 @@ struct tic_ctx {
     std::vector<Slot> bslots;
     size_t bslot_img_bytes = 0, bslot_coef_bytes = 0;
     int bslot_h = -1, bslot_w = -1, bslot_chunk = 0;
+    // host side of the batch pipeline: the device's NUMA node and the CPUs of that node this process may run on
+    int numa_node = -1;
+    bool numa_bind = true;      // the pipeline's own threads (staging, read-back, hand-out) bind themselves to those CPUs
+    cpu_set_t numa_cpus;
+    int numa_ncpus = 0;
+    // how the last batch call took its input: frames copied to the device from where the caller holds them (pinned or registered
+    // memory) / frames staged through the pipeline's pinned slots (pageable memory)
+    int last_batch_direct_frames = 0, last_batch_staged_frames = 0;
     std::string err;
     char arch[128] = {0};
 };
+
+// NUMA node of a device (its PCI function's numa_node in sysfs) and the CPUs of that node within this process's affinity mask.
+static void find_numa(tic_ctx *ctx) {
+    CPU_ZERO(&ctx->numa_cpus);
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, ctx->device) != hipSuccess) return;
+    for (char *p = bus; *p; p++) *p = (char)tolower(*p);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    const int ok = fscanf(f, "%d", &node);
+    fclose(f);
+    if (ok != 1 || node < 0) return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return;
+    char list[4096] = {0};
+    const size_t n = fread(list, 1, sizeof list - 1, f);
+    fclose(f);
+    list[n] = 0;
+    cpu_set_t mine;
+    CPU_ZERO(&mine);
+    if (sched_getaffinity(0, sizeof mine, &mine) != 0) return;
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) { // "0-63,128-191"
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1) b = a;
+        if (k < 1) continue;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &mine)) { CPU_SET(c, &ctx->numa_cpus); ctx->numa_ncpus++; }
+    }
+    ctx->numa_node = node;
+}
+// Called at the start of every thread the pipeline creates (never on the caller's thread).
+static void bind_pipeline_thread(const tic_ctx *ctx) {
+    if (ctx->numa_bind && ctx->numa_node >= 0 && ctx->numa_ncpus > 0) (void)sched_setaffinity(0, sizeof ctx->numa_cpus, &ctx->numa_cpus);
+}
 
 static thread_local std::string g_create_err;
 
@@ -209,6 +258,7 @@ static int create_impl(tic_ctx *ctx, int device) {
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
         return set_err(nullptr, TIC_E_HIP, "cannot open device %d: %s", device, hipGetErrorString(e));
     snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
+    find_numa(ctx);
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_err(nullptr, TIC_E_NODEVICE, "device %d is %s; this library contains gfx950 (MI355X) code only", device,
                        prop.gcnArchName);
@@ -281,6 +331,47 @@ int tic_host_free_pinned(tic_ctx *ctx, void *hptr) {
     if (!ctx) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipHostFree(hptr));
+    return TIC_OK;
+}
+// Pins memory the caller already holds (hipHostRegister): the batch entry points then copy such frames to the device from where
+// they lie instead of staging them through their own pinned slots.
+int tic_host_register(tic_ctx *ctx, void *hptr, size_t bytes) {
+    TIC_LOCK(ctx);
+    if (!ctx || !hptr || bytes == 0) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostRegister(hptr, bytes, hipHostRegisterDefault));
+    return TIC_OK;
+}
+int tic_host_unregister(tic_ctx *ctx, void *hptr) {
+    TIC_LOCK(ctx);
+    if (!ctx || !hptr) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostUnregister(hptr));
+    return TIC_OK;
+}
+// NUMA placement of the batch pipeline's host side.  *node = NUMA node of the context's device (-1 unknown), *ncpus = CPUs of that
+// node this process may run on.  The pipeline's own threads bind to them unless binding is switched off (enable = 0); the pinned
+// staging slots come from hipHostMalloc, which places them on the device's node by itself.
+int tic_numa_info(tic_ctx *ctx, int *node, int *ncpus) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    if (node) *node = ctx->numa_node;
+    if (ncpus) *ncpus = ctx->numa_ncpus;
+    return TIC_OK;
+}
+int tic_set_numa_binding(tic_ctx *ctx, int enable) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    ctx->numa_bind = enable != 0;
+    return TIC_OK;
+}
+// How the last tic_compress_batch / tic_dctq_batch call took its frames: copied from the caller's pinned or registered memory /
+// staged through the pipeline's slots.
+int tic_last_batch_input_path(tic_ctx *ctx, int *direct_frames, int *staged_frames) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    if (direct_frames) *direct_frames = ctx->last_batch_direct_frames;
+    if (staged_frames) *staged_frames = ctx->last_batch_staged_frames;
     return TIC_OK;
 }
 int tic_memcpy_h2d(tic_ctx *ctx, void *dst, const void *src, size_t bytes) {
@@ -752,7 +843,7 @@ static void stage_frame(uint8_t *dst, size_t pitch, const uint8_t *src, ptrdiff_
 
 // Stages the frames of a chunk into the slot's pinned buffer on several threads: one thread copies ~10 GB/s, which
 // would cap a 1080p batch at ~5,000 frames/s - below what PCIe and the GPU take.
-static void stage_chunk(uint8_t *pin, size_t img_bytes, size_t pitch, const uint8_t *const *images, int first, int cnt,
+static void stage_chunk(const tic_ctx *ctx, uint8_t *pin, size_t img_bytes, size_t pitch, const uint8_t *const *images, int first, int cnt,
                         ptrdiff_t row_stride, int h, int w) {
     unsigned hw = std::thread::hardware_concurrency();
     int T = (int)(hw ? hw / 2 : 4);
@@ -765,9 +856,46 @@ static void stage_chunk(uint8_t *pin, size_t img_bytes, size_t pitch, const uint
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++)
         th.emplace_back([=]() {
+            bind_pipeline_thread(ctx);
             for (int k = t; k < cnt; k += T) stage_frame(pin + (size_t)k * img_bytes, pitch, images[first + k], row_stride, h, w);
         });
     for (auto &x : th) x.join();
+}
+
+// Host -> device copy of a chunk.  Frames the caller holds in pinned or registered memory, rows back to back, go to the device from
+// where they lie (one copy for the chunk when the frames follow each other in memory, else one per frame); anything else is staged
+// into the slot's pinned buffer first (pageable memory: the runtime would stage it too, synchronously and through a small bounce
+// buffer).  Returns the number of frames that took the direct path.
+static bool host_pointer_is_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); // (plain malloc'ed memory: "invalid value", not an error of ours)
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+static hipError_t upload_chunk(tic_ctx *ctx, Slot &s, size_t img_bytes, size_t pitch, const uint8_t *const *images, int first, int cnt,
+                               ptrdiff_t row_stride, int h, int w, hipStream_t st, int *direct) {
+    *direct = 0;
+    const bool dense = (size_t)row_stride == pitch && pitch == (size_t)w; // the device layout IS the caller's layout
+    bool pinned = dense;
+    for (int k = 0; k < cnt && pinned; k++)
+        pinned = host_pointer_is_pinned(images[first + k]) && host_pointer_is_pinned(images[first + k] + img_bytes - 1);
+    if (!pinned) {
+        BT_START();
+        stage_chunk(ctx, s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w);
+        BT_STOP(0);
+        return hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
+    }
+    *direct = cnt;
+    bool contiguous = true;
+    for (int k = 1; k < cnt && contiguous; k++) contiguous = images[first + k] == images[first] + (size_t)k * img_bytes;
+    if (contiguous) return hipMemcpyAsync(s.d_img, images[first], img_bytes * cnt, hipMemcpyHostToDevice, st);
+    for (int k = 0; k < cnt; k++) {
+        const hipError_t e = hipMemcpyAsync((char *)s.d_img + (size_t)k * img_bytes, images[first + k], img_bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
@@ -855,7 +983,9 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
     bool closing = false;
     std::atomic<int> first_err{TIC_OK};
 
+    ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = 0;
     auto consumer = [&]() {
+        bind_pipeline_thread(ctx);
         (void)hipSetDevice(ctx->device);
         for (;;) {
             std::pair<int, int> job;
@@ -901,11 +1031,11 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
             s.remaining = cnt;
         }
         hipStream_t st = ctx->bstream[c & 1];
+        int direct = 0;
+        hipError_t e = upload_chunk(ctx, s, img_bytes, pitch, images, first, cnt, row_stride, h, w, st, &direct);
+        ctx->last_batch_direct_frames += direct;
+        ctx->last_batch_staged_frames += cnt - direct;
         BT_START();
-        stage_chunk(s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w); // into pinned memory
-        BT_STOP(0);
-        BT_START();
-        hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
             a.fallback_count = nullptr;
@@ -1023,6 +1153,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
             const char *src = (const char *)s.pin_out;
             const unsigned long long *lens = s.h_lens;
             auto hand_out = [=](int t, int T) {
+                if (T > 1) bind_pipeline_thread(ctx);
                 for (int k = t; k < cnt; k += T) memcpy(outs[first + k], src + (size_t)k * row, (size_t)lens[k]);
             };
             const int T = cnt < 4 ? 1 : 4;
@@ -1053,7 +1184,9 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     std::vector<char> busy(S, 0);   // slot submitted and not yet released by the hand-out thread
     bool stop_read = false, stop_hand = false;
     int fin_result = TIC_OK;
+    ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = 0;
     std::thread reader([&]() {
+        bind_pipeline_thread(ctx);
         (void)hipSetDevice(ctx->device);
         for (;;) {
             int k;
@@ -1082,6 +1215,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         cv_hand.notify_one();
     });
     std::thread hander([&]() {
+        bind_pipeline_thread(ctx);
         for (;;) {
             int k;
             {
@@ -1116,11 +1250,11 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         }
         s.first = first;
         s.count = cnt;
+        int direct = 0;
+        hipError_t e = upload_chunk(ctx, s, img_bytes, pitch, images, first, cnt, row_stride, h, w, st, &direct);
+        ctx->last_batch_direct_frames += direct;
+        ctx->last_batch_staged_frames += cnt - direct;
         BT_START();
-        stage_chunk(s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w); // into pinned memory
-        BT_STOP(0);
-        BT_START();
-        hipError_t e = hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             DctqArgs a = make_args(ctx, s.d_img, h, w, (ptrdiff_t)pitch, quality, s.d_coef);
             a.fallback_count = nullptr;

@@ -1,16 +1,25 @@
 // tic_comm.hip - the path's only collective (north star): an all-gather of per-frame compressed sizes
 // across the ranks of a node (one process per GPU), on RCCL, behind the C-ABI - no torch in the product.
 //
-// librccl.so is opened on first use (it is half a gigabyte; single-GPU users never load it).  Rendezvous: rank 0 creates
-// the RCCL unique id and publishes it as a small file (written under a temporary name, then renamed); the other ranks poll
-// for it.  The caller names the file - something unique to the launch, e.g. /tmp/tic_rdv_<MASTER_PORT>_<launcher pid>.
+// librccl.so is opened on first use (it is half a gigabyte; single-GPU users never load it) and is not a build-time dependency
+// either: the six entry points and the handful of types used here are declared below (values as in rccl.h of ROCm 7.x).
+//
+// Rendezvous: rank 0 creates the RCCL unique id and publishes it as a small file; the other ranks poll for it
+// (tic_rdv_publish / tic_rdv_wait below).  The caller names the file - something unique to the launch AND to the communicator,
+// e.g. /tmp/tic_rdv_<MASTER_PORT>_<launcher pid>_<launcher start time>_<sequence number> (tinyimgcodec_amd/distributed.py).
+// The file is created exclusively (O_CREAT|O_EXCL|O_NOFOLLOW, mode 0600: never through a symlink, never over somebody else's
+// file) under a temporary name and renamed into place; rank 0 removes whatever an earlier, crashed launch left under either
+// name first, removes the file on every failure after publishing, and removes it once the first collective has completed.
+// A reader accepts a file only if it carries the magic, the expected payload size and a publishing time not older than the
+// reader's own process (a leftover of an earlier launch is ignored, not believed).
 #ifndef _GNU_SOURCE
 #define _GNU_SOURCE // dladdr
 #endif
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,7 +29,19 @@
 
 #include <string>
 
+// ---- the part of RCCL's C API this file uses (rccl.h: ncclComm_t, ncclUniqueId, ncclResult_t, ncclDataType_t, ncclRedOp_t) ----
+struct ncclComm;
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint64 = 5, ncclFloat64 = 8;
+static constexpr ncclRedOp_t ncclMax = 2;
+
 #include "../../include/tinyimgcodec_hip.h"
+#include "tic_hooks.h"
 
 extern "C" __attribute__((visibility("hidden"))) int tic_ctx_device(const tic_ctx *ctx);
 extern "C" __attribute__((visibility("hidden"))) void *tic_ctx_stream(const tic_ctx *ctx);
@@ -67,7 +88,105 @@ static int ensure_bufs(tic_comm *c, size_t send_bytes, size_t recv_bytes) {
     return TIC_OK;
 }
 
+// ---- rendezvous file ----------------------------------------------------------------------------------------------------
+namespace {
+struct RdvHeader {
+    char magic[8];          // "TICRDV1\0"
+    uint64_t published_ns;  // CLOCK_REALTIME at publication
+    uint64_t payload_bytes;
+};
+const char kRdvMagic[8] = {'T', 'I', 'C', 'R', 'D', 'V', '1', 0};
+
+uint64_t now_realtime_ns() {
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+// CLOCK_REALTIME at which this process started (0 if /proc cannot tell): start time in clock ticks since boot against the uptime.
+uint64_t process_start_realtime_ns() {
+    FILE *f = fopen("/proc/self/stat", "r");
+    if (!f) return 0;
+    char buf[2048];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char *p = strrchr(buf, ')'); // the command name may contain anything: fields are counted behind it
+    if (!p) return 0;
+    unsigned long long start_ticks = 0;
+    int field = 2;
+    for (p++; *p && field < 22; p++)
+        if (*p == ' ') field++;
+    if (field != 22 || sscanf(p, "%llu", &start_ticks) != 1) return 0;
+    double up = 0.0;
+    f = fopen("/proc/uptime", "r");
+    if (!f) return 0;
+    const int ok = fscanf(f, "%lf", &up);
+    fclose(f);
+    const long hz = sysconf(_SC_CLK_TCK);
+    if (ok != 1 || hz <= 0) return 0;
+    const double age_s = up - (double)start_ticks / (double)hz;
+    const uint64_t now = now_realtime_ns();
+    if (age_s < 0 || (uint64_t)(age_s * 1e9) > now) return 0;
+    return now - (uint64_t)(age_s * 1e9);
+}
+} // namespace
+
 extern "C" {
+
+// Publishes `payload` under `path` (see the head of this file).  Returns TIC_OK or TIC_E_ARG with the reason in tic_comm_last_error(NULL).
+int tic_rdv_publish(const char *path, const void *payload, size_t bytes) {
+    if (!path || !*path || (!payload && bytes)) return comm_fail(nullptr, TIC_E_ARG, "bad rendezvous arguments", nullptr);
+    const std::string p(path), tmp = p + ".tmp";
+    (void)unlink(p.c_str());   // leftovers of an earlier launch that used the same name
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_NOFOLLOW | O_WRONLY | O_CLOEXEC, 0600);
+    if (fd < 0) return comm_fail(nullptr, TIC_E_ARG, "cannot create the rendezvous file", (tmp + ": " + strerror(errno)).c_str());
+    RdvHeader h;
+    memcpy(h.magic, kRdvMagic, 8);
+    h.published_ns = now_realtime_ns();
+    h.payload_bytes = bytes;
+    bool ok = write(fd, &h, sizeof h) == (ssize_t)sizeof h && (bytes == 0 || write(fd, payload, bytes) == (ssize_t)bytes);
+    ok = (fsync(fd) == 0) && ok;
+    ok = (close(fd) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), p.c_str()) != 0) {
+        (void)unlink(tmp.c_str());
+        return comm_fail(nullptr, TIC_E_ARG, "cannot publish the rendezvous file", p.c_str());
+    }
+    return TIC_OK;
+}
+
+// Waits (at most timeout_ms) for a rendezvous file at `path` whose payload has `bytes` bytes and which was published no earlier
+// than `not_before_ns` (CLOCK_REALTIME; 0 = this process's own start), and copies the payload out.
+int tic_rdv_wait(const char *path, void *payload, size_t bytes, int timeout_ms, uint64_t not_before_ns) {
+    if (!path || !*path || (!payload && bytes)) return comm_fail(nullptr, TIC_E_ARG, "bad rendezvous arguments", nullptr);
+    if (not_before_ns == 0) {
+        const uint64_t st = process_start_realtime_ns();
+        not_before_ns = st > 2000000000ull ? st - 2000000000ull : 0; // (clock-tick granularity of the start time)
+    }
+    const uint64_t t_end = now_realtime_ns() + (uint64_t)(timeout_ms < 0 ? 0 : timeout_ms) * 1000000ull;
+    bool saw_stale = false;
+    for (;;) {
+        const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+        if (fd >= 0) {
+            RdvHeader h;
+            struct stat st;
+            const bool whole = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size == sizeof h + bytes &&
+                               read(fd, &h, sizeof h) == (ssize_t)sizeof h && memcmp(h.magic, kRdvMagic, 8) == 0 && h.payload_bytes == bytes;
+            if (whole && h.published_ns >= not_before_ns) {
+                const bool got = bytes == 0 || read(fd, payload, bytes) == (ssize_t)bytes;
+                close(fd);
+                if (got) return TIC_OK;
+            } else {
+                if (whole) saw_stale = true;
+                close(fd);
+            }
+        }
+        if (now_realtime_ns() >= t_end) break;
+        struct timespec ts = {0, 20 * 1000 * 1000};
+        nanosleep(&ts, nullptr);
+    }
+    return comm_fail(nullptr, TIC_E_ARG, saw_stale ? "only a stale rendezvous file (older than this process) was found" : "rendezvous file did not appear", path);
+}
 
 const char *tic_comm_last_error(const tic_comm *c) { return c ? c->err.c_str() : g_comm_err.c_str(); }
 
@@ -92,7 +211,7 @@ int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_pa
     if (hipSetDevice(tic_ctx_device(ctx)) != hipSuccess) { delete c; return comm_fail(nullptr, TIC_E_HIP, "hipSetDevice failed", nullptr); }
     // TIC_COMM_FORCE_RCCL: a single rank goes through RCCL too (library load, communicator, collectives on the context's stream):
     // the only way to exercise this file on a one-GPU box (tests/test_gpu_parity.py::test_rccl_single_rank_smoke)
-    const bool forced = world == 1 && getenv("TIC_COMM_FORCE_RCCL") != nullptr;
+    const bool forced = world == 1 && tic::test_hook("TIC_COMM_FORCE_RCCL") != nullptr; // (tic_hooks.h: off unless TIC_TEST_HOOKS=1)
     if (world > 1 || forced) {
         if (world > 1 && (!rendezvous_path || !*rendezvous_path)) { delete c; return comm_fail(nullptr, TIC_E_ARG, "rendezvous path required for world > 1", nullptr); }
         // The RCCL that belongs to the HIP runtime this library runs on: the one in the same directory.  (A bare soname would
@@ -121,38 +240,29 @@ int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_pa
 #undef SYM
         ncclUniqueId id;
         memset(&id, 0, sizeof id);
-        const std::string path(rendezvous_path ? rendezvous_path : ""), tmp = path + ".tmp";
+        const std::string path(rendezvous_path ? rendezvous_path : "");
+        bool published = false;
         if (forced && path.empty()) {
             ncclResult_t r = c->GetUniqueId(&id);
             if (r != ncclSuccess) { const char *e = c->GetErrorString(r); delete c; return comm_fail(nullptr, TIC_E_HIP, "ncclGetUniqueId failed", e); }
         } else if (rank == 0) {
             ncclResult_t r = c->GetUniqueId(&id);
             if (r != ncclSuccess) { const char *e = c->GetErrorString(r); delete c; return comm_fail(nullptr, TIC_E_HIP, "ncclGetUniqueId failed", e); }
-            FILE *f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(&id, sizeof id, 1, f) != 1) { if (f) fclose(f); delete c; return comm_fail(nullptr, TIC_E_ARG, "cannot write the rendezvous file", tmp.c_str()); }
-            fclose(f);
-            if (rename(tmp.c_str(), path.c_str()) != 0) { delete c; return comm_fail(nullptr, TIC_E_ARG, "cannot publish the rendezvous file", path.c_str()); }
+            const int rc = tic_rdv_publish(path.c_str(), &id, sizeof id);
+            if (rc != TIC_OK) { delete c; return rc; }
+            published = true;
         } else {
-            bool got = false;
-            for (int tries = 0; tries < 6000 && !got; tries++) { // up to 2 minutes
-                struct stat st;
-                if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == sizeof id) {
-                    FILE *f = fopen(path.c_str(), "rb");
-                    if (f) {
-                        got = fread(&id, sizeof id, 1, f) == 1;
-                        fclose(f);
-                    }
-                }
-                if (!got) {
-                    struct timespec ts = {0, 20 * 1000 * 1000};
-                    nanosleep(&ts, nullptr);
-                }
-            }
-            if (!got) { delete c; return comm_fail(nullptr, TIC_E_ARG, "rendezvous file did not appear", path.c_str()); }
+            const int rc = tic_rdv_wait(path.c_str(), &id, sizeof id, 120000, 0);
+            if (rc != TIC_OK) { delete c; return rc; }
         }
         (void)hipGetLastError(); // RCCL reads the thread's last HIP error: a stale one from an earlier, unrelated call would fail it
         ncclResult_t r = c->CommInitRank(&c->comm, world, id, rank);
-        if (r != ncclSuccess) { const char *e = c->GetErrorString(r); delete c; return comm_fail(nullptr, TIC_E_HIP, "ncclCommInitRank failed", e); }
+        if (r != ncclSuccess) {
+            const char *e = c->GetErrorString(r);
+            if (published) (void)unlink(path.c_str());
+            delete c;
+            return comm_fail(nullptr, TIC_E_HIP, "ncclCommInitRank failed", e);
+        }
     }
     *out = c;
     if (c->comm) { // everybody has read the id once a first collective has completed: rank 0 removes the file

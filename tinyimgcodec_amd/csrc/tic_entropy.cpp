@@ -15,6 +15,7 @@
 
 #include "../../include/tinyimgcodec_hip.h"
 #include "tic_entropy.h"
+#include "tic_hooks.h"
 #include "tic_tables.h"
 
 #include <algorithm>
@@ -400,11 +401,11 @@ inline bool block_fast(const EncTables &T, const uint8_t *p, size_t pos0, int16_
 // position and running DC behind them.
 size_t decode_parallel(const EncTables &T, const uint8_t *data, size_t nbits, size_t n, int16_t *zz, size_t &pos_out, int &dc_out) {
     const size_t first_bit = 128;
-    if (n < 16384 || nbits < first_bit + (1u << 21) || getenv("TIC_DECODE_SERIAL")) return 0;
+    if (n < 16384 || nbits < first_bit + (1u << 21) || test_hook("TIC_DECODE_SERIAL")) return 0; // (tic_hooks.h: off unless TIC_TEST_HOOKS=1)
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)(hw ? hw / 2 : 4);
     nt = nt < 2 ? 2 : (nt > 16 ? 16 : nt);
-    if (const char *e = getenv("TIC_DECODE_THREADS")) nt = atoi(e) < 1 ? 1 : (atoi(e) > 64 ? 64 : atoi(e));
+    if (const char *e = test_hook("TIC_DECODE_THREADS")) nt = atoi(e) < 1 ? 1 : (atoi(e) > 64 ? 64 : atoi(e));
     const size_t fast_end = nbits - 2048; // a block may START on the fast path up to here
     const size_t span = (fast_end - first_bit + (size_t)nt - 1) / (size_t)nt;
     struct Trace {

@@ -39,6 +39,7 @@
 #include <string.h>
 
 #include "tic_entropy_gpu.h"
+#include "tic_hooks.h"
 #include "tic_tables.h"
 
 namespace tic {
@@ -687,7 +688,7 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
     const size_t cap_parts = (work_bytes - 256) / kPerPart;
     // frames of more than `direct` groups take the offsets in two levels (tile sums); TIC_ENT_DIRECT_GROUPS moves the switch
     size_t direct = 8192;
-    if (const char *e = getenv("TIC_ENT_DIRECT_GROUPS")) direct = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = test_hook("TIC_ENT_DIRECT_GROUPS")) direct = (size_t)strtoull(e, nullptr, 10); // (tic_hooks.h: off unless TIC_TEST_HOOKS=1)
     if (direct > 8192) direct = 8192; // the placing kernel's 32-bit sums rely on it
     const size_t tiles_per_frame = groups_per_frame > direct ? (groups_per_frame + kTileGroups - 1) / kTileGroups : 0;
     const size_t ntiles = tiles_per_frame * (size_t)nframes;

@@ -1,0 +1,24 @@
+// tic_hooks.h - the one gate in front of every environment variable that changes which code path the library takes.
+//
+// Production never consults the environment for that: a stray variable cannot silently change a kernel path or a decoder.
+// With TIC_TEST_HOOKS=1 in the environment WHEN THE LIBRARY IS FIRST USED, the test suite (and tools/) may set
+//   TIC_ENT_DIRECT_GROUPS   device entropy stage: group count above which stream offsets are summed in two levels
+//   TIC_DECODE_SERIAL       host Huffman decoder: always the serial decoder
+//   TIC_DECODE_THREADS      host Huffman decoder: threads of the parallel decoder
+//   TIC_COMM_FORCE_RCCL     a single rank goes through RCCL too (the only way to exercise tic_comm.hip on a one-GPU box)
+//   TIC_TUNE, TIC_SPLIT, TIC_SCHED, TIC_CHUNK, TIC_MAX_WGS   schedule knobs of the strip kernel's launcher
+// and these are then read at every call (tests flip them inside one process).
+#pragma once
+#include <stdlib.h>
+
+namespace tic {
+inline bool test_hooks_enabled() {
+    static const bool on = [] {
+        const char *v = getenv("TIC_TEST_HOOKS");
+        return v != nullptr && v[0] == '1' && v[1] == 0;
+    }();
+    return on;
+}
+// Value of test hook `name`, or nullptr when hooks are off (the usual case: one load of a static flag) or the variable is unset.
+inline const char *test_hook(const char *name) { return test_hooks_enabled() ? getenv(name) : nullptr; }
+} // namespace tic

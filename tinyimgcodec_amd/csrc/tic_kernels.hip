@@ -23,6 +23,7 @@
 #include <string.h>
 #include <type_traits>
 
+#include "tic_hooks.h"
 #include "tic_kernels.h"
 #include "tic_math.h"
 
@@ -2265,13 +2266,19 @@ struct Tunables {
     int split[8];
 };
 static Tunables read_tunables() {
-    auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
+    // (tic_hooks.h: the product reads no knob from the environment unless TIC_TEST_HOOKS=1; the experiment library always does)
+#ifdef TIC_ABLATION
+    auto knob = [](const char *k) { return (const char *)getenv(k); };
+#else
+    auto knob = [](const char *k) { return test_hook(k); };
+#endif
+    auto geti = [&](const char *k, int d) { const char *v = knob(k); return v ? atoi(v) : d; };
     Tunables t;
     t.max_wgs = geti("TIC_MAX_WGS", 0);             // persistent grid size (0: resident workgroups of the chip)
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
     t.chunk = geti("TIC_CHUNK", kMaxStripsPerWave); // strips per wave of schedules 1 and 2
     // per-round row weights of the team schedule ("0" disables it)
-    const char *sp = getenv("TIC_SPLIT") ? getenv("TIC_SPLIT") : "16,13,10,7,4,2";
+    const char *sp = knob("TIC_SPLIT") ? knob("TIC_SPLIT") : "16,13,10,7,4,2";
     for (int k = 0; k < 8; k++) t.split[k] = 0;
     for (int k = 0; k < 8 && sp && *sp; k++) {
         t.split[k] = atoi(sp);
@@ -2289,7 +2296,11 @@ static Tunables read_tunables() {
     return t;
 }
 static Tunables tunables() {
+#ifdef TIC_ABLATION
     static const bool live = getenv("TIC_TUNE") != nullptr;
+#else
+    static const bool live = test_hook("TIC_TUNE") != nullptr;
+#endif
     static const Tunables once = read_tunables();
     return live ? read_tunables() : once;
 }

@@ -29,9 +29,24 @@ def shard_range(n_frames, rank, world):
     return lo, hi
 
 
+_rdv_seq = 0
+
+
+def _launcher_start_ticks():
+    """Start time (clock ticks since boot) of the launcher process: with its pid it names ONE launcher instance, pid reuse or not."""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
+    except (OSError, ValueError, IndexError):
+        return 0
+
+
 def default_rendezvous_path():
-    """A file name unique to one launch of a one-process-per-GPU job: the ranks are children of the same launcher."""
-    return "/tmp/tic_rdv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+    """A file name unique to one launch of a one-process-per-GPU job and to one communicator of that job: the ranks are
+    children of the same launcher (same pid, same start time) and create their communicators in the same order."""
+    global _rdv_seq
+    _rdv_seq += 1
+    return "/tmp/tic_rdv_%s_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), _launcher_start_ticks(), _rdv_seq)
 
 
 class RcclComm:
