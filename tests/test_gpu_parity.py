@@ -893,3 +893,41 @@ def test_bench_lines_name_their_scaling_baseline(tmp_path):
     assert two["config"]["gathered_sizes"]["first"] == one["config"]["gathered_sizes"]["first"]
     assert abs(two["config"]["per_rank"]["kernel_only_mpix_s"] * 2 - two["value"]) < 1.0
     assert "NOT the N = 1 line's `value`" in two["scaling_baseline"]["value"]
+
+
+def test_decoder_edges_round3(ctx, golden, monkeypatch):
+    """decoder_edges.npz (reference-generated, round 3): same exception class as the reference for streams shorter than the header
+    (struct.error) and for streams flagged as carrying a Huffman table (ValueError); same pixels for the stream the reference's
+    adaptive-table writer produces; and for LONG damaged streams - the 1080p frame of BASELINE config 3 with a bit flipped in
+    the middle, and cut at 60 % - the reference's pixels from BOTH host decoders (parallel and serial)."""
+    import struct
+
+    g = golden("decoder_edges")
+    for name in [str(n) for n in g["names"]]:
+        bs = g[name + "_bs"].tobytes()
+        if int(g[name + "_ok"]):
+            assert np.array_equal(T.decompress(bs, ctx=ctx), g[name + "_out"]), name
+        else:
+            exc = {"error": struct.error, "ValueError": ValueError}[str(g[name + "_exc"])]
+            with pytest.raises(exc):
+                T.decompress(bs, ctx=ctx)
+    h, w = [int(v) for v in g["long_shape"]]
+    s = T.compress(rand_frame(int(g["long_seed"]), h, w), 50, ctx=ctx)
+    assert sha(s) == str(g["long_stream_sha"]) and len(s) == int(g["long_stream_len"])  # the stream the recipes apply to
+    for name in [str(n) for n in g["long_names"]]:
+        kind, at, mask = [int(v) for v in g[name + "_recipe"]]
+        data = bytearray(s)
+        if kind == 0:
+            data[at] ^= mask
+        else:
+            data = data[:at]
+        for serial in (False, True):
+            if serial:
+                monkeypatch.setenv("TIC_DECODE_SERIAL", "1")
+            else:
+                monkeypatch.delenv("TIC_DECODE_SERIAL", raising=False)
+            out = T.decompress(bytes(data), ctx=ctx)
+            assert sha(out.tobytes()) == str(g[name + "_sha"]), (name, serial)
+            for (y, x), crop in zip(g["long_crops_at"], g[name + "_crops"]):
+                assert np.array_equal(out[y:y + 64, x:x + 64], crop), (name, serial, int(y), int(x))
+    monkeypatch.delenv("TIC_DECODE_SERIAL", raising=False)

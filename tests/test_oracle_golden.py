@@ -235,3 +235,18 @@ def test_numpy_scipy_restatement_equals_the_c_oracle(oracle):
         dc, ac = oracle.encode(img, q)
         assert np.array_equal(got["dc"], dc) and np.array_equal(got["ac"], ac), (h, w, q)
     assert list(np_encode.ZIGZAG[:10]) == [0, 1, 8, 16, 9, 2, 3, 10, 17, 24]
+
+
+def test_decoder_edges_round3(oracle, golden):
+    """decoder_edges.npz (reference-generated): streams shorter than the header and streams with an embedded-table flag make
+    the reference raise (the oracle reports an error for exactly those); the stream the reference's own adaptive-table writer
+    produces and the same flag bytes in front of an ordinary payload decode to the reference's pixels."""
+    g = golden("decoder_edges")
+    for name in [str(n) for n in g["names"]]:
+        bs = g[name + "_bs"].tobytes()
+        if int(g[name + "_ok"]):
+            assert np.array_equal(oracle.decompress(bs), g[name + "_out"]), name
+        else:
+            assert str(g[name + "_exc"]) in ("error", "ValueError"), name  # struct.error / ValueError
+            with pytest.raises(oracle.OracleError):
+                oracle.decompress(bs)

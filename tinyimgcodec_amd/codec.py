@@ -19,7 +19,8 @@ Documented differences from the reference (all outside its working domain):
   * auto_generate_huffman_table=True raises NotImplementedError (that path is broken in the reference:
     the table flag is written big-endian and read little-endian, codec.py:111/119);
   * quality > 100 raises ValueError (the reference produces streams with negative divisors);
-  * streams carrying the custom-table flag are rejected by decompress(); scaled_dct streams (the reference's C encoder) are
+  * streams whose little-endian flag word has bit 31 set (an embedded Huffman table) raise ValueError in decompress() - what the
+    reference raises for every such stream that does not hold a well-formed table; scaled_dct streams (the reference's C encoder) are
     decoded for exponents 0..62 (the C encoder writes 0..3).
 """
 import ctypes as C
@@ -232,7 +233,13 @@ def parse_header(data):
 def decompress(data, ctx=None):
     ctx = _ctx(ctx)
     buf = _as_bytes_view(data)  # one view for the header and the payload: the stream is not copied
-    hdr = parse_header(buf)
+    hdr = parse_header(buf)     # struct.error for fewer than 16 bytes, as codec.py:118-119
+    if hdr["flag"] & (1 << 31):
+        # codec.py:124-126 parses a Huffman table from the stream here.  The reference's own writer cannot produce such a stream
+        # (it writes the flag MSB-first and reads it back little-endian: codec.py:111/119), and on anything that is not a
+        # well-formed table its read_huffman_table ends in ValueError (tests/golden/decoder_edges.npz); embedded tables are out
+        # of scope here, so every such stream gets that exception
+        raise ValueError("stream carries an embedded Huffman table (little-endian flag bit 31): not supported")
     out = np.zeros((hdr["height"], hdr["width"]), dtype=np.uint8)
     with ctx.lock:
         ctx.check(N.load().tic_decompress(ctx.handle, buf.ctypes.data, buf.size, out.ctypes.data, out.size))

@@ -98,10 +98,7 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
     return j < n ? j : p - j;
 }
 
-#ifndef TIC_WAVES_PER_WG
-#define TIC_WAVES_PER_WG 4 // (8 measured in the experiment library: tools/Makefile ablate8, profiles/r02_ab_wg8.txt)
-#endif
-constexpr int kWavesPerWG = TIC_WAVES_PER_WG;
+constexpr int kWavesPerWG = 4;      // (8-wave workgroups, three per CU, measured level: profiles/r02_ab_wg8.txt)
 constexpr int kLdsStrideDw = 68;    // dwords per block in the transpose buffer (64 + 4 pad; bank analysis in DESIGN.md)
 constexpr int kZzStrideB = 144;     // bytes per block in the zig-zag staging buffer (128 + 16 pad)
 constexpr int kLdsWaveBytes = 8 * kLdsStrideDw * 4; // 2176 B per wave (>= 8*144)
@@ -182,48 +179,6 @@ __device__ __forceinline__ void exact_block(uint32_t colLo, uint32_t colHi, uint
     }
 }
 
-// Second-level path for a block whose float32 result tripped its guard band: the same AAN butterflies in float64
-// (error ~1e-13 in coefficient units, against ~1e-12 for the reference itself).  A rounding is decided when no
-// .5 tie lies within 1e-9 (in quantised units) of t.  Undecided rational coefficients (exact ties are common there)
-// are reported through ok_rational and settled by special_block(); anything else undecided makes the function
-// return false for the lane, and the caller falls back to the exact order for that block.  Lane mapping and LDS use as exact_block().
-__device__ __forceinline__ bool second_level_block(uint32_t colLo, uint32_t colHi, uint32_t *lds, int b, int i,
-                                                   const double *mul64, int q[8], bool &ok_rational) {
-    double c[8];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        c[r] = (double)((int)((colLo >> (8 * r)) & 0xffu) - 128);
-        c[r + 4] = (double)((int)((colHi >> (8 * r)) & 0xffu) - 128);
-    }
-    dct8_aan(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
-    uint32_t w[8], wh[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = (uint32_t)__double2loint(c[k]);
-    transpose8x8_dwords(lds, b, i, w);
-#pragma unroll
-    for (int k = 0; k < 8; k++) wh[k] = (uint32_t)__double2hiint(c[k]);
-    transpose8x8_dwords(lds, b, i, wh);
-#pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = __hiloint2double((int)wh[k], (int)w[k]);
-    dct8_aan(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
-    const double *mul = mul64 + i * 8; // index u*8+v (global constants or the wave's LDS copy)
-    bool ok = true;
-    ok_rational = true;
-    const bool rat_lane = (i & 3) == 0; // frequency rows u = 0 and u = 4 hold the rational coefficients at v = 0, 4
-#pragma unroll
-    for (int v = 0; v < 8; v++) {
-        const double t = c[v] * mul[v];
-        const double r = rint(t);
-        const bool decided = fabs(t - r) < 0.5 - 1e-9;
-        if (rat_lane && (v == 0 || v == 4))
-            ok_rational = ok_rational && decided; // an exact tie: settled by the rational sub-path, not the exact order
-        else
-            ok = ok && decided;
-        q[v] = (int)r;
-    }
-    return ok;
-}
-
 // Writes the lane's 8 coefficients (natural positions i*8+v) into zig-zag order in LDS, then each lane stores
 // 16 bytes: a wave writes its 8 blocks as one contiguous 1 KiB segment.
 __device__ __forceinline__ void store_zigzag(uint32_t *lds, int b, int i, const uint16_t zz[8], const int q[8],
@@ -286,12 +241,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Kernel 2: the hybrid path.  The production kernel is dctq_strip_kernel further down; its round-1 predecessor
-// dctq_hybrid_kernel (workgroup-shared post-pass behind a barrier) is kept in the experiment library as the A/B baseline.
+// Kernel 2: the production kernel (dctq_strip_kernel below): float32 fast path behind a guard band, wave-local batch pass.
 //
 // Persistent waves, each walking its strips (strip = 8 horizontally adjacent blocks) in the order the launcher chose:
 // team schedule when the grid fits the chip at once, chunked schedule for larger grids (launch_dctq).
-// Main loop, per strip (unrolled x3, pixel registers rotate by name):
+// Main loop, per strip (unrolled x3, the landing registers of the pixel loads rotate by name):
 //   load   : lane 8*r + b reads the 8 bytes of pixel row r of block b -> every 8 lanes read 64 contiguous bytes; inline
 //            assembly + hand-counted vmcnt keep two strips in flight.
 //   pass 1 : float32 AAN along the pixel row held by the lane (no cross-lane traffic); the level shift is folded
@@ -299,33 +253,22 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 //   xpose  : 8x8 dword transpose per block through wave-private LDS (conflict-free slot layout); lane 8*b + v then
 //            holds column v.
 //   pass 2 : float32 AAN down that column; quantise with the magic-number rounding trick; the guard test is the largest
-//            distance to the rounded value per lane against two per-column thresholds.
+//            distance to the rounded value per lane against three per-column thresholds.
 //   store  : int16 results scattered to zig-zag order in LDS, read back 16 B per lane, 1 KiB contiguous per wave.
-//   trips  : blocks of a strip in which a lane tripped its guard band are settled after the loop (round 1: by the
-//            workgroup, from LDS lists; round 2: by the wave itself, from its batch - see dctq_strip_kernel).
-// Template parameter ABL: 0 = production; every other value is a timing-only build whose output is wrong by
-// construction (experiment library only).
+//   trips  : blocks of a strip in which a lane tripped its guard band are settled after the loop by the wave itself, from its
+//            batch.
+// The timing-only builds of this kernel (parts of the loop left out), its option / cache-policy / prefetch-depth variants, the
+// in-kernel stamps and the kernels that were explored and dropped (round-1 hybrid kernel with a workgroup-shared post-pass,
+// dynamic strip queue, one block per lane) live in tools/experiments/tic_kernels_experiments.hip, built by tools/Makefile only.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
 constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
-constexpr int kMaxStripsPerWave = 16;             // strips per wave are capped so that the trip list cannot overflow
-#ifdef TIC_ABLATION
-constexpr int kListEntries = 8 * kMaxStripsPerWave; // one entry per block in the worst case (512 B per wave)
-constexpr int kStash = 8;                          // pixels of the first 8 entries of each kind are kept in LDS (1 KiB)
-#endif
+constexpr int kMaxStripsPerWave = 16;             // default chunk of the chunked schedule (strips per wave)
 
-// Quantiser of the fast path.  t = z*mul; adding kMagic rounds t to an integer (half-even) whose two's complement
-// sits in the low mantissa bits (no v_rndne / v_cvt); d = t - rint(t) feeds the guard-band test.
-__device__ __forceinline__ void quant_magic(float z, float mul, uint32_t &bits, float &d) {
-    const float t = z * mul;
-    const float s = t + kMagic;
-    bits = __float_as_uint(s);
-    d = t - (s - kMagic);
-}
-
-// Round-2 form with fused multiply-adds: s = RN(z*mul + magic) is rint(z*mul) of the EXACT product (one rounding, half-even),
-// d = RN(z*mul - rint(z*mul)).  Three instructions per coefficient instead of four (v_fmaak, v_sub, v_fmac), and the
-// float32 rounding of the product - 1024 * 2^-23 of every guard band - no longer occurs (the bands are kept as they are).
+// Quantiser of the fast path: s = RN(z*mul + magic) is rint(z*mul) of the EXACT product (one rounding, half-even; adding
+// kMagic = 1.5 * 2^23 puts the integer's two's complement into the low mantissa bits: no v_rndne / v_cvt), d = RN(z*mul - rint(z*mul))
+// is the distance that feeds the guard-band test.  Three instructions per coefficient (v_fmaak, v_sub, v_fmac); the product is
+// never rounded on its own, which is what tools/fastpath_error_bound.py's "multiplier" term assumes.
 __device__ __forceinline__ void quant_fma(float z, float mul, uint32_t &bits, float &d) {
     const float s = fmaf(z, mul, kMagic);
     bits = __float_as_uint(s);
@@ -333,457 +276,15 @@ __device__ __forceinline__ void quant_fma(float z, float mul, uint32_t &bits, fl
     d = fmaf(z, mul, nr);
 }
 
-// Rational coefficients (u,v) in {0,4}x{0,4} of the lane's block on their exact float64 sub-path (SURVEY
-// Appendix A, consequence 2): for integer pixels the column pass outputs 0 and 4 are (integer sum) * constant,
-// one rounding each, and the row pass outputs 0 and 4 need 8 additions in pocketfft's order.
-// col: the lane's pixel column (lane 8*b + c).  Lanes c = 0 and c = 4 return the two quantised values of
-// frequency row u = c: r0 = (u,0), r4 = (u,4).
-struct RationalConsts { // per-lane constants of special_block(), loaded ahead of the dependent chain
-    double rdiv0, rdiv4, div0, div4;
-};
-__device__ __forceinline__ RationalConsts load_rational_consts(const DctqConsts *__restrict__ C, int i) {
-    RationalConsts k;
-    k.rdiv0 = C->rdiv[i * 8];
-    k.rdiv4 = C->rdiv[i * 8 + 4];
-    k.div0 = C->div[i * 8];
-    k.div4 = C->div[i * 8 + 4];
-    return k;
-}
-__device__ __forceinline__ void special_block(uint32_t colLo, uint32_t colHi, uint32_t *ldsT, int b, int i,
-                                              const RationalConsts &K, int &r0i, int &r4i) {
-#pragma clang fp contract(off)
-    int x0 = colLo & 0xff, x1 = (colLo >> 8) & 0xff, x2 = (colLo >> 16) & 0xff, x3 = colLo >> 24;
-    int x4 = colHi & 0xff, x5 = (colHi >> 8) & 0xff, x6 = (colHi >> 16) & 0xff, x7 = colHi >> 24;
-    int ea = x0 + x7 + x3 + x4, eb = x1 + x2 + x5 + x6;
-    double y0 = (double)(ea + eb - 1024) * (kSq2h * 0.5);
-    double y4 = (double)(ea - eb) * (kTW3 * 0.5);
-    double *dl = reinterpret_cast<double *>(ldsT) + b * 16;
-    dl[i] = y0;
-    dl[8 + i] = y4;
-    wave_lds_fence();
-    r0i = 0;
-    r4i = 0;
-    if ((i & 3) == 0) { // lane i = 0 finishes frequency row u = 0, lane i = 4 row u = 4
-        const double *yr = dl + (i ? 8 : 0);
-        double a0 = yr[0], a1 = yr[1], a2 = yr[2], a3 = yr[3], a4 = yr[4], a5 = yr[5], a6 = yr[6], a7 = yr[7];
-        double p07 = a0 + a7, p34 = a3 + a4, p12 = a1 + a2, p56 = a5 + a6;
-        double A = p07 + p34, B = p12 + p56;
-        double E0 = A + B, E4 = A - B;
-        double X0 = E0 * (kSq2h * 0.5), X4 = E4 * (kTW3 * 0.5);
-        double t0 = X0 * K.rdiv0, t4 = X4 * K.rdiv4;
-        double r0 = rint(t0), r4 = rint(t4);
-        // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
-        if (fabs(fabs(t0 - r0) - 0.5) < 1e-9) r0 = rint(X0 / K.div0);
-        if (fabs(fabs(t4 - r4) - 0.5) < 1e-9) r4 = rint(X4 / K.div4);
-        r0i = (int)r0;
-        r4i = (int)r4;
-    }
-    wave_lds_fence();
-}
-
-// Trip list entry: raster index of a block that left the fast path.  Blocks needing only their rational
-// coefficients fill the list from the front, blocks to redo entirely fill it from the back.
-__device__ __forceinline__ uint32_t byte_any(unsigned long long m) { // bit k = (byte k of m != 0)
-    m |= m >> 4;
-    m |= m >> 2;
-    m |= m >> 1;
-    m &= 0x0101010101010101ull;
-    return (uint32_t)((m * 0x0102040810204080ull) >> 56);
-}
-
-// ST / LD: cache policy of the coefficient stores / pixel loads (0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt).
-template <int ST>
-__device__ __forceinline__ void store16_policy(void *p, const uint4 &v) {
+// Coefficient stores: 16 B per lane, write-through and non-temporal (`sc1 nt`).  Write-through: the launch does not end with a
+// write-back of 33 MB of dirty L2 lines (plain stores: +1.5-1.8 us per 4096^2 launch).  Non-temporal on top of it: with plain
+// `sc1` the kernel took 13.0 us on data that is not already in the Infinity Cache against 9.7 us (16384^2: 150 against 127 us;
+// profiles/r03_ablate_cold.txt, r03_microbench7_cold_floors.txt); replaying one cache-resident frame the two are level.
+__device__ __forceinline__ void store16_wt_nt(void *p, const uint4 &v) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 d = {v.x, v.y, v.z, v.w};
-    if (ST == 0) *reinterpret_cast<uint4 *>(p) = v;
-    else if (ST == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(d) : "memory");
-    else if (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
-    else if (ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(d) : "memory");
 }
-
-#ifdef TIC_ABLATION // the round-1 kernel: kept in the experiment library as the A/B baseline
-#define TIC_STAMP(k)                                                                                  \
-    do {                                                                                              \
-        if (ABL == 8 && a.dbg != nullptr && lane == 0)                                                \
-            a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-
-template <int ABL, int ST = 0, int LD = 0>
-__global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
-    __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
-    __shared__ uint32_t list_all[kWavesPerWG][kListEntries];
-    __shared__ uint2 stash_all[kWavesPerWG][2 * kStash * 8]; // [kind][entry][row] pixel rows of tripped blocks
-    // timing-only builds (ABL != 0; their outputs are wrong by construction): which parts of the loop are present
-    constexpr bool kArith = !(ABL == 1 || ABL == 6 || ABL == 11); // butterflies, quantiser, guard test
-    constexpr bool kLds = !(ABL == 2 || ABL == 6 || ABL == 10);   // the two LDS hand-offs
-    constexpr bool kMem = !(ABL == 9 || ABL == 10 || ABL == 11);  // pixel loads and coefficient stores
-    if (ABL == 12) return; // timing-only: launch + dispatch of the grid, nothing else
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *ldsT = ldsT_all[wave];
-    char *ldsZ = reinterpret_cast<char *>(ldsZ_all[wave]);
-    uint32_t *list = list_all[wave];
-    uint2 *stash = stash_all[wave];
-    const DctqConsts *__restrict__ C = a.consts;
-    a.img += (long)blockIdx.y * a.frame_stride_in; // batch: one grid row per frame
-    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.y * a.frame_stride_out);
-
-    const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
-    const int b = lane >> 3, i = lane & 7;   // compute phase: column / frequency v = i of block b
-    int nS = 0, nG = 0;                      // wave-uniform list fill counts
-    const int nfast = a.fast_ty * a.fast_tx; // strips handled here: complete, 8-byte aligned, no padding
-
-    {
-        // per-lane constants for horizontal frequency v = i (L2-resident; loaded once per wave)
-        // (issued with inline assembly like the pixel loads below, so that every VMEM instruction of the loop phase is
-        // counted by hand: a compiler-inserted wait for these would not know about the pixel loads issued after them
-        // and would drain all of them on the first strip)
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        f32x4 m0, m1;
-        f32x2 thr;
-        u32x4 zzv;
-        {
-            const uint32_t o32 = (uint32_t)i * 32u, o16 = (uint32_t)i * 16u, o8 = (uint32_t)i * 8u;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(m0) : "v"(o32), "s"(C->mulT) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(m1) : "v"(o32), "s"(C->mulT) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(thr) : "v"(o8), "s"(C->thrT) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zzv) : "v"(o16), "s"(C->zzofsT) : "memory");
-        }
-        // LDS layouts of the loop (bank model: MI355X_MICROARCH.md, LDS; enumerated in tools/lds_bank_model.py).  Both
-        // staging buffers are arrays of 16-byte slots without padding.
-        // Transpose: Y[r][v] of block b lives in slot (r>>2)*64 + v*8 + (b ^ 4*((v>>1)&1)), dword r&3.  A write
-        // instruction (fixed v; lanes = (block, row)) covers all 32 banks once per 32-lane group; a 16-byte read
-        // (lanes = (block, v)) covers all 64 banks once per 16-lane group: no conflicts on either side (the padded
-        // [block][v][r] layout used before had 2-way conflicts on every read).
-        uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // v in {0,1,4,5}: + v*32 dwords
-        uint32_t *twB = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * (lb ^ 4); // v in {2,3,6,7}
-        const uint4 *tr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // rows 0..3; rows 4..7 at +64 slots
-        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
-        const uint32_t st_off = (uint32_t)lane * 16u;                       // lane offset inside the strip's 1 KiB output
-        const long row8 = 8 * a.stride;
-
-        // Strip walk (all scalar): ONE cursor, that of the prefetch.  It yields, per strip, the 32-bit byte offset of
-        // the strip's first pixel and the raster index of its first block; the block index travels to the store
-        // with the pixel register (both rotate by name in the unrolled loop), so nothing is recomputed.
-        int t_first;
-        long t_lim;
-        if (a.team_count > 0) {
-            const int r = blockIdx.x / a.team_count, t = blockIdx.x - r * a.team_count;
-            int row0 = 0, row1 = 0; // (constant indices only: a dynamic index would move the argument struct to scratch)
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (r == k) { row0 = a.split[k]; row1 = a.split[k + 1]; }
-            const int rows = row1 - row0;
-            t_first = __builtin_amdgcn_readfirstlane((row0 * a.team_count + t) * kWavesPerWG + wave);
-            t_lim = (long)t_first + (long)rows * a.tstep;
-        } else if (a.round_wgs > 0) {
-            const int rho = blockIdx.x / a.round_wgs, wl = blockIdx.x - rho * a.round_wgs;
-            const long base = (long)rho * a.round_wgs * a.wg_span;
-            t_first = __builtin_amdgcn_readfirstlane((int)base + wl * kWavesPerWG + wave);
-            t_lim = base + (long)a.round_wgs * a.wg_span;
-        } else {
-            t_first = __builtin_amdgcn_readfirstlane(blockIdx.x * a.wg_stride + wave);
-            t_lim = (long)blockIdx.x * a.wg_stride + a.wg_span;
-        }
-        const int t_end = t_lim < (long)nfast ? (int)t_lim : nfast; // first strip past this wave's walk
-        const int n_my = t_first < t_end ? (t_end - t_first + a.tstep - 1) / a.tstep : 0; // strips of this wave
-        int txp = t_first % a.fast_tx;
-        const int ty_first = t_first / a.fast_tx;
-        uint32_t in_off = (uint32_t)ty_first * (uint32_t)row8 + (uint32_t)txp * 64u; // frames are < 4 GiB (launcher)
-        uint32_t oblk = (uint32_t)ty_first * (uint32_t)a.bw + (uint32_t)txp * 8u;
-        const uint32_t ob_first = oblk;
-        uint32_t src_off = 0; // a load past the end of the walk re-reads the wave's last strip (strip 0 if it has none)
-        int n_issued = 0;
-        // Pixel loads are issued with inline assembly and waited for with explicit, counted s_waitcnt: the compiler's
-        // own bookkeeping waits for the newest load at the loop's back-edge (it takes the minimum over the entry and
-        // back-edge paths, and a register rotation by copy needs the copied load to have landed), which shortens the
-        // prefetch distance to one strip.  Contract: between two TIC_LOADs there is exactly one other VMEM
-        // instruction, the strip's 1 KiB store (the "memory" clobbers keep it on its side of the asm statements).
-        const uint8_t *img_s = a.img;
-#define TIC_LOAD(P, OB)                                                                                      \
-    do {                                                                                                     \
-        src_off = n_issued < n_my ? in_off : src_off;                                                        \
-        OB = oblk;                                                                                           \
-        const uint8_t *src = img_s + src_off;                                                                \
-        if (!kMem) P = ((unsigned long long)(ld_off * 2654435761u + src_off) << 24) ^ (ld_off + oblk); /* compute-only build */ \
-        else if (LD == 0) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        else if (LD == 1) asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        else if (LD == 2) asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        else if (LD == 3) asm volatile("global_load_dwordx2 %0, %1, %2 sc0 sc1" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        else asm volatile("global_load_dwordx2 %0, %1, %2 sc1 nt" : "=v"(P) : "v"(ld_off), "s"(src) : "memory"); \
-        n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
-        if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
-    } while (0)
-#define TIC_WAIT(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(P) : : "memory")
-        TIC_STAMP(0);
-        if (ABL == 13) { // timing-only: prologue (arguments, constants, walk set-up), no strips
-            if (n_my < 0) a.out[lane] = (int16_t)(m0.x + m1.x + thr.x + (float)zzv.x + (float)in_off + (float)oblk);
-            return;
-        }
-        unsigned long long p0, p1, p2;
-        uint32_t ob0, ob1, ob2;
-        TIC_LOAD(p0, ob0);
-        TIC_LOAD(p1, ob1);
-        // the four constant loads are older than the pixel loads: they have landed when only those are in flight
-        asm volatile("s_waitcnt vmcnt(2)" : "+v"(m0), "+v"(m1), "+v"(thr), "+v"(zzv) : : "memory");
-        // Zig-zag staging: scan positions 8c..8c+7 of block b live in slot c*8 + (b ^ 4*((c>>1)&1)).  The eight 2-byte
-        // scatter writes then cost their 4-cycle issue minimum (at most 2-way conflicts), the 16-byte read none.
-        auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
-            return reinterpret_cast<int16_t *>(ldsZ + (ofs >> 4) * 128 + (ofs & 15) + 16 * (b ^ (4 * ((ofs >> 5) & 1))));
-        };
-        int16_t *zp0 = zz_ptr(zzv.x & 0xffff), *zp1 = zz_ptr(zzv.x >> 16), *zp2 = zz_ptr(zzv.y & 0xffff), *zp3 = zz_ptr(zzv.y >> 16);
-        int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
-        const uint4 *zr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (4 * ((i >> 1) & 1)))), 16));
-
-        // one strip: everything from the pixel row held in px to the 1 KiB store, then the schedule advances
-        int left = n_my;
-        uint4 acc = make_uint4(0, 0, 0, 0);
-        auto process = [&](const unsigned long long px, const uint32_t ob) {
-            // ---- pass 1: along the pixel row (the fast path is free to choose the pass order) ------------------
-            const uint32_t lo0 = (uint32_t)px, hi0 = (uint32_t)(px >> 32);
-            // (assembly: from C casts the compiler makes SDWA integer adds of the first butterfly stage followed by
-            // v_cvt_f32_i32 - 28 instructions where these 8 conversions and 8 float adds do)
-            float d0, d1, d2, d3, d4, d5, d6, d7;
-            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d0) : "v"(lo0));
-            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d1) : "v"(lo0));
-            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d2) : "v"(lo0));
-            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d3) : "v"(lo0));
-            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d4) : "v"(hi0));
-            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d5) : "v"(hi0));
-            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d6) : "v"(hi0));
-            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d7) : "v"(hi0));
-            if (kArith) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
-            d0 -= 1024.0f;
-            float e0 = d0, e1 = d1, e2 = d2, e3 = d3, e4 = d4, e5 = d5, e6 = d6, e7 = d7;
-            if (kLds) {
-                twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
-                twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
-                twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
-                wave_lds_fence();
-                const uint4 ra = tr[0], rb = tr[64];
-                wave_lds_fence();
-                e0 = __uint_as_float(ra.x); e1 = __uint_as_float(ra.y); e2 = __uint_as_float(ra.z);
-                e3 = __uint_as_float(ra.w); e4 = __uint_as_float(rb.x); e5 = __uint_as_float(rb.y);
-                e6 = __uint_as_float(rb.z); e7 = __uint_as_float(rb.w);
-            }
-            // ---- pass 2: down the column of horizontal frequency v = i ------------------------------------------
-            uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
-            unsigned long long cA = 0, cB = 0; // lanes whose guard band tripped (A: u in 1,2,3,5,6,7; B: u in 0,4)
-            if (kArith) {
-                dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
-                float r0, r1, r2, r3, r4, r5, r6, r7;
-                quant_magic(e0, m0.x, q0, r0);
-                quant_magic(e1, m0.y, q1, r1);
-                quant_magic(e2, m0.z, q2, r2);
-                quant_magic(e3, m0.w, q3, r3);
-                quant_magic(e4, m1.x, q4, r4);
-                quant_magic(e5, m1.y, q5, r5);
-                quant_magic(e6, m1.z, q6, r6);
-                quant_magic(e7, m1.w, q7, r7);
-                float mA = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
-                mA = fmaxf(fmaxf(mA, fabsf(r5)), fabsf(r6));
-                mA = fmaxf(mA, fabsf(r7));
-                const float mB = fmaxf(fabsf(r0), fabsf(r4));
-                cA = __ballot(mA > thr.x);
-                cB = __ballot(mB > thr.y);
-            } else {
-                q0 = __float_as_uint(e0); q1 = __float_as_uint(e1); q2 = __float_as_uint(e2); q3 = __float_as_uint(e3);
-                q4 = __float_as_uint(e4); q5 = __float_as_uint(e5); q6 = __float_as_uint(e6); q7 = __float_as_uint(e7);
-            }
-            uint4 val;
-            if (kLds) {
-                *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
-                *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
-            } else {
-                val = make_uint4((q0 & 0xffff) | (q1 << 16), (q2 & 0xffff) | (q3 << 16), (q4 & 0xffff) | (q5 << 16), (q6 & 0xffff) | (q7 << 16));
-            }
-            // ---- guard band bookkeeping, all scalar: lanes v in {0,4} hold the rational coefficients at u in {0,4} ------
-            if (__builtin_expect((cA | cB) != 0ull, 0)) { // rare: remember the tripped blocks for the post-pass
-                const unsigned long long kRat = 0x1111111111111111ull;
-                const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
-                const uint32_t gm = byte_any(mG), sm = byte_any(mS) & ~gm;
-                const uint32_t blk = ob + (uint32_t)b;
-                const uint32_t below = (1u << b) - 1u;
-                if (i == 0 && ((sm >> b) & 1u)) list[nS + __builtin_popcount(sm & below)] = blk;
-                if (i == 0 && ((gm >> b) & 1u)) list[kListEntries - 1 - nG - __builtin_popcount(gm & below)] = blk;
-                // keep the pixels of the first few tripped blocks in LDS so the post-pass need not reload them:
-                // this lane still holds pixel row lr of block lb of the strip
-                {
-                    const uint32_t lbelow = (1u << lb) - 1u;
-                    const int es = nS + __builtin_popcount(sm & lbelow), eg = nG + __builtin_popcount(gm & lbelow);
-                    if (((sm >> lb) & 1u) && es < kStash) stash[es * 8 + lr] = make_uint2(lo0, hi0);
-                    if (((gm >> lb) & 1u) && eg < kStash) stash[(kStash + eg) * 8 + lr] = make_uint2(lo0, hi0);
-                }
-                nS += __builtin_popcount(sm);
-                nG += __builtin_popcount(gm);
-            }
-            // ---- zig-zag ordered blocks -> global: 16 B per lane, 1 KiB contiguous per wave ---------------------------
-            if (kLds) {
-                wave_lds_fence();
-                val = *zr;
-                wave_lds_fence();
-            }
-            if (!kMem) { acc.x ^= val.x; acc.y ^= val.y; acc.z ^= val.z; acc.w ^= val.w; } // compute-only build: no store
-            else store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off, val);
-            left--;
-        };
-        // Two strips ahead (loads L, stores S): strip j is consumed after L(j+2) is issued; in steady state the
-        // instructions younger than L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.
-        // The three pixel registers rotate by name (loop unrolled by three).  Three strips ahead measured 2 % slower.
-        do {
-            if (left == 0) break;
-            TIC_LOAD(p2, ob2); TIC_WAIT(p0, 2); process(p0, ob0);
-            if (left == 0) break;
-            TIC_LOAD(p0, ob0); TIC_WAIT(p1, 3); process(p1, ob1);
-            while (left != 0) {
-                TIC_LOAD(p1, ob1); TIC_WAIT(p2, 4); process(p2, ob2);
-                if (left == 0) break;
-                TIC_LOAD(p2, ob2); TIC_WAIT(p0, 4); process(p0, ob0);
-                if (left == 0) break;
-                TIC_LOAD(p0, ob0); TIC_WAIT(p1, 4); process(p1, ob1);
-            }
-        } while (0);
-        // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
-        if (!kMem) { // one store per wave, to its first strip (always inside the frame)
-            if (n_my > 0) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob_first << 7) + st_off) = acc;
-            return;
-        }
-#undef TIC_LOAD
-#undef TIC_WAIT
-    }
-
-    // ---- post-pass over the recorded blocks, shared by the workgroup ------------------------------------------------------
-    // All four waves end their loops at about the same time; the recorded blocks are few and each pass over them is
-    // a long dependent float64 chain for a single wave.  So the work is split by kind across the waves of the
-    // workgroup instead of being done serially by the wave that recorded it: waves 0 and 2 take the rational-tie
-    // entries of wave pairs {0,1} and {2,3}, waves 1 and 3 take the full-redo entries of the same pairs.
-    // (Patches go to addresses stored to earlier by another wave of this workgroup: every wave drains its own
-    // stores before the barrier, so the patch is ordered after them.)
-    TIC_STAMP(1); // end of main loop
-    __shared__ int cnt_all[kWavesPerWG][2];
-    if (lane == 0) {
-        cnt_all[wave][0] = nS;
-        cnt_all[wave][1] = nG;
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    TIC_STAMP(2); // own stores drained
-    __syncthreads();
-    TIC_STAMP(3); // barrier passed
-    if (ABL == 3) return;
-    const int src0 = wave & 2, src1 = src0 + 1;      // the pair of waves whose entries this wave serves
-    const bool do_ties = (wave & 1) == 0;
-    const int kind = do_ties ? 0 : 1;
-    const int n0 = cnt_all[src0][kind], n1 = cnt_all[src1][kind];
-    const int ntot = n0 + n1;
-    if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[((size_t)blockIdx.x * kWavesPerWG + wave) * 8 + 7] = (unsigned long long)ntot;
-    if (ntot == 0) return;
-    if ((do_ties && (ABL == 5 || ABL == 7)) || (!do_ties && ABL == 4)) return;
-    // entry e of the concatenated lists of the two served waves -> (block id, pixel rows of the block for lane i)
-    auto fetch = [&](int e, bool have, uint32_t &blk, uint32_t &lo, uint32_t &hi) {
-        const int ee = have ? e : 0;
-        const int sw = ee < n0 ? src0 : src1; // source wave and index in its list
-        const int idx = ee < n0 ? ee : ee - n0;
-        blk = do_ties ? list_all[sw][idx] : list_all[sw][kListEntries - 1 - idx];
-        if (idx < kStash) { // lane 8*b + i: pixel row i of its block, from the recording wave's LDS stash ...
-            const uint2 pv = stash_all[sw][((do_ties ? 0 : kStash) + idx) * 8 + i];
-            lo = pv.x;
-            hi = pv.y;
-        } else { // ... or from memory: blocks of the fast rectangle are complete and 8-byte aligned
-            const uint32_t by = blk / (uint32_t)a.bw, bx = blk - by * (uint32_t)a.bw;
-            const uint2 pv = *reinterpret_cast<const uint2 *>(a.img + ((long)by * 8 + i) * a.stride + (long)bx * 8);
-            lo = pv.x;
-            hi = pv.y;
-        }
-        transpose8x8_bytes(lo, hi, i); // -> pixel column i
-    };
-    const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8); // fetched before the dependent chains start
-    if (do_ties) { // rational coefficients only (exact ties, ~2 % of blocks); 8 blocks per pass
-        const RationalConsts KR = load_rational_consts(C, i);
-        for (int base = 0; base < ntot; base += 8) {
-            const bool have = base + b < ntot;
-            uint32_t blk, lo, hi;
-            fetch(base + b, have, blk, lo, hi);
-            TIC_STAMP(4); // pixels fetched + transposed
-            int r0, r4;
-            special_block(lo, hi, ldsT, b, i, KR, r0, r4);
-            TIC_STAMP(5); // rational sub-path done
-            if (have && (i & 3) == 0) {
-                int16_t *ob = a.out + (size_t)blk * 64;
-                ob[(zo.x & 0xffffu) >> 1] = (int16_t)r0; // zig-zag slots of (u,0) and (u,4)
-                ob[(zo.z & 0xffffu) >> 1] = (int16_t)r4;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        TIC_STAMP(6); // patches landed
-        return;
-    }
-    // whole blocks (~0.3 % of blocks at q=50); 8 blocks per pass
-    char *zzblk = ldsZ + b * kZzStrideB;
-    const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
-    for (int base = 0; base < ntot; base += 8) {
-        const bool have = base + b < ntot;
-        uint32_t blk, lo, hi;
-        fetch(base + b, have, blk, lo, hi);
-        TIC_STAMP(4);
-        // second level first (float64 butterflies, ~half the work of the exact order); its results go straight to
-        // the zig-zag staging buffer so that nothing stays live across the exact order, which runs only for blocks
-        // the second level cannot decide (a rational-coefficient tie in the same block, or a true tie elsewhere)
-        bool ok;
-        {
-            int qe[8];
-            if (ABL == 7) {
-                ok = true;
-#pragma unroll
-                for (int v = 0; v < 8; v++) qe[v] = (int)(lo >> v) + (int)hi; // timing-only: no exact arithmetic
-            } else {
-                bool ok_rat;
-                ok = second_level_block(lo, hi, ldsT, b, i, C->mul64, qe, ok_rat);
-                if (__ballot(!ok_rat && have) != 0ull) { // a rational tie inside a redo block: exact sub-path (cheap)
-                    const RationalConsts KR = load_rational_consts(C, i);
-                    int r0, r4;
-                    special_block(lo, hi, ldsT, b, i, KR, r0, r4);
-                    if ((i & 3) == 0) {
-                        qe[0] = r0;
-                        qe[4] = r4;
-                    }
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < 8; v++)
-                *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
-        }
-        TIC_STAMP(5); // second level done
-        const unsigned long long bad = __ballot(!ok && have);
-        if (bad != 0ull) {
-            int qx[8];
-            exact_block(lo, hi, ldsT, b, i, C, qx);
-            if ((bad >> (8 * b)) & 0xffull) {
-#pragma unroll
-                for (int v = 0; v < 8; v++)
-                    *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qx[v];
-            }
-        }
-        wave_lds_fence();
-        const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
-        wave_lds_fence();
-        if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
-    }
-    if (ABL == 8) {
-        __builtin_amdgcn_s_waitcnt(0);
-        TIC_STAMP(6);
-    }
-    if (!do_ties && a.fallback_count != nullptr && lane == 0) atomicAdd(a.fallback_count, (unsigned long long)ntot);
-}
-
-#endif // TIC_ABLATION
 
 // ---------------------------------------------------------------------------------------------------------
 // Kernel 2 (round 2): the strip kernel with a wave-local batch pass - no barrier, no store drain, no global patches.
@@ -803,7 +304,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 5) void dctq_hybrid_kernel(DctqAr
 // Measured against the alternatives on a 4096^2 frame (profiles/r02_ablate.txt): workgroup-shared
 // post-pass behind a barrier (round 1) +2.0 us over the loop; settling every tripped strip inside the loop +2.9 us (a wave
 // with four tripped strips ends 2 us after its neighbours: static schedule, dependent float64 chains); this batch pass
-// +0.9 us.  Resources: 72 VGPRs, 21.4 KiB of LDS per workgroup, six workgroups per CU (OCC).
+// +0.9 us.  Resources: 72 + 8 reserved VGPRs, 21.5 KiB of LDS per workgroup, six workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxStripsPerWave2 = 64;                 // one bit per strip of a wave's walk in the exact-redo mask
 constexpr int kBatch = 8;                              // entries of the wave's batch
@@ -873,34 +374,20 @@ __device__ __forceinline__ void wave_redo_block(const uint8_t *px /* 64 pixels, 
     wave_lds_fence();
 }
 
-// OPT: A/B switches of the experiment library (bit 0: fused quantiser, bit 1: tripped blocks sit out the strip's store);
-// the product is built with all of them on.
-template <int ABL, int ST = 0, int LD = 0, int OPT = 15, int OCC = 6, int PF = 2>
-__global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vgpr(72))) void dctq_strip_kernel(DctqArgs a) {
+__global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr(72))) void dctq_strip_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) unsigned char cst_blk[kStripBlkBytes]; // constants, shared by the workgroup
     __shared__ __attribute__((aligned(16))) uint32_t bat_all[kWavesPerWG][kBatchWaveBytes / 4];
-    constexpr bool kArith = !(ABL == 1 || ABL == 6 || ABL == 11); // timing-only builds, as in the kernel above
-    constexpr bool kLds = !(ABL == 2 || ABL == 6 || ABL == 10);
-    constexpr bool kLdsT = kLds && ABL != 21; // timing-only: without the transpose through LDS
-    constexpr bool kLdsZ = kLds && ABL != 20; // timing-only: without the zig-zag staging through LDS
-    constexpr bool kMem = !(ABL == 9 || ABL == 10 || ABL == 11);
-    constexpr bool kRare = !(ABL == 3 || ABL == 22); // ABL 3: tripped blocks are ignored (timing only); 22: guard test kept, no branch
-    constexpr bool kBatchPass = ABL != 23;           // ABL 23: blocks join the batch but the batch pass is skipped (timing only)
-    unsigned long long t_entry = 0, t_karg = 0, t_desc = 0;
-    if (ABL == 8) t_entry = __builtin_amdgcn_s_memtime();
-    if (ABL == 12) return; // timing-only: launch + dispatch of the grid, nothing else
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *ldsT = ldsT_all[wave];
     char *ldsZ = reinterpret_cast<char *>(ldsZ_all[wave]);
-    const double *cst_mul64 = reinterpret_cast<const double *>(cst_blk + 448);     // [64] index u*8+v
     const uint16_t *cst_zz = reinterpret_cast<const uint16_t *>(cst_blk + 960);    // [64] index u*8+v
     const double *cst_rat = reinterpret_cast<const double *>(cst_blk + 1088);      // div[4] then rdiv[4]: (0,0) (0,4) (4,0) (4,4)
     uint4 *bat_img = reinterpret_cast<uint4 *>(bat_all[wave]);                      // [kBatch][8] 16-byte pieces: zig-zag images
     uint2 *bat_pix = reinterpret_cast<uint2 *>(bat_all[wave] + kBatch * 32);        // [kBatch][8] pixel rows
-    uint32_t *bat_id = bat_all[wave] + kBatch * 48;                                 // [kBatch] block index | kind << 31
+    uint32_t *bat_id = bat_all[wave] + kBatch * 48;                                 // [kBatch] block index
     const DctqConsts *__restrict__ C = a.consts;
     a.img += (long)blockIdx.z * a.frame_stride_in; // batch of frames: one grid plane per frame
     a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.z * a.frame_stride_out);
@@ -908,42 +395,41 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
     const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
     const int b = lane >> 3, i = lane & 7;   // compute phase: column / frequency v = i of block b
     unsigned long long mask_exact = 0;       // strips of this wave's walk to redo in the exact order (wave-uniform)
-    uint32_t n_second = 0;                   // blocks sent to the second level (statistics)
+    uint32_t n_second = 0;                   // blocks recomputed in float64 (statistics)
     int nE = 0;                              // entries in the batch (wave-uniform)
     uint32_t kind_mask = 0;                  // bit e: entry e tripped on an irrational coefficient (wave-uniform, scalar register)
     int t_first, n_my;
     const uint32_t st_off = (uint32_t)lane * 16u; // lane offset inside a strip's 1 KiB output
     {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         f32x4 m0, m1;
         f32x4 thr;
         u32x4 zzv;
-        // Constants: the workgroup copies the quality's 2176-byte block into LDS, 34 lanes of every wave one 16-byte piece
+        // Constants: the workgroup copies the quality's 2304-byte block into LDS, 36 lanes of every wave one 16-byte piece
         // each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
         // loads per wave in front of the first pixel load: four such loads more cost 0.67 us on a 4096^2 launch).
-        // Every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_WAIT).
+        // Every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_TAKE).
         u32x4 c_fill;
         {
-            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 34 pieces of 16 bytes per wave
+            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 36 pieces of 16 bytes per wave
             static_assert(kPpw * kWavesPerWG == kStripBlkPieces && kPpw <= 64, "constant block must split evenly over the waves");
             const uint32_t piece = lane < kPpw ? (uint32_t)(wave * kPpw + lane) : (uint32_t)kStripBlkPieces - 1u;
             const uint32_t fo = piece * 16u;
             asm volatile("global_load_dwordx4 v[76:79], %0, %1" : : "v"(fo), "s"(C->strip_blk) : "memory", "v76", "v77", "v78", "v79"); // (lands in reserved registers: see TIC_LOAD)
         }
-        // LDS layouts of the loop: as in the kernel above (conflict-free transpose and zig-zag staging)
+        // LDS layouts of the loop (conflict-free transpose and zig-zag staging)
         uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // v in {0,1,4,5}: + v*32 dwords
         uint32_t *twB = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * (lb ^ 4); // v in {2,3,6,7}
         const uint4 *tr = reinterpret_cast<const uint4 *>(
             __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // rows 0..3; rows 4..7 at +64 slots
         const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
 
-        // Strip walk: one scalar cursor (that of the prefetch), see the kernel above.  Its start state takes ~25 scalar
-        // instructions: no division (magic multipliers from the launcher), no per-workgroup memory.  (Measured: the round-1
-        // prologue's ~250 scalar instructions per wave - four integer divisions - made the last of a CU's five workgroups
-        // issue its first load 3,000 cycles after the first, the 20 waves of a CU share one scalar unit; a table of
-        // per-wave start states read with s_load was as slow: the scalar cache serves misses to distinct lines one by one.)
+        // Strip walk: one scalar cursor (that of the prefetch).  Its start state takes ~25 scalar instructions: no division
+        // (magic multipliers from the launcher), no per-workgroup memory.  (Measured: the round-1 prologue's ~250 scalar
+        // instructions per wave - four integer divisions - made the last of a CU's five workgroups issue its first load 3,000
+        // cycles after the first, the 20 waves of a CU share one scalar unit; a table of per-wave start states read with s_load
+        // was as slow: the scalar cache serves misses to distinct lines one by one.)
         uint32_t tf, t_lim;
         if (a.team_count > 0) { // 2-D grid: x = team, y = round
             const uint32_t r = blockIdx.y;
@@ -973,8 +459,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
         int txp = (int)(tf - ty_first * (uint32_t)a.fast_tx);
         uint32_t in_off = ty_first * (uint32_t)(8 * a.stride) + (uint32_t)txp * 64u; // frames are < 4 GiB (launcher)
         uint32_t oblk = ty_first * (uint32_t)a.bw + (uint32_t)txp * 8u;
-        if (ABL == 8) t_desc = __builtin_amdgcn_s_memtime(); // start state known
-        const uint32_t ob_first = oblk;
         uint32_t src_off = 0; // a load past the end of the walk re-reads the wave's last strip (strip 0 if it has none)
         int n_issued = 0;
         const uint8_t *img_s = a.img;
@@ -985,69 +469,36 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
         // compiler then believes the value exists from that statement on and is free to copy it - a phi move, a coalescing with a
         // register tuple - before it has landed, and to reuse a register that a load in flight will still write.  It happened not
         // to; tools/microbench7.hip faulted exactly that way.  Accumulator registers would do too, but the compiler then splits the
-        // 80 registers 40:40 and spills.)  tests/test_host_cpu.py checks in the disassembly that no instruction outside these
-        // statements touches v72..v79.
+        // 80 registers 40:40 and spills.)  tests/test_host_cpu.py checks in the disassembly of the shipped binary that no
+        // instruction outside these statements touches v72..v79.
 #define TIC_RSV_CLOBBER "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
 #define TIC_LOAD(R, OB)                                                                                      \
     do {                                                                                                     \
         src_off = n_issued < n_my ? in_off : src_off;                                                        \
         OB = oblk;                                                                                           \
-        const uint8_t *src = img_s + src_off;                                                                \
-        if (!kMem) { /* compute-only build: TIC_TAKE makes up the pixels */ }                                \
-        else if (LD == 0) asm volatile("global_load_dwordx2 v[" R "], %0, %1" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
-        else if (LD == 1) asm volatile("global_load_dwordx2 v[" R "], %0, %1 nt" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
-        else if (LD == 2) asm volatile("global_load_dwordx2 v[" R "], %0, %1 sc1" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
-        else if (LD == 3) asm volatile("global_load_dwordx2 v[" R "], %0, %1 sc0 sc1" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
-        else asm volatile("global_load_dwordx2 v[" R "], %0, %1 sc1 nt" : : "v"(ld_off), "s"(src) : TIC_RSV_CLOBBER); \
+        asm volatile("global_load_dwordx2 v[" R "], %0, %1" : : "v"(ld_off), "s"(img_s + src_off) : TIC_RSV_CLOBBER); \
         n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
         if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
     } while (0)
     // waits until all but the N youngest vector-memory operations are done, then converts the strip's eight pixels straight out
     // of the landing registers v[R0], v[R1] (which keep the strip's bytes until the pair is loaded again, two strips later: the
-    // rare paths fetch the raw words from there, TIC_RAW)
+    // rare paths fetch the raw words from there, raw_words)
 #define TIC_TAKE(D, R0, R1, N)                                                                               \
-    do {                                                                                                     \
-        if (kMem)                                                                                            \
-            asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_cvt_f32_ubyte0 %0, v" #R0 "\n\tv_cvt_f32_ubyte1 %1, v" #R0 "\n\tv_cvt_f32_ubyte2 %2, v" #R0 \
-                         "\n\tv_cvt_f32_ubyte3 %3, v" #R0 "\n\tv_cvt_f32_ubyte0 %4, v" #R1 "\n\tv_cvt_f32_ubyte1 %5, v" #R1                       \
-                         "\n\tv_cvt_f32_ubyte2 %6, v" #R1 "\n\tv_cvt_f32_ubyte3 %7, v" #R1                                                       \
-                         : "=v"(D[0]), "=v"(D[1]), "=v"(D[2]), "=v"(D[3]), "=v"(D[4]), "=v"(D[5]), "=v"(D[6]), "=v"(D[7]) : : TIC_RSV_CLOBBER); \
-        else {                                                                                               \
-            const uint32_t slo = ld_off * 2654435761u + kstrip * 40503u, shi = slo ^ (oblk << 7);            \
-            for (int q_ = 0; q_ < 4; q_++) { D[q_] = (float)((slo >> (8 * q_)) & 0xffu); D[4 + q_] = (float)((shi >> (8 * q_)) & 0xffu); } \
-        }                                                                                                    \
-    } while (0)
-        if (ABL == 8 && a.dbg != nullptr && lane == 0) {
-            unsigned long long *d = a.dbg + (((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8;
-            d[0] = t_entry;
-            d[1] = __builtin_amdgcn_s_memtime(); // set-up done, first pixel load about to issue
-            d[5] = t_karg;
-            d[7] = t_desc;
-        }
-        if (ABL == 13) { // timing-only: prologue (arguments, constants, walk set-up), no strips
-            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v76" : "=v"(c_fill.x) : : "memory", "v76", "v77", "v78", "v79");
-            if (n_my < 0) a.out[lane] = (int16_t)((float)c_fill.x + (float)in_off + (float)oblk);
-            return;
-        }
-        uint32_t ob0, ob1, ob2, ob3 = 0;
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_cvt_f32_ubyte0 %0, v" #R0 "\n\tv_cvt_f32_ubyte1 %1, v" #R0 "\n\tv_cvt_f32_ubyte2 %2, v" #R0 \
+                 "\n\tv_cvt_f32_ubyte3 %3, v" #R0 "\n\tv_cvt_f32_ubyte0 %4, v" #R1 "\n\tv_cvt_f32_ubyte1 %5, v" #R1                       \
+                 "\n\tv_cvt_f32_ubyte2 %6, v" #R1 "\n\tv_cvt_f32_ubyte3 %7, v" #R1                                                       \
+                 : "=v"(D[0]), "=v"(D[1]), "=v"(D[2]), "=v"(D[3]), "=v"(D[4]), "=v"(D[5]), "=v"(D[6]), "=v"(D[7]) : : TIC_RSV_CLOBBER)
+        uint32_t ob0, ob1, ob2;
         uint32_t kstrip = 0; // ordinal of the strip in this wave's walk
         TIC_LOAD("72:73", ob0);
-        if (!(OPT & 16)) TIC_LOAD("74:75", ob1);
-        // the constant piece is older than the pixel loads: it has landed when only those are in flight
-#define TIC_TAKE_CONSTS(N)                                                                                                 \
-    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_mov_b32 %0, v76\n\tv_mov_b32 %1, v77\n\tv_mov_b32 %2, v78\n\tv_mov_b32 %3, v79" \
-                 : "=v"(c_fill.x), "=v"(c_fill.y), "=v"(c_fill.z), "=v"(c_fill.w) : : "memory", "v76", "v77", "v78", "v79")
-        if (OPT & 16) TIC_TAKE_CONSTS(1);
-        else TIC_TAKE_CONSTS(2);
-#undef TIC_TAKE_CONSTS
+        TIC_LOAD("74:75", ob1);
+        // the constant piece is older than the pixel loads: it has landed when only those are in flight.  (Issuing the second
+        // pixel load behind the barrier instead: +0.13 us, profiles/r02_ab_opt_switches.txt.)
+        asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, v76\n\tv_mov_b32 %1, v77\n\tv_mov_b32 %2, v78\n\tv_mov_b32 %3, v79"
+                     : "=v"(c_fill.x), "=v"(c_fill.y), "=v"(c_fill.z), "=v"(c_fill.w) : : "memory", "v76", "v77", "v78", "v79");
         if (lane < kStripBlkPieces / kWavesPerWG) *reinterpret_cast<u32x4 *>(cst_blk + (wave * (kStripBlkPieces / kWavesPerWG) + lane) * 16) = c_fill;
         // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
-        // The second strip's load goes out behind the barrier: the CU's memory pipeline returns data in request order, and
-        // with both loads up front the first strip of the CU's last wave queued behind 39 others (first data 1,400 cycles
-        // after entry for the first workgroup of a CU, 5,000 for the fifth).
-        if (OPT & 16) TIC_LOAD("74:75", ob1);
-        if (PF == 3) TIC_LOAD("76:77", ob2); // experiment: three strips ahead
         m0 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32);
         m1 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32 + 16);
         thr = *reinterpret_cast<const f32x4 *>(cst_blk + 2176 + i * 16); // accept thresholds of column v = i: u in {1,2,3} | {5,6,7} | {0,4}
@@ -1062,89 +513,60 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
         wave_lds_fence();
 
         int left = n_my;
-        uint4 acc = make_uint4(0, 0, 0, 0);
         // raw pixel words of the strip in work, out of its landing registers (rare paths only)
         auto raw_words = [&](auto tag, uint32_t &lo, uint32_t &hi) {
             constexpr int R = decltype(tag)::value;
-            if (!kMem) { lo = ld_off * 2654435761u + kstrip * 40503u; hi = lo ^ (oblk << 7); }
-            else if constexpr (R == 72) asm volatile("v_mov_b32 %0, v72\n\tv_mov_b32 %1, v73" : "=v"(lo), "=v"(hi) : : "memory");
+            static_assert(R == 72 || R == 74 || R == 76, "landing register pair");
+            if constexpr (R == 72) asm volatile("v_mov_b32 %0, v72\n\tv_mov_b32 %1, v73" : "=v"(lo), "=v"(hi) : : "memory");
             else if constexpr (R == 74) asm volatile("v_mov_b32 %0, v74\n\tv_mov_b32 %1, v75" : "=v"(lo), "=v"(hi) : : "memory");
-            else if constexpr (R == 76) asm volatile("v_mov_b32 %0, v76\n\tv_mov_b32 %1, v77" : "=v"(lo), "=v"(hi) : : "memory");
-            else asm volatile("v_mov_b32 %0, v78\n\tv_mov_b32 %1, v79" : "=v"(lo), "=v"(hi) : : "memory");
+            else asm volatile("v_mov_b32 %0, v76\n\tv_mov_b32 %1, v77" : "=v"(lo), "=v"(hi) : : "memory");
         };
         auto process = [&](auto tag, const float (&px)[8], const uint32_t ob) {
             // ---- pass 1: along the pixel row (the pixels arrive converted: TIC_TAKE) -----------------------------
             float d0 = px[0], d1 = px[1], d2 = px[2], d3 = px[3], d4 = px[4], d5 = px[5], d6 = px[6], d7 = px[7];
-            if (kArith) dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
+            dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
             d0 -= 1024.0f;
-            float e0 = d0, e1 = d1, e2 = d2, e3 = d3, e4 = d4, e5 = d5, e6 = d6, e7 = d7;
-            if (kLdsT) {
-                twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
-                twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
-                twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
-                wave_lds_fence();
-                const uint4 ra = tr[0], rb = tr[64];
-                wave_lds_fence();
-                e0 = __uint_as_float(ra.x); e1 = __uint_as_float(ra.y); e2 = __uint_as_float(ra.z);
-                e3 = __uint_as_float(ra.w); e4 = __uint_as_float(rb.x); e5 = __uint_as_float(rb.y);
-                e6 = __uint_as_float(rb.z); e7 = __uint_as_float(rb.w);
-            }
+            twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
+            twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
+            twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
+            wave_lds_fence();
+            const uint4 ra = tr[0], rb = tr[64];
+            wave_lds_fence();
+            float e0 = __uint_as_float(ra.x), e1 = __uint_as_float(ra.y), e2 = __uint_as_float(ra.z), e3 = __uint_as_float(ra.w);
+            float e4 = __uint_as_float(rb.x), e5 = __uint_as_float(rb.y), e6 = __uint_as_float(rb.z), e7 = __uint_as_float(rb.w);
             // ---- pass 2: down the column of horizontal frequency v = i ----------------------------------------
+            dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
             uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
-            unsigned long long cA = 0, cB = 0; // lanes whose guard band tripped (A: u in 1,2,3,5,6,7; B: u in 0,4)
-            if (kArith) {
-                dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
-                float r0, r1, r2, r3, r4, r5, r6, r7;
-                if (OPT & 1) quant_fma(e0, m0.x, q0, r0); else quant_magic(e0, m0.x, q0, r0);
-                if (OPT & 1) quant_fma(e1, m0.y, q1, r1); else quant_magic(e1, m0.y, q1, r1);
-                if (OPT & 1) quant_fma(e2, m0.z, q2, r2); else quant_magic(e2, m0.z, q2, r2);
-                if (OPT & 1) quant_fma(e3, m0.w, q3, r3); else quant_magic(e3, m0.w, q3, r3);
-                if (OPT & 1) quant_fma(e4, m1.x, q4, r4); else quant_magic(e4, m1.x, q4, r4);
-                if (OPT & 1) quant_fma(e5, m1.y, q5, r5); else quant_magic(e5, m1.y, q5, r5);
-                if (OPT & 1) quant_fma(e6, m1.z, q6, r6); else quant_magic(e6, m1.z, q6, r6);
-                if (OPT & 1) quant_fma(e7, m1.w, q7, r7); else quant_magic(e7, m1.w, q7, r7);
-                const float mA1 = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
-                const float mA2 = fmaxf(fmaxf(fabsf(r5), fabsf(r6)), fabsf(r7));
-                const float mB = fmaxf(fabsf(r0), fabsf(r4));
-                cA = __ballot(mA1 > thr.x) | __ballot(mA2 > thr.y);
-                cB = __ballot(mB > thr.z);
-            } else {
-                q0 = __float_as_uint(e0); q1 = __float_as_uint(e1); q2 = __float_as_uint(e2); q3 = __float_as_uint(e3);
-                q4 = __float_as_uint(e4); q5 = __float_as_uint(e5); q6 = __float_as_uint(e6); q7 = __float_as_uint(e7);
-            }
-            uint4 val;
-            if (kLdsZ) {
-                *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
-                *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
-                wave_lds_fence();
-                val = *zr;
-                wave_lds_fence();
-            } else {
-                val = make_uint4(perm_b32(q1, q0, 0x05040100u), perm_b32(q3, q2, 0x05040100u), perm_b32(q5, q4, 0x05040100u), perm_b32(q7, q6, 0x05040100u));
-            }
+            float r0, r1, r2, r3, r4, r5, r6, r7;
+            quant_fma(e0, m0.x, q0, r0); quant_fma(e1, m0.y, q1, r1); quant_fma(e2, m0.z, q2, r2); quant_fma(e3, m0.w, q3, r3);
+            quant_fma(e4, m1.x, q4, r4); quant_fma(e5, m1.y, q5, r5); quant_fma(e6, m1.z, q6, r6); quant_fma(e7, m1.w, q7, r7);
+            // guard test: three groups per column, u in {1,2,3} | {5,6,7} | {0,4} (tic_math.h thrG)
+            const float mA1 = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
+            const float mA2 = fmaxf(fmaxf(fabsf(r5), fabsf(r6)), fabsf(r7));
+            const float mB = fmaxf(fabsf(r0), fabsf(r4));
+            const unsigned long long cA = __ballot(mA1 > thr.x) | __ballot(mA2 > thr.y); // lanes whose guard band tripped: u in 1,2,3,5,6,7
+            const unsigned long long cB = __ballot(mB > thr.z);                           // ... u in 0,4
+            *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
+            *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
+            wave_lds_fence();
+            uint4 val = *zr;
+            wave_lds_fence();
             char *dst = reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off;
-            if (ABL == 22) mask_exact += cA ^ (cB << 1); // timing-only: the guard test's result is consumed, nothing else happens
             // ---- a guard band tripped somewhere in the strip (one strip in five at q=50) ------------------------------
-            if (kRare && kLdsT && kLdsZ && kMem && __builtin_expect((cA | cB) != 0ull, 0)) {
+            if (__builtin_expect((cA | cB) != 0ull, 0)) {
                 const unsigned long long kRat = 0x1111111111111111ull; // lanes v in {0,4}: rational coefficients at u in {0,4}
                 const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
                 // per block: an irrational trip / any trip.  Lane l answers for block l & 7 (byte l & 7 of the lane masks); the
                 // low byte of the ballot is the 8-bit block mask (6 vector instructions; folding the bytes on the scalar unit
                 // took ~40 dependent scalar instructions per tripped strip)
-                uint32_t gm, fm;
-                if (OPT & 8) {
-                    const uint32_t sh = 8u * (uint32_t)i;
-                    gm = (uint32_t)__ballot(((mG >> sh) & 0xffull) != 0ull) & 0xffu;
-                    fm = (uint32_t)__ballot((((mG | mS) >> sh) & 0xffull) != 0ull) & 0xffu;
-                } else {
-                    gm = byte_any(mG);
-                    fm = gm | byte_any(mS);
-                }
+                const uint32_t sh = 8u * (uint32_t)i;
+                const uint32_t gm = (uint32_t)__ballot(((mG >> sh) & 0xffull) != 0ull) & 0xffu;
+                const uint32_t fm = (uint32_t)__ballot((((mG | mS) >> sh) & 0xffull) != 0ull) & 0xffu;
                 const int nnew = __builtin_popcount(fm);
                 uint32_t lo0, hi0;
                 raw_words(tag, lo0, hi0);
-                if (nE + nnew <= kBatch && (fm != 0xffu || !(OPT & 2))) {
-                    // the blocks join the batch: id + kind, pixel rows (this lane holds row lr of block lb), staged image
+                if (nE + nnew <= kBatch && fm != 0xffu) {
+                    // the blocks join the batch: id, kind, pixel rows (this lane holds row lr of block lb), staged image
                     const uint32_t below = (1u << b) - 1u, lbelow = (1u << lb) - 1u;
                     const bool mine = (fm >> b) & 1u;
                     const int e = nE + __builtin_popcount(fm & below);
@@ -1155,13 +577,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
                     if ((fm >> lb) & 1u) bat_pix[(nE + __builtin_popcount(fm & lbelow)) * 8 + lr] = make_uint2(lo0, hi0);
                     // the tripped blocks leave with the batch pass; the others now (at least one lane stores: the strip's one
                     // vector-memory instruction is issued on every path, which the counted waits rely on)
-                    if (!mine || !(OPT & 2)) store16_policy<ST>(dst, val);
+                    if (!mine) store16_wt_nt(dst, val);
                     nE += nnew;
                     n_second += (uint32_t)__builtin_popcount(gm);
                 } else if (gm != 0u) {
                     // no room and an irrational trip: the whole strip is redone in the exact order after the loop
                     mask_exact |= 1ull << kstrip;
-                    store16_policy<ST>(dst, val);
+                    store16_wt_nt(dst, val);
                 } else {
                     // no room, rational ties only (tie-dense content, e.g. flat areas with an odd grey level): exact sub-path
                     // for the four rational coefficients of all eight blocks, here and now
@@ -1177,42 +599,21 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
                     wave_lds_fence();
                     val = *zr;
                     wave_lds_fence();
-                    store16_policy<ST>(dst, val);
+                    store16_wt_nt(dst, val);
                 }
-            } else if (!kMem) { acc.x ^= val.x; acc.y ^= val.y; acc.z ^= val.z; acc.w ^= val.w; } // compute-only build: no store
-            else store16_policy<ST>(dst, val); // 16 B per lane, 1 KiB contiguous per wave
+            } else
+                store16_wt_nt(dst, val); // 16 B per lane, 1 KiB contiguous per wave
             left--;
             kstrip++;
         };
         // Two strips ahead: strip j is consumed after L(j+2) is issued; in steady state the instructions younger than
         // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.  (A rare branch issues at most
-        // the same single store per strip.)
+        // the same single store per strip.  Three strips ahead: no faster, profiles/r02_ab_prefetch_depth.txt, r03_ablate_cold.txt.)
         float pxf[8];
-#define TIC_STEP(ALOAD, OBL, A0, A1, OBP, N) TIC_LOAD(ALOAD, OBL); TIC_TAKE(pxf, A0, A1, N); process(std::integral_constant<int, A0>(), pxf, OBP)
-        if (PF == 3) { // experiment (variant 610): L(j+3) is issued before strip j is consumed; steady state vmcnt(6)
-            do {
-                if (left == 0) break;
-                TIC_STEP("78:79", ob3, 72, 73, ob0, 3);
-                if (left == 0) break;
-                TIC_STEP("72:73", ob0, 74, 75, ob1, 4);
-                if (left == 0) break;
-                TIC_STEP("74:75", ob1, 76, 77, ob2, 5);
-                while (left != 0) {
-                    TIC_STEP("76:77", ob2, 78, 79, ob3, 6);
-                    if (left == 0) break;
-                    TIC_STEP("78:79", ob3, 72, 73, ob0, 6);
-                    if (left == 0) break;
-                    TIC_STEP("72:73", ob0, 74, 75, ob1, 6);
-                    if (left == 0) break;
-                    TIC_STEP("74:75", ob1, 76, 77, ob2, 6);
-                }
-            } while (0);
-        } else
+#define TIC_STEP(RLOAD, OBL, R0, R1, OBP, N) TIC_LOAD(RLOAD, OBL); TIC_TAKE(pxf, R0, R1, N); process(std::integral_constant<int, R0>(), pxf, OBP)
         do {
             if (left == 0) break;
-            TIC_LOAD("76:77", ob2); TIC_TAKE(pxf, 72, 73, 2);
-            if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
-            process(std::integral_constant<int, 72>(), pxf, ob0);
+            TIC_STEP("76:77", ob2, 72, 73, ob0, 2);
             if (left == 0) break;
             TIC_STEP("72:73", ob0, 74, 75, ob1, 3);
             while (left != 0) {
@@ -1224,11 +625,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
             }
         } while (0);
 #undef TIC_STEP
-        if (!kMem) { // one store per wave, to its first strip (always inside the frame)
-            if (n_my > 0) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob_first << 7) + st_off) = acc;
-            return;
-        }
-        if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 3] = __builtin_amdgcn_s_memtime(); // loop left
         // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved until
         // only the wave's last store is outstanding
         asm volatile("s_waitcnt vmcnt(1)" : : : TIC_RSV_CLOBBER);
@@ -1236,16 +632,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
 #undef TIC_TAKE
 #undef TIC_RSV_CLOBBER
     }
-    // ---- the batch pass ("slim" form; OPT bit 2 off: the round-2a form kept for A/B) ----------------------------------------------
-    if ((OPT & 4) && kBatchPass && nE != 0) {
-        const double *cst_cos = reinterpret_cast<const double *>(cst_blk + 1152); // orthonormal DCT-II matrix, index k*8+n
+    // ---- the batch pass -------------------------------------------------------------------------------------------------
+    if (nE != 0) {
+        const double *cst_cos = reinterpret_cast<const double *>(cst_blk + 1152);  // orthonormal DCT-II matrix, index k*8+n
         const double *cst_rdiv = reinterpret_cast<const double *>(cst_blk + 1664); // 1/div, index u*8+v
-        // (1) entries that tripped on an irrational coefficient: whole-wave float64 recompute, one block at a time
-        // (the kinds sit in a scalar register: round 2 read every entry's id back from LDS here, ~100 cycles per entry on the
-        // launch's tail, although most entries are tie entries that need nothing in this step)
+        // (1) entries that tripped on an irrational coefficient: whole-wave float64 recompute, one block at a time.  (The kinds
+        // sit in a scalar register: round 2 read every entry's id back from LDS here, ~100 cycles per entry on the launch's
+        // tail, although most entries are tie entries that need nothing in this step.)
         const uint32_t m_all = (1u << nE) - 1u;
-        uint32_t m_rat = ABL == 24 ? m_all : (m_all & ~kind_mask), m_exact = 0; // entries that need the rational sub-path / the exact operation order
-        for (uint32_t todo = ABL == 24 ? 0u : kind_mask; todo != 0u; todo &= todo - 1u) {
+        uint32_t m_rat = m_all & ~kind_mask, m_exact = 0; // entries that need the rational sub-path / the exact operation order
+        for (uint32_t todo = kind_mask; todo != 0u; todo &= todo - 1u) {
             const int e = __builtin_ctz(todo);
             unsigned long long ur, uo;
             wave_redo_block(reinterpret_cast<const uint8_t *>(bat_pix + e * 8), reinterpret_cast<double *>(ldsT), cst_cos, cst_rdiv, cst_zz,
@@ -1280,69 +676,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
         }
         wave_lds_fence();
         const uint4 val = bat_img[e * 8 + i];
-        if (!(OPT & 2)) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-        if (have) store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)blk << 7) + (uint32_t)i * 16u, val);
-    }
-    // ---- the batch pass: lane 8*b + i serves entry b ---------------------------------------------------------------------
-    if (ABL == 22 && mask_exact == 0x123456789ull) a.out[lane] = 1; // (keeps the accumulated value alive)
-    if (ABL == 22) mask_exact = 0;
-    if (!(OPT & 4) && kBatchPass && nE != 0) {
-        const bool have = b < nE;
-        const int e = have ? b : 0;
-        const uint32_t id = bat_id[e];
-        const bool isG = have && ((kind_mask >> e) & 1u) != 0u && ABL != 24; // (ABL 24, timing only: no second level, every entry is treated as a tie entry)
-        const uint32_t blk = id;
-        const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
-        uint32_t lo = rowv.x, hi = rowv.y;
-        transpose8x8_bytes(lo, hi, i); // -> pixel column i
-        const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8); // byte offsets in the image of (u = i, v = 0..7)
-        const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
-        int16_t *img16 = reinterpret_cast<int16_t *>(bat_img + e * 8);
-        bool need_rat = have && !isG; // tie entries: the four rational coefficients
-        if (__ballot(isG) != 0ull) {
-            int qe[8];
-            bool ok_rat;
-            const bool ok = second_level_block(lo, hi, ldsT, b, i, cst_mul64, qe, ok_rat);
-            if (isG) {
-#pragma unroll
-                for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qe[v];
-            }
-            need_rat = need_rat || (isG && !ok_rat);
-            const unsigned long long bad = __ballot(isG && !ok); // a true tie of an irrational coefficient: exact order
-            if (bad != 0ull) {
-                int qx[8];
-                exact_block(lo, hi, ldsT, b, i, C, qx);
-                if ((bad >> (8 * b)) & 0xffull) {
-#pragma unroll
-                    for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qx[v];
-                    need_rat = false;
-                }
-            }
-        }
-        const unsigned long long m_rat = __ballot(need_rat);
-        if (m_rat != 0ull) {
-            RationalConsts KR;
-            KR.div0 = cst_rat[(i >> 2) * 2];
-            KR.div4 = cst_rat[(i >> 2) * 2 + 1];
-            KR.rdiv0 = cst_rat[4 + (i >> 2) * 2];
-            KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
-            int r0, r4;
-            special_block(lo, hi, ldsT, b, i, KR, r0, r4);
-            if ((i & 3) == 0 && ((m_rat >> (8 * b)) & 0xffull) != 0ull) {
-                img16[(zo.x & 0xffffu) >> 1] = (int16_t)r0; // (i,0)
-                img16[(zo.z & 0xffffu) >> 1] = (int16_t)r4; // (i,4)
-            }
-        }
-        wave_lds_fence();
-        const uint4 val = bat_img[e * 8 + i];
-        if (!(OPT & 2)) asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); // A/B: the loop stored the tripped blocks too; wait for those stores
-        if (have) store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)blk << 7) + (uint32_t)i * 16u, val);
-    }
-    if (ABL == 8 && a.dbg != nullptr && lane == 0) {
-        unsigned long long *d = a.dbg + (((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8;
-        d[4] = __builtin_amdgcn_s_memtime(); // batch pass done (its stores issued)
-        d[6] = (unsigned long long)n_my | ((unsigned long long)(n_second & 0xffffu) << 32) | ((unsigned long long)nE << 48) |
-               ((unsigned long long)(mask_exact != 0ull) << 63);
+        if (have) store16_wt_nt(reinterpret_cast<char *>(a.out) + ((unsigned long long)blk << 7) + (uint32_t)i * 16u, val);
     }
     if (a.fallback_count != nullptr && lane == 0 && n_second != 0) atomicAdd(a.fallback_count, (unsigned long long)n_second);
     // ---- strips the batch had no room for: the exact operation order, whole strip ---------------------------------------
@@ -1368,751 +702,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
         store_zigzag(reinterpret_cast<uint32_t *>(ldsZ), b, i, zz, q, a.out, s);
     }
 }
-
-#ifdef TIC_ABLATION
-// ---------------------------------------------------------------------------------------------------------
-// Kernel 2c (round 2, explored alternative; experiment library only, variant 70): the strip kernel with a dynamic strip queue.
-// Parity-green, but slower than the static walk: 11.5 us against 10.4 us on a 4096^2 frame in the same run (8.1 against
-// 7.1 with the rare paths compiled out).  The tickets cost ~45 scalar instructions and an LDS atomic per strip, the
-// prologue grows to ~200 scalar instructions (the waves of a CU share one scalar unit: first loads issued after
-// 1,600-3,300 cycles), 16 waves per CU instead of 20, and the queue hands the last strips to the youngest - slowest -
-// waves (2,500 cycles per strip against 1,300 for the oldest), so the tail it was meant to remove stays.
-//
-// Same strip loop and the same wave-local batch pass as dctq_strip_kernel above.  What differs is who processes which
-// strip: a workgroup is a TEAM of up to 16 waves (one team per CU on frames that fill the chip) sharing a ticket counter
-// in LDS.  Ticket c of team g is strip ((c >> rs) * G + g) << rs | (c & (2^rs - 1)): runs of 2^rs adjacent strips per
-// team, teams interleaved (the address pattern of the static team schedule).  A wave takes its first two tickets
-// statically (wave, wave + W), every further one with an LDS atomic requested one strip ahead of its use.
-// Why: with a static walk the launch ends when the slowest wave ends, and waves differ - the ones whose strips tripped
-// run a batch pass (1,500 cycles, 3,000 with a second-level entry), late-dispatched workgroups get fewer issue slots
-// (age-ordered arbitration).  In-kernel stamps of the static kernel on a 4096^2 frame: median wave end 14,200 cycles,
-// last wave 17,600.  With tickets a wave that is slow simply takes fewer strips.
-// Tie-dense content cannot overflow anything: a wave whose batch is more than half full (or that holds two strips for
-// the exact-order redo) stops taking tickets, drains its pipeline, settles batch and redo list and starts over.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kQMaxWaves = 16;
-constexpr int kQXList = 16;                                               // strips waiting for the exact-order redo
-constexpr int kQWaveBytes = kTWaveBytes + kZzWaveBytes + kBatchWaveBytes + kQXList * 4 + 256; // 5248 B per wave (the last 256: ticket scratch)
-constexpr int kQHeadBytes = kStripBlkBytes + 16;                         // constants + ticket counter
-
-template <int ABL, int ST = 2>
-__global__ __launch_bounds__(kQMaxWaves * 64, 1) void dctq_queue_kernel(DctqArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    constexpr bool kRare = !(ABL == 3);
-    unsigned long long t_entry = 0;
-    if (ABL == 8) t_entry = __builtin_amdgcn_s_memtime();
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t W = (uint32_t)a.q_waves, G = (uint32_t)a.q_teams, rs = (uint32_t)a.q_run_shift, g = blockIdx.x;
-    unsigned char *cst_blk = lds_dyn;
-    uint32_t *q_ctr = reinterpret_cast<uint32_t *>(lds_dyn + kStripBlkBytes);
-    unsigned char *wbase = lds_dyn + kQHeadBytes + wave * kQWaveBytes;
-    uint32_t *ldsT = reinterpret_cast<uint32_t *>(wbase);
-    char *ldsZ = reinterpret_cast<char *>(wbase + kTWaveBytes);
-    uint32_t *bat = reinterpret_cast<uint32_t *>(wbase + kTWaveBytes + kZzWaveBytes);
-    uint4 *bat_img = reinterpret_cast<uint4 *>(bat);                   // [kBatch][8] 16-byte pieces: zig-zag images
-    uint2 *bat_pix = reinterpret_cast<uint2 *>(bat + kBatch * 32);     // [kBatch][8] pixel rows
-    uint32_t *bat_id = bat + kBatch * 48;                              // [kBatch] block index | kind << 31
-    uint32_t *xlist = reinterpret_cast<uint32_t *>(wbase + kTWaveBytes + kZzWaveBytes + kBatchWaveBytes); // [kQXList] strip indices
-    const double *cst_mul64 = reinterpret_cast<const double *>(cst_blk + 448);  // [64] index u*8+v
-    const uint16_t *cst_zz = reinterpret_cast<const uint16_t *>(cst_blk + 960); // [64] index u*8+v
-    const double *cst_rat = reinterpret_cast<const double *>(cst_blk + 1088);   // div[4] then rdiv[4]: (0,0) (0,4) (4,0) (4,4)
-    const DctqConsts *__restrict__ C = a.consts;
-    a.img += (long)blockIdx.z * a.frame_stride_in; // batch of frames: one grid plane per frame
-    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.z * a.frame_stride_out);
-
-    const uint32_t nfast = (uint32_t)a.fast_ty * (uint32_t)a.fast_tx; // strips of the frame's fast rectangle
-    uint32_t n_second = 0, n_strips = 0, n_flush = 0;
-    int nE = 0, nX = 0;      // entries in the batch / in the redo list (wave-uniform)
-    bool stop = false;       // take no further tickets until batch and redo list are settled
-    bool exhausted = false;  // the team's queue is empty
-    if (threadIdx.x == 0) *q_ctr = 2u * W; // the first two tickets of every wave are static
-
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    // constants: the team copies the quality's 1152-byte block into LDS, one 16-byte piece per lane of the first lanes of
-    // every wave (every vector-memory instruction from here to the end of the strip loop is issued by hand and counted)
-    u32x4 c_fill;
-    const uint32_t ppw = (uint32_t)a.q_ppw; // pieces per wave = ceil(72 / W)
-    {
-        const uint32_t piece = (uint32_t)lane < ppw ? (uint32_t)wave * ppw + (uint32_t)lane : (uint32_t)kStripBlkPieces - 1u;
-        const uint32_t fo = (piece < (uint32_t)kStripBlkPieces ? piece : (uint32_t)kStripBlkPieces - 1u) * 16u;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c_fill) : "v"(fo), "s"(C->strip_blk) : "memory");
-    }
-    // ticket -> strip: index inside the fast rectangle, byte offset of its first pixel, raster index of its first block
-    const uint32_t run_mask = (1u << rs) - 1u, row8 = (uint32_t)(8 * a.stride);
-    auto strip_of = [&](uint32_t c, uint32_t &t, uint32_t &in_off, uint32_t &ob) -> bool {
-        t = ((((c >> rs) * G) + g) << rs) + (c & run_mask);
-        if (t >= nfast) return false;
-        const uint32_t ty = a.magic_fast_tx ? __umulhi(t, a.magic_fast_tx) : t; // (magic 0: one strip per row)
-        const uint32_t tx = t - ty * (uint32_t)a.fast_tx;
-        in_off = ty * row8 + tx * 64u; // frames are < 4 GiB (launcher)
-        ob = ty * (uint32_t)a.bw + tx * 8u;
-        return true;
-    };
-    // Ticket = LDS atomic add issued by hand at the start of a strip and picked up at its end, in the same straight-line
-    // code: lane 0 on the team's counter, the other lanes (and lane 0 too when no ticket is wanted) on scratch words of
-    // their own - no exec juggling, no branch around the instruction.  (Written as atomicAdd under `if (lane == 0)` the
-    // compiler's atomic optimiser turns it into mbcnt + ds_add + readfirstlane with the wait right behind it: every strip
-    // then stalls for an LDS round trip under load, 8.5 us instead of 6.8 for a 4096^2 frame.  And the result must not
-    // travel through a loop-carried vector register: the compiler may copy that register before the atomic has returned -
-    // it cannot know - and the copy holds garbage.)
-    const uint32_t tk_junk = (uint32_t)(uintptr_t)(wbase + kQWaveBytes - 256) + (uint32_t)lane * 4u;
-    const uint32_t tk_addr = lane == 0 ? (uint32_t)(uintptr_t)q_ctr : tk_junk;
-    const uint32_t tk_one = 1u;
-    auto take_ticket = [&](bool want) -> uint32_t {
-        uint32_t v;
-        const uint32_t ad = want ? tk_addr : tk_junk;
-        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(v) : "v"(ad), "v"(tk_one) : "memory");
-        return v;
-    };
-    auto ticket_value = [&](uint32_t v) -> uint32_t { // wait for the atomic, lane 0's result
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    };
-    const uint8_t *img_s = a.img;
-    // one pixel load (always issued, so that the counted waits hold; an invalid slot re-reads strip 0)
-#define TIC_QLOAD(P, IO, VLD)                                                                               \
-    do {                                                                                                    \
-        const uint8_t *src = img_s + __builtin_amdgcn_readfirstlane((VLD) ? (IO) : 0u);                     \
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P) : "v"(ld_off), "s"(src) : "memory");       \
-    } while (0)
-#define TIC_WAIT(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(P) : : "memory")
-
-    bool first = true;
-    for (;;) {
-        // Everything the strip loop keeps in registers is (re)derived here, from a lane id the compiler cannot see through:
-        // nothing of it stays live across the batch pass at the end of this block (the pass needs the registers: with the
-        // loop's 40 lane-constant values hoisted out, the kernel spilled).
-        int lane_l = lane;
-        asm volatile("" : "+v"(lane_l));
-        const int lr = lane_l >> 3, lb = lane_l & 7; // load phase: pixel row lr of block lb
-        const int b = lane_l >> 3, i = lane_l & 7;   // compute phase: column / frequency v = i of block b
-        const uint32_t st_off = (uint32_t)lane_l * 16u; // lane offset inside a strip's 1 KiB output
-        uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // transpose, v in {0,1,4,5}: + v*32 dwords
-        uint32_t *twB = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * (lb ^ 4); // v in {2,3,6,7}
-        const uint4 *tr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // rows 0..3; rows 4..7 at +64 slots
-        const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
-        auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
-            return reinterpret_cast<int16_t *>(ldsZ + (ofs >> 4) * 128 + (ofs & 15) + 16 * (b ^ (4 * ((ofs >> 5) & 1))));
-        };
-        const uint4 *zr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (4 * ((i >> 1) & 1)))), 16));
-        // ---- prime the pipeline: two strips in flight ------------------------------------------------------------------
-        unsigned long long p0, p1, p2;
-        uint32_t ob0 = 0, ob1 = 0, ob2 = 0, t0 = 0, t1 = 0, t2 = 0, io = 0;
-        bool v0, v1, v2 = false;
-        {
-            uint32_t c0, c1;
-            if (first) {
-                c0 = (uint32_t)wave;
-                c1 = (uint32_t)wave + W;
-            } else {
-                c0 = ticket_value(take_ticket(true));
-                c1 = ticket_value(take_ticket(true));
-            }
-            v0 = strip_of(c0, t0, io, ob0);
-            TIC_QLOAD(p0, io, v0);
-            v1 = strip_of(c1, t1, io, ob1);
-            TIC_QLOAD(p1, io, v1);
-            if (!v1) exhausted = true;
-        }
-        if (first) {
-            if (ABL == 8 && a.dbg != nullptr && lane == 0) {
-                unsigned long long *d = a.dbg + ((size_t)blockIdx.x * kQMaxWaves + wave) * 8;
-                d[0] = t_entry;
-                d[1] = __builtin_amdgcn_s_memtime(); // first pixel loads issued
-            }
-            // the constant piece is older than the pixel loads: it has landed when only those are in flight
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(c_fill) : : "memory");
-            if ((uint32_t)lane < ppw && (uint32_t)wave * ppw + (uint32_t)lane < (uint32_t)kStripBlkPieces)
-                *reinterpret_cast<u32x4 *>(cst_blk + ((uint32_t)wave * ppw + (uint32_t)lane) * 16u) = c_fill;
-            // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about);
-            // it also publishes the ticket counter
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
-            first = false;
-        }
-        const f32x4 m0 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32);
-        const f32x4 m1 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32 + 16);
-        const f32x2 thr = *reinterpret_cast<const f32x2 *>(cst_blk + 256 + i * 8);
-        const u32x4 zzv = *reinterpret_cast<const u32x4 *>(cst_blk + 320 + i * 16);
-        int16_t *zp0 = zz_ptr(zzv.x & 0xffff), *zp1 = zz_ptr(zzv.x >> 16), *zp2 = zz_ptr(zzv.y & 0xffff), *zp3 = zz_ptr(zzv.y >> 16);
-        int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
-        uint32_t c_next = 0;   // ticket of the next slot (scalar; taken during the previous strip)
-        bool has_next = false;
-        if (!stop && !exhausted) { c_next = ticket_value(take_ticket(true)); has_next = true; }
-
-        // one strip: everything from the pixel row held in px to the 1 KiB store
-        auto process = [&](const unsigned long long px, const uint32_t ob, const uint32_t tcur) {
-            const bool want = !stop && !exhausted;
-            const uint32_t tkv = take_ticket(want); // the ticket after next: requested now, read at the end of this strip
-            // ---- pass 1: along the pixel row ------------------------------------------------------------------
-            const uint32_t lo0 = (uint32_t)px, hi0 = (uint32_t)(px >> 32);
-            float d0, d1, d2, d3, d4, d5, d6, d7;
-            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d0) : "v"(lo0));
-            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d1) : "v"(lo0));
-            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d2) : "v"(lo0));
-            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d3) : "v"(lo0));
-            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d4) : "v"(hi0));
-            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d5) : "v"(hi0));
-            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d6) : "v"(hi0));
-            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d7) : "v"(hi0));
-            dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
-            d0 -= 1024.0f;
-            twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
-            twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
-            twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
-            wave_lds_fence();
-            const uint4 ra = tr[0], rb = tr[64];
-            wave_lds_fence();
-            float e0 = __uint_as_float(ra.x), e1 = __uint_as_float(ra.y), e2 = __uint_as_float(ra.z), e3 = __uint_as_float(ra.w);
-            float e4 = __uint_as_float(rb.x), e5 = __uint_as_float(rb.y), e6 = __uint_as_float(rb.z), e7 = __uint_as_float(rb.w);
-            // ---- pass 2: down the column of horizontal frequency v = i ----------------------------------------
-            dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
-            uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
-            float r0, r1, r2, r3, r4, r5, r6, r7;
-            quant_fma(e0, m0.x, q0, r0);
-            quant_fma(e1, m0.y, q1, r1);
-            quant_fma(e2, m0.z, q2, r2);
-            quant_fma(e3, m0.w, q3, r3);
-            quant_fma(e4, m1.x, q4, r4);
-            quant_fma(e5, m1.y, q5, r5);
-            quant_fma(e6, m1.z, q6, r6);
-            quant_fma(e7, m1.w, q7, r7);
-            float mA = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
-            mA = fmaxf(fmaxf(mA, fabsf(r5)), fabsf(r6));
-            mA = fmaxf(mA, fabsf(r7));
-            const float mB = fmaxf(fabsf(r0), fabsf(r4));
-            const unsigned long long cA = __ballot(mA > thr.x); // lanes whose guard band tripped: u in 1,2,3,5,6,7
-            const unsigned long long cB = __ballot(mB > thr.y); // u in 0,4
-            *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
-            *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
-            wave_lds_fence();
-            uint4 val = *zr;
-            wave_lds_fence();
-            char *dst = reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off;
-            // ---- a guard band tripped somewhere in the strip (one strip in five at q=50) ------------------------------
-            if (kRare && __builtin_expect((cA | cB) != 0ull, 0)) {
-                const unsigned long long kRat = 0x1111111111111111ull; // lanes v in {0,4}: rational coefficients at u in {0,4}
-                const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
-                const uint32_t gm = byte_any(mG), fm = gm | byte_any(mS); // blocks with an irrational trip / with any trip
-                const int nnew = __builtin_popcount(fm);
-                if (nE + nnew <= kBatch && fm != 0xffu) {
-                    // the blocks join the batch: id + kind, pixel rows (this lane holds row lr of block lb), staged image
-                    const uint32_t below = (1u << b) - 1u, lbelow = (1u << lb) - 1u;
-                    const bool mine = (fm >> b) & 1u;
-                    const int e = nE + __builtin_popcount(fm & below);
-                    if (mine) bat_img[e * 8 + i] = val;
-                    if (mine && i == 0) bat_id[e] = (ob + (uint32_t)b) | (((gm >> b) & 1u) << 31);
-                    if ((fm >> lb) & 1u) bat_pix[(nE + __builtin_popcount(fm & lbelow)) * 8 + lr] = make_uint2(lo0, hi0);
-                    // the tripped blocks leave with the batch pass; the others now (at least one lane stores: the strip's one
-                    // vector-memory instruction is issued on every path, which the counted waits rely on)
-                    if (!mine) store16_policy<ST>(dst, val);
-                    nE += nnew;
-                    n_second += (uint32_t)__builtin_popcount(gm);
-                } else if (gm != 0u) {
-                    // no room and an irrational trip: the whole strip is redone in the exact order by the flush below
-                    xlist[nX < kQXList ? nX : kQXList - 1] = tcur;
-                    nX++;
-                    store16_policy<ST>(dst, val);
-                } else {
-                    // no room, rational ties only (tie-dense content, e.g. flat areas with an odd grey level): exact sub-path
-                    // for the four rational coefficients of all eight blocks, here and now
-                    uint2 *pb = reinterpret_cast<uint2 *>(ldsT);
-                    pb[lb * 8 + lr] = make_uint2(lo0, hi0);
-                    wave_lds_fence();
-                    const uint2 rowv = pb[lane]; // row i of block b
-                    wave_lds_fence();
-                    uint32_t lo = rowv.x, hi = rowv.y;
-                    transpose8x8_bytes(lo, hi, i); // -> pixel column i
-                    RationalConsts KR;
-                    KR.div0 = cst_rat[(i >> 2) * 2];
-                    KR.div4 = cst_rat[(i >> 2) * 2 + 1];
-                    KR.rdiv0 = cst_rat[4 + (i >> 2) * 2];
-                    KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
-                    int s0, s4;
-                    special_block(lo, hi, ldsT, b, i, KR, s0, s4);
-                    if ((i & 3) == 0) { // lane i = 0: (0,0) and (0,4) at scan positions 0, 14; lane i = 4: (4,0), (4,4) at 10, 39
-                        *zz_ptr(i ? 20u : 0u) = (int16_t)s0;
-                        *zz_ptr(i ? 78u : 28u) = (int16_t)s4;
-                    }
-                    wave_lds_fence();
-                    val = *zr;
-                    wave_lds_fence();
-                    store16_policy<ST>(dst, val);
-                }
-                if (nE > kBatch / 2 || nX >= 2) stop = true; // settle before taking more work (tie-dense content only)
-            } else store16_policy<ST>(dst, val); // 16 B per lane, 1 KiB contiguous per wave
-            n_strips++;
-            c_next = ticket_value(tkv);
-            has_next = want; // (a ticket taken is a strip owed, even if `stop` was raised meanwhile)
-        };
-        // the next slot: the ticket taken during the previous strip (if any), and the slot's load
-#define TIC_QNEXT(P, OB, TT, VLD)                                                                           \
-    do {                                                                                                    \
-        VLD = false;                                                                                        \
-        if (has_next) {                                                                                     \
-            has_next = false;                                                                               \
-            VLD = strip_of(c_next, TT, io, OB);                                                             \
-            if (!(VLD)) exhausted = true;                                                                   \
-        }                                                                                                   \
-        TIC_QLOAD(P, io, VLD);                                                                              \
-    } while (0)
-        // Two strips ahead (loads L, stores S): strip j is consumed after L(j+2) is issued; in steady state the instructions
-        // younger than L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips of a run see 2 and 3.
-        do {
-            if (!v0) break;
-            TIC_QNEXT(p2, ob2, t2, v2); TIC_WAIT(p0, 2);
-            if (ABL == 8 && a.dbg != nullptr && lane == 0 && n_strips == 0) a.dbg[((size_t)blockIdx.x * kQMaxWaves + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
-            process(p0, ob0, t0);
-            if (!v1) break;
-            TIC_QNEXT(p0, ob0, t0, v0); TIC_WAIT(p1, 3); process(p1, ob1, t1);
-            while (v2) {
-                TIC_QNEXT(p1, ob1, t1, v1); TIC_WAIT(p2, 4); process(p2, ob2, t2);
-                if (!v0) break;
-                TIC_QNEXT(p2, ob2, t2, v2); TIC_WAIT(p0, 4); process(p0, ob0, t0);
-                if (!v1) break;
-                TIC_QNEXT(p0, ob0, t0, v0); TIC_WAIT(p1, 4); process(p1, ob1, t1);
-            }
-        } while (0);
-        // (a pending ticket cannot be left over: the loop only ends on a slot that got no strip, and such a slot is created
-        // only when no ticket was pending or the queue was empty)
-        if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[((size_t)blockIdx.x * kQMaxWaves + wave) * 8 + 3] = __builtin_amdgcn_s_memtime(); // loop left
-        // loads of slots without a strip may still be in flight: their registers stay reserved until then
-        asm volatile("s_waitcnt vmcnt(1)" : "+v"(p0), "+v"(p1), "+v"(p2) : : "memory");
-
-        // ---- the batch pass: lane 8*b + i serves entry b ------------------------------------------------------------------
-        if (nE != 0) {
-            const bool have = b < nE;
-            const int e = have ? b : 0;
-            const uint32_t id = bat_id[e];
-            const bool isG = have && (id >> 31) != 0u;
-            const uint32_t blk = id & 0x7fffffffu;
-            const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
-            uint32_t lo = rowv.x, hi = rowv.y;
-            transpose8x8_bytes(lo, hi, i); // -> pixel column i
-            const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8); // byte offsets in the image of (u = i, v = 0..7)
-            const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
-            int16_t *img16 = reinterpret_cast<int16_t *>(bat_img + e * 8);
-            bool need_rat = have && !isG; // tie entries: the four rational coefficients
-            if (__ballot(isG) != 0ull) {
-                int qe[8];
-                bool ok_rat;
-                const bool ok = second_level_block(lo, hi, ldsT, b, i, cst_mul64, qe, ok_rat);
-                if (isG) {
-#pragma unroll
-                    for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qe[v];
-                }
-                need_rat = need_rat || (isG && !ok_rat);
-                const unsigned long long bad = __ballot(isG && !ok); // a true tie of an irrational coefficient: exact order
-                if (bad != 0ull) {
-                    int qx[8];
-                    exact_block(lo, hi, ldsT, b, i, C, qx);
-                    if ((bad >> (8 * b)) & 0xffull) {
-#pragma unroll
-                        for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qx[v];
-                        need_rat = false;
-                    }
-                }
-            }
-            const unsigned long long m_rat = __ballot(need_rat);
-            if (m_rat != 0ull) {
-                RationalConsts KR;
-                KR.div0 = cst_rat[(i >> 2) * 2];
-                KR.div4 = cst_rat[(i >> 2) * 2 + 1];
-                KR.rdiv0 = cst_rat[4 + (i >> 2) * 2];
-                KR.rdiv4 = cst_rat[4 + (i >> 2) * 2 + 1];
-                int s0, s4;
-                special_block(lo, hi, ldsT, b, i, KR, s0, s4);
-                if ((i & 3) == 0 && ((m_rat >> (8 * b)) & 0xffull) != 0ull) {
-                    img16[(zo.x & 0xffffu) >> 1] = (int16_t)s0; // (i,0)
-                    img16[(zo.z & 0xffffu) >> 1] = (int16_t)s4; // (i,4)
-                }
-            }
-            wave_lds_fence();
-            const uint4 val = bat_img[e * 8 + i];
-            wave_lds_fence();
-            if (have) store16_policy<ST>(reinterpret_cast<char *>(a.out) + ((unsigned long long)blk << 7) + (uint32_t)i * 16u, val);
-            nE = 0;
-        }
-        // ---- strips the batch had no room for: the exact operation order, whole strip -----------------------------------
-        if (nX != 0) {
-            asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); // the wave's fast-path stores to these strips must have landed
-            const uint4 zzn = *reinterpret_cast<const uint4 *>(cst_zz + i * 8);
-            const uint16_t zz[8] = {(uint16_t)zzn.x, (uint16_t)(zzn.x >> 16), (uint16_t)zzn.y, (uint16_t)(zzn.y >> 16),
-                                    (uint16_t)zzn.z, (uint16_t)(zzn.z >> 16), (uint16_t)zzn.w, (uint16_t)(zzn.w >> 16)};
-            const int n = nX < kQXList ? nX : kQXList;
-            for (int k = 0; k < n; k++) {
-                const uint32_t t = xlist[k];
-                const uint32_t ty = t / (uint32_t)a.fast_tx, tx = t - ty * (uint32_t)a.fast_tx;
-                Strip s;
-                s.by = (int)ty;
-                s.bx = (int)tx * 8 + b;
-                s.valid = true;
-                s.oblk = (size_t)ty * a.bw + s.bx;
-                uint32_t lo, hi;
-                load_block_row(a.img, a.h, a.w, a.stride, true, s, i, lo, hi);
-                transpose8x8_bytes(lo, hi, i);
-                int q[8];
-                exact_block(lo, hi, ldsT, b, i, C, q);
-                store_zigzag(reinterpret_cast<uint32_t *>(ldsZ), b, i, zz, q, a.out, s);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-            nX = 0;
-        }
-        n_flush++;
-        if (exhausted) break;
-        stop = false;
-    }
-#undef TIC_QLOAD
-#undef TIC_QNEXT
-#undef TIC_WAIT
-    if (ABL == 8 && a.dbg != nullptr && lane == 0) {
-        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * kQMaxWaves + wave) * 8;
-        d[4] = __builtin_amdgcn_s_memtime();
-        d[6] = (unsigned long long)n_strips | ((unsigned long long)(n_second & 0xffffu) << 32) | ((unsigned long long)n_flush << 48);
-    }
-    if (a.fallback_count != nullptr && lane == 0 && n_second != 0) atomicAdd(a.fallback_count, (unsigned long long)n_second);
-}
-
-#endif // TIC_ABLATION
-
-#ifdef TIC_ABLATION // explored alternative, experiment library only
-// ---------------------------------------------------------------------------------------------------------
-// Kernel 2b: one block per lane (explored alternative; variant 40).
-//
-// The strip kernel above is bounded by the CU's LDS store path and by VALU in equal parts (68 LDS cycles per strip,
-// serialised over the four SIMDs).  Here a lane owns a whole 8x8 block: its eight 8-byte row loads
-// are, per instruction, 512 contiguous bytes of the wave's 64 consecutive blocks; both DCT passes, the quantiser, the
-// guard test and the zig-zag order (a renaming of registers) stay in the lane's registers.  LDS is used once, to turn
-// "128 bytes per lane" into 1 KiB-contiguous store instructions (2 LDS cycles per block against 8.5).
-// A wave = 64 consecutive blocks of the fast rectangle, a workgroup = 4 independent waves (no barrier, no loop): the
-// hardware dispatcher overlaps the load, compute and store phases of different waves.  Quantiser multipliers and
-// thresholds are wave-uniform (scalar registers).
-// Pass order: down the columns first, as the reference (axis -2, then -1).  Outputs 0 and 4 of the column pass are
-// exact integers, which is all the exact float64 sub-path of the four rational coefficients needs: it runs in the
-// lane, right after the row passes u = 0 and u = 4, under a wave-uniform branch (taken when any of the 64 blocks
-// has such a coefficient inside its guard band).  Blocks with any other coefficient inside its band (0.3 %) are
-// redone after the wave's stores by the 8-lanes-per-block float64 routines above, 8 blocks per pass.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kStageStrideB = 144;                       // bytes per block in the store-staging buffer (128 + 16 pad)
-constexpr int kStageWaveBytes = 64 * kStageStrideB;      // 9216 B per wave
-
-// Exact float64 sub-path of the rational coefficients (u,0) and (u,4), u in {0,4}, from the eight exact column-pass
-// outputs e[c] (integers; special_block() is the 8-lanes-per-block form of the same arithmetic, pocketfft's order).
-__device__ __forceinline__ void rational_row_exact(const float e[8], double kcol, double rdiv0, double rdiv4, double div0,
-                                                   double div4, int &r0i, int &r4i) {
-#pragma clang fp contract(off)
-    const double a0 = (double)e[0] * kcol, a1 = (double)e[1] * kcol, a2 = (double)e[2] * kcol, a3 = (double)e[3] * kcol;
-    const double a4 = (double)e[4] * kcol, a5 = (double)e[5] * kcol, a6 = (double)e[6] * kcol, a7 = (double)e[7] * kcol;
-    const double p07 = a0 + a7, p34 = a3 + a4, p12 = a1 + a2, p56 = a5 + a6;
-    const double A = p07 + p34, B = p12 + p56;
-    const double E0 = A + B, E4 = A - B;
-    const double X0 = E0 * (kSq2h * 0.5), X4 = E4 * (kTW3 * 0.5);
-    const double t0 = X0 * rdiv0, t4 = X4 * rdiv4;
-    double r0 = rint(t0), r4 = rint(t4);
-    // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
-    if (fabs(fabs(t0 - r0) - 0.5) < 1e-9) r0 = rint(X0 / div0);
-    if (fabs(fabs(t4 - r4) - 0.5) < 1e-9) r4 = rint(X4 / div4);
-    r0i = (int)r0;
-    r4i = (int)r4;
-}
-
-// Rare path of the one-block-per-lane kernel: one lane per (tie block, row u in {0,4}) runs the exact sub-path from the column-pass
-// outputs parked in the owner's slot and leaves the two results at slot + 128.
-__device__ __forceinline__ void lane_tie_pass(char *stage, const DctqConsts *__restrict__ C, unsigned long long m_tie, int lane) {
-    wave_lds_fence();
-    const int ntie = __builtin_popcountll(m_tie);
-    for (int base = 0; base < ntie; base += 32) {
-        int src = -1; // lane that owns the block of entry base + (lane >> 1)
-        unsigned long long todo = m_tie;
-        for (int k = 0; k < base + 32 && todo != 0ull; k++) {
-            const int pos = __builtin_ctzll(todo);
-            if (k == base + (lane >> 1)) src = pos;
-            todo &= todo - 1ull;
-        }
-        if (src >= 0) {
-            const bool row4 = (lane & 1) != 0;
-            const float4 *slot = reinterpret_cast<const float4 *>(stage + src * kStageStrideB + 64 + (lane & 1) * 32);
-            const float4 ea = slot[0], eb = slot[1];
-            const float e[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
-            const double rdiv0 = row4 ? C->rdiv[32] : C->rdiv[0], rdiv4 = row4 ? C->rdiv[36] : C->rdiv[4];
-            const double div0 = row4 ? C->div[32] : C->div[0], div4 = row4 ? C->div[36] : C->div[4];
-            int r0, r4;
-            rational_row_exact(e, row4 ? kTW3 * 0.5 : kSq2h * 0.5, rdiv0, rdiv4, div0, div4, r0, r4);
-            *reinterpret_cast<int2 *>(stage + src * kStageStrideB + 128 + (lane & 1) * 8) = make_int2(r0, r4);
-        }
-    }
-}
-
-// Rare path: float64 recompute of block `src` (pixels parked in its owner's slot) by the whole wave, straight from the
-// definition.  Lane (u,c) first forms t[u][c] = sum_r M[u][r] x[r][c], then X[u][v=c] = sum_k M[v][k] t[u][k]; decided
-// roundings go to their zig-zag slot of the 128-byte block image.  Returns whether some coefficient other than the
-// rational four stayed undecided (a true tie: the block then needs the exact operation order).
-__device__ __forceinline__ bool lane_redo_block(const char *stage, const double *cos_tab, double *tbuf, char *img128,
-                                             const DctqConsts *__restrict__ C, int src, int lane) {
-    const int u = lane >> 3, c = lane & 7;
-    const uint8_t *xs = reinterpret_cast<const uint8_t *>(stage + src * kStageStrideB);
-    double t = 0.0;
-#pragma unroll
-    for (int r = 0; r < 8; r++) t += cos_tab[u * 8 + r] * (double)((int)xs[r * 8 + c] - 128);
-    tbuf[u * 8 + c] = t;
-    wave_lds_fence();
-    double X = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) X += cos_tab[c * 8 + k] * tbuf[u * 8 + k];
-    const double tq = X / C->div[lane], rq = rint(tq);
-    const bool decided = fabs(tq - rq) < 0.5 - 1e-9;
-    if (decided) *reinterpret_cast<int16_t *>(img128 + C->zzofs[lane]) = (int16_t)(int)rq;
-    const bool rational = (lane & 0x1b) == 0; // (u,v) in {0,4} x {0,4}
-    const bool slow = __ballot(!decided && !rational) != 0ull;
-    wave_lds_fence();
-    return slow;
-}
-
-template <int ABL>
-__global__ __launch_bounds__(kWavesPerWG * 64, 4) void dctq_lane_kernel(DctqArgs a) {
-    // Per lane a 144-byte slot: [0,64) the block's pixels, [64,128) column-pass outputs 0 and 4, [128,144) results of the
-    // rational sub-path; at the end the first 128 bytes become the store-staging area.
-    __shared__ __attribute__((aligned(16))) char stage_all[kWavesPerWG][kStageWaveBytes];
-    __shared__ __attribute__((aligned(16))) double redo_all[kWavesPerWG][64 + 16]; // per wave: t[8][8] and a 128-byte block image
-    __shared__ __attribute__((aligned(16))) double cos_tab[64]; // every wave writes the same values (no barrier needed)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const DctqConsts *__restrict__ C = a.consts;
-    a.img += (long)blockIdx.y * a.frame_stride_in; // batch: one grid row per frame
-    a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.y * a.frame_stride_out);
-    const double cos_mine = C->cosm[lane];
-
-    const int fbw = a.fast_tx * 8;                 // blocks per row of the fast rectangle
-    const int nbf = a.fast_ty * fbw;               // blocks in it
-    const int B0 = (blockIdx.x * kWavesPerWG + wave) * 64;
-    if (B0 >= nbf) return;
-    const bool valid = B0 + lane < nbf;
-    const int B = valid ? B0 + lane : nbf - 1;     // lanes past the end compute on the last block, store nothing
-    const int by = B / fbw, bx = B - by * fbw;
-    const uint32_t oblk = (uint32_t)by * (uint32_t)a.bw + (uint32_t)bx;
-
-    // ---- load: row r of every lane's block; per instruction the wave reads 512 contiguous bytes per block row ------
-    const uint8_t *pix = a.img + (long)by * 8 * a.stride + bx * 8;
-    uint2 px[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) px[r] = *reinterpret_cast<const uint2 *>(pix + (long)r * a.stride);
-    char *stage = stage_all[wave];
-    cos_tab[lane] = cos_mine;
-    {
-        uint4 *slot = reinterpret_cast<uint4 *>(stage + lane * kStageStrideB); // pixels parked for the rare paths
-#pragma unroll
-        for (int r = 0; r < 4; r++) slot[r] = make_uint4(px[2 * r].x, px[2 * r].y, px[2 * r + 1].x, px[2 * r + 1].y);
-    }
-
-    // ---- bytes -> float.  (Assembly: written as C casts the compiler turns the first butterfly stage into SDWA integer
-    // adds followed by v_cvt_f32_i32 - 28 instructions per 8 pixels where 8 conversions and 8 float adds do.) ----------
-    float y[8][8]; // y[r][c], then Y[u][c] after the column pass, then Z[u][v]
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint32_t lo = px[r].x, hi = px[r].y;
-        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(y[r][0]) : "v"(lo));
-        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(y[r][1]) : "v"(lo));
-        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(y[r][2]) : "v"(lo));
-        asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(y[r][3]) : "v"(lo));
-        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(y[r][4]) : "v"(hi));
-        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(y[r][5]) : "v"(hi));
-        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(y[r][6]) : "v"(hi));
-        asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(y[r][7]) : "v"(hi));
-    }
-    // ---- pass 1 down the columns; the level shift is folded into output 0 (column sum - 8 * 128, an exact integer) -----
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        if (ABL != 1) dct8_aan(y[0][c], y[1][c], y[2][c], y[3][c], y[4][c], y[5][c], y[6][c], y[7][c]);
-        y[0][c] -= 1024.0f;
-    }
-    // outputs 0 and 4 of the column pass are exact integers: parked in the lane's (still unused) staging slot for the
-    // exact sub-path of the rational coefficients, should one of them land in its guard band
-    {
-        float4 *slot = reinterpret_cast<float4 *>(stage + lane * kStageStrideB + 64);
-        slot[0] = make_float4(y[0][0], y[0][1], y[0][2], y[0][3]);
-        slot[1] = make_float4(y[0][4], y[0][5], y[0][6], y[0][7]);
-        slot[2] = make_float4(y[4][0], y[4][1], y[4][2], y[4][3]);
-        slot[3] = make_float4(y[4][4], y[4][5], y[4][6], y[4][7]);
-    }
-    // ---- pass 2 along the rows, quantise (index v*8+u of mulT is the multiplier of coefficient (u,v)) -------------------
-    // Rows in order; a scan pair (zig-zag positions 2k, 2k+1) is packed into its output dword as soon as the later of
-    // its two rows is done, so that at most ~8 unpacked values are alive at a time (register pressure).
-    uint32_t bits[64];   // natural index u*8+v: rint(t) in the low 16 bits
-    uint32_t w[32];      // output dwords, zig-zag order
-    float mx[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // max |t - rint(t)| per guard class; [4] = class 0 of row 4
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        if (ABL != 1) dct8_aan(y[u][0], y[u][1], y[u][2], y[u][3], y[u][4], y[u][5], y[u][6], y[u][7]);
-#pragma unroll
-        for (int v = 0; v < 8; v++) {
-            float d;
-            quant_magic(y[u][v], C->mulT[v * 8 + u], bits[u * 8 + v], d);
-            const int k = (u == 4 && kLaneClass[u * 8 + v] == 0) ? 4 : kLaneClass[u * 8 + v];
-            mx[k] = fmaxf(mx[k], fabsf(d));
-        }
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            const int p0 = kZigzag[2 * k], p1 = kZigzag[2 * k + 1]; // natural indices of the scan pair
-            const int last_row = (p0 >> 3) > (p1 >> 3) ? (p0 >> 3) : (p1 >> 3);
-            if (last_row == u) w[k] = perm_b32(bits[p1], bits[p0], 0x05040100u);
-        }
-        // One row at a time: left alone, the compiler interleaves three rows for instruction-level parallelism that the
-        // four resident waves already provide, and spills ~35 registers doing so.  The empty asm ties the next row's
-        // inputs to this row's results (a scheduling barrier alone does not order pure arithmetic).
-        if (u < 7)
-            asm volatile("" : "+v"(y[u + 1][0]), "+v"(y[u + 1][1]), "+v"(y[u + 1][2]), "+v"(y[u + 1][3]), "+v"(y[u + 1][4]),
-                         "+v"(y[u + 1][5]), "+v"(y[u + 1][6]), "+v"(y[u + 1][7])
-                         : "v"(bits[u * 8]), "v"(bits[u * 8 + 1]), "v"(bits[u * 8 + 2]), "v"(bits[u * 8 + 3]), "v"(bits[u * 8 + 4]),
-                           "v"(bits[u * 8 + 5]), "v"(bits[u * 8 + 6]), "v"(bits[u * 8 + 7]), "v"(mx[0]), "v"(mx[1]), "v"(mx[2]),
-                           "v"(mx[3]), "v"(mx[4]));
-    }
-    const bool tie0 = (mx[0] > C->thrC[0]) && valid, tie4 = (mx[4] > C->thrC[0]) && valid;
-    // ---- rational coefficients inside their guard band (exact ties, ~2 % of blocks): exact float64 sub-path, one lane
-    // per (block, row u in {0,4}), from the parked column-pass outputs; the owners then patch their registers ---------
-    {
-        const unsigned long long m_tie = __ballot(tie0 | tie4);
-        if (ABL != 3 && ABL != 4 && m_tie != 0ull) {
-            lane_tie_pass(stage, C, m_tie, lane);
-            wave_lds_fence();
-            const int4 fix = *reinterpret_cast<const int4 *>(stage + lane * kStageStrideB + 128);
-            // scan positions of (0,0), (0,4), (4,0), (4,4): 0, 14, 10, 39 -> halves of w[0], w[7], w[5], w[19]
-            static_assert(kZigzag[0] == 0 && kZigzag[14] == 4 && kZigzag[10] == 32 && kZigzag[39] == 36, "zig-zag slots");
-            w[0] = tie0 ? perm_b32(w[0], (uint32_t)fix.x, 0x07060100u) : w[0];   // low half
-            w[7] = tie0 ? perm_b32(w[7], (uint32_t)fix.y, 0x07060100u) : w[7];   // position 14: low half
-            w[5] = tie4 ? perm_b32(w[5], (uint32_t)fix.z, 0x07060100u) : w[5];   // position 10: low half
-            w[19] = tie4 ? perm_b32((uint32_t)fix.w, w[19], 0x05040100u) : w[19]; // position 39: high half
-            wave_lds_fence();
-        }
-    }
-    const bool trip_redo = ((mx[1] > C->thrC[1]) | (mx[2] > C->thrC[2]) | (mx[3] > C->thrC[3])) && valid;
-
-    // ---- blocks with another coefficient inside its guard band (0.3 %): the whole wave recomputes the block in float64
-    // straight from the definition (lane (u,c): t[u][c] = sum_r M[u][r] x[r][c]; lane (u,v): X = sum_c M[v][c] t[u][c];
-    // error ~1e-13 against ~1e-12 of the reference itself).  A rounding is decided when no .5 tie lies within 1e-9; the
-    // decided values replace the owner's packed words.  Undecided ones: rational ties (already settled above) or a true
-    // tie elsewhere - then the block goes to the exact-order routine after the stores.
-    unsigned long long m_slow = 0ull;
-    if (ABL == 4) w[31] += (uint32_t)(tie0 | tie4 | trip_redo); // timing build: guard arithmetic kept, rare paths not taken
-    {
-        const unsigned long long m_redo = __ballot(trip_redo);
-        if (ABL != 3 && ABL != 4 && m_redo != 0ull) {
-            double *tbuf = redo_all[wave];                                  // t[8][8]
-            char *img128 = reinterpret_cast<char *>(redo_all[wave] + 64);   // the block's 128 output bytes
-            wave_lds_fence();
-            for (unsigned long long todo = m_redo; todo != 0ull; todo &= todo - 1ull) {
-                const int src = __builtin_ctzll(todo);
-                if (lane == src) {
-                    uint4 *o = reinterpret_cast<uint4 *>(img128);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
-                }
-                wave_lds_fence();
-                if (lane_redo_block(stage, cos_tab, tbuf, img128, C, src, lane)) m_slow |= 1ull << src;
-                {
-                    const uint4 *o = reinterpret_cast<const uint4 *>(img128);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const uint4 v4 = o[j];
-                        if (lane == src) { w[4 * j] = v4.x; w[4 * j + 1] = v4.y; w[4 * j + 2] = v4.z; w[4 * j + 3] = v4.w; }
-                    }
-                }
-                wave_lds_fence();
-            }
-            if (a.fallback_count != nullptr && lane == 0) atomicAdd(a.fallback_count, (unsigned long long)__builtin_popcountll(m_redo));
-        }
-    }
-
-    // ---- zig-zag order is a renaming; pack two int16 per dword, stage 128 B per lane, store 1 KiB per instruction ----
-    wave_lds_fence();
-    {
-        uint4 *mine = reinterpret_cast<uint4 *>(stage + lane * kStageStrideB);
-#pragma unroll
-        for (int j = 0; j < 8; j++) mine[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        // 16-byte piece c = 64*j + lane of the wave's 1024 pieces: piece (c & 7) of the block of lane (c >> 3)
-        const int src = 8 * j + (lane >> 3);
-        const uint4 val = *reinterpret_cast<const uint4 *>(stage + src * kStageStrideB + (lane & 7) * 16);
-        const uint32_t ob = (uint32_t)__shfl((int)oblk, src, 64);
-        if (B0 + src < nbf)
-            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + (lane & 7) * 16) = val;
-    }
-
-    // ---- blocks the float64 recompute could not decide: exact-order routine, 8 lanes per block, after the stores ------
-    // (never seen on real data: needs a coefficient other than the rational four within 1e-9 of a tie)
-    const unsigned long long m_redo = m_slow;
-    if (m_redo == 0ull) return;
-    __builtin_amdgcn_s_waitcnt(0);
-    wave_lds_fence();
-    const int nredo = __builtin_popcountll(m_redo);
-    const int b = lane >> 3, i = lane & 7;
-    uint32_t *ldsT = reinterpret_cast<uint32_t *>(stage);                        // 2176 B of the (now free) staging buffer
-    char *zzblk = stage + kLdsWaveBytes + b * kZzStrideB;                        // 1152 B behind it
-    const uint4 zo = *reinterpret_cast<const uint4 *>(C->zzofs + i * 8);
-    const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
-    unsigned long long todo = m_redo;
-    for (int base = 0; base < nredo; base += 8) {
-        const bool have = base + b < nredo;
-        int src = 0; // lane that owns the block of entry base + b
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int pos = todo ? __builtin_ctzll(todo) : 0;
-            if (b == k) src = pos;
-            todo &= todo - 1ull;
-        }
-        const uint32_t blk = (uint32_t)__shfl((int)oblk, src, 64);
-        uint32_t lo, hi;
-        {
-            Strip s;
-            s.by = (int)(blk / (uint32_t)a.bw);
-            s.bx = (int)(blk - (uint32_t)s.by * (uint32_t)a.bw);
-            s.valid = true;
-            s.oblk = blk;
-            load_block_row(a.img, a.h, a.w, a.stride, a.aligned8, s, i, lo, hi);
-            transpose8x8_bytes(lo, hi, i); // -> pixel column i
-        }
-        bool ok;
-        {
-            int qe[8];
-            bool ok_rat;
-            ok = second_level_block(lo, hi, ldsT, b, i, C->mul64, qe, ok_rat);
-            if (__ballot(!ok_rat && have) != 0ull) { // a rational tie inside a redo block: exact sub-path (cheap)
-                const RationalConsts KR = load_rational_consts(C, i);
-                int r0, r4;
-                special_block(lo, hi, ldsT, b, i, KR, r0, r4);
-                if ((i & 3) == 0) {
-                    qe[0] = r0;
-                    qe[4] = r4;
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < 8; v++)
-                *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qe[v];
-        }
-        const unsigned long long bad = __ballot(!ok && have);
-        if (bad != 0ull) {
-            int qx[8];
-            exact_block(lo, hi, ldsT, b, i, C, qx);
-            if ((bad >> (8 * b)) & 0xffull) {
-#pragma unroll
-                for (int v = 0; v < 8; v++)
-                    *reinterpret_cast<int16_t *>(zzblk + ((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu)) = (int16_t)qx[v];
-            }
-        }
-        wave_lds_fence();
-        const uint4 val = *reinterpret_cast<const uint4 *>(zzblk + i * 16);
-        wave_lds_fence();
-        if (have) *reinterpret_cast<uint4 *>(a.out + (size_t)blk * 64 + i * 8) = val;
-    }
-}
-
-#endif // TIC_ABLATION
 
 // ---------------------------------------------------------------------------------------------------------
 // Kernel 1b: exact path for integer images outside 0..255 (the reference transforms any integers: codec.py:29 is
@@ -2259,195 +848,96 @@ __global__ void selftest_transpose_kernel(const uint2 *in, uint2 *out_dpp, uint2
 // ---- launchers ---------------------------------------------------------------------------------------------
 static inline int grid_for(int ntiles) { return (ntiles + kWavesPerWG - 1) / kWavesPerWG; }
 
-// Tuning knobs (environment): read once, or at every launch when TIC_TUNE is set (experiment scripts).
+// Schedule knobs of the strip kernel's launcher.  The product uses the defaults below; the environment is consulted only behind
+// the test-hook gate (tic_hooks.h, TIC_TEST_HOOKS=1: tests/test_gpu_parity.py::test_strip_schedules_are_equivalent drives every
+// schedule against the exact kernel) - read once, or at every launch when TIC_TUNE is set too.
 struct Tunables {
-    int max_wgs, sched, chunk, lds_pad, nocap;
-    int q_waves, q_teams, q_run; // queue kernel: waves per team, teams, log2 of the run length (0 / 0 / -1 = defaults)
+    int max_wgs, sched, chunk;
     int split[8];
 };
 static Tunables read_tunables() {
-    // (tic_hooks.h: the product reads no knob from the environment unless TIC_TEST_HOOKS=1; the experiment library always does)
-#ifdef TIC_ABLATION
-    auto knob = [](const char *k) { return (const char *)getenv(k); };
-#else
-    auto knob = [](const char *k) { return test_hook(k); };
-#endif
-    auto geti = [&](const char *k, int d) { const char *v = knob(k); return v ? atoi(v) : d; };
+    auto geti = [](const char *k, int d) { const char *v = test_hook(k); return v ? atoi(v) : d; };
     Tunables t;
     t.max_wgs = geti("TIC_MAX_WGS", 0);             // persistent grid size (0: resident workgroups of the chip)
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
     t.chunk = geti("TIC_CHUNK", kMaxStripsPerWave); // strips per wave of schedules 1 and 2
-    // per-round row weights of the team schedule ("0" disables it)
-    const char *sp = knob("TIC_SPLIT") ? knob("TIC_SPLIT") : "16,13,10,7,4,2";
+    // per-round row weights of the team schedule ("0" disables it): the six workgroups of a CU reach their first pixel
+    // 1,400 ... 6,200 cycles after their own entry (profiles/r03_stamps_tail.txt), later rounds get fewer strip rows
+    const char *sp = test_hook("TIC_SPLIT") ? test_hook("TIC_SPLIT") : "16,13,10,7,4,2";
     for (int k = 0; k < 8; k++) t.split[k] = 0;
     for (int k = 0; k < 8 && sp && *sp; k++) {
         t.split[k] = atoi(sp);
         sp = strchr(sp, ',');
         if (sp) sp++;
     }
-    t.q_waves = geti("TIC_QWAVES", 0);
-    t.q_teams = geti("TIC_QTEAMS", 0);
-    t.q_run = geti("TIC_QRUN", -1);
-    t.nocap = t.lds_pad = 0;
-#ifdef TIC_ABLATION
-    t.nocap = geti("TIC_NOCAP", 0);                 // experiment, timing builds only: ignore the strips-per-wave bound
-    t.lds_pad = geti("TIC_LDS_PAD", 0);             // experiment: extra dynamic LDS per workgroup (lowers occupancy)
-#endif
     return t;
 }
 static Tunables tunables() {
-#ifdef TIC_ABLATION
-    static const bool live = getenv("TIC_TUNE") != nullptr;
-#else
     static const bool live = test_hook("TIC_TUNE") != nullptr;
-#endif
     static const Tunables once = read_tunables();
     return live ? read_tunables() : once;
 }
 
+// variant 1: the exact kernel for every block; variant 2: the strip kernel on the rectangle of complete 64x8 strips with 8-byte
+// aligned rows, the exact kernel on what is left (right / bottom padding).
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (a.ntiles <= 0) return hipSuccess;
+    if (variant != 1 && variant != 2) return hipErrorInvalidValue;
     dim3 block(kWavesPerWG * 64);
     a.nwaves = a.step_ty = a.step_tx = 0;
     a.fast_ty = a.fast_tx = 0;
     a.rem_mode = 0;
-    if (variant != 17 && variant != 52 && variant != 71) a.dbg = nullptr;
+    a.dbg = nullptr;
     const int nf = a.nframes > 0 ? a.nframes : 1;
     if (variant == 1) {
         hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles), nf), block, 0, stream, a);
         return hipGetLastError();
     }
-    // hybrid kernel: rectangle of complete 64x8 strips with 8-byte aligned rows; the exact kernel takes the rest
     const int bh = a.ntiles / a.tiles_x;
     a.fast_tx = (a.aligned8 && (long)a.h * a.stride < (1L << 32)) ? a.w / 64 : 0; // 32-bit pixel offsets in the walk
     a.fast_ty = a.h / 8;
     const int nfast = a.fast_tx * a.fast_ty;
-#ifdef TIC_ABLATION
-    const bool lane_kernel = variant == 40 || variant == 41;
-#else
-    const bool lane_kernel = false;
-    if (variant != 2) return hipErrorInvalidValue; // the product library holds the exact and the production kernel only
-#endif
-    if (nfast > 0 && lane_kernel) {
-#ifdef TIC_ABLATION
-        // one block per lane (explored alternative): 64 blocks per wave, 256 per workgroup, no loop
-        const long nbf = (long)nfast * 8;
-        const dim3 grid((unsigned)((nbf + kWavesPerWG * 64 - 1) / (kWavesPerWG * 64)), nf);
-        if (variant == 41)
-            hipLaunchKernelGGL(dctq_lane_kernel<4>, grid, block, 0, stream, a);
-        else
-            hipLaunchKernelGGL(dctq_lane_kernel<0>, grid, block, 0, stream, a);
-#endif
-#ifdef TIC_ABLATION
-    } else if (nfast > 0 && variant >= 70 && variant < 80) {
-        // queue kernel: teams of W waves with a ticket counter in LDS (dctq_queue_kernel)
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        }
-        const Tunables tune = tunables();
-        if ((unsigned long long)nfast * (unsigned long long)a.fast_tx >= (1ull << 32)) {
-            a.fast_tx = a.fast_ty = 0; // the magic division of the ticket -> strip mapping would not be exact: exact kernel
-        } else {
-            int W, G;
-            if (nf == 1) {
-                if (nfast >= cus * kQMaxWaves * 2) { W = kQMaxWaves; G = cus; }                 // one team per CU
-                else { W = 4; G = (nfast + 7) / 8; if (G > cus * 4) G = cus * 4; if (G < 1) G = 1; } // small frames: teams of 4 waves, >= 2 strips per wave
-            } else { // a batch: every frame has its own teams (grid plane per frame)
-                W = nfast >= kQMaxWaves * 8 ? kQMaxWaves : 4;
-                G = nfast / (W * 16);
-                if (G < 1) G = 1;
-                if (G > cus) G = cus;
-            }
-            if (tune.q_waves > 0) W = tune.q_waves > kQMaxWaves ? kQMaxWaves : tune.q_waves;
-            if (tune.q_teams > 0) G = tune.q_teams;
-            a.q_waves = W;
-            a.q_teams = G;
-            a.q_run_shift = tune.q_run >= 0 ? tune.q_run : 2;
-            a.q_ppw = (kStripBlkPieces + W - 1) / W;
-            a.magic_fast_tx = a.fast_tx <= 1 ? 0u : (uint32_t)((1ull << 32) / (unsigned long long)a.fast_tx + 1ull);
-            const size_t lds = (size_t)kQHeadBytes + (size_t)W * kQWaveBytes;
-            const dim3 qgrid(G, 1, nf), qblock(W * 64);
-#define TIC_QLAUNCH(ABL)                                                                                            \
-    do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dctq_queue_kernel<ABL, 2>),                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kQHeadBytes + kQMaxWaves * kQWaveBytes); \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        hipLaunchKernelGGL((dctq_queue_kernel<ABL, 2>), qgrid, qblock, lds, stream, a);                              \
-    } while (0)
-            switch (variant) {
-#ifdef TIC_ABLATION
-            case 71: TIC_QLAUNCH(8); break; // stamps
-            case 72: TIC_QLAUNCH(3); break; // tripped blocks ignored (timing only)
-#endif
-            default: TIC_QLAUNCH(0); break;
-            }
-#undef TIC_QLAUNCH
-        }
-#endif
-    } else if (nfast > 0) {
-        // strip kernels, persistent waves: each wave loops over its strips.  Variants 2, 10-22, 1xx, 2xx: round-1 kernel with
-        // the workgroup-shared post-pass (trip lists: at most 16 strips per wave); 50-59, 3xx, 4xx: wave-local rare paths
-        // (one mask bit per strip: at most 64 strips per wave).
-        const bool new_kernel = variant == 2 || (variant >= 50 && variant < 70) || variant >= 300;
-        const int max_strips = new_kernel ? kMaxStripsPerWave2 : kMaxStripsPerWave;
+    if (nfast > 0) {
+        // persistent waves, each looping over its strips; one mask bit per strip of a wave's walk: at most 64 strips per wave
+        const int max_strips = kMaxStripsPerWave2;
         int wgs = grid_for(nfast);
         // persistent grid = exactly the workgroups the chip holds at once (CUs x resident workgroups per CU): a larger
         // grid runs in two uneven rounds, a smaller one leaves wave slots empty (measured: 15.0 us at 1280 workgroups
         // vs 16.3 us at 2048 on a 4096^2 frame)
         static int cus = 256;
-        static const int resident_new = [] {
+        static const int resident = [] {
             int dev = 0, per_cu = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<0, 4, 0, 15>, kWavesPerWG * 64, 0) != hipSuccess ||
-                per_cu < 1)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel, kWavesPerWG * 64, 0) != hipSuccess || per_cu < 1)
                 per_cu = 4;
-            // 72 VGPRs and 21.4 KiB of LDS allow 7 workgroups per CU; 6 measured best (a seventh lengthens the start ramp by
-            // as much as it hides: profiles/r02_ab_occupancy.txt)
+            // 80 VGPRs and 21.5 KiB of LDS allow 6 workgroups per CU (7 measured no better when the kernel still fitted them:
+            // a seventh lengthens the start ramp by as much as it hides, profiles/r02_ab_occupancy.txt)
             if (per_cu > 6) per_cu = 6;
             return cus * per_cu;
         }();
-#ifdef TIC_ABLATION
-        static const int resident_old = [] {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_hybrid_kernel<0>, kWavesPerWG * 64, 0) != hipSuccess ||
-                per_cu < 1)
-                per_cu = 4;
-            return cus * per_cu;
-        }();
-        const int resident = new_kernel ? resident_new : resident_old;
-#else
-        const int resident = resident_new;
-#endif
         const Tunables tune = tunables();
         const int cap_env = tune.max_wgs > 0 ? tune.max_wgs : resident;
         int cap = cap_env / nf; // a batch shares the chip's wave slots between its frames
         if (cap < 64) cap = 64;
         if (wgs > cap) wgs = cap;
         const int min_wgs = (nfast + kWavesPerWG * max_strips - 1) / (kWavesPerWG * max_strips);
-        if (wgs < min_wgs && !(tune.nocap && variant >= 10)) wgs = min_wgs; // strips per wave are bounded (trip list / mask)
+        if (wgs < min_wgs) wgs = min_wgs; // strips per wave are bounded (exact-redo mask)
         a.nwaves = wgs * kWavesPerWG;
         a.wg_stride = kWavesPerWG;
         a.tstep = a.nwaves;
         a.wg_span = nfast;
-        const int sched_env = tune.sched, chunk_env = tune.chunk;
         a.round_wgs = 0;
         a.team_count = 0;
-        const int S = chunk_env < 1 ? 1 : (chunk_env > max_strips ? max_strips : chunk_env);
+        const int S = tune.chunk < 1 ? 1 : (tune.chunk > max_strips ? max_strips : tune.chunk);
         const int min_wgs16 = (nfast + kWavesPerWG * kMaxStripsPerWave - 1) / (kWavesPerWG * kMaxStripsPerWave);
-        const bool multi_round = (long)min_wgs16 * nf > (long)cap_env && !(tune.nocap && variant >= 10); // more workgroups than the chip holds at once
-        if (sched_env == 1 && multi_round) { // each workgroup streams a contiguous chunk of 4*S strips
+        const bool multi_round = (long)min_wgs16 * nf > (long)cap_env; // more workgroups than the chip holds at once
+        if (tune.sched == 1 && multi_round) { // each workgroup streams a contiguous chunk of 4*S strips
             a.wg_stride = a.wg_span = kWavesPerWG * S;
             a.tstep = kWavesPerWG;
             wgs = (nfast + a.wg_stride - 1) / a.wg_stride;
             a.nwaves = wgs * kWavesPerWG;
-        } else if (sched_env == 2 && multi_round && nf == 1) { // rounds of `resident` workgroups walking a dense range together
+        } else if (tune.sched == 2 && multi_round && nf == 1) { // rounds of `resident` workgroups walking a dense range together
             a.round_wgs = cap_env;
             a.wg_span = kWavesPerWG * S;
             a.tstep = a.round_wgs * kWavesPerWG;
@@ -2471,7 +961,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
                 if (a.split[r + 1] - a.split[r] > max_strips) a.team_count = 0; // strips per wave are bounded: fall back
             }
             a.split[R] = rows_total;
-            if (new_kernel && rows_total > 255) a.team_count = 0; // the round-2 kernel takes the row boundaries as bytes
+            if (rows_total > 255) a.team_count = 0; // the kernel takes the row boundaries as bytes
             if (a.team_count == 0) a.tstep = a.nwaves;
         }
         a.step_ty = a.tstep / a.fast_tx;
@@ -2480,21 +970,15 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
         a.in_wrap32 = (uint32_t)(8 * a.stride - (long)a.fast_tx * 64);
         a.oblk_step = (uint32_t)((long)a.step_ty * a.bw + (long)a.step_tx * 8);
         a.oblk_wrap = (uint32_t)((long)a.bw - (long)a.fast_tx * 8);
-        const dim3 grid(wgs, nf);
-        // round-2 kernel: division-free prologue (magic multipliers), team schedule on a 2-D grid
-        dim3 grid2(wgs, 1, nf);
-        bool launch_fast = true;
-        if (new_kernel) {
-            // exactness of the magic divisions: n * d < 2^32 for every dividend n the prologue can form; frames beyond that
-            // (more than ~10^5 pixels wide and millions of strips) go through the exact kernel as a whole
-            const unsigned long long dmax = (unsigned long long)(a.round_wgs > 0 ? a.round_wgs : a.tstep);
-            if ((unsigned long long)nfast * (unsigned long long)a.fast_tx >= (1ull << 32) ||
-                ((unsigned long long)nfast + dmax) * dmax >= (1ull << 32)) {
-                launch_fast = false;
-                a.fast_tx = a.fast_ty = 0;
-            }
-        }
-        if (launch_fast) {
+        // division-free prologue (magic multipliers), team schedule on a 2-D grid.  Exactness of the magic divisions:
+        // n * d < 2^32 for every dividend n the prologue can form; frames beyond that (more than ~10^5 pixels wide and
+        // millions of strips) go through the exact kernel as a whole
+        dim3 grid(wgs, 1, nf);
+        const unsigned long long dmax = (unsigned long long)(a.round_wgs > 0 ? a.round_wgs : a.tstep);
+        if ((unsigned long long)nfast * (unsigned long long)a.fast_tx >= (1ull << 32) ||
+            ((unsigned long long)nfast + dmax) * dmax >= (1ull << 32)) {
+            a.fast_tx = a.fast_ty = 0;
+        } else {
             auto magic = [](long d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (unsigned long long)d + 1ull); }; // 0: divisor 1
             a.magic_fast_tx = magic(a.fast_tx);
             a.magic_tstep = magic(a.round_wgs > 0 ? a.round_wgs : a.tstep);
@@ -2505,66 +989,9 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
                     if (k < 8) a.split_lo |= (unsigned long long)(a.split[k] & 0xff) << (8 * k);
                     else a.split_hi = (unsigned long long)(a.split[k] & 0xff);
                 }
-                grid2 = dim3(a.team_count, R, nf);
+                grid = dim3(a.team_count, R, nf);
             }
-#ifdef TIC_ABLATION
-#define TIC_LAUNCH(ABL) hipLaunchKernelGGL(dctq_hybrid_kernel<ABL>, grid, block, tune.lds_pad, stream, a)
-#define TIC_LAUNCH2(ABL) hipLaunchKernelGGL((dctq_strip_kernel<ABL, 4>), grid2, block, tune.lds_pad, stream, a)
-#endif
-        switch (variant) {
-#ifdef TIC_ABLATION
-        case 10: TIC_LAUNCH(1); break;
-        case 11: TIC_LAUNCH(2); break;
-        case 12: TIC_LAUNCH(3); break;
-        case 13: TIC_LAUNCH(4); break;
-        case 14: TIC_LAUNCH(5); break;
-        case 15: TIC_LAUNCH(6); break;
-        case 16: TIC_LAUNCH(7); break;
-        case 17: TIC_LAUNCH(8); break;
-        case 18: TIC_LAUNCH(9); break;
-        case 19: TIC_LAUNCH(10); break;
-        case 20: TIC_LAUNCH(11); break;
-        case 21: TIC_LAUNCH(12); break;
-        case 22: TIC_LAUNCH(13); break;
-        case 50: TIC_LAUNCH2(0); break;
-        case 51: TIC_LAUNCH2(3); break;  // rare paths compiled out
-        case 52: TIC_LAUNCH2(8); break;  // stamps
-        case 53: TIC_LAUNCH2(12); break; // empty
-        case 54: TIC_LAUNCH2(13); break; // prologue only
-        case 55: TIC_LAUNCH2(6); break;  // streaming skeleton
-        case 56: TIC_LAUNCH2(1); break;  // no arithmetic
-        case 57: TIC_LAUNCH2(9); break;  // compute only
-        case 60: hipLaunchKernelGGL((dctq_strip_kernel<20, 4>), grid2, block, tune.lds_pad, stream, a); break; // no zig-zag staging
-        case 61: hipLaunchKernelGGL((dctq_strip_kernel<21, 4>), grid2, block, tune.lds_pad, stream, a); break; // no transpose
-        case 62: hipLaunchKernelGGL((dctq_strip_kernel<2, 4>), grid2, block, tune.lds_pad, stream, a); break;  // no LDS in the loop
-        case 63: hipLaunchKernelGGL((dctq_strip_kernel<3, 4>), grid2, block, tune.lds_pad, stream, a); break;  // tripped blocks ignored
-        case 64: hipLaunchKernelGGL((dctq_strip_kernel<1, 4>), grid2, block, tune.lds_pad, stream, a); break;  // no arithmetic
-        case 65: hipLaunchKernelGGL((dctq_strip_kernel<9, 4>), grid2, block, tune.lds_pad, stream, a); break;  // compute only
-        case 66: hipLaunchKernelGGL((dctq_strip_kernel<22, 4>), grid2, block, tune.lds_pad, stream, a); break; // guard test only
-        case 67: hipLaunchKernelGGL((dctq_strip_kernel<23, 4>), grid2, block, tune.lds_pad, stream, a); break; // no batch pass
-        case 68: hipLaunchKernelGGL((dctq_strip_kernel<24, 4>), grid2, block, tune.lds_pad, stream, a); break; // batch pass without the second level
-        case 500: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 0>), grid2, block, tune.lds_pad, stream, a); break;
-        case 501: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 1>), grid2, block, tune.lds_pad, stream, a); break;
-        case 502: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 2>), grid2, block, tune.lds_pad, stream, a); break;
-        case 503: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 3>), grid2, block, tune.lds_pad, stream, a); break;
-        case 507: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 7>), grid2, block, tune.lds_pad, stream, a); break;
-        case 515: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 15>), grid2, block, tune.lds_pad, stream, a); break;
-        case 531: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 31>), grid2, block, tune.lds_pad, stream, a); break;
-        case 610: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 15, 6, 3>), grid2, block, tune.lds_pad, stream, a); break; // three strips ahead
-#define TIC_POL(S, L)                                                                                                  \
-    case 100 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<0, S, L>), grid, block, tune.lds_pad, stream, a); break; \
-    case 200 + 10 * S + L: hipLaunchKernelGGL((dctq_hybrid_kernel<6, S, L>), grid, block, tune.lds_pad, stream, a); break; \
-    case 300 + 10 * S + L: hipLaunchKernelGGL((dctq_strip_kernel<0, S, L>), grid2, block, tune.lds_pad, stream, a); break; \
-    case 400 + 10 * S + L: hipLaunchKernelGGL((dctq_strip_kernel<6, S, L>), grid2, block, tune.lds_pad, stream, a); break;
-        TIC_POL(1, 0) TIC_POL(2, 0) TIC_POL(3, 0) TIC_POL(4, 0) TIC_POL(0, 1) TIC_POL(0, 2) TIC_POL(0, 4)
-        TIC_POL(2, 1) TIC_POL(2, 2) TIC_POL(4, 1) TIC_POL(3, 1) TIC_POL(1, 1)
-#undef TIC_POL
-        case 9: TIC_LAUNCH(0); break; // the round-1 kernel (plain stores)
-#endif
-        default: hipLaunchKernelGGL((dctq_strip_kernel<0, 4, 0, 15>), grid2, block, 0, stream, a); break; // the production kernel (stores: sc1 nt)
-        }
-#undef TIC_LAUNCH
-#undef TIC_LAUNCH2
+            hipLaunchKernelGGL(dctq_strip_kernel, grid, block, 0, stream, a);
         }
     } else {
         a.fast_tx = a.fast_ty = 0;
