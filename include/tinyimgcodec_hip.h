@@ -121,6 +121,10 @@ int tic_dctq_dev_timed_rotating(tic_ctx *ctx, const void *const *d_images, void 
  * when measuring) the blocks it had to redo on the exact path; tic_last_fallback_blocks returns the count
  * accumulated since the previous call and resets it. */
 int tic_set_stats(tic_ctx *ctx, int enable);
+/* Device entropy stage: which packing kernel.  max_quality < 1 (default): 8 lanes per block for every frame.  max_quality >= 1: a
+ * lane per block (a wave = 64 blocks) for qualities up to it; a frame in which a block needs more than 512 bits is transparently
+ * packed again with the 8-lane kernel (and the limit then drops below that quality).  Same bytes either way. */
+int tic_set_entropy_lane_kernel(tic_ctx *ctx, int max_quality);
 int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count);
 
 /* ---- entropy stage (host): replaces the per-block loops of compress() codec.py:133-164:

@@ -931,3 +931,32 @@ def test_decoder_edges_round3(ctx, golden, monkeypatch):
             for (y, x), crop in zip(g["long_crops_at"], g[name + "_crops"]):
                 assert np.array_equal(out[y:y + 64, x:x + 64], crop), (name, serial, int(y), int(x))
     monkeypatch.delenv("TIC_DECODE_SERIAL", raising=False)
+
+
+def test_device_entropy_lane_kernel_and_its_fallback(oracle):
+    """The device entropy stage packs with a lane per block (at most 512 bits per block) and runs again with the 8-lane kernel when
+    a block needs more (noise at high quality): same bytes as the oracle either way, for single frames and for the batch pipeline,
+    also when the overflow first shows up in the middle of a batch; sparse content (most of the walk skipped) and frames whose
+    last partition is not full included."""
+    c = T.Context(0)  # a fresh context: the fallback decision is remembered per context
+    c.check(N.load().tic_set_entropy_lane_kernel(c.handle, 99))  # (the 8-lane kernel is the default: DESIGN.md 5.4)
+    try:
+        noise = rand_frame(5151, 264, 520)           # 33 x 65 blocks: the last wave holds 33 blocks
+        smooth = np.add.outer(np.arange(264), np.arange(520)).astype(np.uint8)
+        sparse = np.full((264, 520), 128, np.uint8)
+        sparse[100:108, 200:208] = rand_frame(1, 8, 8)
+        for q in (30, 50, 84, 85, 93, 96, 60):       # 93 / 96: blocks of 600-900 bits -> fallback; then back to a low quality
+            for img in (noise, smooth, sparse):
+                assert T.compress(img, q, ctx=c) == oracle.compress(img, q), q
+        c2 = T.Context(0)
+        c2.check(N.load().tic_set_entropy_lane_kernel(c2.handle, 99))
+        try:
+            frames = [rand_frame(6000 + i, 136, 264) for i in range(20)]
+            frames[17] = np.where(rand_frame(7, 136, 264) > 127, 255, 0).astype(np.uint8)  # a few huge blocks late in the batch
+            for q in (80, 84):
+                got = T.compress_batch(frames, q, threads=0, ctx=c2)
+                assert got == [oracle.compress(f, q) for f in frames], q
+        finally:
+            c2.close()
+    finally:
+        c.close()

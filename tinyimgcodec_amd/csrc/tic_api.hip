@@ -98,6 +98,13 @@ struct tic_ctx {
     void *d_ent_work = nullptr;                 // workspace of the device entropy stage (tile sums, bit counts, staging slots)
     size_t ent_work_bytes = 0;
     int ent_parity = 0;
+    // Which packing kernel the device entropy stage starts with: the lane-per-block kernel up to this quality, the 8-lane kernel
+    // above it.  -1 (the default): always the 8-lane kernel - round 3 built the lane-per-block kernel and measured it no faster
+    // (4096^2 noise: pack 26 us either way, place 13.5 against 8.5 us; Lenna tiled: 21 + 7 against 24 + 8.5 us; DESIGN.md
+    // section 5.4), so it stays selectable (tic_set_entropy_lane_kernel) and tested, not default.  With it on, a frame in which a block needs more
+    // than 512 bits (noise at quality >= ~85) makes it raise error 4: the stage is run again with the 8-lane kernel and the limit
+    // drops below that quality for the rest of the context's life.
+    int ent_lane_max_quality = -1;
     void *d_stream_buf = nullptr;
     size_t d_stream_cap = 0;
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
@@ -603,6 +610,15 @@ int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t 
 }
 #endif
 
+// Device entropy stage: pack with a lane per block (max_quality >= 1: for qualities up to it, with the automatic fall-back to the
+// 8-lane kernel described at ent_lane_max_quality) or always with 8 lanes per block (max_quality < 1, the default).
+int tic_set_entropy_lane_kernel(tic_ctx *ctx, int max_quality) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    ctx->ent_lane_max_quality = max_quality < 1 ? -1 : (max_quality > 99 ? 99 : max_quality);
+    return TIC_OK;
+}
+
 int tic_set_stats(tic_ctx *ctx, int enable) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
@@ -760,14 +776,20 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     // writes the header and puts {payload bits, error} into the host-mapped status block; nothing is written past the
     // caller's buffer
     const size_t cap_words = ((cap - 16) / 16) * 4; // whole 16-byte units behind the header
-    const int par = ctx->ent_parity;
-    ctx->ent_parity ^= 1;
-    HIPCHK(ctx, entropy_gpu_fused((const int16_t *)d_coeffs_zz, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, d_out, 0,
-                                  cap_words, h, w, quality, nullptr, ctx->d_stat, ctx->d_err + par, ctx->d_err + (par ^ 1), ctx->stream));
-    HIPCHK(ctx, wait_stream(ctx));
-    const unsigned long long status[2] = {((volatile unsigned long long *)ctx->h_stat)[0], ((volatile unsigned long long *)ctx->h_stat)[1]};
-    const unsigned long long total_bits = status[0];
-    const int err = (int)(status[1] & 0xffffffffull);
+    unsigned long long total_bits = 0;
+    int err = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const int mode = (attempt == 0 && quality <= ctx->ent_lane_max_quality) ? kEntropyLanePerBlock : kEntropyEightLanes;
+        const int par = ctx->ent_parity;
+        ctx->ent_parity ^= 1;
+        HIPCHK(ctx, entropy_gpu_fused((const int16_t *)d_coeffs_zz, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, d_out, 0,
+                                      cap_words, h, w, quality, nullptr, ctx->d_stat, ctx->d_err + par, ctx->d_err + (par ^ 1), mode, ctx->stream));
+        HIPCHK(ctx, wait_stream(ctx));
+        total_bits = ((volatile unsigned long long *)ctx->h_stat)[0];
+        err = (int)(((volatile unsigned long long *)ctx->h_stat)[1] & 0xffffffffull);
+        if (err != 4 || mode == kEntropyEightLanes) break;
+        ctx->ent_lane_max_quality = quality - 1; // a block of this frame needs more than a lane string holds: 8-lane kernel from here on
+    }
     if (err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
     const size_t payload = (size_t)((total_bits + 7) / 8);
     if (err == 2 || 16 + payload > cap)
@@ -1076,6 +1098,7 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
 
 // Batch compress with the entropy stage on the device: per chunk one H2D copy, one transform launch, the three
 // entropy steps, then only the finished streams (and 8 bytes of length per frame) come back.
+constexpr int kRetryEightLanes = -1000; // internal: compress_batch_gpu asks tic_compress_batch for another run with the 8-lane packing kernel
 static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
                               int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
     int rc = check_geometry(ctx, h, w, row_stride, quality);
@@ -1107,7 +1130,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         BT_STOP(2);
         if (ev != hipSuccess) return set_err(ctx, TIC_E_HIP, "batch chunk failed");
         if (*s.h_err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
-        if (*s.h_err == 3) return set_err(ctx, TIC_E_HIP, "device entropy stage: look-back gave up (internal error)");
+        if (*s.h_err == 4) return kRetryEightLanes; // a block exceeds the lane-per-block kernel's strings: the whole call is run again
         if (*s.h_err) return set_err(ctx, TIC_E_SPACE, "device entropy stage: stream buffer too small");
         // The streams come back into the slot's pinned buffer (asynchronous DMA; a copy straight into the caller's pageable
         // buffers is staged by the runtime, ~0.15 ms each) and are handed out by a few threads.
@@ -1268,7 +1291,8 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         s.parity ^= 1;
         if (e == hipSuccess) // entropy stage of the whole chunk: pack + place (headers, lengths); no zero fill
             e = entropy_gpu_fused((const int16_t *)s.d_coef, nblk, cnt, ctx->d_huff, s.d_work, s.work_bytes, s.d_streams, bound,
-                                  (bound - 16) / 4, h, w, quality, s.d_lens, nullptr, s.d_err + par, s.d_err + (par ^ 1), st);
+                                  (bound - 16) / 4, h, w, quality, s.d_lens, nullptr, s.d_err + par, s.d_err + (par ^ 1),
+                                  quality <= ctx->ent_lane_max_quality ? kEntropyLanePerBlock : kEntropyEightLanes, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_lens, s.d_lens, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err + par, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(s.done, st);
@@ -1303,7 +1327,14 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
 int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,
                        uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads) {
     TIC_LOCK(ctx);
-    if (threads <= 0) return compress_batch_gpu(ctx, images, n, h, w, row_stride, quality, outs, caps, out_lens);
+    if (threads <= 0) {
+        int rc = compress_batch_gpu(ctx, images, n, h, w, row_stride, quality, outs, caps, out_lens);
+        if (rc == kRetryEightLanes) {
+            ctx->ent_lane_max_quality = quality - 1;
+            rc = compress_batch_gpu(ctx, images, n, h, w, row_stride, quality, outs, caps, out_lens);
+        }
+        return rc;
+    }
     return batch_impl(ctx, images, n, h, w, row_stride, quality, nullptr, outs, caps, out_lens, threads, true);
 }
 

@@ -11,6 +11,8 @@ namespace tic {
 struct HuffDev {
     uint32_t ac_sym[256], ac_bits[256];
     uint32_t dc_sym[16], dc_bits[16];
+    // the same in one word per symbol (lane-per-block packing kernel): (total bits << 27) | (codeword << size); 0: no code
+    uint32_t ac_pack[256], dc_pack[16];
 };
 void build_huff_dev(HuffDev *t);
 
@@ -21,9 +23,14 @@ void build_huff_dev(HuffDev *t);
 // of frame 0, error}.  *d_err: 1 = a coefficient without a Huffman code, 2 = a stream does not fit; it must be zero on
 // entry, and the placing kernel zeroes *d_err_next, the flag of the next call (two flags used in turn need no memset
 // between calls).
+// mode: kEntropyLanePerBlock - the packing kernel with a lane per block (a wave = 64 blocks, up to 512 bits per block);
+//       *d_err = 4 when a block needs more: the caller runs the stage again with kEntropyEightLanes, the packing kernel with
+//       8 lanes per block, which has no such limit (any block the format allows).  Both feed the same placing kernel.
+enum { kEntropyLanePerBlock = 0, kEntropyEightLanes = 1 };
 size_t entropy_fused_work_bytes(size_t nblocks_total);
 hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int nframes, const HuffDev *d_tab, void *d_work,
                              size_t work_bytes, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w, int quality,
-                             unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next, hipStream_t stream);
+                             unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next, int mode,
+                             hipStream_t stream);
 
 } // namespace tic

@@ -66,6 +66,8 @@ void build_huff_dev(HuffDev *t) {
         }
         code <<= 1;
     }
+    for (int i = 0; i < 256; i++) t->ac_pack[i] = t->ac_bits[i] ? ((t->ac_bits[i] << 27) | t->ac_sym[i]) : 0u; // <= 26 bits each
+    for (int i = 0; i < 16; i++) t->dc_pack[i] = (t->dc_bits[i] && i <= 11) ? ((t->dc_bits[i] << 27) | t->dc_sym[i]) : 0u;
 }
 
 namespace {
@@ -470,6 +472,205 @@ __global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The packing kernel, round-3 form: a LANE per block, a wave per partition of 64 blocks.
+//
+// Round 2's kernel above (8 lanes per block, 8 scan positions per lane) is instruction-bound at 471 vector instructions per
+// wave of 8 blocks (59 per block) whatever the content: the lane that owns scan positions 0..7 is never idle, so a wave walks all
+// eight of its positions at full cost even when the other 56 coefficients of every block are zero (Lenna 23.7 us against
+// 24.9 us for noise, 4096^2), and 46 % of its LDS cycles are bank conflicts of the 8-byte table look-ups and the merge's atomics.
+// Here a lane owns a whole block: its 64 coefficients sit in 32 registers (coalesced 16-byte loads, transposed through LDS with
+// a conflict-free 144-byte block stride), the walk over the scan positions is unrolled, a position costs ~26 vector
+// instructions only where some lane of the wave has a non-zero coefficient there (exec-masked body, skipped by the hardware
+// when no lane is active), nothing where none has, and the walk ends at the wave's last non-zero group of 8 positions.  No
+// zero-run scan across lanes (the run is position minus last non-zero position), one 4-byte table word per symbol.
+// Every lane packs into its own bit string in LDS (word i of lane l at str[i * 64 + l]: 64 lanes, 64 banks), at most W words;
+// a prefix over the lanes then places the strings in the wave's image of its bit range exactly as above.  A block that needs
+// more than W words (32 * W bits; noise at quality >= ~85) raises error 4 and the stage is run again with the kernel above,
+// which takes any block the format allows.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kPB = 64;          // blocks per partition = per wave
+constexpr int kGroupL = 4;       // partitions (waves) per workgroup = per group sum
+constexpr int kTStrideB = 144;   // bytes per block in the transpose buffer: 128 + 16, so that the lanes' 16-byte reads (stride
+                                 // 144 B = 9 bank groups of 16 B, odd) fall on 16 different bank groups in every group of 16 lanes
+template <int W>
+struct PackL {
+    static constexpr int kImageWords = kPB * W + 4;                       // the wave's bit range, whole 16-byte pieces
+    static constexpr int kStrWords = (W + 1) * 64;                        // lane strings (+ one row that takes overflowing words)
+    static constexpr int kWaveWords = (kStrWords + kImageWords) > (kPB * kTStrideB / 4) ? (kStrWords + kImageWords) : (kPB * kTStrideB / 4);
+    static constexpr int kStageWords = kImageWords;                        // staging slot of a partition
+};
+
+template <int W, int ABL = 0> // ABL != 0: timing-only builds of the experiment library (1: no walk, 2: no coefficient loads, 4: no slot store, 8: no merge)
+__global__ __launch_bounds__(kGroupL * 64) void entropy_pack_lane_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
+                                                                     unsigned long long blocks_per_frame, unsigned long long parts_per_frame,
+                                                                     unsigned long long groups_per_frame, uint32_t *__restrict__ stage,
+                                                                     uint32_t *__restrict__ nbits, uint32_t *__restrict__ gsum,
+                                                                     int *__restrict__ err_flag) {
+    typedef PackL<W> P;
+    __shared__ uint32_t ac_tab[256];
+    __shared__ uint32_t dc_tab[16];
+    __shared__ uint32_t wbits[kGroupL];
+    __shared__ __attribute__((aligned(16))) uint32_t buf_all[kGroupL][P::kWaveWords];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ac_tab[threadIdx.x] = tab->ac_pack[threadIdx.x]; // 256 threads, 256 entries
+    if (threadIdx.x < 16) dc_tab[threadIdx.x] = tab->dc_pack[threadIdx.x];
+    uint32_t *buf = buf_all[wave];
+    const unsigned long long frame = blockIdx.x / groups_per_frame, g = blockIdx.x - frame * groups_per_frame;
+    const unsigned long long pif = g * (unsigned long long)kGroupL + (unsigned long long)wave; // partition inside the frame
+    const unsigned long long part = frame * parts_per_frame + pif;
+    const bool active = pif < parts_per_frame;
+    const unsigned long long first_in_frame = pif * (unsigned long long)kPB;
+    const unsigned long long nblk_part = !active ? 0ull : (blocks_per_frame - first_in_frame < (unsigned long long)kPB ? blocks_per_frame - first_in_frame : (unsigned long long)kPB);
+    const bool valid = (unsigned long long)lane < nblk_part; // this lane's block exists
+    uint32_t wave_bits = 0;
+    if (active) {
+        // ---- coefficients: 8 KiB per wave in eight coalesced 1 KiB loads, transposed through LDS: lane l ends with block l --------
+        const int16_t *src = zz + (frame * blocks_per_frame + first_in_frame) * 64ull;
+        uint4 ld[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const unsigned long long bl = (unsigned long long)(i * 8 + (lane >> 3)); // block of this 16-byte piece
+            if (ABL & 2) ld[i] = make_uint4((uint32_t)(lane * 2654435761u + i) & 0x00030007u, (uint32_t)(bl * 40503u) & 0x00010003u, 0u, i < 2 ? 0x00010000u : 0u);
+            else ld[i] = bl < nblk_part ? *reinterpret_cast<const uint4 *>(src + bl * 64ull + (unsigned long long)(lane & 7) * 8ull) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        int prev_dc = 0; // DC of the block in front of the wave's first (codec.py:34-35: DPCM over the blocks of one frame, the first raw)
+        if (lane == 0 && first_in_frame != 0ull) prev_dc = (int)src[-64];
+        char *tb = reinterpret_cast<char *>(buf);
+#pragma unroll
+        for (int i = 0; i < 8; i++) *reinterpret_cast<uint4 *>(tb + (i * 8 + (lane >> 3)) * kTStrideB + (lane & 7) * 16) = ld[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t c[32]; // c[j] = scan positions 2j (low half) and 2j + 1 (high half) of the lane's block
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(tb + lane * kTStrideB + i * 16);
+            c[4 * i] = v.x; c[4 * i + 1] = v.y; c[4 * i + 2] = v.z; c[4 * i + 3] = v.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (the buffer is about to be reused for the strings and the image)
+        const int dc = (int)(int16_t)(c[0] & 0xffffu);
+        int dc_prev = __shfl_up(dc, 1, 64);
+        if (lane == 0) dc_prev = prev_dc;
+        const int dc_diff = dc - dc_prev; // (frame's first block: prev_dc = 0)
+        // groups of 8 scan positions in which some lane of the wave has a non-zero AC coefficient: where the walk may stop
+        uint32_t wave_groups = 0;
+#pragma unroll
+        for (int gq = 0; gq < 8; gq++) {
+            const uint32_t any = (gq == 0 ? (c[0] & 0xffff0000u) : c[4 * gq]) | c[4 * gq + 1] | c[4 * gq + 2] | c[4 * gq + 3];
+            if (__ballot(any != 0u && valid) != 0ull) wave_groups |= 1u << gq;
+        }
+        if (ABL & 1) wave_groups = 0u;
+        __syncthreads(); // the tables are in LDS
+        // ---- the walk: symbols -> the lane's private bit string -------------------------------------------------------------
+        uint32_t *str = buf + lane;                        // word i of this lane: str[i * 64]
+        uint32_t *image = buf + P::kStrWords;              // the wave's bit range (bit 0 = MSB of word 0)
+        uint32_t cur = 0u, sh = 0u, full = 0u;             // word under construction (MSB first), bits used in it, complete words behind it
+        int err = 0;
+        // branch-free append of the n-bit symbol v (1 <= n <= 26; n = 0, v = 0 is a no-op): the word under construction goes to
+        // LDS whenever it is complete (row W takes whatever overflows the lane's W words and is never read)
+        auto put = [&](uint32_t v, uint32_t n) {
+            const uint32_t x = v << ((32u - n) & 31u);                          // the symbol left-aligned
+            const uint32_t hi = cur | (x >> sh);
+            const uint32_t lo = __builtin_amdgcn_alignbit(x, 0u, sh);            // the bits that did not fit (0 for sh = 0)
+            const uint32_t nsh = sh + n;
+            const bool done = nsh >= 32u;
+            str[(full < (uint32_t)W ? full : (uint32_t)W) * 64u] = hi;
+            cur = done ? lo : hi;
+            sh = nsh & 31u;
+            full += done ? 1u : 0u;
+        };
+        const uint32_t zrl = ac_tab[0xF0], eob = ac_tab[0];
+        if (valid) { // DC: category code + value bits (huffman.py:41-63 with dc_ac = DC)
+            const int sz = size_category(dc_diff);
+            const uint32_t e = dc_tab[sz & 15];
+            const bool bad = e == 0u || sz > 11; // (|difference| up to 65535: size 16 wraps to the valid entry 0, hence the bound)
+            err |= bad ? 1 : 0;
+            put(bad ? 0u : ((e & 0x7ffffffu) | value_bits(dc_diff, sz)), bad ? 0u : (e >> 27));
+        }
+        // The AC walk, a group of 8 scan positions at a time (groups in which no lane of the wave has a non-zero coefficient are
+        // skipped; the walk ends behind the wave's last such group).  Phase 1 of a group is eight INDEPENDENT chains - coefficient ->
+        // size category -> table word -> symbol and length (length 0 for a zero coefficient) - which the hardware overlaps; phase 2
+        // appends the eight symbols in order (the only serial part: ~4 dependent instructions per symbol).  (The first form of this
+        // kernel ran `if (v != 0) { look up; append }` position by position: one dependent chain of ~30 instructions and an LDS round
+        // trip per position, 26 us for 4096^2 noise at 4 waves per SIMD - the same as the 8-lane kernel it was to replace.)
+        uint32_t last6 = 0u; // (position of the last non-zero coefficient, DC counting as one) << 6
+#pragma unroll
+        for (int gq = 0; gq < 8; gq++) {
+            if ((wave_groups >> gq) == 0u) break;               // no lane has anything from here on
+            if (((wave_groups >> gq) & 1u) == 0u) continue;     // nothing in this group (zero runs are position differences: nothing to count)
+            uint32_t sym[8], len[8], trun[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int p = gq * 8 + j;
+                if (p == 0) { sym[j] = 0u; len[j] = 0u; trun[j] = 0u; continue; } // (the DC went first)
+                const int v = (p & 1) ? ((int)c[p >> 1] >> 16) : ((int)(c[p >> 1] << 16) >> 16);
+                const bool nz = v != 0 && valid;
+                const uint32_t t = (uint32_t)((p - 1) << 6) - last6; // zero run in front of this coefficient, << 6
+                int sz = size_category(v);                           // 1..16 for an int16; sizes above 10 have no code (KeyError in the reference)
+                sz = sz > 11 ? 11 : sz;
+                const uint32_t e = ac_tab[((t >> 2) & 0xf0u) + (uint32_t)sz]; // ((run mod 16) << 4) | size: the ZRLs below take the multiples of 16
+                err |= (nz && e == 0u) ? 1 : 0;
+                sym[j] = nz ? ((e & 0x7ffffffu) | (e ? value_bits(v, sz) : 0u)) : 0u;
+                len[j] = nz ? (e >> 27) : 0u;
+                trun[j] = nz ? t : 0u;
+                last6 = nz ? ((uint32_t)p << 6) : last6;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int p = gq * 8 + j;
+                if (p >= 17 && __builtin_expect(__ballot(trun[j] >= (16u << 6)) != 0ull, 0)) { // ZRL = (15,0) for every 16 zeros, huffman.py:26-28
+                    for (uint32_t t = trun[j]; t >= (16u << 6); t -= 16u << 6) put(zrl & 0x7ffffffu, zrl >> 27);
+                }
+                put(sym[j], len[j]);
+            }
+        }
+        if (valid) put(eob & 0x7ffffffu, eob >> 27); // EOB = (0,0) always closes the block (huffman.py:33)
+        const uint32_t my_bits = valid ? full * 32u + sh : 0u;
+        if (my_bits > 32u * (uint32_t)W) err |= 4; // the block does not fit a lane string: the caller falls back to the 8-lane kernel
+        if (err) atomicMax(err_flag, (err & 1) ? 1 : 4);
+        // ---- lane strings -> the wave's image ---------------------------------------------------------------------------------
+        const uint32_t incl = wave_prefix_sum_u32(my_bits);
+        wave_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const bool fits = __ballot(my_bits > 32u * (uint32_t)W) == 0ull;
+        if (!fits) wave_bits = 0; // (error 4 is raised: this run's output is discarded; keep every index in range)
+        const uint32_t nwords = (wave_bits + 31u) >> 5;
+        for (uint32_t i = (uint32_t)lane * 4u; i < nwords + 1u; i += 256u) *reinterpret_cast<uint4 *>(image + i) = make_uint4(0u, 0u, 0u, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (fits && !(ABL & 8)) {
+            const uint32_t lane_pos = incl - my_bits;
+            const uint32_t w0 = lane_pos >> 5, s0 = lane_pos & 31u;
+            const int nw = (int)((my_bits + 31u) >> 5);
+            for (int wq = 0; wq < nw; wq++) {
+                const uint32_t v = (wq == nw - 1 && (my_bits & 31u)) ? cur : str[wq * 64]; // the partial word never left the lane
+                atomicOr(image + w0 + wq, v >> s0);
+                if (s0) atomicOr(image + w0 + wq + 1, v << (32u - s0));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t *slot = stage + part * (unsigned long long)P::kStageWords;
+        for (uint32_t i = (uint32_t)lane * 4u; i < nwords && !(ABL & 4); i += 256u) { // (whole 16-byte pieces: the slot and the image are padded)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const uint4 q = *reinterpret_cast<const uint4 *>(image + i);
+            const u32x4 d = {q.x, q.y, q.z, q.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(slot + i), "v"(d) : "memory");
+        }
+        if (lane == 0) nbits[part] = wave_bits;
+    } else {
+        __syncthreads();
+    }
+    if (lane == 0) wbits[wave] = wave_bits;
+    __syncthreads();
+    if (threadIdx.x == 0) gsum[blockIdx.x] = wbits[0] + wbits[1] + wbits[2] + wbits[3]; // bits of the group: the coarse level of the stream offsets
+}
+
 constexpr int kTileGroups = 256; // groups per tile sum: the second level of the offsets, only for frames of many groups
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
@@ -492,14 +693,16 @@ __global__ __launch_bounds__(256) void entropy_tilesum_kernel(const uint32_t *__
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-constexpr int kPlace = 32;   // partitions per workgroup of the placing kernel (a multiple of kGroup)
-constexpr int kSlotLds = 64; // words of every partition's slot that workgroup fetches into LDS up front (typically 55 are used)
+constexpr int kSlotLds = 64; // words of every partition's slot a workgroup fetches into LDS up front (8-block partitions: typically 55 are used)
 
 // Places kPlace partitions in the frame's stream.  One workgroup per (frame, kPlace partitions); it owns the output words
 // whose first bit lies in its partitions' bit range and assembles each from the partitions that meet in it.  The kernel is
 // latency-bound (4 waves per workgroup, a few words per thread), so everything it needs from memory - group sums, bit
 // counts, the head of every slot - is requested at once, before the first dependent step.
-template <int ABL> // ABL != 0: timing-only builds (tools/), wrong output
+// kPlace: partitions per workgroup (a multiple of kGrp, the partitions per packing workgroup = per group sum); kSlotWords: words
+// per staging slot; kHeads: the head of every slot is fetched into LDS up front (partitions of 8 blocks: a slot seldom has more than
+// 64 words); partitions of 64 blocks are read from memory, every word by the lane that assembles it (coalesced).
+template <int ABL, int kPlace, int kGrp, int kSlotWords, bool kHeads> // ABL != 0: timing-only builds (tools/), wrong output
 __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__restrict__ stage, const uint32_t *__restrict__ nbits,
                                                             const uint32_t *__restrict__ gsum, const unsigned long long *__restrict__ tile_sum,
                                                             unsigned long long parts_per_frame, unsigned long long groups_per_frame,
@@ -514,12 +717,12 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
     __shared__ unsigned long long base_word; // stream word that holds the workgroup's first bit
     __shared__ unsigned long long ws[2][4];
     __shared__ int long_slot;
-    __shared__ uint32_t lds[kN * kSlotLds];
+    __shared__ uint32_t lds[kHeads ? kN * kSlotLds : 1];
     const unsigned long long frame = blockIdx.x / places_per_frame, gp = blockIdx.x - frame * places_per_frame;
     const unsigned long long p0 = gp * (unsigned long long)kPlace;
-    const unsigned long long g = gp * (unsigned long long)(kPlace / kGroup); // first packing group of this workgroup
+    const unsigned long long g = gp * (unsigned long long)(kPlace / kGrp); // first packing group of this workgroup
     const uint32_t *fn = nbits + frame * parts_per_frame;
-    const uint32_t *fstage = stage + (frame * parts_per_frame + p0) * (unsigned long long)kStageWords;
+    const uint32_t *fstage = stage + (frame * parts_per_frame + p0) * (unsigned long long)kSlotWords;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- every load of the prologue, back to back --------------------------------------------------------------------------
     const unsigned long long pl = p0 + (unsigned long long)lane;
@@ -560,7 +763,7 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
 #pragma unroll
     for (int r = 0; r < kPer; r++) {
         const int i = wave + 4 * r;
-        head[r] = (!(ABL & 2) && i < kN && p0 + (unsigned long long)i < parts_per_frame) ? fstage[(unsigned long long)i * (unsigned long long)kStageWords + lane] : 0u;
+        head[r] = (kHeads && !(ABL & 2) && i < kN && p0 + (unsigned long long)i < parts_per_frame) ? fstage[(unsigned long long)i * (unsigned long long)kSlotWords + lane] : 0u;
     }
     // ---- offsets ---------------------------------------------------------------------------------------------------------------
     if (tiles_per_frame) { // frames beyond 8192^2: 64-bit sums
@@ -577,7 +780,7 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
 #pragma unroll
     for (int r = 0; r < kPer; r++) {
         const int i = wave + 4 * r;
-        if (i < kN) lds[i * kSlotLds + lane] = head[r];
+        if (kHeads && i < kN) lds[i * kSlotLds + lane] = head[r];
     }
     __syncthreads();
     const unsigned long long frame_bits = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
@@ -588,7 +791,7 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
         const uint32_t a = (uint32_t)(base & 31ull);
         if (lane < kN) roff[lane] = a + (incl - (uint32_t)nb);
         if (lane == kN - 1) roff[kN] = a + incl;
-        const int any_long = __any(nb > (unsigned long long)(kSlotLds * 32)); // a slot longer than its LDS copy: read the slots directly
+        const int any_long = !kHeads || __any(nb > (unsigned long long)(kSlotLds * 32)); // a slot longer than its LDS copy: read the slots directly
         if (lane == 0) {
             long_slot = any_long;
             base_word = base >> 5;
@@ -645,7 +848,7 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
     } else if (in_lds)
         assemble([&](int i, uint32_t w0) { return lds[i * kSlotLds + (int)w0]; });
     else
-        assemble([&](int i, uint32_t w0) { return fstage[(unsigned long long)i * (unsigned long long)kStageWords + w0]; });
+        assemble([&](int i, uint32_t w0) { return fstage[(unsigned long long)i * (unsigned long long)kSlotWords + w0]; });
     if (gp == 0 && threadIdx.x == 0) { // make_header (codec.py:102-114), the frame's length, the caller's status
         uint32_t *hdr = reinterpret_cast<uint32_t *>(out + frame * out_frame_stride);
         hdr[0] = (uint32_t)h; // struct.pack("III") little-endian == native order here
@@ -668,59 +871,90 @@ __global__ __launch_bounds__(256) void entropy_place_kernel(const uint32_t *__re
 
 } // namespace
 
-// Workspace layout: [tile sums u64 x cap | group sums u32 x cap | bits per partition u32 x cap | staging slots x cap]; both
-// functions below derive cap from the same formula, so a workspace sized by the first always passes the check of the second.
+// Workspace layout: [tile sums u64 x cap | group sums u32 x cap | bits per partition u32 x cap | staging slots]; cap = partitions
+// of the 8-block form (the 64-block form has an eighth of them and slots eight times as long, within a few words: the staging area
+// of the one covers the other).  Both functions below derive cap from the same formula, so a workspace sized by the first always
+// passes the check of the second.
+constexpr int kLaneW = 16;                                   // words per block of the lane-per-block packing kernel: 512 bits
 static constexpr size_t kPerPart = 8 + 4 + 4 + (size_t)kStageWords * 4;
+static_assert((size_t)PackL<kLaneW>::kStageWords <= 8 * (size_t)kStageWords, "a 64-block slot fits the room of eight 8-block slots");
 
 size_t entropy_fused_work_bytes(size_t nblocks_total) {
-    const size_t npart = (nblocks_total + 7) / 8 + 8;
+    const size_t npart = (nblocks_total + 7) / 8 + 8 * 9; // (+ a partition of 64 blocks rounded up per frame end, generously)
     return npart * kPerPart + 256;
 }
 
 hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int nframes, const HuffDev *d_tab, void *d_work,
                              size_t work_bytes, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w, int quality,
-                             unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next, hipStream_t stream) {
+                             unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next, int mode,
+                             hipStream_t stream) {
     if (blocks_per_frame == 0 || nframes <= 0) return hipSuccess;
-    const size_t parts_per_frame = (blocks_per_frame + 7) / 8;
-    const size_t groups_per_frame = (parts_per_frame + kGroup - 1) / kGroup;
+    const bool lane_form = mode == kEntropyLanePerBlock;
+    const size_t part_blocks = lane_form ? (size_t)kPB : 8, grp = lane_form ? (size_t)kGroupL : (size_t)kGroup;
+    const size_t place = lane_form ? 8 : 32; // partitions per placing workgroup
+    const size_t parts_per_frame = (blocks_per_frame + part_blocks - 1) / part_blocks;
+    const size_t groups_per_frame = (parts_per_frame + grp - 1) / grp;
     const size_t npart = parts_per_frame * (size_t)nframes, ngroup = groups_per_frame * (size_t)nframes;
     if (work_bytes < 256 + kPerPart) return hipErrorInvalidValue;
-    const size_t cap_parts = (work_bytes - 256) / kPerPart;
+    const size_t cap_parts = (work_bytes - 256) / kPerPart; // in 8-block partitions
     // frames of more than `direct` groups take the offsets in two levels (tile sums); TIC_ENT_DIRECT_GROUPS moves the switch
     size_t direct = 8192;
     if (const char *e = test_hook("TIC_ENT_DIRECT_GROUPS")) direct = (size_t)strtoull(e, nullptr, 10); // (tic_hooks.h: off unless TIC_TEST_HOOKS=1)
     if (direct > 8192) direct = 8192; // the placing kernel's 32-bit sums rely on it
     const size_t tiles_per_frame = groups_per_frame > direct ? (groups_per_frame + kTileGroups - 1) / kTileGroups : 0;
     const size_t ntiles = tiles_per_frame * (size_t)nframes;
-    if (npart > cap_parts || ngroup > cap_parts || ngroup > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t slot_words = lane_form ? (size_t)PackL<kLaneW>::kStageWords : (size_t)kStageWords;
+    if (npart > cap_parts || ngroup > cap_parts || ngroup > 0x7fffffffull || npart * slot_words > cap_parts * (size_t)kStageWords) return hipErrorInvalidValue;
     unsigned long long *tile_sum = (unsigned long long *)d_work; // (never more tiles than groups, never more groups than partitions)
     uint32_t *gsum = (uint32_t *)(tile_sum + cap_parts);
     uint32_t *nbits = gsum + cap_parts;
     uint32_t *stage = nbits + cap_parts;
     const dim3 pack_grid((unsigned)ngroup);
+    if (lane_form) {
+#define TIC_PACKL(A)                                                                                                                             \
+    hipLaunchKernelGGL((entropy_pack_lane_kernel<kLaneW, A>), pack_grid, dim3(kGroupL * 64), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, \
+                       (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err)
 #ifdef TIC_ABLATION
-    static const int abl = getenv("TIC_ENT_ABL") ? atoi(getenv("TIC_ENT_ABL")) : 0;
+        static const int labl = getenv("TIC_ENT_ABL") ? atoi(getenv("TIC_ENT_ABL")) : 0;
+        switch (labl) {
+        case 1: TIC_PACKL(1); break;
+        case 2: TIC_PACKL(2); break;
+        case 3: TIC_PACKL(3); break;
+        case 4: TIC_PACKL(4); break;
+        case 7: TIC_PACKL(7); break;
+        case 8: TIC_PACKL(8); break;
+        case 15: TIC_PACKL(15); break;
+        default: TIC_PACKL(0); break;
+        }
+#else
+        TIC_PACKL(0);
+#endif
+#undef TIC_PACKL
+    } else {
+#ifdef TIC_ABLATION
+        static const int abl = getenv("TIC_ENT_ABL") ? atoi(getenv("TIC_ENT_ABL")) : 0;
 #define TIC_PACK(A)                                                                                                            \
     hipLaunchKernelGGL(entropy_pack_kernel<A>, pack_grid, dim3(kGroup * 64), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, \
                        (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err)
-    switch (abl) {
-    case 1: TIC_PACK(1); break;
-    case 2: TIC_PACK(2); break;
-    case 3: TIC_PACK(3); break;
-    case 4: TIC_PACK(4); break;
-    case 7: TIC_PACK(7); break;
-    case 8: TIC_PACK(8); break;
-    case 16: TIC_PACK(16); break;
-    case 32: TIC_PACK(32); break;
-    case 64: TIC_PACK(64); break;
-    case 256: TIC_PACK(256); break;
-    default: TIC_PACK(0); break;
-    }
+        switch (abl) {
+        case 1: TIC_PACK(1); break;
+        case 2: TIC_PACK(2); break;
+        case 3: TIC_PACK(3); break;
+        case 4: TIC_PACK(4); break;
+        case 7: TIC_PACK(7); break;
+        case 8: TIC_PACK(8); break;
+        case 16: TIC_PACK(16); break;
+        case 32: TIC_PACK(32); break;
+        case 64: TIC_PACK(64); break;
+        case 256: TIC_PACK(256); break;
+        default: TIC_PACK(0); break;
+        }
 #undef TIC_PACK
 #else
-    hipLaunchKernelGGL(entropy_pack_kernel<0>, pack_grid, dim3(kGroup * 64), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame,
-                       (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err);
+        hipLaunchKernelGGL(entropy_pack_kernel<0>, pack_grid, dim3(kGroup * 64), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame,
+                           (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err);
 #endif
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ntiles) {
@@ -728,26 +962,31 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
                            (unsigned long long)tiles_per_frame, tile_sum);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    const size_t places_per_frame = (parts_per_frame + kPlace - 1) / kPlace;
-#define TIC_PLACE(A)                                                                                                                      \
-    hipLaunchKernelGGL(entropy_place_kernel<A>, dim3((unsigned)(places_per_frame * (size_t)nframes)), dim3(256), 0, stream, stage, nbits, gsum, \
-                       tile_sum, (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame,                               \
-                       (unsigned long long)places_per_frame, (unsigned long long)tiles_per_frame, (unsigned char *)d_out,                  \
-                       (unsigned long long)out_frame_stride, (unsigned long long)cap_words, h, w, quality, d_lens, d_err, d_err_next, d_status)
+    const size_t places_per_frame = (parts_per_frame + place - 1) / place;
+#define TIC_PLACE_ARGS                                                                                                                     \
+    dim3((unsigned)(places_per_frame * (size_t)nframes)), dim3(256), 0, stream, stage, nbits, gsum, tile_sum, (unsigned long long)parts_per_frame, \
+        (unsigned long long)groups_per_frame, (unsigned long long)places_per_frame, (unsigned long long)tiles_per_frame, (unsigned char *)d_out,   \
+        (unsigned long long)out_frame_stride, (unsigned long long)cap_words, h, w, quality, d_lens, d_err, d_err_next, d_status
+    if (lane_form) {
+        hipLaunchKernelGGL((entropy_place_kernel<0, 8, kGroupL, PackL<kLaneW>::kStageWords, false>), TIC_PLACE_ARGS);
+    } else {
 #ifdef TIC_ABLATION
-    static const int pabl = getenv("TIC_PLACE_ABL") ? atoi(getenv("TIC_PLACE_ABL")) : 0;
-    switch (pabl) {
-    case 1: TIC_PLACE(1); break;
-    case 2: TIC_PLACE(2); break;
-    case 3: TIC_PLACE(3); break;
-    case 4: TIC_PLACE(4); break;
-    case 7: TIC_PLACE(7); break;
-    default: TIC_PLACE(0); break;
-    }
-#else
-    TIC_PLACE(0);
-#endif
+        static const int pabl = getenv("TIC_PLACE_ABL") ? atoi(getenv("TIC_PLACE_ABL")) : 0;
+#define TIC_PLACE(A) hipLaunchKernelGGL((entropy_place_kernel<A, 32, kGroup, kStageWords, true>), TIC_PLACE_ARGS)
+        switch (pabl) {
+        case 1: TIC_PLACE(1); break;
+        case 2: TIC_PLACE(2); break;
+        case 3: TIC_PLACE(3); break;
+        case 4: TIC_PLACE(4); break;
+        case 7: TIC_PLACE(7); break;
+        default: TIC_PLACE(0); break;
+        }
 #undef TIC_PLACE
+#else
+        hipLaunchKernelGGL((entropy_place_kernel<0, 32, kGroup, kStageWords, true>), TIC_PLACE_ARGS);
+#endif
+    }
+#undef TIC_PLACE_ARGS
     return hipGetLastError();
 }
 

@@ -10,6 +10,8 @@ if os.environ.get('TIC_USE_ABLATE'):
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N
 L = N.load(); ctx = T.Context(0)
+if os.environ.get('TIC_ENT_LANE'):  # the lane-per-block packing kernel (not the default)
+    ctx.check(L.tic_set_entropy_lane_kernel(ctx.handle, 99))
 dim = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 h = w = dim
