@@ -960,3 +960,18 @@ def test_device_entropy_lane_kernel_and_its_fallback(oracle):
             c2.close()
     finally:
         c.close()
+
+
+def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch):
+    """The strip walk uses 32-bit pixel offsets; a frame of 4 GiB or more is cut into bands of whole block rows, one launch each
+    (round 2 ran such frames on the exact kernel only).  TIC_BAND_BYTES lowers the limit so that a 3000 x 2112 frame is cut into
+    several bands, the last one with bottom padding: same coefficients as the exact kernel."""
+    img = rand_frame(31, 3003, 2112)
+    f = DevFrame(ctx, img)
+    ref = f.run(50, N.KERNEL_EXACT)
+    for limit in (str(2304 * 1000), str(2304 * 8), str(2304 * 2999)):
+        monkeypatch.setenv("TIC_BAND_BYTES", limit)
+        assert np.array_equal(f.run(50, N.KERNEL_HYBRID), ref), limit
+    monkeypatch.delenv("TIC_BAND_BYTES")
+    assert np.array_equal(f.run(50, N.KERNEL_HYBRID), ref)
+    f.free()

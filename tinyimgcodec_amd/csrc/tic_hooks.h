@@ -7,6 +7,7 @@
 //   TIC_DECODE_THREADS      host Huffman decoder: threads of the parallel decoder
 //   TIC_COMM_FORCE_RCCL     a single rank goes through RCCL too (the only way to exercise tic_comm.hip on a one-GPU box)
 //   TIC_TUNE, TIC_SPLIT, TIC_SCHED, TIC_CHUNK, TIC_MAX_WGS   schedule knobs of the strip kernel's launcher
+//   TIC_BAND_BYTES          size from which a frame is transformed in bands of block rows (4 GiB in production)
 // and these are then read at every call (tests flip them inside one process).
 #pragma once
 #include <stdlib.h>

@@ -263,7 +263,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
 constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
-constexpr int kMaxStripsPerWave = 16;             // default chunk of the chunked schedule (strips per wave)
+constexpr int kMaxStripsPerWave = 16;             // a grid is "larger than the chip" when its waves would walk more strips than this
+constexpr int kChunkStrips = 8;                   // chunked schedule: strips per wave (a workgroup streams 32 adjacent strips).  With the
+                                                  // sc1 nt stores 8 beats round 2's 16: 256 x 1080p 270 against 288 us, 8192^2 37.3 against
+                                                  // 38.4, 16384^2 120 against 121 (profiles/r03_ab_chunk.txt)
 
 // Quantiser of the fast path: s = RN(z*mul + magic) is rint(z*mul) of the EXACT product (one rounding, half-even; adding
 // kMagic = 1.5 * 2^23 puts the integer's two's complement into the low mantissa bits: no v_rndne / v_cvt), d = RN(z*mul - rint(z*mul))
@@ -860,7 +863,7 @@ static Tunables read_tunables() {
     Tunables t;
     t.max_wgs = geti("TIC_MAX_WGS", 0);             // persistent grid size (0: resident workgroups of the chip)
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
-    t.chunk = geti("TIC_CHUNK", kMaxStripsPerWave); // strips per wave of schedules 1 and 2
+    t.chunk = geti("TIC_CHUNK", kChunkStrips);      // strips per wave of schedules 1 and 2
     // per-round row weights of the team schedule ("0" disables it): the six workgroups of a CU reach their first pixel
     // 1,400 ... 6,200 cycles after their own entry (profiles/r03_stamps_tail.txt), later rounds get fewer strip rows
     const char *sp = test_hook("TIC_SPLIT") ? test_hook("TIC_SPLIT") : "16,13,10,7,4,2";
@@ -892,6 +895,28 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (variant == 1) {
         hipLaunchKernelGGL(dctq_exact_kernel, dim3(grid_for(a.ntiles), nf), block, 0, stream, a);
         return hipGetLastError();
+    }
+    // The strip walk keeps 32-bit pixel offsets: a frame of 4 GiB or more is transformed in bands of whole block rows, one launch
+    // per band (the stage has no dependency between block rows: the DC is not differenced here).  Round 2 sent such frames to
+    // the exact kernel as a whole.  (TIC_BAND_BYTES, a test hook, lowers the limit so that the banding can be tested on small frames.)
+    {
+        long limit = 1L << 32;
+        if (const char *e = test_hook("TIC_BAND_BYTES")) limit = atol(e) > 0 ? atol(e) : limit;
+        if (a.aligned8 && nf == 1 && a.w >= 64 && (long)a.h * a.stride >= limit) {
+            const long band = (limit - 1) / a.stride / 8 * 8; // pixel rows per band
+            if (band >= 8) {
+                for (long y0 = 0; y0 < a.h; y0 += band) {
+                    DctqArgs b = a;
+                    b.h = (int)((long)a.h - y0 < band ? (long)a.h - y0 : band);
+                    b.img = a.img + y0 * a.stride;
+                    b.out = a.out + (y0 / 8) * (long)a.bw * 64;
+                    b.ntiles = ((b.h + 7) / 8) * b.tiles_x;
+                    const hipError_t e = launch_dctq(b, variant, stream);
+                    if (e != hipSuccess) return e;
+                }
+                return hipSuccess;
+            }
+        }
     }
     const int bh = a.ntiles / a.tiles_x;
     a.fast_tx = (a.aligned8 && (long)a.h * a.stride < (1L << 32)) ? a.w / 64 : 0; // 32-bit pixel offsets in the walk

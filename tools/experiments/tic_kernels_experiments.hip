@@ -2287,7 +2287,7 @@ static Tunables read_tunables() {
     Tunables t;
     t.max_wgs = geti("TIC_MAX_WGS", 0);             // persistent grid size (0: resident workgroups of the chip)
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
-    t.chunk = geti("TIC_CHUNK", kMaxStripsPerWave); // strips per wave of schedules 1 and 2
+    t.chunk = geti("TIC_CHUNK", 8);                 // strips per wave of schedules 1 and 2 (the product's kChunkStrips)
     // per-round row weights of the team schedule ("0" disables it)
     const char *sp = knob("TIC_SPLIT") ? knob("TIC_SPLIT") : "16,13,10,7,4,2";
     for (int k = 0; k < 8; k++) t.split[k] = 0;
