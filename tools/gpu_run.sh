@@ -22,7 +22,9 @@ for step in "$@"; do
     microbench2) run microbench2 240 ./tools/bin/microbench2 ;;
     microbench3) run microbench3 240 ./tools/bin/microbench3 ;;
     microbench4) run microbench4 300 ./tools/bin/microbench4 ;;
+    microbench5) run microbench5 300 ./tools/bin/microbench5 ;;
     microbench6) run microbench6 300 ./tools/bin/microbench6 ;;
+    microbench7) run microbench7 300 ./tools/bin/microbench7 ;;
     parity)     run parity 600 python tools/parity_variant.py ${TIC_PARITY_VARIANTS:-50} ;;
     ab_pol)     run ab_pol 600 python tools/ab.py --dims 4096 --rounds ${TIC_AB_ROUNDS:-5} --iters 400 --variants ${TIC_AB_VARIANTS:-2,50} "" ;;
     ab_pol16k)  run ab_pol16k 600 python tools/ab.py --dims 16384 --rounds 4 --iters 20 --variants ${TIC_AB_VARIANTS16:-2,50} "" ;;
