@@ -177,6 +177,10 @@ int tic_idctq_scaled(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int e
  * encoder (header flag 1<<30 -> scaled_dct branch): host Huffman/RLE decode (huffman.py:36-38,66-98), GPU dequantise +
  * inverse DCT (utils.py:40-45,52) + clip + truncating uint8 cast.  out: uint8[h*w]. */
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap);
+/* Which Huffman decoder the context's last tic_decompress used: 1 = the device decoder (streams of >= 16,384 blocks: only the
+ * stream crosses PCIe upwards, only the pixels downwards), 2 = the host decoder (short streams; any long stream in which the
+ * device decoder met something unusual - the host's bit-serial path reproduces the reference's behaviour on malformed streams). */
+int tic_last_decode_path(tic_ctx *ctx);
 
 /* ---- multi-GPU (the reference has no counterpart: it is single-process, codec.py:133-164 runs one image
  *      at a time).  One process per GPU; a batch shards by independent frames (frame i -> rank i / ceil(B/G)) with no

@@ -975,3 +975,44 @@ def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch)
     monkeypatch.delenv("TIC_BAND_BYTES")
     assert np.array_equal(f.run(50, N.KERNEL_HYBRID), ref)
     f.free()
+
+
+def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monkeypatch):
+    """Streams of >= 16,384 blocks are Huffman-decoded on the device (speculative measuring per 2048-bit range, parallel stitch,
+    decode, DC prefix sum): same pixels as the host decoders and as the oracle on noise at three qualities, natural, smooth and
+    sparse content, a frame whose block count is not a multiple of anything convenient, and streams damaged in the middle or cut
+    short (there the device decoder either succeeds on the true chain or gives up and the host's bit-serial path takes over)."""
+    L = N.load()
+    lenna = golden("lenna")["img"]
+    frames = {
+        "noise 2048x2048": (rand_frame(71, 2048, 2048), (10, 50, 90)),
+        "noise ragged 1500x1999": (rand_frame(72, 1500, 1999), (50,)),
+        "lenna tiled 2048x2048": (np.ascontiguousarray(np.tile(lenna, (4, 4))), (50, 90)),
+        "smooth": (np.add.outer(np.arange(1600) // 3, np.arange(1800) // 5).astype(np.uint8), (50,)),
+        "smooth, large": (np.add.outer(np.arange(4096) // 3, np.arange(6144) // 5).astype(np.uint8), (90,)),
+        "sparse": (np.where(rand_frame(73, 1536, 1536) > 253, 255, 128).astype(np.uint8), (50,)),
+    }
+    for name, (img, quals) in frames.items():
+        for q in quals:
+            s = T.compress(img, q, ctx=ctx)
+            want = oracle.decompress(s)
+            monkeypatch.delenv("TIC_DECODE_HOST", raising=False)
+            got = T.decompress(s, ctx=ctx)
+            long_enough = len(s) * 8 >= 128 + (1 << 21)  # (shorter streams decode serially on the host in well under a millisecond)
+            assert L.tic_last_decode_path(ctx.handle) == (1 if long_enough else 2), (name, q, len(s))
+            assert np.array_equal(got, want), (name, q)
+            monkeypatch.setenv("TIC_DECODE_HOST", "1")
+            assert np.array_equal(T.decompress(s, ctx=ctx), want), (name, q, "host")
+            assert L.tic_last_decode_path(ctx.handle) == 2
+            monkeypatch.delenv("TIC_DECODE_HOST")
+            if q == 50:  # damage: a flipped bit in the middle, a cut at 70 %, garbage behind a cut
+                rng = np.random.default_rng(len(s))
+                for k in range(3):
+                    bad = bytearray(s)
+                    if k == 0:
+                        bad[len(s) // 2 + 7] ^= 0x04
+                    elif k == 1:
+                        bad = bad[: len(s) * 7 // 10]
+                    else:
+                        bad = bad[: len(s) // 3] + bytes(rng.integers(0, 256, 4096, dtype=np.uint8))
+                    assert np.array_equal(T.decompress(bytes(bad), ctx=ctx), oracle.decompress(bytes(bad))), (name, q, k)

@@ -19,7 +19,9 @@
 
 #include "../../include/tinyimgcodec_hip.h"
 #include "tic_entropy.h"
+#include "tic_entropy_dec_gpu.h"
 #include "tic_entropy_gpu.h"
+#include "tic_hooks.h"
 #include "tic_kernels.h"
 #include "tic_math.h"
 
@@ -107,6 +109,12 @@ struct tic_ctx {
     int ent_lane_max_quality = -1;
     void *d_stream_buf = nullptr;
     size_t d_stream_cap = 0;
+    // device Huffman decoder (tic_decompress of long streams): tables, workspace, status
+    DecLutsDev *d_dec_luts = nullptr;
+    void *d_dec_work = nullptr;
+    size_t dec_work_bytes = 0;
+    DecStatus *h_dec_status = nullptr, *d_dec_status = nullptr; // host-mapped
+    int last_decode_path = 0;                                  // 0 none, 1 device decoder, 2 host decoder (tic_last_decode_path)
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
     std::vector<Slot> bslots;
     size_t bslot_img_bytes = 0, bslot_coef_bytes = 0;
@@ -249,6 +257,9 @@ void tic_destroy(tic_ctx *ctx) {
     if (ctx->h_stat) (void)hipHostFree(ctx->h_stat);
     if (ctx->h_zz) (void)hipHostFree(ctx->h_zz);
     if (ctx->d_stream_buf) (void)hipFree(ctx->d_stream_buf);
+    if (ctx->d_dec_luts) (void)hipFree(ctx->d_dec_luts);
+    if (ctx->d_dec_work) (void)hipFree(ctx->d_dec_work);
+    if (ctx->h_dec_status) (void)hipHostFree(ctx->h_dec_status);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1345,21 +1356,10 @@ int tic_dctq_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int
 }
 
 // ---- decode ---------------------------------------------------------------------------------------------
+// Inverse stage on coefficients that already sit in ctx->d_coef (int16 [N][64] zig-zag, DC integrated) -> pixels in `out`.
 // scaled_exp < 0: decode() proper; >= 0: its scaled_dct branch with 2 ** scaled_exp (codec.py:59-62)
-static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, int scaled_exp, uint8_t *out, size_t cap) {
-    if (!ctx) return TIC_E_ARG;
-    if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size");
-    if (scaled_exp < 0 && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
-    if (scaled_exp > 62) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d outside 0..62", scaled_exp);
-    const size_t n = num_blocks(h, w);
-    if (n == 0) return TIC_OK;
-    if (!coeffs_zz) return set_err(ctx, TIC_E_ARG, "null coefficient pointer");
-    if (!out || (size_t)h * (size_t)w > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+static int idct_from_device(tic_ctx *ctx, int h, int w, int quality, int scaled_exp, uint8_t *out) {
     const size_t pitch = align_up((size_t)w, 256);
-    int rc = ensure_scratch(ctx, pitch * (size_t)h, n * 128);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_coef, coeffs_zz, n * 128, hipMemcpyHostToDevice, ctx->stream));
     IdctArgs a;
     a.coeffs = (const int16_t *)ctx->d_coef;
     a.out = (uint8_t *)ctx->d_img;
@@ -1380,6 +1380,79 @@ static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int 
     return TIC_OK;
 }
 
+static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, int scaled_exp, uint8_t *out, size_t cap) {
+    if (!ctx) return TIC_E_ARG;
+    if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size");
+    if (scaled_exp < 0 && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
+    if (scaled_exp > 62) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d outside 0..62", scaled_exp);
+    const size_t n = num_blocks(h, w);
+    if (n == 0) return TIC_OK;
+    if (!coeffs_zz) return set_err(ctx, TIC_E_ARG, "null coefficient pointer");
+    if (!out || (size_t)h * (size_t)w > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t pitch = align_up((size_t)w, 256);
+    int rc = ensure_scratch(ctx, pitch * (size_t)h, n * 128);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_coef, coeffs_zz, n * 128, hipMemcpyHostToDevice, ctx->stream));
+    return idct_from_device(ctx, h, w, quality, scaled_exp, out);
+}
+
+// Long streams: Huffman + run-length decode on the device (tic_entropy_dec_gpu.hip).  Returns TIC_OK with *done = true when the
+// coefficients of all N blocks are in ctx->d_coef; *done = false (and TIC_OK) when the device decoder met something unusual or does
+// not apply - the caller then decodes on the host, which reproduces the reference's behaviour on malformed streams.
+static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h, int w, bool *done) {
+    *done = false;
+    const size_t n = num_blocks(h, w);
+    // the host parallel decoder's own threshold: shorter streams are decoded serially in well under a millisecond
+    if (n < 16384 || len * 8 < 128 + (1u << 21) || len * 8 >= (1ull << 32) || test_hook("TIC_DECODE_SERIAL") || test_hook("TIC_DECODE_HOST")) return TIC_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_dec_luts) {
+        DecLutsDev *l = new DecLutsDev();
+        dec_luts_fill(l->dc11, l->ac11, l->ac16);
+        hipError_t e = hipMalloc((void **)&ctx->d_dec_luts, sizeof(DecLutsDev));
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_dec_luts, l, sizeof(DecLutsDev), hipMemcpyHostToDevice);
+        delete l;
+        if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_dec_status, 64, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_dec_status, ctx->h_dec_status, 0);
+        if (e != hipSuccess) return set_err(ctx, TIC_E_HIP, "device decoder set-up failed: %s", hipGetErrorString(e));
+    }
+    const size_t pitch = align_up((size_t)w, 256);
+    int rc = ensure_scratch(ctx, pitch * (size_t)h, n * 128);
+    if (rc) return rc;
+    const size_t padded = align_up(len, 4) + 16;
+    if (padded > ctx->d_stream_cap) {
+        if (ctx->d_stream_buf) HIPCHK(ctx, hipFree(ctx->d_stream_buf));
+        ctx->d_stream_buf = nullptr;
+        ctx->d_stream_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_stream_buf, padded));
+        ctx->d_stream_cap = padded;
+    }
+    const size_t wb = entropy_decode_gpu_work_bytes(len, n);
+    if (wb > ctx->dec_work_bytes) {
+        if (ctx->d_dec_work) HIPCHK(ctx, hipFree(ctx->d_dec_work));
+        ctx->d_dec_work = nullptr;
+        ctx->dec_work_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_dec_work, wb));
+        ctx->dec_work_bytes = wb;
+    }
+    HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_stream_buf + (len & ~(size_t)3), 0, padded - (len & ~(size_t)3), ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stream_buf, data, len, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, entropy_decode_gpu(ctx->d_stream_buf, len, n, ctx->d_dec_luts, ctx->d_dec_work, ctx->dec_work_bytes, (int16_t *)ctx->d_coef,
+                                   ctx->d_dec_status, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    DecStatus st;
+    memcpy(&st, ctx->h_dec_status, sizeof st); // (host-mapped: the stream has drained)
+    if (st.giveup != 0 || st.m == 0 || st.m > n) return TIC_OK; // the host decoder takes the whole stream
+    if (st.m < n) { // the blocks that start in the stream's last 2048 bits: serial on the host, a few KB uploaded behind the others
+        std::vector<int16_t> tail((n - (size_t)st.m) * 64);
+        entropy_decode_tail(data, len, h, w, (size_t)st.m, (size_t)st.pos_out, st.dc_out, tail.data());
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_coef + (size_t)st.m * 128, tail.data(), tail.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (`tail` leaves scope)
+    }
+    *done = true;
+    return TIC_OK;
+}
+
 int tic_idctq(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, uint8_t *out, size_t cap) {
     TIC_LOCK(ctx);
     return idctq_impl(ctx, coeffs_zz, h, w, quality, -1, out, cap);
@@ -1389,6 +1462,13 @@ int tic_idctq_scaled(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int e
     TIC_LOCK(ctx);
     if (ctx && exponent < 0) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d outside 0..62", exponent);
     return idctq_impl(ctx, coeffs_zz, h, w, 50, exponent, out, cap);
+}
+
+// Which decoder the last tic_decompress of this context used: 1 = device Huffman decoder, 2 = host decoder (short streams,
+// anything unusual in a long one), 0 = none yet.
+int tic_last_decode_path(tic_ctx *ctx) {
+    TIC_LOCK(ctx);
+    return ctx ? ctx->last_decode_path : TIC_E_ARG;
 }
 
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
@@ -1406,6 +1486,15 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
     const size_t n = num_blocks(h, w);
     if (n == 0) return TIC_OK;
     if (!out || (size_t)h * (size_t)w > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+    {   // long streams: the Huffman decode runs on the device too; only the stream goes up and the pixels come down
+        bool done = false;
+        const int rc = decode_on_device(ctx, data, len, h, w, &done);
+        if (rc) return rc;
+        if (done) {
+            ctx->last_decode_path = 1;
+            return idct_from_device(ctx, h, w, scaled ? 50 : quality, scaled ? quality : -1, out);
+        }
+    }
     // coefficients land in a pinned buffer kept on the context: no page faults on a fresh 32 MB vector per call, and the upload
     // runs at PCIe speed instead of through the runtime's staging of pageable memory
     if (n * 128 > ctx->h_zz_bytes) {
@@ -1417,6 +1506,7 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
         ctx->h_zz_bytes = n * 128;
     }
     entropy_decode(data, len, h, w, ctx->h_zz);
+    ctx->last_decode_path = 2;
     return idctq_impl(ctx, ctx->h_zz, h, w, scaled ? 50 : quality, scaled ? quality : -1, out, cap);
 }
 

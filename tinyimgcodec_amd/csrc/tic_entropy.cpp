@@ -550,25 +550,13 @@ size_t decode_parallel(const EncTables &T, const uint8_t *data, size_t nbits, si
 
 } // namespace
 
-int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
-    const EncTables &T = tables();
-    const size_t n = num_blocks(h, w);
-    BitReader r{data, len * 8, 128};
-    int running_dc = 0; // np.cumsum(dc), codec.py:53
-    size_t b_first = 0;
-    {
-        size_t pos = 0;
-        int dc = 0;
-        const size_t done = decode_parallel(T, data, len * 8, n, zz, pos, dc); // zeroes and fills blocks [0, done)
-        if (done) {
-            b_first = done;
-            r.pos = pos;
-            running_dc = dc;
-        }
-    }
-    memset(zz + b_first * 64, 0, (n - b_first) * 64 * sizeof(int16_t)); // (everything, if the parallel attempt gave up)
+namespace {
+// The serial decoder from block b_first at read position r.pos with running DC `running_dc`: blocks [b_first, n) into zz (zeroed
+// here), zz indexed from block b_first (zz points at block b_first).
+void decode_serial_from(const EncTables &T, BitReader &r, int running_dc, size_t b_first, size_t n, int16_t *zz) {
+    memset(zz, 0, (n - b_first) * 64 * sizeof(int16_t));
     for (size_t b = b_first; b < n; b++) {
-        int16_t *c = zz + b * 64;
+        int16_t *c = zz + (b - b_first) * 64;
         int sym, v;
         // Fast path for a whole block while the stream is long enough for any valid block (<= 64 x 27 bits): table
         // look-ups, coefficients written in place.  Anything unusual - a prefix that is no codeword, more than 63
@@ -612,7 +600,44 @@ int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
         if (m > 63) continue;
         memcpy(c + 1, tmp, (size_t)m * sizeof(int16_t));
     }
+}
+} // namespace
+
+int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz) {
+    const EncTables &T = tables();
+    const size_t n = num_blocks(h, w);
+    BitReader r{data, len * 8, 128};
+    int running_dc = 0; // np.cumsum(dc), codec.py:53
+    size_t b_first = 0;
+    {
+        size_t pos = 0;
+        int dc = 0;
+        const size_t done = decode_parallel(T, data, len * 8, n, zz, pos, dc); // zeroes and fills blocks [0, done)
+        if (done) {
+            b_first = done;
+            r.pos = pos;
+            running_dc = dc;
+        }
+    }
+    decode_serial_from(T, r, running_dc, b_first, n, zz + b_first * 64); // (everything, if the parallel attempt gave up)
     return TIC_OK;
+}
+
+// Blocks [first_block, n) from read position pos_bits with running DC `running_dc` (what the device decoder leaves to the host:
+// the blocks that start in the last 2048 bits of the stream) into zz_tail, which holds n - first_block blocks.
+int entropy_decode_tail(const uint8_t *data, size_t len, int h, int w, size_t first_block, size_t pos_bits, int running_dc, int16_t *zz_tail) {
+    const size_t n = num_blocks(h, w);
+    if (first_block >= n) return TIC_OK;
+    BitReader r{data, len * 8, pos_bits};
+    decode_serial_from(tables(), r, running_dc, first_block, n, zz_tail);
+    return TIC_OK;
+}
+
+void dec_luts_fill(uint16_t *dc11, uint16_t *ac11, uint16_t *ac16) {
+    const EncTables &T = tables();
+    memcpy(dc11, T.dcd.lut11, sizeof T.dcd.lut11);
+    memcpy(ac11, T.acd.lut11, sizeof T.acd.lut11);
+    memcpy(ac16, T.acd.lut, sizeof T.acd.lut);
 }
 
 } // namespace tic

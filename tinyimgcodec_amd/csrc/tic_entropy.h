@@ -11,4 +11,8 @@ int entropy_encode(const int16_t *zz, int h, int w, int quality, uint8_t *out, s
 int parse_header(const uint8_t *data, size_t len, int *h, int *w, int *quality, uint32_t *flag);
 // Huffman + run-length decode into int16 [N][64] zig-zag with the DC already integrated (np.cumsum).
 int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz);
+// What the device decoder (tic_entropy_dec_gpu.hip) leaves to the host: blocks [first_block, N) from read position pos_bits with
+// running DC running_dc, into zz_tail (N - first_block blocks); and the decoder's look-up tables for the device.
+int entropy_decode_tail(const uint8_t *data, size_t len, int h, int w, size_t first_block, size_t pos_bits, int running_dc, int16_t *zz_tail);
+void dec_luts_fill(uint16_t *dc11, uint16_t *ac11, uint16_t *ac16);
 } // namespace tic

@@ -3,7 +3,8 @@
 // Production never consults the environment for that: a stray variable cannot silently change a kernel path or a decoder.
 // With TIC_TEST_HOOKS=1 in the environment WHEN THE LIBRARY IS FIRST USED, the test suite (and tools/) may set
 //   TIC_ENT_DIRECT_GROUPS   device entropy stage: group count above which stream offsets are summed in two levels
-//   TIC_DECODE_SERIAL       host Huffman decoder: always the serial decoder
+//   TIC_DECODE_SERIAL       Huffman decoder: always the host's serial decoder
+//   TIC_DECODE_HOST         Huffman decoder: never the device decoder (host parallel / serial as the stream's length says)
 //   TIC_DECODE_THREADS      host Huffman decoder: threads of the parallel decoder
 //   TIC_COMM_FORCE_RCCL     a single rank goes through RCCL too (the only way to exercise tic_comm.hip on a one-GPU box)
 //   TIC_TUNE, TIC_SPLIT, TIC_SCHED, TIC_CHUNK, TIC_MAX_WGS   schedule knobs of the strip kernel's launcher
