@@ -1001,6 +1001,12 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
             long_enough = len(s) * 8 >= 128 + (1 << 21)  # (shorter streams decode serially on the host in well under a millisecond)
             assert L.tic_last_decode_path(ctx.handle) == (1 if long_enough else 2), (name, q, len(s))
             assert np.array_equal(got, want), (name, q)
+            if name == "noise 2048x2048":  # every range length, and the second try with 2048 bits when 512 is shorter than the blocks (q=90)
+                for rb in ("512", "1024", "2048"):
+                    monkeypatch.setenv("TIC_DECODE_RANGE", rb)
+                    assert np.array_equal(T.decompress(s, ctx=ctx), want), (name, q, rb)
+                    assert L.tic_last_decode_path(ctx.handle) == 1, (name, q, rb)
+                monkeypatch.delenv("TIC_DECODE_RANGE")
             monkeypatch.setenv("TIC_DECODE_HOST", "1")
             assert np.array_equal(T.decompress(s, ctx=ctx), want), (name, q, "host")
             assert L.tic_last_decode_path(ctx.handle) == 2

@@ -1437,11 +1437,24 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     }
     HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_stream_buf + (len & ~(size_t)3), 0, padded - (len & ~(size_t)3), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_stream_buf, data, len, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, entropy_decode_gpu(ctx->d_stream_buf, len, n, ctx->d_dec_luts, ctx->d_dec_work, ctx->dec_work_bytes, (int16_t *)ctx->d_coef,
-                                   ctx->d_dec_status, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // stream bits per lane from the average block length (rounded up to 4 average blocks): noise at q=50 (220 bits per block) takes
+    // 1024, natural images 512, noise at q >= 85 2048; a range without a synchronisation point (a block longer than the range) makes
+    // the stitch give up with bit 4: one more try with 2048 before the host decoder takes over
+    int range_bits = 512;
+    while (range_bits < 2048 && (size_t)range_bits * n < 4 * (len * 8)) range_bits *= 2;
+    if (const char *e = test_hook("TIC_DECODE_RANGE")) range_bits = atoi(e);
     DecStatus st;
-    memcpy(&st, ctx->h_dec_status, sizeof st); // (host-mapped: the stream has drained)
+    for (;;) {
+        HIPCHK(ctx, entropy_decode_gpu(ctx->d_stream_buf, len, n, ctx->d_dec_luts, ctx->d_dec_work, ctx->dec_work_bytes, (int16_t *)ctx->d_coef,
+                                       ctx->d_dec_status, range_bits, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(&st, ctx->h_dec_status, sizeof st); // (host-mapped: the stream has drained)
+        if (st.giveup == 4 && range_bits < 2048) {
+            range_bits = 2048;
+            continue;
+        }
+        break;
+    }
     if (st.giveup != 0 || st.m == 0 || st.m > n) return TIC_OK; // the host decoder takes the whole stream
     if (st.m < n) { // the blocks that start in the stream's last 2048 bits: serial on the host, a few KB uploaded behind the others
         std::vector<int16_t> tail((n - (size_t)st.m) * 64);

@@ -23,8 +23,10 @@ struct DecStatus {
 
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks);
 // d_stream_words: the whole stream (header included) in device memory, 4-byte aligned, readable for 8 bytes past its end.
-// Asynchronous on `stream`; *d_status is complete when the stream has drained.
+// range_bits: 512, 1024 or 2048 stream bits per lane (shorter = more lanes = faster, but every range must hold a block start of
+// the true chain: giveup has bit 4 set when one did not - try 2048).  Asynchronous on `stream`; *d_status is complete when the
+// stream has drained.
 hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
-                              size_t work_bytes, int16_t *d_zz, DecStatus *d_status, hipStream_t stream);
+                              size_t work_bytes, int16_t *d_zz, DecStatus *d_status, int range_bits, hipStream_t stream);
 
 } // namespace tic

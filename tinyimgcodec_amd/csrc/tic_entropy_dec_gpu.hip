@@ -32,8 +32,12 @@
 namespace tic {
 namespace {
 
-constexpr int kRange = 2048;            // stream bits per range (a block is at most 64 x 27 = 1,728 bits long)
-constexpr int kCap = kRange / 6 + 2;    // block starts a range can hold (a block has at least 6 bits: 2-bit DC code + EOB)
+// Stream bits per range: 512, 1024 or 2048 (a block is at most 64 x 27 = 1,728 bits long), chosen by the caller from the stream's
+// average block length: the kernels are latency-bound per lane (one dependent chain of table look-ups), so their time goes with the
+// bits a lane walks, and a 7 MB stream cut into 2048-bit ranges is only 440 waves for 1,024 SIMDs.  The stitch needs every range
+// to hold a synchronisation point: a range shorter than the stream's long blocks makes it give up (the caller then tries 2048).
+constexpr int kRangeMax = 2048;
+__host__ __device__ constexpr uint32_t cap_of(uint32_t range) { return range / 6u + 2u; } // block starts a range can hold (a block has at least 6 bits: 2-bit DC code + EOB)
 
 // 32 stream bits (MSB first) from bit `pos`; the two big-endian words around it are cached in registers and reloaded when the
 // position leaves them (a symbol is 5-8 bits on average: one reload per ~5 symbols).
@@ -94,14 +98,14 @@ __device__ __forceinline__ void load_ac11(uint16_t *lds, const DecLutsDev *__res
 }
 
 __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ words, const DecLutsDev *__restrict__ L, uint32_t fast_end,
-                                                         uint32_t nranges, uint16_t *__restrict__ starts, uint32_t *__restrict__ nrec,
+                                                         uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts, uint32_t *__restrict__ nrec,
                                                          uint32_t *__restrict__ endpos, int *__restrict__ lastbrk, DecStatus *__restrict__ st) {
     __shared__ uint16_t ac11[2048];
     load_ac11(ac11, L);
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= nranges) return;
-    const uint32_t lo = 128u + t * (uint32_t)kRange;
-    const uint32_t hi = lo + (uint32_t)kRange < fast_end ? lo + (uint32_t)kRange : fast_end;
+    const uint32_t lo = 128u + t * range;
+    const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
     BitWin win = {0xffffffffu, 0u, 0u};
     uint32_t pos = lo, cnt = 0;
     int brk = -1;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
         int d;
         uint32_t used;
         if (block_dev<false>(words, L, ac11, pos, win, nullptr, d, used)) {
-            if (cnt < (uint32_t)kCap) starts[(size_t)t * kCap + cnt] = (uint16_t)(pos - lo);
+            if (cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(pos - lo);
             cnt++;
             pos += used;
         } else {
@@ -121,14 +125,14 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
             pos++;
         }
     }
-    if (cnt > (uint32_t)kCap) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
+    if (cnt > cap_of(range)) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
     nrec[t] = cnt;
     endpos[t] = pos;
     lastbrk[t] = brk;
 }
 
 __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restrict__ words, const DecLutsDev *__restrict__ L, uint32_t fast_end,
-                                                        uint32_t nranges, const uint16_t *__restrict__ starts, const uint32_t *__restrict__ nrec,
+                                                        uint32_t range, uint32_t nranges, const uint16_t *__restrict__ starts, const uint32_t *__restrict__ nrec,
                                                         const uint32_t *__restrict__ endpos, const int *__restrict__ lastbrk,
                                                         uint32_t *__restrict__ nblk, uint32_t *__restrict__ pstart, DecStatus *__restrict__ st) {
     __shared__ uint16_t ac11[2048];
@@ -140,16 +144,16 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
         pstart[0] = 128u;
         return;
     }
-    const uint32_t lo = 128u + t * (uint32_t)kRange;
-    const uint32_t hi = lo + (uint32_t)kRange < fast_end ? lo + (uint32_t)kRange : fast_end;
+    const uint32_t lo = 128u + t * range;
+    const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
     uint32_t pos = endpos[t - 1]; // hypothesis: where the true chain enters this range
     pstart[t] = pos;
     if (pos >= fast_end) { // the chain left the fast part of the stream in front of this range
         nblk[t] = 0u;
         return;
     }
-    const uint16_t *tr = starts + (size_t)t * kCap;
-    const uint32_t n = nrec[t] < (uint32_t)kCap ? nrec[t] : (uint32_t)kCap;
+    const uint16_t *tr = starts + (size_t)t * cap_of(range);
+    const uint32_t n = nrec[t] < cap_of(range) ? nrec[t] : cap_of(range);
     BitWin win = {0xffffffffu, 0u, 0u};
     uint32_t by_hand = 0;
     for (;;) {
@@ -293,15 +297,19 @@ __global__ __launch_bounds__(64) void dec_decode_kernel(const uint32_t *__restri
 
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
     const size_t nbits = stream_bytes * 8;
-    const size_t nranges = nbits / kRange + 2;
+    const size_t nranges = nbits / 512 + 2; // (the smallest range: most ranges, and the most room per stream bit)
     const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
-    return nranges * ((size_t)kCap * 2 + 8 * 4) + nblocks * 4 + ntiles * 8 * 2 + 16384; // (six 4-byte arrays per range; every piece is rounded up to 256 B)
+    return nranges * ((size_t)cap_of(512) * 2 + 8 * 4) + nblocks * 4 + ntiles * 8 * 2 + 16384; // (six 4-byte arrays per range; every piece is rounded up to 256 B)
 }
 
 hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
-                              size_t work_bytes, int16_t *d_zz, DecStatus *d_status, hipStream_t stream) {
+                              size_t work_bytes, int16_t *d_zz, DecStatus *d_status, int range_bits, hipStream_t stream) {
     const size_t nbits = stream_bytes * 8;
-    if (nbits < 128 + 2048 + (size_t)kRange || nbits >= (1ull << 32) || nblocks == 0) return hipErrorInvalidValue;
+    if (range_bits != 512 && range_bits != 1024 && range_bits != 2048) return hipErrorInvalidValue;
+    const uint32_t range = (uint32_t)range_bits;
+    const uint32_t kCap = cap_of(range);
+    const int kRange = range_bits;
+    if (nbits < 128 + 2048 + (size_t)kRangeMax || nbits >= (1ull << 32) || nblocks == 0) return hipErrorInvalidValue;
     if (work_bytes < entropy_decode_gpu_work_bytes(stream_bytes, nblocks)) return hipErrorInvalidValue;
     const uint32_t fast_end = (uint32_t)(nbits - 2048); // a block may START on the fast path up to here (as in the host decoder)
     const uint32_t nranges = (uint32_t)((fast_end - 128 + kRange - 1) / kRange);
@@ -322,8 +330,8 @@ hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, s
     hipError_t e = hipMemsetAsync(d_status, 0, sizeof(DecStatus), stream);
     if (e != hipSuccess) return e;
     const dim3 gr((nranges + 63) / 64), bl(64);
-    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, d_luts, fast_end, nranges, starts, nrec, endpos, lastbrk, d_status);
-    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, d_luts, fast_end, nranges, starts, nrec, endpos, lastbrk, nblk, pstart, d_status);
+    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, d_status);
+    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, nblk, pstart, d_status);
     // first block of every range: exclusive scan of the true block counts
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const int32_t *)nblk, (size_t)nranges, tiles_r);
     hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(kTile), 0, stream, tiles_r, ntiles_r, totals);

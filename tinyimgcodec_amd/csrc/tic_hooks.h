@@ -4,6 +4,7 @@
 // With TIC_TEST_HOOKS=1 in the environment WHEN THE LIBRARY IS FIRST USED, the test suite (and tools/) may set
 //   TIC_ENT_DIRECT_GROUPS   device entropy stage: group count above which stream offsets are summed in two levels
 //   TIC_DECODE_SERIAL       Huffman decoder: always the host's serial decoder
+//   TIC_DECODE_RANGE        device Huffman decoder: stream bits per lane (512, 1024, 2048) instead of the choice by block length
 //   TIC_DECODE_HOST         Huffman decoder: never the device decoder (host parallel / serial as the stream's length says)
 //   TIC_DECODE_THREADS      host Huffman decoder: threads of the parallel decoder
 //   TIC_COMM_FORCE_RCCL     a single rank goes through RCCL too (the only way to exercise tic_comm.hip on a one-GPU box)
