@@ -247,8 +247,8 @@ def _true_tie_block():
 
 def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden):
     """Every rare path of the production kernel against the exact kernel and the oracle: the wave's batch (ties, second level,
-    exact order inside the batch), batch overflow with rational ties only (exact sub-path inside the loop: flat areas with an
-    odd grey level tie on DC in every block), batch overflow with irrational trips (whole strip redone in the exact order)."""
+    exact order inside the batch), batch overflow with rational ties only (flat blocks from the DC table, anything else through
+    the exact sub-path inside the loop), batch overflow with irrational trips (whole strip redone in the exact order)."""
     tt = _true_tie_block()
     mix = rand_frame(5, 1024, 2048)
     for k in range(0, 128 * 256, 37):
@@ -256,12 +256,27 @@ def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden):
         mix[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = tt
     half = rand_frame(11, 512, 1024)
     half[:, 512:] = 77  # right half flat and odd: eight DC ties per strip there, none in the random half
+    rs = np.random.RandomState(77)
+    levels = rs.permutation(np.arange(64 * 256, dtype=np.int64) % 256).reshape(64, 256).astype(np.uint8)  # one grey level per block
+    flat_mix = np.repeat(np.repeat(levels, 8, 0), 8, 1)
+    noise_at = rs.rand(64, 256) < 0.3
+    flat_mix = np.where(np.repeat(np.repeat(noise_at, 8, 0), 8, 1), rand_frame(78, 512, 2048), flat_mix)
+    yy, xx = np.mgrid[0:512, 0:2048]
+    banded = ((xx // 3 + yy // 5) // 8 * 8 + 1).astype(np.uint8)  # 32 levels, all odd: steps cross blocks, most blocks are flat
+    ab = rs.randint(0, 256, (64, 256, 2))
+    checker = np.where((yy + xx) % 2 == 0, np.repeat(np.repeat(ab[..., 0], 8, 0), 8, 1), np.repeat(np.repeat(ab[..., 1], 8, 0), 8, 1)).astype(np.uint8)
     frames = {
         "flat odd grey (DC tie in every block)": (np.full((1024, 2048), 129, np.uint8), (50, 90)),
         "irrational true tie in every block": (np.tile(tt, (128, 256)), (50,)),
         "random + scattered irrational true ties": (mix, (50,)),
         "tie goldens tiled": (np.tile(golden("tie_blocks")["img"].astype(np.uint8), (8, 16)), (50, 37, 90)),
         "half random, half flat odd": (half, (50,)),
+        # flat-block table of the overflow path (DctqConsts::dcflat): every grey level, every kind of divisor
+        "flat blocks of every grey level": (np.repeat(np.repeat(levels, 8, 0), 8, 1), (50, 1, 10, 25, 49, 51, 75, 90, 99)),
+        "flat blocks of every grey level among noise": (flat_mix, (50, 75)),
+        "posterised ramp (banded content)": (banded, (50, 30, 80)),
+        # dense rational ties that are NOT flat (sum 32 (a + b) with a + b = 2 mod 4): the float64 sub-path inside the loop
+        "two-level checkerboards": (checker, (50, 90)),
     }
     for name, (img, quals) in frames.items():
         f = DevFrame(ctx, img)

@@ -409,13 +409,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         f32x4 m0, m1;
         f32x4 thr;
         u32x4 zzv;
-        // Constants: the workgroup copies the quality's 2304-byte block into LDS, 36 lanes of every wave one 16-byte piece
+        // Constants: the workgroup copies the quality's 2816-byte block into LDS, 44 lanes of every wave one 16-byte piece
         // each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
         // loads per wave in front of the first pixel load: four such loads more cost 0.67 us on a 4096^2 launch).
         // Every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_TAKE).
         u32x4 c_fill;
         {
-            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 36 pieces of 16 bytes per wave
+            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 44 pieces of 16 bytes per wave
             static_assert(kPpw * kWavesPerWG == kStripBlkPieces && kPpw <= 64, "constant block must split evenly over the waves");
             const uint32_t piece = lane < kPpw ? (uint32_t)(wave * kPpw + lane) : (uint32_t)kStripBlkPieces - 1u;
             const uint32_t fo = piece * 16u;
@@ -524,6 +524,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
             else if constexpr (R == 74) asm volatile("v_mov_b32 %0, v74\n\tv_mov_b32 %1, v75" : "=v"(lo), "=v"(hi) : : "memory");
             else asm volatile("v_mov_b32 %0, v76\n\tv_mov_b32 %1, v77" : "=v"(lo), "=v"(hi) : : "memory");
         };
+        // are all tripped blocks of the strip (bits of fm) flat?  lane (lr, lb) of the load layout holds pixel row lr of block lb
+        auto flat_ties = [&](uint32_t lo0, uint32_t hi0, uint32_t fm) {
+            const uint32_t first = (uint32_t)__shfl((int)lo0, lane & 7, 64);                               // row 0 of this lane's block
+            const bool row_flat = lo0 == hi0 && lo0 == perm_b32(0u, lo0, 0x00000000u) && lo0 == first;  // 8 equal bytes, equal to row 0's
+            unsigned long long mf = __ballot(row_flat);
+            mf &= mf >> 32;
+            mf &= mf >> 16;
+            mf &= mf >> 8; // bit lb: all eight rows of block lb are flat and equal
+            return (fm & ~(uint32_t)mf & 0xffu) == 0u;
+        };
         auto process = [&](auto tag, const float (&px)[8], const uint32_t ob) {
             // ---- pass 1: along the pixel row (the pixels arrive converted: TIC_TAKE) -----------------------------
             float d0 = px[0], d1 = px[1], d2 = px[2], d3 = px[3], d4 = px[4], d5 = px[5], d6 = px[6], d7 = px[7];
@@ -587,8 +597,21 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
                     // no room and an irrational trip: the whole strip is redone in the exact order after the loop
                     mask_exact |= 1ull << kstrip;
                     store16_wt_nt(dst, val);
+                } else if (flat_ties(lo0, hi0, fm)) {
+                    // no room, rational ties only, and every tripped block is FLAT (64 equal pixels).  Such a block has exactly one
+                    // non-zero coefficient, and with an odd grey level its DC sits on a .5 tie at q = 50: flat areas, banded and
+                    // upscaled content trip in every strip.  The reference's DC of a flat block depends on the grey level alone
+                    // (DctqConsts::dcflat, computed on the host in the exact operation order): no float64 here.  (Round 2 sent those
+                    // strips through the sub-path below: flat 201 took 10.9 us, Lenna in 32 grey levels 12.5, noise 10.1.)
+                    const uint32_t grey = (uint32_t)__shfl((int)lo0, b, 64) & 0xffu; // (load layout: lane b holds row 0 of block b)
+                    const int16_t dcv = reinterpret_cast<const int16_t *>(cst_blk + 2304)[grey];
+                    if (i == 0 && ((fm >> b) & 1u)) *zz_ptr(0u) = dcv;
+                    wave_lds_fence();
+                    val = *zr;
+                    wave_lds_fence();
+                    store16_wt_nt(dst, val);
                 } else {
-                    // no room, rational ties only (tie-dense content, e.g. flat areas with an odd grey level): exact sub-path
+                    // no room, rational ties only (tie-dense content that is not flat, e.g. two-level patterns): exact sub-path
                     // for the four rational coefficients of all eight blocks, here and now
                     uint2 *pb = reinterpret_cast<uint2 *>(ldsT);
                     pb[lb * 8 + lr] = make_uint2(lo0, hi0);

@@ -191,13 +191,17 @@ struct DctqConsts {
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
     uint16_t zzofsT[64]; // index v*8+u: same offsets, transposed (lane v holds u = 0..7)
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
+    int16_t dcflat[256]; // quantised DC of a block whose 64 pixels all have the value p, EXACTLY as the reference computes it (float64,
+                         // pocketfft order, IEEE divide, half-even): every such block with an odd grey level sits on a .5 tie of the DC at
+                         // q = 50 (X = 8 (p - 128), div = 16), so flat, banded and upscaled content is tie-dense; the strip kernel settles
+                         // those blocks from this table instead of the float64 sub-path
     // Everything the strip kernel needs, packed as the image its workgroups copy into LDS with one 16-byte load per lane
     // (144 lanes): [0,256) mulT, [256,320) thrT (round-2 grouping, experiment kernels), [320,448) zzofsT, [448,960) mul64,
     // [960,1088) zzofs, [1088,1152) div then rdiv of the rational coefficients (0,0) (0,4) (4,0) (4,4), [1152,1664) cosm,
-    // [1664,2176) rdiv, [2176,2304) thrG.
-    alignas(16) unsigned char strip_blk[2304];
+    // [1664,2176) rdiv, [2176,2304) thrG, [2304,2816) dcflat.
+    alignas(16) unsigned char strip_blk[2816];
 };
-constexpr int kStripBlkBytes = 2304;
+constexpr int kStripBlkBytes = 2816;
 constexpr int kStripBlkPieces = kStripBlkBytes / 16;
 
 // Accept threshold of the fast path as a float: the kernel accepts a rounding when fl32(|t - rint(t)|) <= thr.  The distance
@@ -265,6 +269,14 @@ inline bool build_consts(int quality, DctqConsts *c) {
     for (int k = 0; k < 8; k++)
         for (int n = 0; n < 8; n++)
             c->cosm[k * 8 + n] = (k == 0 ? sqrt(0.125) : 0.5) * cos((2 * n + 1) * k * 3.14159265358979323846 / 16.0);
+    for (int pval = 0; pval < 256; pval++) { // a constant block: the column pass gives (y, 0, ..., 0) in every column, the row pass runs on eight y
+        double col[8], row[8];
+        for (int r = 0; r < 8; r++) col[r] = (double)(pval - 128);
+        dct8_exact(col[0], col[1], col[2], col[3], col[4], col[5], col[6], col[7]);
+        for (int k = 0; k < 8; k++) row[k] = col[0];
+        dct8_exact(row[0], row[1], row[2], row[3], row[4], row[5], row[6], row[7]);
+        c->dcflat[pval] = (int16_t)rint(row[0] / c->div[0]);
+    }
     for (int k = 0; k < 64; k++) {
         int nat = kZigzag[k], u = nat >> 3, v = nat & 7;
         c->zzofs[nat] = (uint16_t)(2 * k);
@@ -286,6 +298,7 @@ inline bool build_consts(int quality, DctqConsts *c) {
         memcpy(p + 1152, c->cosm, 512);
         memcpy(p + 1664, c->rdiv, 512);
         memcpy(p + 2176, c->thrG, 128);
+        memcpy(p + 2304, c->dcflat, 512);
     }
     return true;
 }

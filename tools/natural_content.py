@@ -15,6 +15,8 @@ frames = {
     "flat 201": np.full((dim, dim), 201, np.uint8),
     "horizontal gradient": np.tile((np.arange(dim) // 16).astype(np.uint8), (dim, 1)),
     "lenna tiled, quantised to 32 levels": (np.tile(lenna, (8, 8)) // 8 * 8 + 1).astype(np.uint8),
+    "lenna upscaled 8x, 32 levels (flat blocks)": np.kron((lenna // 8 * 8 + 1).astype(np.uint8), np.ones((8, 8), np.uint8)),
+    "checkerboard 100/102 (dense ties, not flat)": np.where(np.add.outer(np.arange(dim), np.arange(dim)) % 2 == 0, 100, 102).astype(np.uint8),
 }
 for name, img in frames.items():
     img = np.ascontiguousarray(img)
