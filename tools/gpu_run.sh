@@ -33,6 +33,7 @@ for step in "$@"; do
     ent_abl)    for a in ${TIC_ENT_ABLS:-0 1 2 3 4 7}; do rm -rf gpurun_out/ent_abl$a; export TIC_USE_ABLATE=1 TIC_ENT_ABL=$a; run ent_abl$a 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ent_abl$a -- python tools/prof_compress_dev.py 4096 100; unset TIC_USE_ABLATE TIC_ENT_ABL; done ;;
     pmc_ent_abl) for a in ${TIC_ENT_ABLS:-0 2 4 7 32}; do rm -rf gpurun_out/pmc_ent_abl$a; export TIC_USE_ABLATE=1 TIC_ENT_ABL=$a; run pmc_ent_abl$a 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_ent_abl$a -- python tools/prof_compress_dev.py 4096 10; unset TIC_USE_ABLATE TIC_ENT_ABL; done ;;
     place_abl)  for a in ${TIC_PLACE_ABLS:-0 1 2 3 4 7}; do rm -rf gpurun_out/place_abl$a; export TIC_USE_ABLATE=1 TIC_PLACE_ABL=$a; run place_abl$a 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/place_abl$a -- python tools/prof_compress_dev.py 4096 100; unset TIC_USE_ABLATE TIC_PLACE_ABL; done ;;
+    stress)     run stress 900 python tools/stress_parity.py ${TIC_STRESS_ITERS:-300} ;;
     content)    run content 300 python tools/natural_content.py ;;
     ab_cold)    run ab_cold 400 python tools/ab_cold.py ;;
     stamps2)    run stamps2 200 python tools/stamps2.py ;;

@@ -14,13 +14,24 @@ t0 = time.time()
 for it in range(iters):
     h, w = shapes[it % len(shapes)]
     q = int(rng.integers(1, 100))
-    kind = it % 3
+    kind = it % 5
     if kind == 0:
         img = rng.integers(0, 256, (h, w), dtype=np.uint8)
     elif kind == 1:  # smooth content: many exact ties
         img = (np.add.outer(np.arange(h), np.arange(w)) // int(rng.integers(1, 9)) % 256).astype(np.uint8)
-    else:            # two-level noise
+    elif kind == 2:  # two-level noise
         img = (rng.integers(0, 2, (h, w), dtype=np.uint8) * int(rng.integers(1, 256))).astype(np.uint8)
+    elif kind == 3:  # mosaic of flat blocks (every grey level) with noise patches: the flat-block table of the overflow path
+        cell = int(rng.choice([8, 8, 16, 24]))
+        lv = rng.integers(0, 256, ((h + cell - 1) // cell, (w + cell - 1) // cell), dtype=np.uint8)
+        img = np.kron(lv, np.ones((cell, cell), np.uint8))[:h, :w]
+        noisy = np.kron(rng.random(((h + 63) // 64, (w + 63) // 64)) < 0.2, np.ones((64, 64), bool))[:h, :w]
+        img = np.where(noisy, rng.integers(0, 256, (h, w), dtype=np.uint8), img).astype(np.uint8)
+    else:            # posterised ramp + two-level checkerboard cells: dense rational ties, flat and not
+        step = int(rng.integers(2, 33))
+        img = ((np.add.outer(np.arange(h) // 3, np.arange(w) // 5) % 256) // step * step + int(rng.integers(0, 2))).astype(np.uint8)
+        chk = (np.add.outer(np.arange(h), np.arange(w)) % 2 == 0) & (np.add.outer(np.arange(h) // 32, np.arange(w) // 32) % 3 == 0)
+        img = np.where(chk, np.uint8(int(rng.integers(0, 256))), img).astype(np.uint8)
     n = L.tic_num_blocks(h, w)
     d_img, d_a, d_b = C.c_void_p(), C.c_void_p(), C.c_void_p()
     ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
