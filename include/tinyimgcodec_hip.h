@@ -125,12 +125,6 @@ int tic_set_stats(tic_ctx *ctx, int enable);
  * lane per block (a wave = 64 blocks) for qualities up to it; a frame in which a block needs more than 512 bits is transparently
  * packed again with the 8-lane kernel (and the limit then drops below that quality).  Same bytes either way. */
 int tic_set_entropy_lane_kernel(tic_ctx *ctx, int max_quality);
-/* ... and which kernel packs when that one does not: TIC_ENTROPY_EIGHT_LANES - 8 lanes per block walk their 8 scan positions each
- * (the cost does not depend on the content); TIC_ENTROPY_SYMBOL_LIST - the symbols of 8 blocks are compacted into a list and coded 64
- * per round, a lane per symbol (rounds follow the content: 6 for noise at q = 50, 1-2 for natural images).  Same bytes either way. */
-#define TIC_ENTROPY_EIGHT_LANES 0
-#define TIC_ENTROPY_SYMBOL_LIST 1
-int tic_set_entropy_kernel(tic_ctx *ctx, int kind);
 int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count);
 
 /* ---- entropy stage (host): replaces the per-block loops of compress() codec.py:133-164:

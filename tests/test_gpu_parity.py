@@ -977,27 +977,6 @@ def test_device_entropy_lane_kernel_and_its_fallback(oracle):
         c.close()
 
 
-def test_device_entropy_symbol_list_kernel(oracle, golden, manifest, monkeypatch):
-    """The other packing kernel of the device entropy stage (a lane per symbol: tic_set_entropy_kernel) through every test of the
-    stage: reference streams, content sweep (ZRL escapes, flat frames, ragged partition counts), two-level offsets, coefficients
-    without a code, the batch pipeline."""
-    c = T.Context(0)
-    c.check(N.load().tic_set_entropy_kernel(c.handle, N.ENTROPY_SYMBOL_LIST))
-    try:
-        test_device_entropy_stage_matches_reference_streams(c, oracle, golden, manifest)
-        test_compress_dev_resident(c, manifest)
-        test_device_entropy_content_sweep(c)
-        test_device_entropy_two_level_offsets(c, monkeypatch)
-        test_coefficient_without_huffman_code_raises_keyerror(c, golden)
-        frames = [rand_frame(6100 + i, 136, 264) for i in range(12)] + [np.tile(golden("lenna")["img"], (1, 1))[:136, :264]]
-        for q in (35, 80):
-            assert T.compress_batch(frames, q, threads=0, ctx=c) == [oracle.compress(f, q) for f in frames], q
-        assert N.load().tic_set_entropy_kernel(c.handle, 7) == N.TIC_E_ARG
-    finally:
-        c.check(N.load().tic_set_entropy_kernel(c.handle, N.ENTROPY_EIGHT_LANES))
-        c.close()
-
-
 def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch):
     """The strip walk uses 32-bit pixel offsets; a frame of 4 GiB or more is cut into bands of whole block rows, one launch each
     (round 2 ran such frames on the exact kernel only).  TIC_BAND_BYTES lowers the limit so that a 3000 x 2112 frame is cut into

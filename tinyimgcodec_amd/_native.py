@@ -13,7 +13,6 @@ LIB_PATH = os.path.join(_HERE, "libtinyimgcodec_hip.so")
 TIC_OK = 0
 TIC_E_ARG, TIC_E_QUALITY, TIC_E_RANGE, TIC_E_SPACE, TIC_E_STREAM, TIC_E_HIP, TIC_E_NODEVICE = -1, -2, -3, -4, -5, -6, -7
 KERNEL_AUTO, KERNEL_EXACT, KERNEL_HYBRID = 0, 1, 2
-ENTROPY_EIGHT_LANES, ENTROPY_SYMBOL_LIST = 0, 1  # tic_set_entropy_kernel
 
 
 class NativeUnavailable(RuntimeError):
@@ -76,7 +75,6 @@ SIGNATURES = {
     ),
     "tic_set_stats": (C.c_int, [_ctxp, C.c_int]),
     "tic_set_entropy_lane_kernel": (C.c_int, [_ctxp, C.c_int]),
-    "tic_set_entropy_kernel": (C.c_int, [_ctxp, C.c_int]),
     "tic_last_fallback_blocks": (C.c_int, [_ctxp, C.POINTER(C.c_ulonglong)]),
     "tic_entropy_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "tic_entropy_encode_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -107,7 +107,6 @@ struct tic_ctx {
     // than 512 bits (noise at quality >= ~85) makes it raise error 4: the stage is run again with the 8-lane kernel and the limit
     // drops below that quality for the rest of the context's life.
     int ent_lane_max_quality = -1;
-    int ent_base_mode = kEntropyEightLanes; // packing kernel without a per-block limit: 8 lanes per block or a lane per symbol (tic_set_entropy_kernel)
     void *d_stream_buf = nullptr;
     size_t d_stream_cap = 0;
     // device Huffman decoder (tic_decompress of long streams): tables, workspace, status
@@ -624,14 +623,6 @@ int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t 
 
 // Device entropy stage: pack with a lane per block (max_quality >= 1: for qualities up to it, with the automatic fall-back to the
 // 8-lane kernel described at ent_lane_max_quality) or always with 8 lanes per block (max_quality < 1, the default).
-// The packing kernel that takes any block: TIC_ENTROPY_EIGHT_LANES (8 lanes per block walk their scan positions) or
-// TIC_ENTROPY_SYMBOL_LIST (the wave's symbols compacted into a list, a lane per symbol).  Streams are identical.
-int tic_set_entropy_kernel(tic_ctx *ctx, int kind) {
-    TIC_LOCK(ctx);
-    if (!ctx || (kind != TIC_ENTROPY_EIGHT_LANES && kind != TIC_ENTROPY_SYMBOL_LIST)) return TIC_E_ARG;
-    ctx->ent_base_mode = kind == TIC_ENTROPY_SYMBOL_LIST ? kEntropySymbolList : kEntropyEightLanes;
-    return TIC_OK;
-}
 int tic_set_entropy_lane_kernel(tic_ctx *ctx, int max_quality) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
@@ -799,7 +790,7 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
     unsigned long long total_bits = 0;
     int err = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
-        const int mode = (attempt == 0 && quality <= ctx->ent_lane_max_quality) ? kEntropyLanePerBlock : ctx->ent_base_mode;
+        const int mode = (attempt == 0 && quality <= ctx->ent_lane_max_quality) ? kEntropyLanePerBlock : kEntropyEightLanes;
         const int par = ctx->ent_parity;
         ctx->ent_parity ^= 1;
         HIPCHK(ctx, entropy_gpu_fused((const int16_t *)d_coeffs_zz, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, d_out, 0,
@@ -807,7 +798,7 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
         HIPCHK(ctx, wait_stream(ctx));
         total_bits = ((volatile unsigned long long *)ctx->h_stat)[0];
         err = (int)(((volatile unsigned long long *)ctx->h_stat)[1] & 0xffffffffull);
-        if (err != 4 || mode != kEntropyLanePerBlock) break;
+        if (err != 4 || mode == kEntropyEightLanes) break;
         ctx->ent_lane_max_quality = quality - 1; // a block of this frame needs more than a lane string holds: 8-lane kernel from here on
     }
     if (err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
@@ -1312,7 +1303,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         if (e == hipSuccess) // entropy stage of the whole chunk: pack + place (headers, lengths); no zero fill
             e = entropy_gpu_fused((const int16_t *)s.d_coef, nblk, cnt, ctx->d_huff, s.d_work, s.work_bytes, s.d_streams, bound,
                                   (bound - 16) / 4, h, w, quality, s.d_lens, nullptr, s.d_err + par, s.d_err + (par ^ 1),
-                                  quality <= ctx->ent_lane_max_quality ? kEntropyLanePerBlock : ctx->ent_base_mode, st);
+                                  quality <= ctx->ent_lane_max_quality ? kEntropyLanePerBlock : kEntropyEightLanes, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_lens, s.d_lens, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_err, s.d_err + par, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(s.done, st);

@@ -26,8 +26,7 @@ void build_huff_dev(HuffDev *t);
 // mode: kEntropyLanePerBlock - the packing kernel with a lane per block (a wave = 64 blocks, up to 512 bits per block);
 //       *d_err = 4 when a block needs more: the caller runs the stage again with kEntropyEightLanes, the packing kernel with
 //       8 lanes per block, which has no such limit (any block the format allows).  Both feed the same placing kernel.
-//       kEntropySymbolList - the packing kernel with a lane per symbol (same partitions as kEntropyEightLanes, no limit either).
-enum { kEntropyLanePerBlock = 0, kEntropyEightLanes = 1, kEntropySymbolList = 2 };
+enum { kEntropyLanePerBlock = 0, kEntropyEightLanes = 1 };
 size_t entropy_fused_work_bytes(size_t nblocks_total);
 hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int nframes, const HuffDev *d_tab, void *d_work,
                              size_t work_bytes, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w, int quality,

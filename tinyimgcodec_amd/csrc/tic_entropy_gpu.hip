@@ -474,156 +474,6 @@ __global__ __launch_bounds__(kGroup * 64) void entropy_pack_kernel(const int16_t
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The packing kernel, symbol-list form: a LANE per SYMBOL.
-//
-// Same partitions, slots and sums as entropy_pack_kernel above (a wave = 8 blocks, it feeds the same placing kernel), same loads
-// (lane 8*b + k holds scan positions 8k..8k+7 of block b).  What differs is the walk: the kernel above lets every lane walk its
-// eight positions in turn, so a wave pays for eight positions whenever ANY of its 64 lanes has a non-zero coefficient there - the
-// lanes that hold positions 0..7 of a block always have, and Lenna (8 symbols per block) costs what noise costs (45 per block).
-// Here the non-zero coefficients of the wave are first compacted into a list in LDS, in stream order (block, scan position):
-// one entry per symbol - the DC difference (always), the non-zero AC coefficients, the block's EOB (always) - each holding the
-// value and the position.  A prefix over the lanes' symbol counts gives every lane its place in the list.  Then 64 symbols are
-// coded per round, one per lane: the zero run is the distance to the previous entry's position (the DC entry of the same block
-// if there is no other: no scan across lanes), size category, one table word, value bits, a prefix over the 64 lengths, and the
-// symbol is ORed into the wave's image of its bit range at its bit position (two LDS atomics).  Rounds = symbols / 64: six for
-// noise at q = 50, one or two for natural images.  ZRL escapes (runs of 16 and more zeros) are a rare, wave-uniform branch.
-// ---------------------------------------------------------------------------------------------------------------------------
-constexpr int kListEntries = 8 * 65 + 8; // DC + 63 AC + EOB per block
-
-template <int ABL> // ABL != 0: timing-only builds (tools/), wrong output: 1 no slot store, 2 no symbol rounds, 4 no list
-__global__ __launch_bounds__(kGroup * 64) void entropy_pack_list_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
-                                                                 unsigned long long blocks_per_frame, unsigned long long parts_per_frame,
-                                                                 unsigned long long groups_per_frame, uint32_t *__restrict__ stage,
-                                                                 uint32_t *__restrict__ nbits, uint32_t *__restrict__ gsum,
-                                                                 int *__restrict__ err_flag) {
-    __shared__ uint32_t tabw[256 + 16]; // one word per symbol: (total bits << 27) | (codeword << size); AC, then DC
-    __shared__ uint32_t wbits[kGroup];
-    __shared__ __attribute__((aligned(16))) uint32_t image_all[kGroup][512]; // kStageWords used
-    __shared__ uint32_t list_all[kGroup][kListEntries];
-    if (threadIdx.x < 256) tabw[threadIdx.x] = tab->ac_pack[threadIdx.x];
-    if (threadIdx.x < 16) tabw[256 + threadIdx.x] = tab->dc_pack[threadIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *image = image_all[wave];
-    uint32_t *list = list_all[wave];
-    reinterpret_cast<uint4 *>(image)[lane] = make_uint4(0u, 0u, 0u, 0u);
-    reinterpret_cast<uint4 *>(image)[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
-    const unsigned long long frame = blockIdx.x / groups_per_frame, g = blockIdx.x - frame * groups_per_frame;
-    const unsigned long long pif = g * (unsigned long long)kGroup + (unsigned long long)wave;
-    const unsigned long long part = frame * parts_per_frame + pif;
-    const bool active = pif < parts_per_frame;
-    uint32_t wave_bits = 0;
-    const unsigned long long bif = pif * 8ull + (unsigned long long)(lane >> 3); // block index inside the frame
-    const int k = lane & 7;
-    const bool valid = active && bif < blocks_per_frame;
-    const unsigned long long frame_first = frame * blocks_per_frame;
-    const unsigned long long blk = frame_first + (valid ? bif : blocks_per_frame - 1);
-    uint4 cw = make_uint4(0u, 0u, 0u, 0u);
-    if (valid) cw = *reinterpret_cast<const uint4 *>(zz + blk * 64 + k * 8);
-    const uint32_t cq[4] = {cw.x, cw.y, cw.z, cw.w};
-    int dc_diff = 0;
-    {
-        // codec.py:34-35: DPCM over the blocks of one frame in raster order, the first block raw
-        const int c0 = (int)(int16_t)(cw.x & 0xffffu);
-        const int prev_in_wave = __shfl_up(c0, 8, 64);
-        if (k == 0 && valid) {
-            int prev = prev_in_wave;
-            if (lane == 0) prev = bif ? (int)zz[(blk - 1) * 64] : 0;
-            dc_diff = bif ? c0 - prev : c0;
-        }
-    }
-    // ---- the list: entry = (value << 10) | (block in wave << 7) | position; position 0 = DC difference, 64 = EOB -----------------
-    uint32_t nz_mask = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t h = (cq[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-        nz_mask |= (h != 0u && !(k == 0 && j == 0)) ? (1u << j) : 0u;
-    }
-    const uint32_t mine = valid ? (uint32_t)__builtin_popcount(nz_mask) + (k == 0 ? 1u : 0u) + (k == 7 ? 1u : 0u) : 0u;
-    const uint32_t incl_n = wave_prefix_sum_u32(mine);
-    const uint32_t nsym = (uint32_t)__builtin_amdgcn_readlane((int)incl_n, 63);
-    const uint32_t posb = ((uint32_t)(lane >> 3) << 7) | (uint32_t)(k * 8);
-    if (!(ABL & 4) && valid) {
-        uint32_t o = incl_n - mine;
-        if (k == 0) list[o++] = ((uint32_t)dc_diff << 10) | posb;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int v = (int)(int16_t)((cq[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-            if ((nz_mask >> j) & 1u) list[o + (uint32_t)__builtin_popcount(nz_mask & ((1u << j) - 1u))] = ((uint32_t)v << 10) | (posb + (uint32_t)j);
-        }
-        if (k == 7) list[o + (uint32_t)__builtin_popcount(nz_mask)] = ((uint32_t)(lane >> 3) << 7) | 64u;
-    }
-    __syncthreads(); // the tables (and, for the wave itself, its list)
-    if (active) {
-        uint32_t base = 0; // bits of the rounds so far (wave-uniform)
-        int err = 0;
-        const uint32_t zw = tabw[0xF0]; // ZRL = (15,0)
-        const uint32_t zcode = zw & 0x07ffffffu, zlen = zw >> 27;
-        if (!(ABL & 2))
-        for (uint32_t t0 = 0; t0 < nsym; t0 += 64u) {
-            const uint32_t t = t0 + (uint32_t)lane;
-            const bool on = t < nsym;
-            const uint32_t e = on ? list[t] : 64u;
-            const uint32_t ep = (on && t != 0u) ? list[t - 1u] : 0u;
-            const int v = (int)e >> 10;
-            const uint32_t pos = e & 127u;
-            const bool is_ac = pos - 1u < 63u;
-            int sz = size_category(v);
-            sz = sz > 15 ? 15 : sz;
-            const uint32_t run = is_ac ? pos - (ep & 127u) - 1u : 0u; // zeros between this coefficient and the entry before it
-            uint32_t idx = ((run & 15u) << 4) | (uint32_t)sz;
-            idx = pos == 0u ? 256u + (uint32_t)sz : idx;
-            const uint32_t tw = tabw[idx]; // (an EOB entry has value 0, run 0: index 0 is the EOB code)
-            err |= (on && tw == 0u) ? 1 : 0; // no code: AC sizes above 10, DC differences above 11 bits (the reference raises KeyError)
-            const uint32_t len = on ? tw >> 27 : 0u;
-            const uint32_t sym = (tw & 0x07ffffffu) | value_bits(v, sz);
-            const uint32_t nzrl = run >> 4; // ZRL = (15,0) escapes in front of the symbol, huffman.py:26-28
-            const uint32_t tot = len + zlen * nzrl;
-            const uint32_t incl = wave_prefix_sum_u32(tot);
-            uint32_t p = base + incl - tot;
-            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (__any(nzrl != 0u)) {
-                for (uint32_t z = 0; z < nzrl; z++) {
-                    const unsigned long long x = ((unsigned long long)zcode << (64u - zlen)) >> (p & 31u);
-                    atomicOr(image + (p >> 5), (uint32_t)(x >> 32));
-                    if ((uint32_t)x) atomicOr(image + (p >> 5) + 1u, (uint32_t)x);
-                    p += zlen;
-                }
-            }
-            if ((ABL & 8) && len != 0u) { // timing only: plain stores instead of the atomics
-                const unsigned long long x = ((unsigned long long)sym << (64u - len)) >> (p & 31u);
-                image[p >> 5] = (uint32_t)(x >> 32);
-                if ((uint32_t)x) image[(p >> 5) + 1u] = (uint32_t)x;
-            } else if ((ABL & 16) && len != 0u) { // timing only: no image write at all
-                const unsigned long long x = ((unsigned long long)sym << (64u - len)) >> (p & 31u);
-                if (x == 0x123456789ull) image[p >> 5] = 1u;
-            } else if (len != 0u) {
-                const unsigned long long x = ((unsigned long long)sym << (64u - len)) >> (p & 31u);
-                atomicOr(image + (p >> 5), (uint32_t)(x >> 32));
-                if ((uint32_t)x) atomicOr(image + (p >> 5) + 1u, (uint32_t)x);
-            }
-        }
-        if (err) atomicMax(err_flag, 1);
-        wave_bits = base;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t nwords = (wave_bits + 31u) >> 5;
-        uint32_t *slot = stage + part * (unsigned long long)kStageWords;
-        if (!(ABL & 1))
-            for (uint32_t i = (uint32_t)lane; i < nwords; i += 64u) store_u32_wt(slot + i, image[i]);
-        if (lane == 0) nbits[part] = wave_bits;
-    }
-    if (lane == 0) wbits[wave] = wave_bits;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int i = 0; i < kGroup; i++) t += wbits[i];
-        gsum[blockIdx.x] = t;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
 // The packing kernel, round-3 form: a LANE per block, a wave per partition of 64 blocks.
 //
 // Round 2's kernel above (8 lanes per block, 8 scan positions per lane) is instruction-bound at 471 vector instructions per
@@ -1039,7 +889,7 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
                              unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next, int mode,
                              hipStream_t stream) {
     if (blocks_per_frame == 0 || nframes <= 0) return hipSuccess;
-    const bool lane_form = mode == kEntropyLanePerBlock, list_form = mode == kEntropySymbolList;
+    const bool lane_form = mode == kEntropyLanePerBlock;
     const size_t part_blocks = lane_form ? (size_t)kPB : 8, grp = lane_form ? (size_t)kGroupL : (size_t)kGroup;
     const size_t place = lane_form ? 8 : 32; // partitions per placing workgroup
     const size_t parts_per_frame = (blocks_per_frame + part_blocks - 1) / part_blocks;
@@ -1080,27 +930,6 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
         TIC_PACKL(0);
 #endif
 #undef TIC_PACKL
-    } else if (list_form) {
-#define TIC_PACKS(A)                                                                                                                   \
-    hipLaunchKernelGGL(entropy_pack_list_kernel<A>, pack_grid, dim3(kGroup * 64), 0, stream, d_zz, d_tab, (unsigned long long)blocks_per_frame, \
-                       (unsigned long long)parts_per_frame, (unsigned long long)groups_per_frame, stage, nbits, gsum, d_err)
-#ifdef TIC_ABLATION
-        static const int sabl = getenv("TIC_ENT_ABL") ? atoi(getenv("TIC_ENT_ABL")) : 0;
-        switch (sabl) {
-        case 1: TIC_PACKS(1); break;
-        case 2: TIC_PACKS(2); break;
-        case 3: TIC_PACKS(3); break;
-        case 4: TIC_PACKS(4); break;
-        case 6: TIC_PACKS(6); break;
-        case 7: TIC_PACKS(7); break;
-        case 8: TIC_PACKS(8); break;
-        case 16: TIC_PACKS(16); break;
-        default: TIC_PACKS(0); break;
-        }
-#else
-        TIC_PACKS(0);
-#endif
-#undef TIC_PACKS
     } else {
 #ifdef TIC_ABLATION
         static const int abl = getenv("TIC_ENT_ABL") ? atoi(getenv("TIC_ENT_ABL")) : 0;

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Needs the symbol-list packing kernel of commit b4b7c1c, which is not in the product: check that commit out to re-run.)
 # Packing kernels of the device entropy stage side by side: 8 lanes per block (default) against the symbol list, noise and Lenna,
 # per-kernel times by rocprofv3.  Usage (on the GPU box): tools/ent_list_ab.sh [dim] [reps]
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1

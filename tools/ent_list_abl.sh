@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Needs the symbol-list packing kernel of commit b4b7c1c, which is not in the product: check that commit out to re-run.)
 # Timing builds of the symbol-list packing kernel (experiment library): 0 full, 1 no slot store, 2 no symbol rounds, 6 no list and no
 # rounds, 7 nothing but loads and counts.  Usage (on the GPU box): tools/ent_list_abl.sh [content] [abls...]
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1

@@ -12,8 +12,6 @@ from tinyimgcodec_amd import _native as N
 L = N.load(); ctx = T.Context(0)
 if os.environ.get('TIC_ENT_LANE'):  # the lane-per-block packing kernel (not the default)
     ctx.check(L.tic_set_entropy_lane_kernel(ctx.handle, 99))
-if os.environ.get('TIC_ENT_LIST'):  # the symbol-list packing kernel
-    ctx.check(L.tic_set_entropy_kernel(ctx.handle, int(os.environ['TIC_ENT_LIST'])))
 dim = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 h = w = dim
@@ -33,7 +31,4 @@ for q in (50,):
     for k in range(reps):
         ctx.check(L.tic_compress_dev(ctx.handle, d_img, h, w, w, q, d_out, cap, C.byref(n)))
     dt = (time.perf_counter() - t) / reps
-    import hashlib
-    buf = np.empty(n.value, np.uint8)
-    ctx.check(L.tic_memcpy_d2h(ctx.handle, buf.ctypes.data, d_out, n.value))
-    print("tic_compress_dev %dx%d q=%d: %.1f us per frame, %.1f Gpix/s, stream %d bytes, sha256 %s" % (h, w, q, dt * 1e6, h * w / dt / 1e9, n.value, hashlib.sha256(buf.tobytes()).hexdigest()[:16]))
+    print("tic_compress_dev %dx%d q=%d: %.1f us per frame, %.1f Gpix/s, stream %d bytes" % (h, w, q, dt * 1e6, h * w / dt / 1e9, n.value))
