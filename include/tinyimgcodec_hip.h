@@ -181,6 +181,10 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
  * stream crosses PCIe upwards, only the pixels downwards), 2 = the host decoder (short streams; any long stream in which the
  * device decoder met something unusual - the host's bit-serial path reproduces the reference's behaviour on malformed streams). */
 int tic_last_decode_path(tic_ctx *ctx);
+/* ... and, when the device decoder handed a long stream to the host decoder, why (0: it did not; bit 1 an incident in the stream's
+ * first range, 4 a range without a synchronisation point, 8 / 16 / 32 an incident on the true chain, 2 trace overflow, 64 no block
+ * produced). */
+int tic_last_decode_giveup(tic_ctx *ctx);
 
 /* ---- multi-GPU (the reference has no counterpart: it is single-process, codec.py:133-164 runs one image
  *      at a time).  One process per GPU; a batch shards by independent frames (frame i -> rank i / ceil(B/G)) with no

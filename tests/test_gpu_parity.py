@@ -993,8 +993,8 @@ def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch)
 
 
 def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monkeypatch):
-    """Streams of >= 16,384 blocks are Huffman-decoded on the device (speculative measuring per 2048-bit range, parallel stitch,
-    decode, DC prefix sum): same pixels as the host decoders and as the oracle on noise at three qualities, natural, smooth and
+    """Streams of >= 16,384 blocks are Huffman-decoded on the device (speculative measuring per range, parallel stitch, block
+    positions, a lane per block decoding, DC prefix sum): same pixels as the host decoders and as the oracle on noise at three qualities, natural, smooth and
     sparse content, a frame whose block count is not a multiple of anything convenient, and streams damaged in the middle or cut
     short (there the device decoder either succeeds on the true chain or gives up and the host's bit-serial path takes over)."""
     L = N.load()
@@ -1015,6 +1015,8 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
             got = T.decompress(s, ctx=ctx)
             long_enough = len(s) * 8 >= 128 + (1 << 21)  # (shorter streams decode serially on the host in well under a millisecond)
             assert L.tic_last_decode_path(ctx.handle) == (1 if long_enough else 2), (name, q, len(s))
+            if long_enough:
+                assert L.tic_last_decode_giveup(ctx.handle) == 0, (name, q)
             assert np.array_equal(got, want), (name, q)
             if name == "noise 2048x2048":  # every range length, and the second try with 2048 bits when 512 is shorter than the blocks (q=90)
                 for rb in ("512", "1024", "2048"):
@@ -1037,3 +1039,5 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
                     else:
                         bad = bad[: len(s) // 3] + bytes(rng.integers(0, 256, 4096, dtype=np.uint8))
                     assert np.array_equal(T.decompress(bytes(bad), ctx=ctx), oracle.decompress(bytes(bad))), (name, q, k)
+                    # (when the device decoder left the stream to the host it says why: a non-zero set of DecStatus::giveup bits)
+                    assert (L.tic_last_decode_path(ctx.handle) == 1) == (L.tic_last_decode_giveup(ctx.handle) == 0) or len(bad) * 8 < 128 + (1 << 21)

@@ -103,6 +103,7 @@ SIGNATURES = {
     "tic_idctq_scaled": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "tic_decompress": (C.c_int, [_ctxp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "tic_last_decode_path": (C.c_int, [_ctxp]),
+    "tic_last_decode_giveup": (C.c_int, [_ctxp]),
     "tic_selftest_transpose": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "tic_comm_create": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "tic_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -115,6 +115,7 @@ struct tic_ctx {
     size_t dec_work_bytes = 0;
     DecStatus *h_dec_status = nullptr, *d_dec_status = nullptr; // host-mapped
     int last_decode_path = 0;                                  // 0 none, 1 device decoder, 2 host decoder (tic_last_decode_path)
+    int last_decode_giveup = 0;                                // why the device decoder handed the last long stream to the host (DecStatus::giveup bits)
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
     std::vector<Slot> bslots;
     size_t bslot_img_bytes = 0, bslot_coef_bytes = 0;
@@ -1455,7 +1456,8 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
         }
         break;
     }
-    if (st.giveup != 0 || st.m == 0 || st.m > n) return TIC_OK; // the host decoder takes the whole stream
+    ctx->last_decode_giveup = st.giveup | ((st.m == 0 || st.m > n) ? 64 : 0);
+    if (ctx->last_decode_giveup != 0) return TIC_OK; // the host decoder takes the whole stream
     if (st.m < n) { // the blocks that start in the stream's last 2048 bits: serial on the host, a few KB uploaded behind the others
         std::vector<int16_t> tail((n - (size_t)st.m) * 64);
         entropy_decode_tail(data, len, h, w, (size_t)st.m, (size_t)st.pos_out, st.dc_out, tail.data());
@@ -1484,9 +1486,17 @@ int tic_last_decode_path(tic_ctx *ctx) {
     return ctx ? ctx->last_decode_path : TIC_E_ARG;
 }
 
+// Diagnostics: the device decoder's reason for leaving the last long stream to the host decoder (0: it did not; bits: 1 an incident
+// in the first range, 4 a range without a synchronisation point, 8 / 16 / 32 an incident on the true chain, 2 trace overflow, 64 no block produced).
+int tic_last_decode_giveup(tic_ctx *ctx) {
+    TIC_LOCK(ctx);
+    return ctx ? ctx->last_decode_giveup : TIC_E_ARG;
+}
+
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
+    ctx->last_decode_giveup = 0;
     int h, w, quality;
     uint32_t flag;
     if (parse_header(data, len, &h, &w, &quality, &flag) != TIC_OK)

@@ -6,24 +6,31 @@
 // re-synchronise: a decoder started at an arbitrary bit as if a block began there lands on true block starts within a block or two.
 // The host decoder uses that on 16 threads (tic_entropy.cpp decode_parallel: 7.7 ms for a 4096^2 stream); this is the same idea on
 // tens of thousands of lanes, and the coefficients never leave the device:
-//   measure   a lane per RANGE of kRange stream bits: measures blocks from the range's first bit as if a block started there (a
-//             guess for every range but the first), recording each block's first bit; an invalid prefix or a block of more than 63
-//             coefficients moves the guess on by one bit.
+//   measure   a lane per RANGE of kRange stream bits: walks the symbols from the range's first bit as if a block started there (a
+//             guess for every range but the first), one symbol per step, recording the first bit of every block that decoded cleanly
+//             from a block-start guess to its EOB; an invalid prefix or a block of more than 63 coefficients does not restart the
+//             walk: it goes on in the AC state (a walk in step with the true symbols stays in step; the next true EOB ends on a true
+//             block start) and the block in work is not recorded.
 //   stitch    a lane per range, all in parallel: HYPOTHESIS: the true chain enters range t where range t-1's trace ended.  From there
-//             the lane measures blocks "by hand" until it lands on a block start the range's own trace recorded; from that entry on
-//             the trace IS the true chain (a block start carries no state), so the trace's end is where the true chain enters range
-//             t+1 - which is the hypothesis for t+1.  Range 0 starts on a true block start, so if EVERY lane finds its
-//             synchronisation point inside its range, induction makes every hypothesis true.  Otherwise: give up.
+//             the lane measures blocks "by hand" (recording their first bits too) until it lands on a block start the range's own
+//             trace recorded; from that entry on the trace IS the true chain (a block start carries no state), so the trace's end is
+//             where the true chain enters range t+1 - which is the hypothesis for t+1.  Range 0 starts on a true block start, so if
+//             EVERY lane finds its synchronisation point inside its range, induction makes every hypothesis true.  Otherwise: give up.
 //   scan      exclusive prefix sum of the ranges' true block counts -> index of each range's first block.
-//   decode    a lane per range decodes its true blocks (by-hand ones and trace ones are consecutive in the stream) through an LDS
-//             image of the block into the int16 [N][64] coefficient array, DC differences aside.
+//   bpos      a lane per range writes the first bit of each of its true blocks (by-hand ones, then the trace from the entry on).
+//   decode    a lane per BLOCK decodes it from its first bit into the (zeroed) int16 [N][64] coefficient array, DC differences aside.
 //   scan      inclusive prefix sum of the DC differences (np.cumsum), saturated into entry 0 of every block.
+// The walks are one dependent chain of look-ups per lane: stream words and tables are staged in LDS (the codewords of 12-16 bits
+// included: as look-ups in memory they stalled a whole wave in every second step), and the chain is kept short - a range for the
+// measure kernel, a block for the decode kernel.  7 MB stream (4096^2 noise, q=50), rocprofv3: measure 282 -> 125 us, decode
+// 102 -> 67 us against the first version of this file (profiles/r03_decoder.txt).
 // Anything unusual ON THE TRUE CHAIN - an invalid prefix, more than 63 coefficients in a block, a range without a synchronisation
 // point, a measurement that failed behind the synchronisation point - raises a flag and the caller decodes the whole stream on the
 // host, whose bit-serial path reproduces the reference's behaviour on malformed streams (exactly the host parallel decoder's rule).
 // Blocks that start in the last 2048 bits of the stream are left to the host as well (`m` blocks are produced here, with the read
 // position and the running DC behind them).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -39,17 +46,54 @@ namespace {
 constexpr int kRangeMax = 2048;
 __host__ __device__ constexpr uint32_t cap_of(uint32_t range) { return range / 6u + 2u; } // block starts a range can hold (a block has at least 6 bits: 2-bit DC code + EOB)
 
-// 32 stream bits (MSB first) from bit `pos`; the two big-endian words around it are cached in registers and reloaded when the
-// position leaves them (a symbol is 5-8 bits on average: one reload per ~5 symbols).
+// The stream bits a workgroup walks, staged in LDS.  A workgroup is one wave, its lanes own 64 consecutive ranges: one contiguous
+// window of 64 ranges plus the longest block a lane may run into behind its range (kOver words).  The kernels are one dependent chain
+// of look-ups per lane; with the window words fetched from global memory (round 3's first version: two dependent loads per ~5
+// symbols, at a few waves per CU) that chain was memory latency: measure 241 us, decode 102 us for a 7 MB stream.  The words are
+// staged byte-swapped (the stream is big-endian) with coalesced loads, one padding word per range so that the lanes - a range apart -
+// fall on different banks.  A word outside the window (cannot happen by the bounds in the kernels) is read from memory.
+constexpr uint32_t kOver = 66;                                   // 1,728 bits of the longest block + the 64-bit window, in words
+constexpr uint32_t kStageMax = 64 * (kRangeMax / 32) + kOver;    // window words of the longest range
+constexpr uint32_t kStageLds = kStageMax + kStageMax / 16 + 2;   // ... with padding (the shortest range pads most)
+struct Bits {
+    const uint32_t *lds, *glob;
+    uint32_t wbase, wcount, sh, nwords; // first word of the window, its length, log2(words per range); words of the stream
+};
+__device__ __forceinline__ uint32_t word_be(const Bits &s, uint32_t wi) {
+    const uint32_t r = wi - s.wbase;
+    if (r < s.wcount) return s.lds[r + (r >> s.sh)];
+    return wi < s.nwords ? __builtin_bswap32(s.glob[wi]) : 0u;
+}
+__device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_word, uint32_t wcount, uint32_t sh, uint32_t nwords) {
+    Bits s;
+    s.lds = lds;
+    s.glob = words;
+    s.wbase = first_word;
+    s.wcount = wcount;
+    s.sh = sh;
+    s.nwords = nwords;
+    for (uint32_t r = threadIdx.x; r < wcount; r += blockDim.x) {
+        const uint32_t wi = first_word + r;
+        lds[r + (r >> sh)] = wi < nwords ? __builtin_bswap32(words[wi]) : 0u;
+    }
+    __syncthreads();
+    return s;
+}
+// the window of 64 consecutive ranges from bit first_bit (128 + 64 k range: a multiple of 32)
+__device__ __forceinline__ Bits stage_bits(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_bit, uint32_t range, uint32_t nwords) {
+    return stage_words(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, range == 512u ? 4u : (range == 1024u ? 5u : 6u), nwords);
+}
+// 32 stream bits (MSB first) from bit `pos`; the two words around it are cached in registers and refetched when the position
+// leaves them (a symbol is 5-8 bits on average: one refetch per ~5 symbols).
 struct BitWin {
     uint32_t idx, a, b;
 };
-__device__ __forceinline__ uint32_t peek32(const uint32_t *__restrict__ words, uint32_t pos, BitWin &c) {
+__device__ __forceinline__ uint32_t peek32(const Bits &words, uint32_t pos, BitWin &c) {
     const uint32_t wi = pos >> 5;
     if (wi != c.idx) {
         c.idx = wi;
-        c.a = __builtin_bswap32(words[wi]);
-        c.b = __builtin_bswap32(words[wi + 1]);
+        c.a = word_be(words, wi);
+        c.b = word_be(words, wi + 1);
     }
     const uint32_t sh = pos & 31u;
     return sh ? __builtin_amdgcn_alignbit(c.a, c.b, 32u - sh) : c.a; // ({a,b} >> (32 - sh)) low word = (a << sh) | (b >> (32 - sh))
@@ -61,14 +105,22 @@ __device__ __forceinline__ int value_of(uint32_t pk, int len, int size) {
     return (x >> (size - 1)) ? (int)x : (int)x - ((1 << size) - 1);
 }
 
+constexpr int kLongFirst = 0xff40, kLongCodes = 0x10000 - kLongFirst; // ac16 entries of the 11-bit prefixes 0x7fa..0x7ff
+constexpr int kLutLds = 4096 + kLongCodes;
+__device__ __forceinline__ uint32_t long_code(const uint16_t *lut, uint32_t pk) {
+    const uint32_t i = (pk >> 16) - (uint32_t)kLongFirst;
+    return i < (uint32_t)kLongCodes ? lut[4096u + i] : 0u;
+}
+
 // One block on the table-driven fast path: the device form of block_fast() in tic_entropy.cpp (same tables, same rules).  STORE: the
 // coefficients 1..63 go to c (zeroed by the caller).  Returns false on anything unusual with nothing consumed.
 template <bool STORE>
-__device__ __forceinline__ bool block_dev(const uint32_t *__restrict__ words, const DecLutsDev *__restrict__ L, const uint16_t *ac11 /* LDS */,
+__device__ __forceinline__ bool block_dev(const Bits &words, const DecLutsDev *__restrict__ L, const uint16_t *lut /* LDS: dc11, ac11 */,
                                           uint32_t pos0, BitWin &win, int16_t *c, int &dc_diff, uint32_t &used) {
+    const uint16_t *ac11 = lut + 2048;
     uint32_t pos = pos0;
     uint32_t pk = peek32(words, pos, win);
-    uint32_t e = L->dc11[pk >> 21];
+    uint32_t e = lut[pk >> 21];
     if (!e) return false; // DC categories are at most 9 bits long
     int len = (int)(e >> 8), size = (int)(e & 15u);
     dc_diff = value_of(pk, len, size);
@@ -77,7 +129,7 @@ __device__ __forceinline__ bool block_dev(const uint32_t *__restrict__ words, co
     for (;;) {
         pk = peek32(words, pos, win);
         e = ac11[pk >> 21];
-        if (!e) e = L->ac16[pk >> 16];
+        if (!e) e = long_code(lut, pk);
         if (!e) return false;
         len = (int)(e >> 8);
         size = (int)(e & 15u);
@@ -92,37 +144,94 @@ __device__ __forceinline__ bool block_dev(const uint32_t *__restrict__ words, co
     return true;
 }
 
-__device__ __forceinline__ void load_ac11(uint16_t *lds, const DecLutsDev *__restrict__ L) {
-    for (int i = threadIdx.x; i < 2048 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(L->ac11)[i];
+// dc11 and ac11 (adjacent in DecLutsDev) into LDS: lut[0..2047] = DC, lut[2048..4095] = AC, lut[4096..4287] = long AC codewords
+__device__ __forceinline__ void load_lut(uint16_t *lds, const DecLutsDev *__restrict__ L) {
+    static_assert(offsetof(DecLutsDev, ac11) == offsetof(DecLutsDev, dc11) + 4096, "dc11 and ac11 are adjacent");
+    for (int i = threadIdx.x; i < 4096 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(L->dc11)[i];
+    // ... and the AC codewords of 12 to 16 bits: their 11-bit prefixes are 0x7fa..0x7ff (the fixed AC table is a complete prefix code:
+    // every other prefix resolves in ac11), i.e. entries 0xff40..0xffff of ac16.  One symbol in a hundred at q = 50 - but with 64 lanes
+    // side by side every second step has one, and as a look-up in the 128 KB table in memory it stalled the whole wave for a microsecond.
+    for (int i = threadIdx.x; i < kLongCodes; i += blockDim.x) lds[4096 + i] = L->ac16[kLongFirst + i];
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ words, const DecLutsDev *__restrict__ L, uint32_t fast_end,
+// One SYMBOL per step, for the lanes of a wave side by side (measure and decode kernels).  block_dev() above is a loop per block:
+// the lanes of a wave then wait for each other at every block end (a wave-step lasts as long as its longest block) - 630 symbol
+// steps per wave where the longest lane has ~250 symbols, 33,000 instructions per wave at one wave per SIMD: measure 241-293 us,
+// decode 102 us for a 7 MB stream.  Here the position inside the block (k: 0 = the DC category comes next) is lane state and a
+// block end is just another step.  Same tables, same rules as block_dev().
+struct Sym {
+    bool bad, eob, dc, nocode; // bad: nocode (an invalid prefix) or more than 63 coefficients in the block
+    uint32_t bits; // code + value bits
+    int k_at;      // AC coefficient: its scan position; the state behind it is k_at + 1
+    int value;
+};
+__device__ __forceinline__ Sym next_symbol(const Bits &words, const DecLutsDev *__restrict__ L, const uint16_t *lut, uint32_t pos, int k, BitWin &win) {
+    const uint32_t pk = peek32(words, pos, win);
+    uint32_t e = lut[(k ? 2048u : 0u) + (pk >> 21)];
+    if (!e && k) e = long_code(lut, pk);
+    Sym s;
+    const int len = (int)(e >> 8), size = (int)(e & 15u);
+    s.dc = k == 0;
+    s.eob = k != 0 && (e & 0xffu) == 0u;
+    s.k_at = k + (int)((e >> 4) & 15u);
+    s.nocode = e == 0u;
+    s.bad = s.nocode || (!s.dc && !s.eob && s.k_at > 63);
+    s.bits = (uint32_t)(len + size);
+    s.value = value_of(pk, len, size);
+    return s;
+}
+
+__global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, const DecLutsDev *__restrict__ L, uint32_t fast_end,
                                                          uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts, uint32_t *__restrict__ nrec,
                                                          uint32_t *__restrict__ endpos, int *__restrict__ lastbrk, DecStatus *__restrict__ st) {
-    __shared__ uint16_t ac11[2048];
-    load_ac11(ac11, L);
+    __shared__ uint16_t lut[kLutLds];
+    __shared__ uint32_t sbits[kStageLds];
+    load_lut(lut, L);
+    const Bits words = stage_bits(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords);
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= nranges) return;
     const uint32_t lo = 128u + t * range;
     const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
     BitWin win = {0xffffffffu, 0u, 0u};
-    uint32_t pos = lo, cnt = 0;
-    int brk = -1;
-    while (pos < hi) {
-        int d;
-        uint32_t used;
-        if (block_dev<false>(words, L, ac11, pos, win, nullptr, d, used)) {
-            if (cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(pos - lo);
-            cnt++;
-            pos += used;
-        } else {
+    uint32_t pos = lo, bstart = lo, cnt = 0; // a block that STARTS in front of `hi` is measured to its end
+    int k = 0, brk = -1;
+    bool clean = true; // the block in work began at a block-start guess and has decoded without an incident so far
+    bool live = pos < hi;
+    while (live) {
+        const Sym s = next_symbol(words, L, lut, pos, k, win);
+        if (s.bad) {
             if (t == 0u) { // the true chain itself: unusual
                 atomicOr(&st->giveup, 1);
-                break;
+                pos = bstart;
+                live = false;
+            } else {
+                // A guess that led nowhere (or, behind the point of synchronisation, a malformed stream).  The walk goes on from the next
+                // bit IN THE AC STATE: most of a block is AC symbols, a walk that has fallen into step with the true symbols stays in
+                // step, and the next true EOB then ends on a true block start.  (The first version went back to the failed block's
+                // first bit + 1 and took it for a block start: every incident threw away up to 63 symbols of walking and the
+                // alignment they had reached - the unluckiest lane of a wave walked 750 symbols for the 210 of its range.)  The block
+                // in work is not recorded; the one behind its EOB is a fresh guess.
+                brk = (int)cnt;
+                pos += s.nocode ? 1u : s.bits; // (a symbol that merely overflows the block is a symbol: the walk stays in step)
+                k = 1;
+                clean = false;
+                if (pos >= hi + 1800u) live = false; // (no EOB in sight far behind the range: its trace ends here, unsynchronised)
             }
-            brk = (int)cnt; // a guess that led nowhere (or, behind the point of synchronisation, a malformed stream): next bit
-            pos++;
+        } else {
+            pos += s.bits;
+            if (s.eob) {
+                if (clean) {
+                    if (cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(bstart - lo);
+                    cnt++;
+                }
+                bstart = pos;
+                clean = true;
+                k = 0;
+                live = pos < hi;
+            } else {
+                k = s.dc ? 1 : s.k_at + 1;
+            }
         }
     }
     if (cnt > cap_of(range)) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
@@ -131,23 +240,26 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
     lastbrk[t] = brk;
 }
 
-__global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restrict__ words, const DecLutsDev *__restrict__ L, uint32_t fast_end,
+__global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, const DecLutsDev *__restrict__ L, uint32_t fast_end,
                                                         uint32_t range, uint32_t nranges, const uint16_t *__restrict__ starts, const uint32_t *__restrict__ nrec,
                                                         const uint32_t *__restrict__ endpos, const int *__restrict__ lastbrk,
-                                                        uint32_t *__restrict__ nblk, uint32_t *__restrict__ pstart, DecStatus *__restrict__ st) {
-    __shared__ uint16_t ac11[2048];
-    load_ac11(ac11, L);
+                                                        uint32_t *__restrict__ nblk, uint16_t *__restrict__ hand,
+                                                        uint32_t *__restrict__ entry, DecStatus *__restrict__ st) {
+    __shared__ uint16_t lut[kLutLds];
+    __shared__ uint32_t sbits[kStageLds];
+    load_lut(lut, L);
+    const Bits words = stage_bits(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords);
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= nranges) return;
+    entry[t] = nrec[t]; // (until the walk below meets the trace: no trace block belongs to the true chain)
     if (t == 0u) {
         nblk[0] = nrec[0];
-        pstart[0] = 128u;
+        entry[0] = 0u;
         return;
     }
     const uint32_t lo = 128u + t * range;
     const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
     uint32_t pos = endpos[t - 1]; // hypothesis: where the true chain enters this range
-    pstart[t] = pos;
     if (pos >= fast_end) { // the chain left the fast part of the stream in front of this range
         nblk[t] = 0u;
         return;
@@ -174,11 +286,13 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
             // from here on the trace walked the true chain: a failed measurement behind this point is the stream's fault
             if (lastbrk[t] > (int)a) atomicOr(&st->giveup, 8);
             nblk[t] = by_hand + (nrec[t] - a);
+            entry[t] = a;
             return;
         }
         int d;
         uint32_t used;
-        if (!block_dev<false>(words, L, ac11, pos, win, nullptr, d, used)) { // unusual on the true chain
+        if (by_hand < cap_of(range)) hand[(size_t)t * cap_of(range) + by_hand] = (uint16_t)want; // first bit of the by-hand block (pos >= lo: the walk enters behind the range before)
+        if (!block_dev<false>(words, L, lut, pos, win, nullptr, d, used)) { // unusual on the true chain
             atomicOr(&st->giveup, 16);
             nblk[t] = by_hand;
             return;
@@ -254,42 +368,58 @@ struct StoreDc {
     }
 };
 
-__global__ __launch_bounds__(64) void dec_decode_kernel(const uint32_t *__restrict__ words, const DecLutsDev *__restrict__ L, uint32_t nranges,
-                                                        const uint32_t *__restrict__ nblk, const uint32_t *__restrict__ pstart,
-                                                        const uint32_t *__restrict__ first_blk, const long long *__restrict__ total_blocks,
-                                                        unsigned long long n_want, int16_t *__restrict__ zz, int32_t *__restrict__ dcdiff,
-                                                        DecStatus *__restrict__ st) {
-    __shared__ uint16_t ac11[2048];
-    __shared__ __attribute__((aligned(16))) int16_t img[64][72]; // a block per lane (64 coefficients + 8 of padding: the lanes' 16-byte
-                                                                 // pieces fall on different bank groups)
-    load_ac11(ac11, L);
+// First bit of every block of the true chain: range t's blocks are the ones its stitch walked by hand, then its trace from the entry
+// on; first_blk[t] (the scan of the counts) is the index of the first of them.
+__global__ __launch_bounds__(64) void dec_bpos_kernel(uint32_t range, uint32_t nranges, const uint16_t *__restrict__ starts, const uint16_t *__restrict__ hand,
+                                                      const uint32_t *__restrict__ nrec, const uint32_t *__restrict__ entry, const uint32_t *__restrict__ nblk,
+                                                      const uint32_t *__restrict__ first_blk, unsigned long long nblocks, uint32_t *__restrict__ bpos) {
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= nranges) return;
+    const uint32_t lo = 128u + t * range, cap = cap_of(range);
+    const uint32_t nr = nrec[t] < cap ? nrec[t] : cap, a = entry[t] < nr ? entry[t] : nr;
+    const uint32_t nb = nblk[t], from_trace = nr - a < nb ? nr - a : nb, by_hand = nb - from_trace;
+    const unsigned long long first = first_blk[t];
+    for (uint32_t i = 0; i < by_hand && i < cap && first + i < nblocks; i++) bpos[first + i] = lo + (uint32_t)hand[(size_t)t * cap + i];
+    for (uint32_t j = 0; j < from_trace && first + by_hand + j < nblocks; j++) bpos[first + by_hand + j] = lo + (uint32_t)starts[(size_t)t * cap + a + j];
+}
+
+// A lane per BLOCK: lane b decodes the block at bpos[b] straight into the (zeroed) int16 [N][64] array: non-zero coefficients only,
+// entry 0 is written by the DC pass.  The 256 consecutive blocks of a workgroup are one contiguous piece of the stream, staged in LDS
+// (up to kBlkWin words: 500 bits per block on average; what lies behind is read from memory).  History: the first version decoded a
+// RANGE per lane, the blocks of its range one after the other through an LDS image - 880 waves for a 7 MB stream, one per SIMD, each
+// a chain of ~500 dependent symbol steps: 102-148 us.  A wave per 64 blocks with an image per lane (26 KB of LDS per wave, six waves
+// per CU): 108 us.  Without the image, four waves sharing tables and window: 24 waves per CU.
+constexpr int kDecodeWG = 256;
+constexpr uint32_t kBlkWin = 4096 + kOver;
+constexpr uint32_t kBlkLds = kBlkWin + kBlkWin / 32 + 2;
+__global__ __launch_bounds__(kDecodeWG) void dec_decode_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, const DecLutsDev *__restrict__ L,
+                                                               const uint32_t *__restrict__ bpos, const long long *__restrict__ total_blocks,
+                                                               unsigned long long n_want, int16_t *__restrict__ zz /* zeroed */, int32_t *__restrict__ dcdiff,
+                                                               DecStatus *__restrict__ st) {
+    __shared__ uint16_t lut[kLutLds];
+    __shared__ uint32_t sbits[kBlkLds];
     const unsigned long long total = (unsigned long long)*total_blocks;
     const unsigned long long m = total < n_want ? total : n_want; // blocks produced here
-    unsigned long long b = first_blk[t];
-    uint32_t pos = pstart[t];
-    int16_t *c = img[threadIdx.x];
+    const unsigned long long b0 = (unsigned long long)blockIdx.x * kDecodeWG, b = b0 + threadIdx.x;
+    if (b0 >= m) return; // (the whole workgroup)
+    load_lut(lut, L);
+    const unsigned long long last = b0 + kDecodeWG - 1 < m - 1 ? b0 + kDecodeWG - 1 : m - 1;
+    const uint32_t w0 = bpos[b0] >> 5, w1 = bpos[last] >> 5;
+    const uint32_t want = w1 >= w0 ? w1 - w0 + kOver : kOver;
+    const Bits words = stage_words(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords);
+    if (b >= m) return;
     BitWin win = {0xffffffffu, 0u, 0u};
-    const uint32_t cnt = nblk[t];
-    for (uint32_t i = 0; i < cnt && b < m; i++, b++) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) reinterpret_cast<uint4 *>(c)[q] = make_uint4(0u, 0u, 0u, 0u);
-        int d;
-        uint32_t used;
-        if (!block_dev<true>(words, L, ac11, pos, win, c, d, used)) { // (the stitch measured this block: cannot fail)
-            atomicOr(&st->giveup, 32);
-            return;
-        }
-        dcdiff[b] = d;
-        uint4 *dst = reinterpret_cast<uint4 *>(zz + b * 64ull);
-#pragma unroll
-        for (int q = 0; q < 8; q++) dst[q] = reinterpret_cast<const uint4 *>(c)[q]; // (entry 0 is written by the DC pass)
-        pos += used;
-        if (b == m - 1) {
-            st->pos_out = pos;
-            st->m = m;
-        }
+    const uint32_t pos = bpos[b];
+    int d;
+    uint32_t used;
+    if (!block_dev<true>(words, L, lut, pos, win, zz + b * 64ull, d, used)) { // (measure or stitch walked this block: cannot fail)
+        atomicOr(&st->giveup, 32);
+        return;
+    }
+    dcdiff[b] = d;
+    if (b == m - 1) {
+        st->pos_out = pos + used;
+        st->m = m;
     }
 }
 
@@ -299,7 +429,7 @@ size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
     const size_t nbits = stream_bytes * 8;
     const size_t nranges = nbits / 512 + 2; // (the smallest range: most ranges, and the most room per stream bit)
     const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
-    return nranges * ((size_t)cap_of(512) * 2 + 8 * 4) + nblocks * 4 + ntiles * 8 * 2 + 16384; // (six 4-byte arrays per range; every piece is rounded up to 256 B)
+    return nranges * ((size_t)cap_of(512) * 2 * 2 + 9 * 4) + nblocks * 8 + ntiles * 8 * 2 + 16384; // (two traces and seven 4-byte arrays per range, two per block; every piece is rounded up to 256 B)
 }
 
 hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
@@ -317,10 +447,11 @@ hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, s
     // workspace carve-up
     char *w = (char *)d_work;
     auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) / 256 * 256; return (void *)p; };
-    uint16_t *starts = (uint16_t *)take((size_t)nranges * kCap * 2);
+    uint16_t *starts = (uint16_t *)take((size_t)nranges * kCap * 2), *hand = (uint16_t *)take((size_t)nranges * kCap * 2);
+    uint32_t *entry = (uint32_t *)take((size_t)nranges * 4), *bpos = (uint32_t *)take(nblocks * 4);
     uint32_t *nrec = (uint32_t *)take((size_t)nranges * 4), *endpos = (uint32_t *)take((size_t)nranges * 4);
     int *lastbrk = (int *)take((size_t)nranges * 4);
-    uint32_t *nblk = (uint32_t *)take((size_t)nranges * 4), *pstart = (uint32_t *)take((size_t)nranges * 4);
+    uint32_t *nblk = (uint32_t *)take((size_t)nranges * 4);
     uint32_t *first_blk = (uint32_t *)take((size_t)nranges * 4);
     int32_t *dcdiff = (int32_t *)take(nblocks * 4);
     long long *tiles_r = (long long *)take((ntiles_r + 1) * 8), *tiles_b = (long long *)take((ntiles_b + 1) * 8);
@@ -330,17 +461,21 @@ hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, s
     hipError_t e = hipMemsetAsync(d_status, 0, sizeof(DecStatus), stream);
     if (e != hipSuccess) return e;
     const dim3 gr((nranges + 63) / 64), bl(64);
-    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, d_status);
-    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, nblk, pstart, d_status);
+    const uint32_t nwords = (uint32_t)((stream_bytes + 3) / 4); // (the caller zero-pads the last word and keeps 16 bytes behind it)
+    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, nwords, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, d_status);
+    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, nwords, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, nblk, hand, entry, d_status);
     // first block of every range: exclusive scan of the true block counts
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const int32_t *)nblk, (size_t)nranges, tiles_r);
     hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(kTile), 0, stream, tiles_r, ntiles_r, totals);
     hipLaunchKernelGGL((scan_apply_kernel<false, StoreU32>), dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const int32_t *)nblk, (size_t)nranges,
                        (const long long *)tiles_r, StoreU32{first_blk});
     e = hipMemsetAsync(dcdiff, 0, nblocks * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_zz, 0, nblocks * 128, stream); // the decode kernel writes the non-zero coefficients only
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dec_decode_kernel, gr, bl, 0, stream, words, d_luts, nranges, nblk, pstart, first_blk, (const long long *)totals,
-                       (unsigned long long)nblocks, d_zz, dcdiff, d_status);
+    hipLaunchKernelGGL(dec_bpos_kernel, gr, bl, 0, stream, range, nranges, (const uint16_t *)starts, (const uint16_t *)hand, (const uint32_t *)nrec,
+                       (const uint32_t *)entry, (const uint32_t *)nblk, (const uint32_t *)first_blk, (unsigned long long)nblocks, bpos);
+    hipLaunchKernelGGL(dec_decode_kernel, dim3((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG)), dim3(kDecodeWG), 0, stream, words, nwords, d_luts, (const uint32_t *)bpos,
+                       (const long long *)totals, (unsigned long long)nblocks, d_zz, dcdiff, d_status);
     // np.cumsum of the DC differences over the blocks (blocks past the ones produced here hold 0 differences: their entry 0 is
     // overwritten by the host's tail, which continues from dc_out)
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, (const int32_t *)dcdiff, nblocks, tiles_b);

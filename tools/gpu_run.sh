@@ -34,6 +34,11 @@ for step in "$@"; do
     pmc_ent_abl) for a in ${TIC_ENT_ABLS:-0 2 4 7 32}; do rm -rf gpurun_out/pmc_ent_abl$a; export TIC_USE_ABLATE=1 TIC_ENT_ABL=$a; run pmc_ent_abl$a 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_ent_abl$a -- python tools/prof_compress_dev.py 4096 10; unset TIC_USE_ABLATE TIC_ENT_ABL; done ;;
     place_abl)  for a in ${TIC_PLACE_ABLS:-0 1 2 3 4 7}; do rm -rf gpurun_out/place_abl$a; export TIC_USE_ABLATE=1 TIC_PLACE_ABL=$a; run place_abl$a 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/place_abl$a -- python tools/prof_compress_dev.py 4096 100; unset TIC_USE_ABLATE TIC_PLACE_ABL; done ;;
     stress)     run stress 900 python tools/stress_parity.py ${TIC_STRESS_ITERS:-300} ;;
+    decomp)     run decomp 200 python tools/prof_decompress.py 4096 30 50; run decomp90 200 python tools/prof_decompress.py 4096 30 90; export TIC_CONTENT=lenna; run decomp_lenna 200 python tools/prof_decompress.py 4096 30 50; unset TIC_CONTENT ;;
+    prof_decomp) rm -rf gpurun_out/prof_decomp; run prof_decomp 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_decomp -- python tools/prof_decompress.py 4096 50 50 ;;
+    pmc_decomp) rm -rf gpurun_out/pmc_decomp; run pmc_decomp 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_decomp -- python tools/prof_decompress.py 4096 5 50 ;;
+    pmc_decomp2) rm -rf gpurun_out/pmc_decomp2; run pmc_decomp2 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc_decomp2 -- python tools/prof_decompress.py 4096 5 50 ;;
+    stress_dec) run stress_dec 600 python tools/stress_decoder.py ${TIC_STRESS_DEC:-150} ;;
     content)    run content 300 python tools/natural_content.py ;;
     ab_cold)    run ab_cold 400 python tools/ab_cold.py ;;
     stamps2)    run stamps2 200 python tools/stamps2.py ;;

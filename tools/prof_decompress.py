@@ -20,4 +20,4 @@ t = time.perf_counter()
 for k in range(reps):
     ctx.check(L.tic_decompress(ctx.handle, s.ctypes.data, s.size, out.ctypes.data, out.size))
 dt = (time.perf_counter() - t) / reps
-print("tic_decompress %dx%d q=%d: %.2f ms per frame (%.1f Gpix/s), stream %d bytes, decoder path %d" % (dim, dim, q, dt * 1e3, dim * dim / dt / 1e9, s.size, L.tic_last_decode_path(ctx.handle)))
+print("tic_decompress %dx%d q=%d: %.2f ms per frame (%.1f Gpix/s), stream %d bytes, decoder path %d (giveup %d)" % (dim, dim, q, dt * 1e3, dim * dim / dt / 1e9, s.size, L.tic_last_decode_path(ctx.handle), L.tic_last_decode_giveup(ctx.handle)))
