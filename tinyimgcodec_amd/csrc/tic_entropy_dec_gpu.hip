@@ -74,7 +74,10 @@ __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__res
     s.nwords = nwords;
     for (uint32_t r = threadIdx.x; r < wcount; r += blockDim.x) {
         const uint32_t wi = first_word + r;
-        lds[r + (r >> sh)] = wi < nwords ? __builtin_bswap32(words[wi]) : 0u;
+        const uint32_t v = wi < nwords ? __builtin_bswap32(words[wi]) : 0u;
+        lds[r + (r >> sh)] = v;
+        if (r != 0u && (r & ((1u << sh) - 1u)) == 0u) lds[r + (r >> sh) - 1u] = v; // the padding word in front of a row repeats the row's
+                                                                                   // first word: word r + 1 always sits right behind word r
     }
     __syncthreads();
     return s;
@@ -155,33 +158,10 @@ __device__ __forceinline__ void load_lut(uint16_t *lds, const DecLutsDev *__rest
     __syncthreads();
 }
 
-// One SYMBOL per step, for the lanes of a wave side by side (measure and decode kernels).  block_dev() above is a loop per block:
-// the lanes of a wave then wait for each other at every block end (a wave-step lasts as long as its longest block) - 630 symbol
-// steps per wave where the longest lane has ~250 symbols, 33,000 instructions per wave at one wave per SIMD: measure 241-293 us,
-// decode 102 us for a 7 MB stream.  Here the position inside the block (k: 0 = the DC category comes next) is lane state and a
-// block end is just another step.  Same tables, same rules as block_dev().
-struct Sym {
-    bool bad, eob, dc, nocode; // bad: nocode (an invalid prefix) or more than 63 coefficients in the block
-    uint32_t bits; // code + value bits
-    int k_at;      // AC coefficient: its scan position; the state behind it is k_at + 1
-    int value;
-};
-__device__ __forceinline__ Sym next_symbol(const Bits &words, const DecLutsDev *__restrict__ L, const uint16_t *lut, uint32_t pos, int k, BitWin &win) {
-    const uint32_t pk = peek32(words, pos, win);
-    uint32_t e = lut[(k ? 2048u : 0u) + (pk >> 21)];
-    if (!e && k) e = long_code(lut, pk);
-    Sym s;
-    const int len = (int)(e >> 8), size = (int)(e & 15u);
-    s.dc = k == 0;
-    s.eob = k != 0 && (e & 0xffu) == 0u;
-    s.k_at = k + (int)((e >> 4) & 15u);
-    s.nocode = e == 0u;
-    s.bad = s.nocode || (!s.dc && !s.eob && s.k_at > 63);
-    s.bits = (uint32_t)(len + size);
-    s.value = value_of(pk, len, size);
-    return s;
-}
-
+// The measure kernel walks one SYMBOL per step, the lanes of a wave side by side.  block_dev() above is a loop per block: the lanes of
+// a wave then wait for each other at every block end (a wave-step lasts as long as its longest block) - 630 symbol steps per wave
+// where the longest lane has ~250 symbols.  In the measure kernel the position inside the block (k: 0 = the DC category comes next)
+// is lane state and a block end is just another step.  Same tables, same rules as block_dev().
 __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, const DecLutsDev *__restrict__ L, uint32_t fast_end,
                                                          uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts, uint32_t *__restrict__ nrec,
                                                          uint32_t *__restrict__ endpos, int *__restrict__ lastbrk, DecStatus *__restrict__ st) {
@@ -193,47 +173,47 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
     if (t >= nranges) return;
     const uint32_t lo = 128u + t * range;
     const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
-    BitWin win = {0xffffffffu, 0u, 0u};
+    // One symbol per step, state updated by selects (the compiler's version of the same loop with if / else had ~25 branches per
+    // step: 40 vector + 40 scalar instructions).  Every read stays inside the staged window: a block that starts in front of `hi`
+    // ends within 1,728 bits of it, a walk that goes on after an incident is cut at hi + 1,800, and the window reaches 2,112 bits
+    // (kOver words) behind the workgroup's last range.
+    const uint32_t stop = hi + 1800u;
     uint32_t pos = lo, bstart = lo, cnt = 0; // a block that STARTS in front of `hi` is measured to its end
-    int k = 0, brk = -1;
-    bool clean = true; // the block in work began at a block-start guess and has decoded without an incident so far
+    int k = 0, brk = -1;   // k: scan position the next AC symbol starts from; 0 = the DC category comes next
+    bool clean = true;     // the block in work began at a block-start guess and has decoded without an incident so far
     bool live = pos < hi;
     while (live) {
-        const Sym s = next_symbol(words, L, lut, pos, k, win);
-        if (s.bad) {
-            if (t == 0u) { // the true chain itself: unusual
-                atomicOr(&st->giveup, 1);
-                pos = bstart;
-                live = false;
-            } else {
-                // A guess that led nowhere (or, behind the point of synchronisation, a malformed stream).  The walk goes on from the next
-                // bit IN THE AC STATE: most of a block is AC symbols, a walk that has fallen into step with the true symbols stays in
-                // step, and the next true EOB then ends on a true block start.  (The first version went back to the failed block's
-                // first bit + 1 and took it for a block start: every incident threw away up to 63 symbols of walking and the
-                // alignment they had reached - the unluckiest lane of a wave walked 750 symbols for the 210 of its range.)  The block
-                // in work is not recorded; the one behind its EOB is a fresh guess.
-                brk = (int)cnt;
-                pos += s.nocode ? 1u : s.bits; // (a symbol that merely overflows the block is a symbol: the walk stays in step)
-                k = 1;
-                clean = false;
-                if (pos >= hi + 1800u) live = false; // (no EOB in sight far behind the range: its trace ends here, unsynchronised)
-            }
-        } else {
-            pos += s.bits;
-            if (s.eob) {
-                if (clean) {
-                    if (cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(bstart - lo);
-                    cnt++;
-                }
-                bstart = pos;
-                clean = true;
-                k = 0;
-                live = pos < hi;
-            } else {
-                k = s.dc ? 1 : s.k_at + 1;
-            }
+        const uint32_t r = (pos >> 5) - words.wbase, sh = pos & 31u;
+        const uint32_t *wp = sbits + r + (r >> words.sh);
+        const uint32_t wa = wp[0], wb = wp[1];
+        const uint32_t pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa; // 32 stream bits from `pos`
+        uint32_t e = lut[(k ? 2048u : 0u) + (pk >> 21)];
+        if (__any(e == 0u && k != 0)) { // a codeword of 12 to 16 bits somewhere in the wave
+            const uint32_t e2 = long_code(lut, pk);
+            e = (e == 0u && k != 0) ? e2 : e;
         }
+        const bool nocode = e == 0u, dc = k == 0;
+        const bool eob = !dc && !nocode && (e & 0xffu) == 0u;
+        const int k_at = k + (int)((e >> 4) & 15u);
+        // An incident: an invalid prefix, or more than 63 coefficients in the block.  The walk is a guess that led nowhere (or, behind
+        // the point of synchronisation, the stream is malformed).  It goes on from here IN THE AC STATE: most of a block is AC symbols, a
+        // walk that has fallen into step with the true symbols stays in step (an overflowing symbol is consumed, an invalid prefix
+        // skips a bit), and the next true EOB then ends on a true block start.  The block in work is not recorded; the one behind its
+        // EOB is a fresh guess.  (The first version went back to the failed block's first bit + 1 and took that for a block start:
+        // every incident threw away up to 63 symbols of walking and the alignment they had reached - the unluckiest lane of a wave
+        // walked 750 symbols for the 210 of its range.)
+        const bool bad = nocode || (!dc && !eob && k_at > 63);
+        pos += nocode ? 1u : (e >> 8) + (e & 15u);
+        const bool rec = eob && clean;
+        if (rec && cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(bstart - lo);
+        cnt += rec ? 1u : 0u;
+        brk = bad ? (int)cnt : brk;
+        clean = bad ? false : (eob ? true : clean);
+        bstart = eob ? pos : bstart;
+        k = bad ? 1 : (eob ? 0 : (dc ? 1 : k_at + 1));
+        live = (eob ? pos < hi : true) && pos < stop;
     }
+    if (t == 0u && brk >= 0) atomicOr(&st->giveup, 1); // an incident on the true chain itself: unusual
     if (cnt > cap_of(range)) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
     nrec[t] = cnt;
     endpos[t] = pos;
