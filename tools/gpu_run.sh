@@ -38,6 +38,8 @@ for step in "$@"; do
     prof_decomp) rm -rf gpurun_out/prof_decomp; run prof_decomp 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_decomp -- python tools/prof_decompress.py 4096 50 50 ;;
     pmc_decomp) rm -rf gpurun_out/pmc_decomp; run pmc_decomp 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_decomp -- python tools/prof_decompress.py 4096 5 50 ;;
     pmc_decomp2) rm -rf gpurun_out/pmc_decomp2; run pmc_decomp2 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc_decomp2 -- python tools/prof_decompress.py 4096 5 50 ;;
+    stress_ent) run stress_ent 600 python tools/stress_entropy.py ${TIC_STRESS_ENT:-300} ;;
+    decomp16k)  run decomp16k 300 python tools/prof_decompress.py 16384 5 50 ;;
     stress_dec) run stress_dec 600 python tools/stress_decoder.py ${TIC_STRESS_DEC:-150} ;;
     content)    run content 300 python tools/natural_content.py ;;
     ab_cold)    run ab_cold 400 python tools/ab_cold.py ;;
