@@ -106,6 +106,29 @@ def test_quality_sweep_vs_goldens(ctx, golden, variant):
 
 
 @pytest.mark.parametrize("variant", [N.KERNEL_EXACT, N.KERNEL_HYBRID])
+def test_flat_banded_and_checkerboard_content_vs_goldens(ctx, golden, variant):
+    """The reference's encode() on tie-dense content (flat blocks of every grey level - the strip kernel's flat-block DC table -, flat /
+    noise / checkerboard blocks side by side, a posterised ramp) at nine qualities, and the same frames tiled so that every wave's
+    batch overflows."""
+    d = golden("flat_blocks")
+    for name in ("flat", "mix", "banded"):
+        img = d[name]
+        f = DevFrame(ctx, img)
+        tiled = DevFrame(ctx, np.tile(img, (8, 4)))
+        by, bx = img.shape[0] // 8, img.shape[1] // 8
+        for q in d["qualities"]:
+            q = int(q)
+            dc, ac = zz_to_dc_ac(f.run(q, variant))
+            assert np.array_equal(dc, d[f"{name}_q{q}_dc"]), (name, q)
+            assert np.array_equal(ac, d[f"{name}_q{q}_ac"]), (name, q)
+            zz = tiled.run(q, variant).reshape(8, by, 4, bx, 64)
+            one = f.run(q, variant).reshape(by, bx, 64)
+            assert np.array_equal(zz, np.broadcast_to(one[None, :, None], zz.shape)), (name, q, "tiled")
+        f.free()
+        tiled.free()
+
+
+@pytest.mark.parametrize("variant", [N.KERNEL_EXACT, N.KERNEL_HYBRID])
 def test_tie_blocks(ctx, golden, variant):
     """DC exactly on .5 ties at q=50: rounding must follow pocketfft's last-ulp error."""
     d = golden("tie_blocks")

@@ -72,6 +72,18 @@ def test_quality_sweep(oracle, golden):
                 oracle.compress(img, q)
 
 
+def test_flat_banded_and_checkerboard_content(oracle, golden):
+    """Tie-dense content (flat blocks of every grey level, flat / noise / checkerboard blocks side by side, a posterised ramp) at nine
+    qualities: the reference's own encode() outputs (tests/golden/gen/make_goldens_r3b.py)."""
+    d = golden("flat_blocks")
+    for name in ("flat", "mix", "banded"):
+        for q in d["qualities"]:
+            q = int(q)
+            dc, ac = oracle.encode(d[name], q)
+            assert np.array_equal(dc, d[f"{name}_q{q}_dc"]), (name, q)
+            assert np.array_equal(ac, d[f"{name}_q{q}_ac"]), (name, q)
+
+
 def test_tie_blocks(oracle, golden):
     """Blocks whose DC sits on an exact .5 tie at q=50: rounding direction follows pocketfft's last ulp."""
     d = golden("tie_blocks")
