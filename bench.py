@@ -346,6 +346,9 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             "kernel_us": round(kernel_ms * 1e3, 3),
             "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels,
             "note": "one frame and one coefficient buffer replayed: the 50 MB working set stays in the 256 MiB Infinity Cache (see cold)",
+            "limiter": "priced against HBM as the contract asks; what actually bounds the loop is the CU's LDS pipeline (72 cycles per strip: "
+            "transpose + zig-zag staging) together with vector issue (100 instructions per strip) - timing builds in DESIGN.md 5.5, "
+            "profiles/r03_ablate_16384.txt - plus the launch's fill and tail at this size; only the cold stream of a 4096^2 frame sits on its memory floor",
         },
     }
     if cold is not None:
