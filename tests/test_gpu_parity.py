@@ -1000,6 +1000,24 @@ def test_device_entropy_lane_kernel_and_its_fallback(oracle):
         c.close()
 
 
+def test_decompress_large_frame_device_against_host_decoder(ctx, monkeypatch):
+    """A 4096 x 8192 noise frame (14 MB stream, 112,000 ranges, 524,288 blocks): the device decoder's pixels against the host decoder's
+    (the oracle would take minutes here; both decoders are pinned on it at smaller sizes)."""
+    L = N.load()
+    img = rand_frame(8192, 4096, 8192)
+    for q in (50, 85):
+        s = T.compress(img, q, ctx=ctx)
+        monkeypatch.delenv("TIC_DECODE_HOST", raising=False)
+        dev = T.decompress(s, ctx=ctx)
+        assert L.tic_last_decode_path(ctx.handle) == 1 and L.tic_last_decode_giveup(ctx.handle) == 0, q
+        monkeypatch.setenv("TIC_DECODE_HOST", "1")
+        host = T.decompress(s, ctx=ctx)
+        assert L.tic_last_decode_path(ctx.handle) == 2
+        monkeypatch.delenv("TIC_DECODE_HOST")
+        assert np.array_equal(dev, host), q
+        assert np.abs(dev.astype(np.int32) - img).mean() < (20 if q == 50 else 10), q  # (a decoded noise frame is close to its source: 14.6 at q = 50)
+
+
 def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch):
     """The strip walk uses 32-bit pixel offsets; a frame of 4 GiB or more is cut into bands of whole block rows, one launch each
     (round 2 ran such frames on the exact kernel only).  TIC_BAND_BYTES lowers the limit so that a 3000 x 2112 frame is cut into
