@@ -177,6 +177,12 @@ int tic_idctq_scaled(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int e
  * encoder (header flag 1<<30 -> scaled_dct branch): host Huffman/RLE decode (huffman.py:36-38,66-98), GPU dequantise +
  * inverse DCT (utils.py:40-45,52) + clip + truncating uint8 cast.  out: uint8[h*w]. */
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap);
+/* decompress() with stream and pixels both resident in device memory - the counterpart of tic_compress_dev (decompress()
+ * codec.py:167-189 between two device buffers).  d_out receives h rows of w pixels, out_stride bytes apart (out_cap: bytes of
+ * the buffer); *h / *w (may be null) receive the geometry of the header.  Long streams never leave the device; short ones and
+ * anything the device decoder hands to the host decoder (tic_last_decode_path / _giveup) make the round trip through host memory. */
+int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_out, ptrdiff_t out_stride, size_t out_cap, int *h,
+                       int *w);
 /* Which Huffman decoder the context's last tic_decompress used: 1 = the device decoder (streams of >= 16,384 blocks: only the
  * stream crosses PCIe upwards, only the pixels downwards), 2 = the host decoder (short streams; any long stream in which the
  * device decoder met something unusual - the host's bit-serial path reproduces the reference's behaviour on malformed streams). */

@@ -1018,6 +1018,43 @@ def test_decompress_large_frame_device_against_host_decoder(ctx, monkeypatch):
         assert np.abs(dev.astype(np.int32) - img).mean() < (20 if q == 50 else 10), q  # (a decoded noise frame is close to its source: 14.6 at q = 50)
 
 
+def test_decompress_dev_resident_round_trip(ctx, oracle):
+    """tic_compress_dev -> tic_decompress_dev with image, stream and pixels resident in device memory: the pixels equal decompress() of the
+    same stream (long streams through the device Huffman decoder, short ones through the host decoder), also with a padded output
+    pitch and a ragged frame; error paths."""
+    L = N.load()
+    for (h, w), q, pad in (((2048, 2048), 50, 0), ((1500, 1999), 75, 49), ((512, 512), 50, 0), ((64, 72), 30, 8)):
+        img = rand_frame(h * 7 + w, h, w)
+        cap = L.tic_compress_bound(h, w)
+        stride = w + pad
+        d_img, d_str, d_pix = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
+        ctx.check(L.tic_dev_alloc(ctx.handle, cap, C.byref(d_str)))
+        ctx.check(L.tic_dev_alloc(ctx.handle, h * stride, C.byref(d_pix)))
+        ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
+        n = C.c_size_t()
+        ctx.check(L.tic_compress_dev(ctx.handle, d_img, h, w, w, q, d_str, cap, C.byref(n)))
+        ctx.check(L.tic_memset_dev(ctx.handle, d_pix, 0xEE, h * stride))
+        hh, ww = C.c_int(), C.c_int()
+        ctx.check(L.tic_decompress_dev(ctx.handle, d_str, n.value, d_pix, stride, h * stride, C.byref(hh), C.byref(ww)))
+        assert (hh.value, ww.value) == (h, w)
+        long_enough = n.value * 8 >= 128 + (1 << 21) and L.tic_num_blocks(h, w) >= 16384
+        assert L.tic_last_decode_path(ctx.handle) == (1 if long_enough else 2), (h, w)
+        pix = np.empty((h, stride), np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, pix.ctypes.data, d_pix, pix.size))
+        stream = np.empty(n.value, np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, stream.ctypes.data, d_str, n.value))
+        want = oracle.decompress(stream.tobytes())
+        assert np.array_equal(pix[:, :w], want), (h, w, q)
+        assert np.all(pix[:, w:] == 0xEE), "bytes between the rows stay untouched"
+        # error paths: output too small, stride below the width, a stream cut inside the header
+        assert L.tic_decompress_dev(ctx.handle, d_str, n.value, d_pix, stride, (h - 1) * stride + w - 1, None, None) == N.TIC_E_SPACE
+        assert L.tic_decompress_dev(ctx.handle, d_str, n.value, d_pix, w - 1, h * stride, None, None) == N.TIC_E_ARG
+        assert L.tic_decompress_dev(ctx.handle, d_str, 15, d_pix, stride, h * stride, None, None) == N.TIC_E_STREAM
+        for p in (d_img, d_str, d_pix):
+            L.tic_dev_free(ctx.handle, p)
+
+
 def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch):
     """The strip walk uses 32-bit pixel offsets; a frame of 4 GiB or more is cut into bands of whole block rows, one launch each
     (round 2 ran such frames on the exact kernel only).  TIC_BAND_BYTES lowers the limit so that a 3000 x 2112 frame is cut into

@@ -1359,7 +1359,8 @@ int tic_dctq_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int
 // ---- decode ---------------------------------------------------------------------------------------------
 // Inverse stage on coefficients that already sit in ctx->d_coef (int16 [N][64] zig-zag, DC integrated) -> pixels in `out`.
 // scaled_exp < 0: decode() proper; >= 0: its scaled_dct branch with 2 ** scaled_exp (codec.py:59-62)
-static int idct_from_device(tic_ctx *ctx, int h, int w, int quality, int scaled_exp, uint8_t *out) {
+static int idct_from_device(tic_ctx *ctx, int h, int w, int quality, int scaled_exp, uint8_t *out, bool out_on_device = false,
+                            size_t out_stride = 0) {
     const size_t pitch = align_up((size_t)w, 256);
     IdctArgs a;
     a.coeffs = (const int16_t *)ctx->d_coef;
@@ -1375,8 +1376,8 @@ static int idct_from_device(tic_ctx *ctx, int h, int w, int quality, int scaled_
     a.scaled = scaled_exp >= 0;
     a.pow2 = scaled_exp >= 0 ? ldexp(1.0, scaled_exp) : 1.0;
     HIPCHK(ctx, launch_idct(a, ctx->stream));
-    HIPCHK(ctx, hipMemcpy2DAsync(out, (size_t)w, ctx->d_img, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost,
-                                 ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(out, out_on_device ? out_stride : (size_t)w, ctx->d_img, pitch, (size_t)w, (size_t)h,
+                                 out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return TIC_OK;
 }
@@ -1401,7 +1402,7 @@ static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int 
 // Long streams: Huffman + run-length decode on the device (tic_entropy_dec_gpu.hip).  Returns TIC_OK with *done = true when the
 // coefficients of all N blocks are in ctx->d_coef; *done = false (and TIC_OK) when the device decoder met something unusual or does
 // not apply - the caller then decodes on the host, which reproduces the reference's behaviour on malformed streams.
-static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h, int w, bool *done) {
+static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h, int w, bool *done, bool src_on_device = false) {
     *done = false;
     const size_t n = num_blocks(h, w);
     // the host parallel decoder's own threshold: shorter streams are decoded serially in well under a millisecond
@@ -1437,7 +1438,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
         ctx->dec_work_bytes = wb;
     }
     HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_stream_buf + (len & ~(size_t)3), 0, padded - (len & ~(size_t)3), ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stream_buf, data, len, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stream_buf, data, len, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     // stream bits per lane from the average block length (rounded up to 4 average blocks): noise at q=50 (220 bits per block) takes
     // 1024, natural images 512, noise at q >= 85 2048; a range without a synchronisation point (a block longer than the range) makes
     // the stitch give up with bit 4: one more try with 2048 before the host decoder takes over
@@ -1460,7 +1461,14 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     if (ctx->last_decode_giveup != 0) return TIC_OK; // the host decoder takes the whole stream
     if (st.m < n) { // the blocks that start in the stream's last 2048 bits: serial on the host, a few KB uploaded behind the others
         std::vector<int16_t> tail((n - (size_t)st.m) * 64);
-        entropy_decode_tail(data, len, h, w, (size_t)st.m, (size_t)st.pos_out, st.dc_out, tail.data());
+        if (src_on_device) { // the end of the stream comes down (a few hundred bytes), the bit positions move with it
+            const size_t off = (size_t)st.pos_out / 8;
+            std::vector<uint8_t> end(len - off);
+            HIPCHK(ctx, hipMemcpy(end.data(), (const char *)ctx->d_stream_buf + off, len - off, hipMemcpyDeviceToHost));
+            entropy_decode_tail(end.data(), len - off, h, w, (size_t)st.m, (size_t)st.pos_out - off * 8, st.dc_out, tail.data());
+        } else {
+            entropy_decode_tail(data, len, h, w, (size_t)st.m, (size_t)st.pos_out, st.dc_out, tail.data());
+        }
         HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_coef + (size_t)st.m * 128, tail.data(), tail.size() * 2, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (`tail` leaves scope)
     }
@@ -1531,6 +1539,57 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
     entropy_decode(data, len, h, w, ctx->h_zz);
     ctx->last_decode_path = 2;
     return idctq_impl(ctx, ctx->h_zz, h, w, scaled ? 50 : quality, scaled ? quality : -1, out, cap);
+}
+
+// decompress() with stream and pixels both resident in HBM (the counterpart of tic_compress_dev): only the 16-byte header, the
+// status and - for the blocks that start in the stream's last 2048 bits - a few hundred bytes cross PCIe.  Short streams and streams
+// the device decoder gives up on come down to the host decoder and their coefficients go back up (the reference's behaviour on
+// malformed streams lives there).  d_out: h rows of w pixels, out_stride bytes apart.
+int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_out, ptrdiff_t out_stride, size_t out_cap, int *h_out, int *w_out) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    ctx->last_decode_giveup = 0;
+    if (!d_stream && len) return set_err(ctx, TIC_E_ARG, "null stream pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    uint8_t head[16] = {0};
+    if (len < 16) return set_err(ctx, TIC_E_STREAM, "stream shorter than the 16-byte header");
+    HIPCHK(ctx, hipMemcpy(head, d_stream, 16, hipMemcpyDeviceToHost));
+    int h, w, quality;
+    uint32_t flag;
+    if (parse_header(head, 16, &h, &w, &quality, &flag) != TIC_OK) return set_err(ctx, TIC_E_STREAM, "stream shorter than the 16-byte header");
+    if (flag & (1u << 31)) return set_err(ctx, TIC_E_STREAM, "streams with an embedded Huffman table are not supported");
+    const bool scaled = (flag & (1u << 30)) != 0;
+    if (h < 0 || w < 0) return set_err(ctx, TIC_E_STREAM, "bad geometry in header");
+    if (scaled && (quality < 0 || quality > 62)) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d in header outside 0..62", quality);
+    if (!scaled && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "quality %d in header outside 1..99", quality);
+    if (h_out) *h_out = h;
+    if (w_out) *w_out = w;
+    const size_t n = num_blocks(h, w);
+    if (n == 0) return TIC_OK;
+    if (out_stride < (ptrdiff_t)w) return set_err(ctx, TIC_E_ARG, "row stride %td smaller than the width %d", out_stride, w);
+    if (!d_out || (size_t)(h - 1) * (size_t)out_stride + (size_t)w > out_cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+    bool done = false;
+    int rc = decode_on_device(ctx, (const uint8_t *)d_stream, len, h, w, &done, true);
+    if (rc) return rc;
+    if (done) {
+        ctx->last_decode_path = 1;
+    } else {
+        std::vector<uint8_t> host(len);
+        HIPCHK(ctx, hipMemcpy(host.data(), d_stream, len, hipMemcpyDeviceToHost));
+        if (n * 128 > ctx->h_zz_bytes) {
+            if (ctx->h_zz) (void)hipHostFree(ctx->h_zz);
+            ctx->h_zz = nullptr;
+            ctx->h_zz_bytes = 0;
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_zz, n * 128, hipHostMallocDefault));
+            ctx->h_zz_bytes = n * 128;
+        }
+        entropy_decode(host.data(), len, h, w, ctx->h_zz);
+        ctx->last_decode_path = 2;
+        rc = ensure_scratch(ctx, align_up((size_t)w, 256) * (size_t)h, n * 128);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_coef, ctx->h_zz, n * 128, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return idct_from_device(ctx, h, w, scaled ? 50 : quality, scaled ? quality : -1, (uint8_t *)d_out, true, (size_t)out_stride);
 }
 
 // ---- self test hook (used by tests/ only; not part of the drop-in surface) --------------------------------

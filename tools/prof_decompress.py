@@ -21,3 +21,18 @@ for k in range(reps):
     ctx.check(L.tic_decompress(ctx.handle, s.ctypes.data, s.size, out.ctypes.data, out.size))
 dt = (time.perf_counter() - t) / reps
 print("tic_decompress %dx%d q=%d: %.2f ms per frame (%.1f Gpix/s), stream %d bytes, decoder path %d (giveup %d)" % (dim, dim, q, dt * 1e3, dim * dim / dt / 1e9, s.size, L.tic_last_decode_path(ctx.handle), L.tic_last_decode_giveup(ctx.handle)))
+
+# the same with stream and pixels resident in HBM (tic_decompress_dev): what the decoder costs without PCIe
+d_s, d_p = C.c_void_p(), C.c_void_p()
+ctx.check(L.tic_dev_alloc(ctx.handle, s.size + 64, C.byref(d_s)))
+ctx.check(L.tic_dev_alloc(ctx.handle, dim * dim, C.byref(d_p)))
+ctx.check(L.tic_memcpy_h2d(ctx.handle, d_s, s.ctypes.data, s.size))
+for k in range(3):
+    ctx.check(L.tic_decompress_dev(ctx.handle, d_s, s.size, d_p, dim, dim * dim, None, None))
+t = time.perf_counter()
+for k in range(reps):
+    ctx.check(L.tic_decompress_dev(ctx.handle, d_s, s.size, d_p, dim, dim * dim, None, None))
+dt = (time.perf_counter() - t) / reps
+back = np.empty((dim, dim), np.uint8)
+ctx.check(L.tic_memcpy_d2h(ctx.handle, back.ctypes.data, d_p, back.size))
+print("tic_decompress_dev %dx%d q=%d: %.2f ms per frame (%.1f Gpix/s), same pixels: %s, decoder path %d" % (dim, dim, q, dt * 1e3, dim * dim / dt / 1e9, bool(np.array_equal(back, out)), L.tic_last_decode_path(ctx.handle)))
