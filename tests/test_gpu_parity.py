@@ -1023,7 +1023,7 @@ def test_decompress_dev_resident_round_trip(ctx, oracle):
     same stream (long streams through the device Huffman decoder, short ones through the host decoder), also with a padded output
     pitch and a ragged frame; error paths."""
     L = N.load()
-    for (h, w), q, pad in (((2048, 2048), 50, 0), ((1500, 1999), 75, 49), ((512, 512), 50, 0), ((64, 72), 30, 8)):
+    for (h, w), q, pad in (((2048, 2048), 50, 0), ((1500, 1999), 75, 49), ((1500, 1999), 75, 0), ((512, 512), 50, 0), ((64, 72), 30, 8), ((200, 333), 60, 4)):
         img = rand_frame(h * 7 + w, h, w)
         cap = L.tic_compress_bound(h, w)
         stride = w + pad

@@ -1375,9 +1375,16 @@ static int idct_from_device(tic_ctx *ctx, int h, int w, int quality, int scaled_
     a.consts = ctx->d_consts + (scaled_exp >= 0 ? 50 : quality); // codec.py:62: quality = 50 on the scaled branch
     a.scaled = scaled_exp >= 0;
     a.pow2 = scaled_exp >= 0 ? ldexp(1.0, scaled_exp) : 1.0;
+    // a device destination whose rows are 8-byte aligned takes the pixels straight from the kernel (its row stores are cropped to w)
+    const bool direct = out_on_device && out_stride % 8 == 0 && (uintptr_t)out % 8 == 0;
+    if (direct) {
+        a.out = out;
+        a.stride = (long)out_stride;
+    }
     HIPCHK(ctx, launch_idct(a, ctx->stream));
-    HIPCHK(ctx, hipMemcpy2DAsync(out, out_on_device ? out_stride : (size_t)w, ctx->d_img, pitch, (size_t)w, (size_t)h,
-                                 out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    if (!direct)
+        HIPCHK(ctx, hipMemcpy2DAsync(out, out_on_device ? out_stride : (size_t)w, ctx->d_img, pitch, (size_t)w, (size_t)h,
+                                     out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return TIC_OK;
 }
