@@ -182,10 +182,13 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
     int k = 0, brk = -1;   // k: scan position the next AC symbol starts from; 0 = the DC category comes next
     bool clean = true;     // the block in work began at a block-start guess and has decoded without an incident so far
     bool live = pos < hi;
+    // The stream words under the read position sit in registers (wa, wb) and the word behind them (wc) is fetched a step ahead: the
+    // walk is sequential, so the only LDS access left on the lane's dependent chain is the table look-up.
+    auto word_at = [&](uint32_t r) { return sbits[r + (r >> words.sh)]; };
+    uint32_t wi = (pos >> 5) - words.wbase; // window-relative index of the word `pos` lies in
+    uint32_t wa = word_at(wi), wb = word_at(wi + 1u), wc = word_at(wi + 2u);
     while (live) {
-        const uint32_t r = (pos >> 5) - words.wbase, sh = pos & 31u;
-        const uint32_t *wp = sbits + r + (r >> words.sh);
-        const uint32_t wa = wp[0], wb = wp[1];
+        const uint32_t sh = pos & 31u;
         const uint32_t pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa; // 32 stream bits from `pos`
         uint32_t e = lut[(k ? 2048u : 0u) + (pk >> 21)];
         if (__any(e == 0u && k != 0)) { // a codeword of 12 to 16 bits somewhere in the wave
@@ -204,6 +207,13 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
         // walked 750 symbols for the 210 of its range.)
         const bool bad = nocode || (!dc && !eob && k_at > 63);
         pos += nocode ? 1u : (e >> 8) + (e & 15u);
+        { // a step consumes at most 27 bits: at most one word boundary is crossed
+            const bool crossed = ((pos >> 5) - words.wbase) != wi;
+            wa = crossed ? wb : wa;
+            wb = crossed ? wc : wb;
+            wi += crossed ? 1u : 0u;
+            wc = word_at(wi + 2u); // (not needed before the next boundary: off the dependent chain)
+        }
         const bool rec = eob && clean;
         if (rec && cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(bstart - lo);
         cnt += rec ? 1u : 0u;
