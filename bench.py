@@ -13,8 +13,10 @@ encode(), codec.py:26-43) over this rank's input, already resident in HBM.
           rank (shard_range), one batched launch of the rank's 256 resident frames per step; afterwards every rank sends its
           shard through the whole pipeline host -> host (tic_compress_batch: pinned staging, H2D || kernels || D2H, entropy
           stage on the device) and the ACTUAL 256 stream sizes of every rank are all-gathered with RCCL (tic_gather_sizes).
-          Barrier and max-over-ranks use RCCL too (torch.distributed.run spawns the ranks; gloo only carries the one-word
-          agreement on whether every rank's RCCL communicator came up, and the whole exchange if one did not).
+          Barrier and max-over-ranks use RCCL too.  No torch anywhere: `python bench.py --gpus N` starts its own N rank
+          processes (tinyimgcodec_amd/launch.py; under torch.distributed.run the ranks are torchrun's), and the ranks agree
+          over small files in the launch's private directory (distributed.FileComm on tic_rdv_publish / tic_rdv_wait) on
+          whether every rank's RCCL communicator came up - that channel carries the whole exchange if one did not.
   --workload config4 runs the N > 1 workload on ONE GPU too (the N = 1 point of a config-4 scaling curve).
 
 SCALING: N = 1 and N > 1 measure DIFFERENT workloads by default (config 2: one 50 MB launch per step, launch gaps included;
@@ -24,8 +26,10 @@ config 4: 1.6 GB per launch).  A curve must compare like with like: every N > 1 
 scaling with no data-path collective (N x by construction, up to clock and power differences between GPUs); the figure that
 can fail to scale is host -> host (PCIe, host DRAM, NUMA), reported beside it.
 
-Rank 0 prints ONE JSON line.  `value` = whole-job Mpixel/s = pixels of all ranks x K / max-over-ranks wall time of the K
-steps.  `roofline.achieved` = algorithmic bytes per launch (3 B/pixel: 1 B read + 2 B written) / average launch duration
+Rank 0 prints ONE JSON line.  `value` = whole-job Mpixel/s = pixels of all ranks x K / max-over-ranks time of the K steps: at
+N = 1 the interval between two HIP events on the launch stream around the K launches (the host clock around the same bracket is
+reported beside it, `config.wall_ms_per_step`: it adds one submission ramp and one completion wake-up per CALL, 40-70 us, which
+at K = 20 would read as 3 us per step), at N > 1 the host clock between the two barriers (K x 280 us).  `roofline.achieved` = algorithmic bytes per launch (3 B/pixel: 1 B read + 2 B written) / average launch duration
 measured with HIP events recorded on the library's own stream around the same K launches; `roofline.cold` = the same with
 12 distinct frame/coefficient buffer pairs in rotation (604 MB > the 256 MiB Infinity Cache: every launch streams from and
 to HBM).  `cpu_baseline` / `cpu_baseline_threads` = the oracle (C restatement of the reference's CPU path) on this host, 1 thread /
@@ -84,56 +88,59 @@ def main():
     ap.add_argument("--workload", choices=["auto", "config2", "config4"], default="auto",
                     help="auto: config 2 at N = 1 (the headline), config 4 at N > 1; config4 at N = 1 = the baseline of a config-4 scaling curve")
     ap.add_argument("--settle-ms", type=float, default=60.0, help="untimed back-to-back launches before the warm-up steps (clock settling)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N > 1 without a launcher: watchdog over the N rank processes (s)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher - N fresh rank processes, one per GPU, rank 0's
+        # JSON line relayed, non-zero exit if any rank fails or the watchdog expires.  Nothing here has touched HIP: the
+        # package import below loads no shared object (tinyimgcodec_amd/launch.py is standard library only).
+        from tinyimgcodec_amd.launch import run_ranks
+
+        sys.exit(run_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout_s=args.launch_timeout))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
 
     import tinyimgcodec_amd as T
     from tinyimgcodec_amd import _native as N
-    from tinyimgcodec_amd.distributed import RcclComm, TorchComm, gather_sizes, shard_range
+    from tinyimgcodec_amd.distributed import FileComm, RcclComm, gather_sizes, shard_range
 
     L = N.load()
-    # The real run: one rank per GPU, RCCL.  TIC_BENCH_BACKEND=gloo + TIC_BENCH_SHARE_GPU=1 rehearse the multi-rank flow on a
-    # one-GPU box: every rank on device 0 (RCCL needs one GPU per rank, so the rehearsal exchanges over gloo).
+    # The real run: one rank per GPU, RCCL.  TIC_BENCH_BACKEND=file + TIC_BENCH_SHARE_GPU=1 rehearse the multi-rank flow on a
+    # one-GPU box: every rank on device 0 (RCCL needs one GPU per rank, so the rehearsal exchanges over the file communicator).
     share_gpu = os.environ.get("TIC_BENCH_SHARE_GPU", "0") == "1"
     ctx = T.Context(0 if share_gpu else local_rank)  # raises loudly if the HIP library / an MI355X is missing
     comm = None
-    comm_note = "RCCL through the C-ABI (tic_comm_create / tic_gather_sizes / tic_comm_allreduce_max)"
+    comm_note = "RCCL through the C-ABI (tic_comm_create_ex / tic_gather_sizes / tic_comm_allreduce_max)"
     if world > 1:
-        import datetime
-
-        import torch.distributed as dist
-
-        # gloo is the control channel: EVERY rank joins it, whatever became of its RCCL communicator, and the ranks agree on
-        # one backend.  (Round 2 fell back per rank: had RCCL failed on some ranks only, the others would have sat in
-        # ncclCommInitRank or in the first all-reduce without a timeout.)  A rank that hangs inside RCCL never reaches the
-        # agreement: the others time out here and exit non-zero, which makes torchrun tear the job down.
+        # The file communicator is the control channel: EVERY rank joins it, whatever became of its RCCL communicator, and the
+        # ranks agree on one backend.  (Falling back per rank would leave the ranks whose RCCL did come up inside
+        # ncclCommInitRank or the first all-reduce without a timeout.)  A rank that hangs inside RCCL never reaches the
+        # agreement: the others time out here and exit non-zero, which makes the launcher tear the job down.
+        backend = os.environ.get("TIC_BENCH_BACKEND", "rccl")
         rccl, rccl_err = None, ""
-        if os.environ.get("TIC_BENCH_BACKEND", "rccl") != "gloo":
+        if backend == "rccl" and not share_gpu:
             try:
                 rccl = RcclComm(ctx, rank, world)
             except Exception as e:  # noqa: BLE001
                 rccl_err = str(e)[:200]
                 sys.stderr.write("bench.py rank %d: RCCL communicator failed (%s)\n" % (rank, e))
-        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
-        gl = TorchComm()
-        ok_everywhere = float(gl.allreduce_max([0.0 if rccl is not None else 1.0])[0]) == 0.0
+        ctl = FileComm(rank, world, name="bench_ctl")
+        ok_everywhere = float(ctl.allreduce_max([0.0 if rccl is not None else 1.0])[0]) == 0.0
         if ok_everywhere:
             comm = rccl
         else:
             if rccl is not None:
                 rccl.close()
-            comm = gl
-            if os.environ.get("TIC_BENCH_BACKEND", "rccl") == "gloo":
-                comm_note = "gloo (TIC_BENCH_BACKEND=gloo rehearsal)"
+            comm = ctl
+            if backend != "rccl" or share_gpu:
+                comm_note = "file communicator (rehearsal: TIC_BENCH_SHARE_GPU=1 puts every rank on device 0, where RCCL cannot run)"
             else:
-                comm_note = "gloo fallback: the RCCL communicator did not come up on every rank (this rank: %s)" % (rccl_err or "ok")
+                comm_note = "file communicator fallback: the RCCL communicator did not come up on every rank (this rank: %s)" % (rccl_err or "ok")
     q = args.quality
     variant = N.KERNEL_HYBRID if args.variant == "hybrid" else N.KERNEL_EXACT
     multi = world > 1 or args.workload == "config4"
@@ -210,6 +217,7 @@ def main():
                     "per_rank": {"kernel_only_mpix_s": round(value / world, 1), "host_to_host_mpix_s": round(pixels / float(red[2]) / 1e6, 1),
                                  "host_to_host_registered_mpix_s": round(pixels / float(red[3]) / 1e6, 1)},
                     "numa": info.get("numa"),
+                    "parity": dict(info["parity"], note="rank 0's shard; every rank checks its own shard and raises on a difference"),
                     "gathered_sizes": {"frames": int(len(sizes)), "total_bytes": int(offsets[-1]), "first": [int(v) for v in sizes[:8]],
                                             "sha256": hashlib.sha256(sizes.astype("<i8").tobytes()).hexdigest()},
                     "device": ctx.arch,
@@ -237,6 +245,8 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
+    if world > 1 and ctl is not comm:
+        ctl.close()
     ctx.close()
 
 
@@ -287,7 +297,8 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
     ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, h, w, pitch, q, d_out, variant, args.steps, C.byref(ms)))
     barrier()
     wall_s = time.perf_counter() - t0
-    kernel_ms = ms.value / args.steps
+    ms_total_timed = ms.value
+    kernel_ms = ms_total_timed / args.steps
 
     cold = None
     if not args.no_cold:
@@ -314,12 +325,12 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             traffic = None
     out = {
         "metric": "Mpixels/s encode (DCT+quant kernel)",
-        "value": round(pixels * args.steps / wall_s / 1e6, 1),
+        "value": round(pixels / (kernel_ms * 1e-3) / 1e6, 1),
         "unit": "Mpix/s",
         "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(wall_s * 1e3 / args.steps, 6),
+        "ms_per_step": round(kernel_ms, 6),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -334,6 +345,14 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             "untimed_note": "back-to-back launches of the same kernel before the W warm-up steps (clock settling) + 1 statistics launch",
             "fallback_blocks_per_launch": fb.value,
             "device": ctx.arch,
+            "timed_region": "the K launches between two HIP events recorded on the launch stream, inside the barrier + device-sync bracket: "
+            "`value`, `ms_per_step` and `roofline.achieved` are all this one interval (value x 3 B = roofline.achieved).  The host "
+            "clock around the same bracket is `wall_ms_per_step`; it adds the fixed cost of one submission ramp and one completion "
+            "wake-up, `wall_overhead_us_total`, which is per CALL, not per step (%d steps here)" % args.steps,
+            "wall_ms_per_step": round(wall_s * 1e3 / args.steps, 6),
+            "wall_overhead_us_total": round((wall_s * 1e3 - ms_total_timed) * 1e3, 1),
+            "wall_overhead_us_per_step": round((wall_s * 1e3 - ms_total_timed) * 1e3 / args.steps, 3),
+            "value_by_wall_clock": round(pixels * args.steps / wall_s / 1e6, 1),
         },
         "roofline": {
             "bound": "hbm",
@@ -402,6 +421,7 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
         ctx.check(L.tic_compress_batch(ctx.handle, inp, count, h, w, w, q, outp, caps, lens, 0))
         t_h2h = time.perf_counter() - t1
     sizes = [int(lens[i]) for i in range(count)]
+    parity = manifest_parity(q, first, sizes, [pool[i, : sizes[i]] for i in range(count)])
     # the same with the caller's frames pinned (tic_host_register): no staging copy on the host, the H2D engine reads the frames
     # where they lie.  One registered block holding the shard, as a capture or decode buffer would be.
     block = np.empty((count, h, w), dtype=np.uint8)
@@ -436,11 +456,40 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
         "numa": {"device_node": int(node.value), "cpus_of_that_node_in_this_process": int(ncpus.value),
                  "note": "the pipeline's own threads bind to those CPUs; pinned slots are placed on the device's node by hipHostMalloc"},
         "stream_bytes_total": int(sum(sizes)),
+        "sizes_sha256": hashlib.sha256(np.asarray(sizes, dtype="<i8").tobytes()).hexdigest(),
+        "parity": parity,
         "untimed_launches": untimed + warmup,
     }
     if timed:
         return info, t_wall, kernel_ms, sizes
     return info, sizes
+
+
+def manifest_parity(q, first, sizes, streams):
+    """Full-size parity of the config-3/4 shard: every stream tic_compress_batch returned against tests/golden/manifest_r4.json -
+    size and sha256 per frame, produced by the UNMODIFIED reference's compress() (codec.py:133-164) on the same seeded frames
+    (tests/golden/gen/make_goldens_r4.py).  Raises on any difference: a benchmark of wrong output is not a benchmark."""
+    path = os.path.join(ROOT, "tests", "golden", "manifest_r4.json")
+    if q != 50 or not os.path.exists(path):
+        return {"status": "unchecked", "why": "no manifest for this quality" if q != 50 else "tests/golden/manifest_r4.json missing"}
+    m = json.load(open(path))
+    by_seed = {f["seed"]: f for f in m["frames"]}
+    checked, sources = 0, set()
+    for i, (n, st) in enumerate(zip(sizes, streams)):
+        f = by_seed.get(1234 + first + i)
+        if f is None:
+            continue
+        digest = hashlib.sha256(np.ascontiguousarray(st).tobytes()).hexdigest()
+        if n != f["bytes"] or digest != f["sha256"]:
+            raise AssertionError("frame %d (seed %d): stream of %d bytes sha256 %s, the reference's has %d bytes sha256 %s"
+                                 % (first + i, 1234 + first + i, n, digest[:16], f["bytes"], f["sha256"][:16]))
+        checked += 1
+        sources.add(f.get("source", "reference"))
+    out = {"status": "ok" if checked == len(sizes) else ("partial" if checked else "unchecked"), "frames_checked": checked, "frames": len(sizes),
+           "against": "tests/golden/manifest_r4.json (per-frame size + sha256 of the %s's compress())" % " / ".join(sorted(sources) or ["reference"])}
+    if first == 0 and len(sizes) == 256 and checked == 256:
+        out["sizes_sha256_matches_manifest"] = hashlib.sha256(np.asarray(sizes, dtype="<i8").tobytes()).hexdigest() == m.get("sizes_sha256_first256")
+    return out
 
 
 def cpu_baseline(img, q, budget_s, threads):

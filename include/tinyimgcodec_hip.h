@@ -202,6 +202,12 @@ int tic_last_decode_giveup(tic_ctx *ctx);
  *      was available to the build); the multi-rank flow is covered by world_size-2 tests over gloo. ---------------------- */
 typedef struct tic_comm tic_comm;
 int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_path, tic_comm **out);
+/* The same with the reader's acceptance window spelled out: not_before_ns = the oldest publication time (CLOCK_REALTIME) a
+ * reader believes - pass the LAUNCHER's start time when ranks may start long after rank 0 published (staggered launchers, a
+ * restarted worker); 0 = the calling process's own start (tic_comm_create), 1 = any age (names inside a directory that is
+ * private to the launch).  timeout_ms <= 0 = two minutes. */
+int tic_comm_create_ex(tic_ctx *ctx, int rank, int world, const char *rendezvous_path, uint64_t not_before_ns, int timeout_ms,
+                       tic_comm **out);
 int tic_comm_destroy(tic_comm *comm);
 int tic_comm_rank(const tic_comm *comm);
 int tic_comm_world(const tic_comm *comm);
@@ -212,8 +218,9 @@ int tic_gather_sizes(tic_comm *comm, const uint64_t *mine, int n_mine, uint64_t 
 int tic_comm_allreduce_max(tic_comm *comm, double *vals, int n);
 /* The rendezvous file of tic_comm_create, usable on its own (no GPU involved): publish = exclusive creation (O_EXCL|O_NOFOLLOW,
  * 0600) under a temporary name + rename, after removing leftovers of the same name; wait = poll (timeout_ms) for a complete
- * file with `bytes` of payload published no earlier than not_before_ns (CLOCK_REALTIME; 0 = the calling process's start:
- * a file an earlier launch left behind is ignored). */
+ * file OWNED BY THE CALLER'S EFFECTIVE USER with `bytes` of payload published no earlier than not_before_ns (CLOCK_REALTIME;
+ * 0 = the calling process's start: a file an earlier launch left behind is ignored; 1 = any age).  The poll interval doubles
+ * from 50 us to 20 ms.  tinyimgcodec_amd/distributed.py builds its torch-free control channel (FileComm) on these two. */
 int tic_rdv_publish(const char *path, const void *payload, size_t bytes);
 int tic_rdv_wait(const char *path, void *payload, size_t bytes, int timeout_ms, uint64_t not_before_ns);
 

@@ -421,6 +421,30 @@ def test_batch_pipeline_matches_single_frame(ctx, manifest):
         assert sha(ac.astype("<i4").tobytes()) == m["ac_i4_sha256"]
 
 
+def test_config3_and_config4_full_size_streams_against_the_reference_manifest(ctx):
+    """BASELINE configs 3 and 4 at FULL size: every one of the 2,048 frames of config 4 (1920x1080, seed 1234 + i, q = 50; the
+    first 256 are config 3) goes through tic_compress_batch in shards of 256, as a rank of config 4 would send them, and every
+    stream's size and sha256 must be what the unmodified reference's compress() (codec.py:133-164) produced for that frame
+    (tests/golden/manifest_r4.json, generator tests/golden/gen/make_goldens_r4.py)."""
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest_r4.json")) as f:
+        m = json.load(f)
+    frames_m = m["frames"]
+    assert len(frames_m) >= 256 and frames_m[0]["seed"] == 1234 and all(f["source"] == "reference" for f in frames_m[:256])
+    checked = 0
+    for lo in range(0, len(frames_m), 256):
+        part = frames_m[lo:lo + 256]
+        frames = [rand_frame(f["seed"], 1080, 1920) for f in part]
+        out = T.compress_batch(frames, 50, threads=0, ctx=ctx)
+        for f, bs in zip(part, out):
+            assert len(bs) == f["bytes"] and sha(bs) == f["sha256"], f["seed"]
+            checked += 1
+        if lo == 0:
+            assert sha(np.asarray([len(b) for b in out], dtype="<i8").tobytes()) == m["sizes_sha256_first256"]
+    assert checked == len(frames_m)
+
+
 def test_batched_launch_matches_per_frame(ctx, oracle):
     """tic_dctq_dev_frames: several frames (ragged size -> remainder strips too) in one launch == oracle per frame."""
     L = N.load()
@@ -903,8 +927,11 @@ def test_batch_takes_registered_frames_in_place(ctx, oracle):
 
 def test_bench_lines_name_their_scaling_baseline(tmp_path):
     """bench.py: --workload config4 on one GPU (the N = 1 point of a config-4 curve) and the two-rank rehearsal on the one GPU
-    of the box (gloo for the exchange: RCCL needs a GPU per rank).  Both lines carry the same workload, per-rank rates and the
-    name of the field an N > 1 value must be compared with; the gathered sizes of the two ranks are the first 16 of the one."""
+    of the box, started AS THE DRIVER TYPES IT - `python bench.py --gpus 2 ...`, no launcher around it, no torch: bench.py spawns
+    its own two rank processes (tinyimgcodec_amd/launch.py); TIC_BENCH_SHARE_GPU=1 puts both on device 0, where the exchange runs
+    over the file communicator (RCCL needs a GPU per rank).  Both lines carry the same workload, per-rank rates and the name of
+    the field an N > 1 value must be compared with; the gathered sizes of the two ranks are the first 16 of the one; every
+    stream of both runs was checked against the reference's manifest (bench.py raises otherwise)."""
     import json
     import socket
     import subprocess
@@ -912,25 +939,34 @@ def test_bench_lines_name_their_scaling_baseline(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     small = ["--shard-frames", "8", "--steps", "2", "--warmup", "1", "--settle-ms", "1"]
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "config4"] + small, capture_output=True, text=True, timeout=600, cwd=root)
+    env0 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TIC_RDV_DIR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "config4"] + small, capture_output=True, text=True, timeout=600, cwd=root, env=env0)
     assert r.returncode == 0, r.stderr[-2000:]
     one = json.loads(r.stdout.strip().splitlines()[-1])
     assert one["n_gpus"] == 1 and "config 4" in one["config"]["workload"] and one["scaling_baseline"]["value"].startswith("`config4.kernel_only_mpix_s`")
     assert one["config"]["per_rank"]["kernel_only_mpix_s"] == one["value"]
+    assert one["config"]["parity"]["status"] == "ok" and one["config"]["parity"]["frames_checked"] == 8
+    env = dict(env0, TIC_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([ln for ln in r.stdout.strip().splitlines() if ln.strip()]) == 1, r.stdout  # ONE JSON line on the job's stdout
+    two = json.loads(r.stdout.strip())
+    assert two["n_gpus"] == 2 and two["config"]["gathered_sizes"]["frames"] == 16 and "file communicator" in two["config"]["comm"]
+    assert two["config"]["gathered_sizes"]["first"] == one["config"]["gathered_sizes"]["first"]
+    assert abs(two["config"]["per_rank"]["kernel_only_mpix_s"] * 2 - two["value"]) < 1.0
+    assert "NOT the N = 1 line's `value`" in two["scaling_baseline"]["value"]
+    assert two["config"]["parity"]["status"] == "ok"
+    # the torchrun form keeps working (torchrun only spawns: nothing in bench.py or the package imports torch)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, TIC_BENCH_BACKEND="gloo", TIC_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + small,
                        capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    two = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
-    assert two["n_gpus"] == 2 and two["config"]["gathered_sizes"]["frames"] == 16 and "gloo" in two["config"]["comm"]
-    assert two["config"]["gathered_sizes"]["first"] == one["config"]["gathered_sizes"]["first"]
-    assert abs(two["config"]["per_rank"]["kernel_only_mpix_s"] * 2 - two["value"]) < 1.0
-    assert "NOT the N = 1 line's `value`" in two["scaling_baseline"]["value"]
+    three = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert three["config"]["gathered_sizes"] == two["config"]["gathered_sizes"]
 
 
 def test_decoder_edges_round3(ctx, golden, monkeypatch):

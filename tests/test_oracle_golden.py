@@ -1,11 +1,12 @@
 """The CPU oracle (oracle/tic_oracle.c) against fixtures produced by the unmodified reference
 (tests/golden/gen/make_goldens.py).  CPU-only; this is what pins the oracle."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
-from conftest import rand_frame
+from conftest import GOLDEN, rand_frame
 
 
 def sha(b):
@@ -262,3 +263,22 @@ def test_decoder_edges_round3(oracle, golden):
             assert str(g[name + "_exc"]) in ("error", "ValueError"), name  # struct.error / ValueError
             with pytest.raises(oracle.OracleError):
                 oracle.decompress(bs)
+
+
+def test_oracle_against_full_size_manifest_r4(oracle):
+    """Round 4: the reference's compress() on the 1920x1080 frames of BASELINE configs 3/4 (manifest_r4.json: size + sha256 per
+    frame, seeds 1234 ...).  The oracle is pinned on a spread of them here (0.1 s each); the GPU tests check every frame."""
+    import hashlib
+    import json
+
+    with open(os.path.join(GOLDEN, "manifest_r4.json")) as f:
+        m = json.load(f)
+    fr = m["frames"]
+    assert (m["height"], m["width"], m["quality"]) == (1080, 1920, 50) and len(fr) >= 256
+    assert [f["seed"] for f in fr] == list(range(1234, 1234 + len(fr)))
+    sizes = np.asarray([f["bytes"] for f in fr], dtype="<i8")
+    assert hashlib.sha256(sizes.tobytes()).hexdigest() == m["sizes_sha256"]
+    assert hashlib.sha256(sizes[:256].tobytes()).hexdigest() == m["sizes_sha256_first256"]
+    for k in sorted(set([0, 1, 100, 255, 256, len(fr) // 2, len(fr) - 1]) & set(range(len(fr)))):
+        bs = oracle.compress(rand_frame(fr[k]["seed"], 1080, 1920), 50)
+        assert len(bs) == fr[k]["bytes"] and hashlib.sha256(bs).hexdigest() == fr[k]["sha256"], fr[k]["seed"]

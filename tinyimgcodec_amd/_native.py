@@ -107,6 +107,7 @@ SIGNATURES = {
     "tic_last_decode_giveup": (C.c_int, [_ctxp]),
     "tic_selftest_transpose": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "tic_comm_create": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "tic_comm_create_ex": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "tic_comm_destroy": (C.c_int, [C.c_void_p]),
     "tic_comm_rank": (C.c_int, [C.c_void_p]),
     "tic_comm_world": (C.c_int, [C.c_void_p]),

@@ -156,19 +156,27 @@ static void find_numa(tic_ctx *ctx) {
     cpu_set_t mine;
     CPU_ZERO(&mine);
     if (sched_getaffinity(0, sizeof mine, &mine) != 0) return;
-    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) { // "0-63,128-191"
-        int a = 0, b = 0;
-        const int k = sscanf(tok, "%d-%d", &a, &b);
-        if (k == 1) b = a;
-        if (k < 1) continue;
-        for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+    // "0-63,128-191": walked with a local cursor (strtol) - contexts are created concurrently, strtok's state is process-global
+    for (const char *p = list; *p;) {
+        while (*p && (*p < '0' || *p > '9')) p++;
+        if (!*p) break;
+        char *end = nullptr;
+        long a = strtol(p, &end, 10), b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
             if (CPU_ISSET(c, &mine)) { CPU_SET(c, &ctx->numa_cpus); ctx->numa_ncpus++; }
     }
     ctx->numa_node = node;
 }
 // Called at the start of every thread the pipeline creates (never on the caller's thread).
 static void bind_pipeline_thread(const tic_ctx *ctx) {
-    if (ctx->numa_bind && ctx->numa_node >= 0 && ctx->numa_ncpus > 0) (void)sched_setaffinity(0, sizeof ctx->numa_cpus, &ctx->numa_cpus);
+    // only when the node offers room for the pipeline's threads (8 stagers + reader + hand-out + consumers): a process mask that
+    // leaves one or two CPUs of the device's node would put all of them on those
+    if (ctx->numa_bind && ctx->numa_node >= 0 && ctx->numa_ncpus >= 8) (void)sched_setaffinity(0, sizeof ctx->numa_cpus, &ctx->numa_cpus);
 }
 
 static thread_local std::string g_create_err;

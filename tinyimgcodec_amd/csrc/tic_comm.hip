@@ -159,18 +159,20 @@ int tic_rdv_publish(const char *path, const void *payload, size_t bytes) {
 // than `not_before_ns` (CLOCK_REALTIME; 0 = this process's own start), and copies the payload out.
 int tic_rdv_wait(const char *path, void *payload, size_t bytes, int timeout_ms, uint64_t not_before_ns) {
     if (!path || !*path || (!payload && bytes)) return comm_fail(nullptr, TIC_E_ARG, "bad rendezvous arguments", nullptr);
-    if (not_before_ns == 0) {
+    if (not_before_ns == 0) { // (1 = any age: for names that are unique to the launch, e.g. inside the launcher's private directory)
         const uint64_t st = process_start_realtime_ns();
         not_before_ns = st > 2000000000ull ? st - 2000000000ull : 0; // (clock-tick granularity of the start time)
     }
     const uint64_t t_end = now_realtime_ns() + (uint64_t)(timeout_ms < 0 ? 0 : timeout_ms) * 1000000ull;
     bool saw_stale = false;
+    long nap_ns = 50 * 1000; // polls double from 50 us to 20 ms: a collective of the file communicator completes in well under a millisecond
     for (;;) {
         const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
         if (fd >= 0) {
             RdvHeader h;
             struct stat st;
-            const bool whole = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size == sizeof h + bytes &&
+            // (a file somebody else planted under a predictable name in a shared /tmp is not ours to believe)
+            const bool whole = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && (size_t)st.st_size == sizeof h + bytes &&
                                read(fd, &h, sizeof h) == (ssize_t)sizeof h && memcmp(h.magic, kRdvMagic, 8) == 0 && h.payload_bytes == bytes;
             if (whole && h.published_ns >= not_before_ns) {
                 const bool got = bytes == 0 || read(fd, payload, bytes) == (ssize_t)bytes;
@@ -182,8 +184,9 @@ int tic_rdv_wait(const char *path, void *payload, size_t bytes, int timeout_ms, 
             }
         }
         if (now_realtime_ns() >= t_end) break;
-        struct timespec ts = {0, 20 * 1000 * 1000};
+        struct timespec ts = {0, nap_ns};
         nanosleep(&ts, nullptr);
+        if (nap_ns < 20 * 1000 * 1000) nap_ns *= 2;
     }
     return comm_fail(nullptr, TIC_E_ARG, saw_stale ? "only a stale rendezvous file (older than this process) was found" : "rendezvous file did not appear", path);
 }
@@ -202,6 +205,12 @@ int tic_comm_destroy(tic_comm *c) {
 }
 
 int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_path, tic_comm **out) {
+    return tic_comm_create_ex(ctx, rank, world, rendezvous_path, 0, 120000, out);
+}
+
+// not_before_ns: the oldest publication time (CLOCK_REALTIME) a reader accepts - the LAUNCHER's start time when the ranks start at
+// different times (a rank restarted or spawned long after rank 0 published), 0 = this process's own start, 1 = any age.
+int tic_comm_create_ex(tic_ctx *ctx, int rank, int world, const char *rendezvous_path, uint64_t not_before_ns, int timeout_ms, tic_comm **out) {
     if (!ctx || !out || world < 1 || rank < 0 || rank >= world) return comm_fail(nullptr, TIC_E_ARG, "bad communicator arguments", nullptr);
     tic_comm *c = new tic_comm();
     c->ctx = ctx;
@@ -252,7 +261,7 @@ int tic_comm_create(tic_ctx *ctx, int rank, int world, const char *rendezvous_pa
             if (rc != TIC_OK) { delete c; return rc; }
             published = true;
         } else {
-            const int rc = tic_rdv_wait(path.c_str(), &id, sizeof id, 120000, 0);
+            const int rc = tic_rdv_wait(path.c_str(), &id, sizeof id, timeout_ms > 0 ? timeout_ms : 120000, not_before_ns);
             if (rc != TIC_OK) { delete c; return rc; }
         }
         (void)hipGetLastError(); // RCCL reads the thread's last HIP error: a stale one from an earlier, unrelated call would fail it
