@@ -224,83 +224,25 @@ def test_guard_band_of_the_fast_path_is_a_bound(tmp_path):
 
 
 
-def _device_code_objects(lib_path, tmp_path):
-    """Unbundles every gfx950 code object embedded in the shared library (one per translation unit)."""
-    import shutil
-    import subprocess
-    llvm = "/opt/rocm/lib/llvm/bin"
-    bundler, objdump, readelf = (os.path.join(llvm, t) for t in ("clang-offload-bundler", "llvm-objdump", "llvm-readelf"))
-    if shutil.which("objcopy") is None or not all(os.path.exists(t) for t in (bundler, objdump, readelf)):
-        pytest.skip("binutils / ROCm llvm tools not available")
-    fat = tmp_path / "fat.bin"
-    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib_path, str(fat)], check=True)
-    blob = fat.read_bytes()
-    magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
-    out = []
-    for k, st in enumerate(starts):
-        part = tmp_path / ("bundle%d.bin" % k)
-        part.write_bytes(blob[st:starts[k + 1] if k + 1 < len(starts) else len(blob)])
-        co = tmp_path / ("dev%d.co" % k)
-        subprocess.run([bundler, "--unbundle", "--type=o", "--input=" + str(part), "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                        "--output=" + str(co)], check=True)
-        out.append((str(co), objdump, readelf))
-    return out
-
-
-def test_strip_kernel_binary_keeps_its_landing_registers_private(tmp_path):
+def test_strip_kernel_binary_keeps_its_landing_registers_private():
     """The production kernel's pixel loads land in v72..v79, registers the compiler may not allocate (amdgpu_num_vgpr(72)):
-    a load in flight must never share a register with anything the compiler placed.  Checked on the SHIPPED binary:
-    in dctq_strip_kernel the only instructions that name v72..v79 are the hand-written loads into them, the byte-to-float
-    conversions out of them (every group of eight directly behind an s_waitcnt vmcnt) and plain moves out of them; the kernel uses no scratch, no accumulator registers and
-    exactly 80 vector registers (six waves per SIMD)."""
-    import re
-    import subprocess
+    a load in flight must never share a register with anything the compiler placed.  Checked on the SHIPPED binary by
+    tinyimgcodec_amd/csrc/lint_strip_kernel.py - the same script csrc/Makefile runs behind the link, where a violation fails the
+    build: in dctq_strip_kernel the only instructions that name v72..v79 are the hand-written loads into them, the byte-to-float
+    conversions out of them (every group of eight directly behind an s_waitcnt vmcnt) and plain moves out of them; no scratch,
+    no accumulator registers, exactly 80 vector registers (six waves per SIMD)."""
+    import importlib.util
     from tinyimgcodec_amd import _native as N
     if not os.path.exists(N.LIB_PATH):
         pytest.skip("library not built")
-    found = False
-    for co, objdump, readelf in _device_code_objects(N.LIB_PATH, tmp_path):
-        dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
-        m = re.search(r"<(_ZN3tic17dctq_strip_kernel\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S)
-        if not m:
-            continue
-        found = True
-        name, body = m.group(1), m.group(2)
-        insns = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.strip()]
-        reserved = re.compile(r"\bv7[2-9]\b|\bv\[(\d+):(\d+)\]")
-
-        def touches(ins):
-            for mm in reserved.finditer(ins):
-                if mm.group(1) is None:
-                    return True
-                if int(mm.group(2)) >= 72 and int(mm.group(1)) <= 79:
-                    return True
-            return False
-
-        n_loads = n_moves = n_cvt = 0
-        for k, ins in enumerate(insns):
-            if not touches(ins):
-                continue
-            if re.match(r"global_load_dwordx2 v\[7[2468]:7[3579]\], v\d+, s\[\d+:\d+\]", ins) or re.match(r"global_load_dwordx4 v\[76:79\], v\d+, s\[\d+:\d+\]", ins):
-                n_loads += 1
-                continue
-            cv = re.match(r"v_cvt_f32_ubyte[0-3](_e32)? v(\d+), v(7[2-9])$", ins)
-            mv = re.match(r"v_mov_b32(_e32)? v(\d+), v(7[2-9])$", ins)
-            assert (cv and int(cv.group(2)) < 72) or (mv and int(mv.group(2)) < 72), "unexpected use of a reserved register: " + ins
-            prev = insns[k - 1]
-            if cv:  # the strip's conversions: one group of eight directly behind the counted wait
-                n_cvt += 1
-                assert prev.startswith("s_waitcnt vmcnt(") or re.match(r"v_cvt_f32_ubyte[0-3](_e32)? v\d+, v7[2-9]$", prev), "a conversion out of a landing register is not behind its counted wait: %s | %s" % (prev, ins)
-            else:   # the constant piece (behind its wait) and the rare paths' raw words (the strip in work: landed long ago)
-                n_moves += 1
-        assert n_loads >= 7 and n_cvt >= 24 and n_cvt % 8 == 0 and n_moves >= 4, (n_loads, n_cvt, n_moves)
-        assert "accvgpr" not in body and "scratch_" not in body
-        notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True, check=True).stdout
-        blk = [e for e in notes.split("\n  - .agpr_count:") if (".name:" in e and name in e)][0]  # the kernel's metadata entry
-        blk = ".agpr_count:" + blk
-        assert re.search(r"\.vgpr_count:\s+80\b", blk) and re.search(r"\.private_segment_fixed_size:\s+0\b", blk) and re.search(r"\.agpr_count:\s+0\b", blk), blk
-    assert found, "dctq_strip_kernel not found in the library"
+    spec = importlib.util.spec_from_file_location("lint_strip_kernel", os.path.join(ROOT, "tinyimgcodec_amd", "csrc", "lint_strip_kernel.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    try:
+        summary = lint.check(N.LIB_PATH)
+    except lint.ToolsMissing as e:
+        pytest.skip(str(e))
+    assert "80 VGPRs" in summary
 
 
 def test_rendezvous_file_is_created_exclusively_and_stale_files_are_ignored(tmp_path):

@@ -652,9 +652,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
             }
         } while (0);
 #undef TIC_STEP
-        // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved until
-        // only the wave's last store is outstanding
-        asm volatile("s_waitcnt vmcnt(1)" : : : TIC_RSV_CLOBBER);
+        // Loads past the end of the walk (clamped addresses) may still be in flight: they land in v72..v79, which nothing behind
+        // the loop names (the compiler never allocates them), so nothing waits for them - nor for the acknowledgement of the
+        // strip stores, which is what rounds 1-3's `s_waitcnt vmcnt(1)` here really waited for (~580 cycles at the head of every
+        // batch pass; profiles/r04_tail_experiments.txt).  The statement stays as a scheduling fence with the same clobbers.
+        asm volatile("; end of the strip walk" : : : TIC_RSV_CLOBBER);
 #undef TIC_LOAD
 #undef TIC_TAKE
 #undef TIC_RSV_CLOBBER

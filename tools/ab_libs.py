@@ -1,12 +1,12 @@
 """A/B timing of two BUILDS of the library in one process (boxes differ by +-5 %, builds must be compared on one box): the product library
 against another .so of the same C-ABI (e.g. an older kernel built into tools/bin/), the same frame, rounds interleaved.  Warm (one
-frame/coefficient pair replayed) and cold (12 rotating pairs).  Usage: python tools/ab_libs.py tools/bin/libother.so [--dim 4096] [--rounds 7]"""
+frame/coefficient pair replayed) and cold (12 rotating pairs).  Usage: python tools/ab_libs.py tools/bin/libother.so [more.so ...] [--dim 4096] [--rounds 7]"""
 import argparse, ctypes as C, statistics, sys
 sys.path.insert(0, '.')
 import numpy as np
 from tinyimgcodec_amd import _native as N
 ap = argparse.ArgumentParser()
-ap.add_argument("other")
+ap.add_argument("other", nargs="+")
 ap.add_argument("--dim", type=int, default=4096)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=2000)
@@ -21,7 +21,10 @@ def bind(path):
     return L
 
 h = w = args.dim
-libs = {"product": bind(N.LIB_PATH), "other": bind(args.other)}
+import os
+libs = {"product": bind(N.LIB_PATH)}
+for pth in args.other:
+    libs[os.path.basename(pth).replace("lib", "").replace(".so", "")] = bind(pth)
 state = {}
 pairs = 12
 for name, L in libs.items():
@@ -47,11 +50,12 @@ def cold(name, iters):
     return ms.value * 1e3 / iters
 # same coefficients?
 a = np.empty((h // 8) * (w // 8) * 64, np.int16); b = np.empty_like(a)
-for name, buf in (("product", a), ("other", b)):
+for name in libs:
     L, ctx, imgs, outs = state[name]
+    buf = a if name == "product" else b
     warm(name, 1)
     assert L.tic_memcpy_d2h(ctx, buf.ctypes.data, outs[0], buf.nbytes) == 0
-print("coefficients identical:", bool(np.array_equal(a, b)))
+    if name != "product": print("coefficients of %s identical to the product's:" % name, bool(np.array_equal(a, b)))
 for name in libs: warm(name, 3000); cold(name, 600)
 res = {(n, m): [] for n in libs for m in ("warm", "cold")}
 for r in range(args.rounds):
@@ -59,4 +63,4 @@ for r in range(args.rounds):
         res[(name, "warm")].append(warm(name, args.iters))
         res[(name, "cold")].append(cold(name, args.iters // 4))
 for (name, mode), v in res.items():
-    print("%-8s %-5s median %.3f us  min %.3f  max %.3f   (%s)" % (name, mode, statistics.median(v), min(v), max(v), " ".join("%.2f" % x for x in v)))
+    print("%-10s %-5s median %.3f us  min %.3f  max %.3f   (%s)" % (name, mode, statistics.median(v), min(v), max(v), " ".join("%.2f" % x for x in v)))
