@@ -416,10 +416,33 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
     outp = (C.c_void_p * count)(*[pool[i].ctypes.data for i in range(count)])
     caps = (C.c_size_t * count)(*([cap] * count))
     lens = (C.c_size_t * count)()
-    for _ in range(2):
-        t1 = time.perf_counter()
-        ctx.check(L.tic_compress_batch(ctx.handle, inp, count, h, w, w, q, outp, caps, lens, 0))
-        t_h2h = time.perf_counter() - t1
+    def h2h(inputs, lens_out, reps=5):
+        """median of `reps` calls after one untimed call (the first call of a shape allocates the slots and faults them in), with
+        the phase times of that call (tic_last_batch_phases)"""
+        runs = []
+        tr = (C.c_double * 8)()
+        for r in range(reps + 1):
+            t1 = time.perf_counter()
+            ctx.check(L.tic_compress_batch(ctx.handle, inputs, count, h, w, w, q, outp, caps, lens_out, 0))
+            dt = time.perf_counter() - t1
+            ctx.check(L.tic_last_batch_phases(ctx.handle, tr))
+            if r:
+                runs.append((dt, {"stage_or_register": round(tr[0], 2), "enqueue": round(tr[1], 2), "slot_wait": round(tr[5], 2),
+                                  "chunk_wait": round(tr[2], 2), "read_back": round(tr[3], 2), "hand_out": round(tr[4], 2),
+                                  "min_max_ms": None}))
+        runs.sort(key=lambda x: x[0])
+        dt, phases = runs[len(runs) // 2]
+        phases["min_max_ms"] = [round(runs[0][0] * 1e3, 2), round(runs[-1][0] * 1e3, 2)]
+        return dt, phases
+
+    # pageable frames staged through the pipeline's pinned slots by copy threads (rounds 1-3's only route for pageable input) ...
+    ctx.check(L.tic_set_auto_register(ctx.handle, 0))
+    t_h2h_staged, ph_staged = h2h(inp, lens)
+    # ... and pinned in place for the duration of the call (the default): one registration over the batch's address range
+    ctx.check(L.tic_set_auto_register(ctx.handle, 1))
+    t_h2h, ph = h2h(inp, lens)
+    n_auto = C.c_int()
+    ctx.check(L.tic_last_batch_auto_registered(ctx.handle, C.byref(n_auto)))
     sizes = [int(lens[i]) for i in range(count)]
     parity = manifest_parity(q, first, sizes, [pool[i, : sizes[i]] for i in range(count)])
     # the same with the caller's frames pinned (tic_host_register): no staging copy on the host, the H2D engine reads the frames
@@ -430,10 +453,7 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
     ctx.check(L.tic_host_register(ctx.handle, block.ctypes.data, block.nbytes))
     inp_r = (C.c_void_p * count)(*[block[i].ctypes.data for i in range(count)])
     lens_r = (C.c_size_t * count)()
-    for _ in range(2):
-        t1 = time.perf_counter()
-        ctx.check(L.tic_compress_batch(ctx.handle, inp_r, count, h, w, w, q, outp, caps, lens_r, 0))
-        t_h2h_reg = time.perf_counter() - t1
+    t_h2h_reg, ph_reg = h2h(inp_r, lens_r)
     n_direct, n_staged = C.c_int(), C.c_int()
     ctx.check(L.tic_last_batch_input_path(ctx.handle, C.byref(n_direct), C.byref(n_staged)))
     ctx.check(L.tic_host_unregister(ctx.handle, block.ctypes.data))
@@ -449,6 +469,15 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
         "host_to_host_mpix_s": round(pixels / t_h2h / 1e6, 1),
         "host_to_host_s": round(t_h2h, 5),
         "host_to_host_frames_per_s": round(count / t_h2h, 1),
+        "host_to_host_phases_ms": ph,
+        "host_to_host_note": "pageable caller frames (256 separate arrays), pinned in place for the call by ONE hipHostRegister over their address "
+        "range (%d of %d frames took that route), median of 5 calls; phases are per pipeline thread and overlap" % (n_auto.value, count),
+        "host_to_host_staged_s": round(t_h2h_staged, 5),
+        "host_to_host_staged_frames_per_s": round(count / t_h2h_staged, 1),
+        "host_to_host_staged_phases_ms": ph_staged,
+        "host_to_host_staged_note": "the same frames copied into the pipeline's pinned slots by 8 host threads (tic_set_auto_register(0): "
+        "rounds 1-3's route for pageable input; it depends on what else runs on the host)",
+        "frames_numa_nodes": frame_nodes(frames),
         "host_to_host_registered_mpix_s": round(pixels / t_h2h_reg / 1e6, 1),
         "host_to_host_registered_s": round(t_h2h_reg, 5),
         "host_to_host_registered_frames_per_s": round(count / t_h2h_reg, 1),
@@ -463,6 +492,20 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
     if timed:
         return info, t_wall, kernel_ms, sizes
     return info, sizes
+
+
+def frame_nodes(frames):
+    """NUMA nodes that hold the caller's frames (move_pages(2) in query mode on a sample of their pages); None where unavailable."""
+    try:
+        libc = C.CDLL(None, use_errno=True)
+        sample = frames[:: max(1, len(frames) // 16)]
+        pages = (C.c_void_p * len(sample))(*[(f.ctypes.data + f.nbytes // 2) & ~4095 for f in sample])
+        status = (C.c_int * len(sample))()
+        if libc.syscall(279, 0, C.c_ulong(len(sample)), pages, None, status, 0) != 0:
+            return None
+        return sorted(set(int(v) for v in status))
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def manifest_parity(q, first, sizes, streams):

@@ -94,6 +94,18 @@ int tic_numa_info(tic_ctx *ctx, int *node, int *ncpus);
 int tic_set_numa_binding(tic_ctx *ctx, int enable);
 /* How the last batch call took its input: frames copied from the caller's pinned/registered memory / frames staged. */
 int tic_last_batch_input_path(tic_ctx *ctx, int *direct_frames, int *staged_frames);
+/* Where the last tic_compress_batch / tic_dctq_batch call spent its time: ms8[0] staging copies into pinned memory (pageable
+ * input) or registration of the caller's frames, [1] enqueueing (H2D copy, kernels, length copies), [2] waiting for chunks,
+ * [3] stream read-back, [4] hand-out into the caller's buffers, [5] waiting for a free slot; [6], [7] unused.  Sums over the
+ * call per pipeline thread (0, 1, 5: the submitting thread; 2, 3: the reading thread; 4: the hand-out thread): they overlap. */
+int tic_last_batch_phases(tic_ctx *ctx, double *ms8);
+/* Pageable frames handed to the batch entry points are pinned IN PLACE for the duration of the call (one hipHostRegister over
+ * the address range of the batch, or of a chunk, when the frames lie close together; unregistered before the call returns) and
+ * read by the copy engine where they lie; frames that lie scattered, and ranges that cannot be registered, are staged through the
+ * pipeline's pinned slots by copy threads.  enable = 0 stages everything (rounds 1-3).  tic_last_batch_auto_registered: how
+ * many frames of the last batch call took the registered route (they also count as "direct" in tic_last_batch_input_path). */
+int tic_set_auto_register(tic_ctx *ctx, int enable);
+int tic_last_batch_auto_registered(tic_ctx *ctx, int *frames);
 int tic_memcpy_h2d(tic_ctx *ctx, void *dst, const void *src, size_t bytes);
 int tic_memcpy_d2h(tic_ctx *ctx, void *dst, const void *src, size_t bytes);
 int tic_memset_dev(tic_ctx *ctx, void *dst, int value, size_t bytes);

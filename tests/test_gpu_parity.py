@@ -925,6 +925,73 @@ def test_batch_takes_registered_frames_in_place(ctx, oracle):
     assert got == want
 
 
+def test_batch_pins_pageable_frames_in_place(ctx, oracle):
+    """Round 4: pageable frames of a batch are registered IN PLACE for the duration of the call when one range covers them (frames
+    allocated one after the other), and staged through the pinned slots otherwise: same streams on every route, equal to the
+    oracle's; nothing stays registered behind the call; tic_set_auto_register(0) restores the staging route."""
+    L = N.load()
+    n, h, w, q = 37, 520, 520, 50  # 270 KB per frame (above the 256 KB floor of the registered route), three chunks
+    block = np.stack([rand_frame(5200 + i, h, w) for i in range(n)])
+    want = [oracle.compress(block[i], q) for i in range(n)]
+    cap = L.tic_compress_bound(h, w)
+    pool = np.empty((n, cap), dtype=np.uint8)
+    outp = (C.c_void_p * n)(*[pool[i].ctypes.data for i in range(n)])
+    caps = (C.c_size_t * n)(*([cap] * n))
+
+    def run(ptrs):
+        lens = (C.c_size_t * n)()
+        inp = (C.c_void_p * n)(*ptrs)
+        pool[:] = 0
+        ctx.check(L.tic_compress_batch(ctx.handle, inp, n, h, w, w, q, outp, caps, lens, 0))
+        d, st, au = C.c_int(), C.c_int(), C.c_int()
+        ctx.check(L.tic_last_batch_input_path(ctx.handle, C.byref(d), C.byref(st)))
+        ctx.check(L.tic_last_batch_auto_registered(ctx.handle, C.byref(au)))
+        return [pool[i, : lens[i]].tobytes() for i in range(n)], d.value, st.value, au.value
+
+    dense = [block[i].ctypes.data for i in range(n)]
+    got, direct, staged, auto = run(dense)                         # one range over the batch
+    assert got == want and (direct, staged, auto) == (n, 0, n)
+    ctx.check(L.tic_host_register(ctx.handle, block.ctypes.data, block.nbytes))   # nothing was left registered: this must succeed
+    ctx.check(L.tic_host_unregister(ctx.handle, block.ctypes.data))
+    ctx.check(L.tic_set_auto_register(ctx.handle, 0))
+    try:
+        got, direct, staged, auto = run(dense)                     # rounds 1-3: copy threads
+        assert got == want and (direct, staged, auto) == (0, n, 0)
+    finally:
+        ctx.check(L.tic_set_auto_register(ctx.handle, 1))
+    # frames that lie scattered (every second frame of a block four times the batch's size, back to front): the batch range is too
+    # sparse, so are the chunks' ranges -> staged
+    big = np.zeros((8 * n, h, w), dtype=np.uint8)
+    for i in range(n):
+        big[8 * (n - 1 - i)] = block[i]
+    got, direct, staged, auto = run([big[8 * (n - 1 - i)].ctypes.data for i in range(n)])
+    assert got == want and (direct, staged, auto) == (0, n, 0)
+    # two dense groups far apart: the batch range is sparse, the chunks' ranges are not (chunk 2 straddles both groups -> staged)
+    far = np.zeros((64 + n, h, w), dtype=np.uint8)
+    far[:16] = block[:16]
+    far[64 + 16:] = block[16:]
+    ptrs = [far[i].ctypes.data for i in range(16)] + [far[64 + i].ctypes.data for i in range(16, n)]
+    got, direct, staged, auto = run(ptrs)
+    assert got == want and auto >= 16 and direct + staged == n
+    # part of the batch registered by the caller already: the batch range cannot be registered over it; every frame still arrives
+    ctx.check(L.tic_host_register(ctx.handle, block[:8].ctypes.data, block[:8].nbytes))
+    try:
+        got, direct, staged, auto = run(dense)
+        assert got == want and direct + staged == n
+    finally:
+        ctx.check(L.tic_host_unregister(ctx.handle, block[:8].ctypes.data))
+    # transform-only batch (tic_dctq_batch) takes the same route
+    zz = [np.empty((L.tic_num_blocks(h, w), 64), np.int16) for _ in range(n)]
+    inp = (C.c_void_p * n)(*dense)
+    zp = (C.c_void_p * n)(*[z.ctypes.data for z in zz])
+    ctx.check(L.tic_dctq_batch(ctx.handle, inp, n, h, w, w, q, zp))
+    au = C.c_int()
+    ctx.check(L.tic_last_batch_auto_registered(ctx.handle, C.byref(au)))
+    assert au.value == n
+    for i in (0, 17, n - 1):
+        assert np.array_equal(zz[i], oracle.encode_zz16(block[i], q))
+
+
 def test_bench_lines_name_their_scaling_baseline(tmp_path):
     """bench.py: --workload config4 on one GPU (the N = 1 point of a config-4 curve) and the two-rank rehearsal on the one GPU
     of the box, started AS THE DRIVER TYPES IT - `python bench.py --gpus 2 ...`, no launcher around it, no torch: bench.py spawns

@@ -28,8 +28,11 @@
 using namespace tic;
 
 namespace {
-#ifdef TIC_ABLATION // phase times of the batch pipeline's host thread (tools/prof_batch.py)
-struct BatchTrace { // (phases 0,1,5 belong to the submitting thread, 2,3,4 to the finishing thread)
+// Phase times of the batch pipeline (tic_last_batch_phases): a handful of steady_clock reads per chunk, summed per context.
+// 0 staging copies into pinned memory (pageable input) or registration of the caller's frames, 1 enqueueing (H2D, kernels, lengths),
+// 2 waiting for a chunk, 3 stream read-back, 4 hand-out into the caller's buffers, 5 waiting for a free slot.
+// (phases 0, 1, 5 belong to the submitting thread, 2 and 3 to the reading thread, 4 to the hand-out thread)
+struct BatchTrace {
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     static std::chrono::steady_clock::time_point &t0() {
         static thread_local std::chrono::steady_clock::time_point v;
@@ -38,17 +41,8 @@ struct BatchTrace { // (phases 0,1,5 belong to the submitting thread, 2,3,4 to t
     void start() { t0() = std::chrono::steady_clock::now(); }
     void stop(int k) { t[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0()).count(); }
 };
-static BatchTrace g_bt;
-#define BT_START() g_bt.start()
-#define BT_STOP(K) g_bt.stop(K)
-extern "C" void tic_debug_batch_trace(double *out8, int reset) {
-    for (int k = 0; k < 8; k++) out8[k] = g_bt.t[k];
-    if (reset) g_bt = BatchTrace();
-}
-#else
-#define BT_START() ((void)0)
-#define BT_STOP(K) ((void)0)
-#endif
+#define BT_START() ctx->bt.start()
+#define BT_STOP(K) ctx->bt.stop(K)
 
 constexpr int kChunk = 16;
 struct Slot {
@@ -83,7 +77,6 @@ struct tic_ctx {
     size_t h_zz_bytes = 0;
     DctqConsts *d_consts = nullptr;   // [100], index = quality
     unsigned long long *d_fallback = nullptr;
-    void *d_dbg = nullptr; // diagnostic stamp buffer (tic_debug_stamps)
     bool stats = false; // count guard-band fallbacks with a global atomic (diagnostic; serialises at ~12 ns per wave)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the host-buffer entry points
@@ -128,6 +121,12 @@ struct tic_ctx {
     // how the last batch call took its input: frames copied to the device from where the caller holds them (pinned or registered
     // memory) / frames staged through the pipeline's pinned slots (pageable memory)
     int last_batch_direct_frames = 0, last_batch_staged_frames = 0;
+    mutable BatchTrace bt; // phase times of the last batch call
+    // Pageable frames of a batch call are pinned in place for the duration of the call where that is one cheap registration
+    // (auto_register_frames) instead of being copied into the pinned slots by CPU threads
+    bool auto_register = true;
+    std::vector<void *> autoregs;      // ranges this call registered (unregistered before it returns)
+    int last_batch_autoreg_frames = 0;
     std::string err;
     char arch[128] = {0};
 };
@@ -209,10 +208,6 @@ static int set_err(tic_ctx *ctx, int code, const char *fmt, ...) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" {
-#ifdef TIC_ABLATION
-int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
-                     unsigned long long *host_out, size_t n_u64, int variant);
-#endif
 
 const char *tic_version(void) { return "tinyimgcodec_amd 0.1.0 (gfx950)"; }
 
@@ -401,6 +396,27 @@ int tic_last_batch_input_path(tic_ctx *ctx, int *direct_frames, int *staged_fram
     if (staged_frames) *staged_frames = ctx->last_batch_staged_frames;
     return TIC_OK;
 }
+// Pageable frames of a batch are pinned in place for the duration of the call where one registration covers them
+// (auto_register_frames); enable = 0 stages them through the pipeline's pinned slots as rounds 1-3 did.
+int tic_set_auto_register(tic_ctx *ctx, int enable) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    ctx->auto_register = enable != 0;
+    return TIC_OK;
+}
+int tic_last_batch_auto_registered(tic_ctx *ctx, int *frames) {
+    TIC_LOCK(ctx);
+    if (!ctx || !frames) return TIC_E_ARG;
+    *frames = ctx->last_batch_autoreg_frames;
+    return TIC_OK;
+}
+int tic_last_batch_phases(tic_ctx *ctx, double *ms8) {
+    TIC_LOCK(ctx);
+    if (!ctx || !ms8) return TIC_E_ARG;
+    for (int k = 0; k < 8; k++) ms8[k] = ctx->bt.t[k] * 1e3;
+    return TIC_OK;
+}
+
 int tic_memcpy_h2d(tic_ctx *ctx, void *dst, const void *src, size_t bytes) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
@@ -471,7 +487,7 @@ static DctqArgs make_args(tic_ctx *ctx, const void *d_image, int h, int w, ptrdi
     a.nframes = 1;
     a.frame_stride_in = 0;
     a.frame_stride_out = 0;
-    a.dbg = (unsigned long long *)ctx->d_dbg;
+    a.dbg = nullptr;
     return a;
 }
 
@@ -498,11 +514,11 @@ int tic_dctq_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_
     if (rc) return rc;
     if (h == 0 || w == 0) return TIC_OK;
     if (!d_image || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "null device pointer");
-    if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
-        return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+    const int v = dctq_kernel_id(variant);
+    if (v < 0) return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
-    HIPCHK(ctx, launch_dctq(a, variant == TIC_KERNEL_EXACT ? 1 : 2, ctx->stream));
+    HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
     return TIC_OK;
 }
 
@@ -524,7 +540,9 @@ int tic_dctq_dev_frames(tic_ctx *ctx, const void *d_images, int nframes, int h, 
     a.frame_stride_in = (long)frame_stride;
     a.frame_stride_out = (long)coeff_frame_stride;
     merge_frames(a);
-    HIPCHK(ctx, launch_dctq(a, variant == TIC_KERNEL_EXACT ? 1 : 2, ctx->stream));
+    const int v = dctq_kernel_id(variant);
+    if (v < 0) return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+    HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
     return TIC_OK;
 }
 
@@ -536,13 +554,8 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
     if (!ms_total || iters < 1 || !d_image || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
-#ifdef TIC_ABLATION
-    const int v = variant == TIC_KERNEL_EXACT ? 1 : (variant >= 10 ? variant : 2); // >= 10: experiment builds (tools/)
-#else
-    if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
-        return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
-    const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
-#endif
+    const int v = dctq_kernel_id(variant);
+    if (v < 0) return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++) HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -559,8 +572,8 @@ int tic_dctq_dev_frames_timed(tic_ctx *ctx, const void *d_images, int nframes, i
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!ms_total || iters < 1 || nframes < 1 || nframes > 65535 || !d_images || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
-    if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
-        return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+    const int v = dctq_kernel_id(variant);
+    if (v < 0) return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
     if (frame_stride < (ptrdiff_t)h * row_stride || coeff_frame_stride < (ptrdiff_t)(num_blocks(h, w) * 128))
         return set_err(ctx, TIC_E_ARG, "frame strides smaller than one frame");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -570,7 +583,6 @@ int tic_dctq_dev_frames_timed(tic_ctx *ctx, const void *d_images, int nframes, i
     a.frame_stride_in = (long)frame_stride;
     a.frame_stride_out = (long)coeff_frame_stride;
     merge_frames(a);
-    const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++) HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -588,18 +600,11 @@ int tic_dctq_dev_timed_rotating(tic_ctx *ctx, const void *const *d_images, void 
     int rc = check_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!ms_total || iters < 1 || npairs < 1 || !d_images || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
-#ifndef TIC_ABLATION
-    if (variant != TIC_KERNEL_EXACT && variant != TIC_KERNEL_HYBRID && variant != TIC_KERNEL_AUTO)
-        return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
-#endif
+    const int v = dctq_kernel_id(variant);
+    if (v < 0) return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
     for (int k = 0; k < npairs; k++)
         if (!d_images[k] || !d_coeffs_zz[k]) return set_err(ctx, TIC_E_ARG, "null device pointer in pair %d", k);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-#ifdef TIC_ABLATION
-    const int v = variant >= 10 ? variant : (variant == TIC_KERNEL_EXACT ? 1 : 2); // experiment variants pass through
-#else
-    const int v = variant == TIC_KERNEL_EXACT ? 1 : 2;
-#endif
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++) {
         DctqArgs a = make_args(ctx, d_images[i % npairs], h, w, row_stride, quality, d_coeffs_zz[i % npairs]);
@@ -610,25 +615,6 @@ int tic_dctq_dev_timed_rotating(tic_ctx *ctx, const void *const *d_images, void 
     HIPCHK(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
     return TIC_OK;
 }
-
-#ifdef TIC_ABLATION
-// Experiment library only (tools/): one launch of a stamp build (variant 17 or 52), per-wave s_memtime stamps to host_out.
-int tic_debug_stamps(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
-                     unsigned long long *host_out, size_t n_u64, int variant) {
-    TIC_LOCK(ctx);
-    int rc = check_geometry(ctx, h, w, row_stride, quality);
-    if (rc) return rc;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!ctx->d_dbg) HIPCHK(ctx, hipMalloc(&ctx->d_dbg, 8192 * 4 * 8 * sizeof(unsigned long long)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg, 0, 8192 * 4 * 8 * sizeof(unsigned long long), ctx->stream));
-    DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
-    HIPCHK(ctx, launch_dctq(a, (variant == 52 || variant == 71) ? variant : 17, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    size_t n = n_u64 < 8192 * 4 * 8 ? n_u64 : 8192 * 4 * 8;
-    HIPCHK(ctx, hipMemcpy(host_out, ctx->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return TIC_OK;
-}
-#endif
 
 // Device entropy stage: pack with a lane per block (max_quality >= 1: for qualities up to it, with the automatic fall-back to the
 // 8-lane kernel described at ent_lane_max_quality) or always with 8 lanes per block (max_quality < 1, the default).
@@ -916,6 +902,44 @@ static bool host_pointer_is_pinned(const void *p) {
     }
     return at.type == hipMemoryTypeHost;
 }
+// Pageable input.  Copying 2 MB frames into the pinned slots costs the host 2 x the batch in DRAM traffic and eight copy threads,
+// and it is what makes the host -> host rate depend on the box: 12.3 ms for 256 x 1080p on a quiet host, 18-22 ms when the copy
+// threads compete with other tenants or sit on the wrong side of the socket link (profiles/r04_numa_probe.txt), while frames the
+// DMA engine reads where they lie take 12.7-13.5 ms everywhere.  hipHostRegister is cheap PER CALL, not per byte - 0.03 ms for a
+// chunk's 36 MB, 0.18 ms for 510 MB, the pages are validated when the copy engine first touches them - but 77 us per call: one by
+// one, 256 frames cost 19.7 ms.  So the frames [first, first + cnt) are registered as ONE range, from the lowest to the highest
+// address, when that range is dense enough to be mostly frames (arrays allocated one after the other are 16 bytes to a few pages
+// apart) - for the whole batch if possible, else chunk by chunk.  Anything that cannot be registered this way (a range with a
+// hole, memory of another kind, part of it registered by the caller already) is staged as before.  Returns true if the frames
+// are now pinned.
+static bool auto_register_frames(tic_ctx *ctx, const uint8_t *const *images, int first, int cnt, size_t img_bytes) {
+    if (!ctx->auto_register || cnt < 1 || img_bytes < (256u << 10)) return false;
+    uintptr_t lo = UINTPTR_MAX, hi = 0;
+    for (int k = 0; k < cnt; k++) {
+        const uintptr_t p = (uintptr_t)images[first + k];
+        if (!p) return false;
+        lo = p < lo ? p : lo;
+        hi = p + img_bytes > hi ? p + img_bytes : hi;
+    }
+    lo &= ~(uintptr_t)4095;
+    hi = (hi + 4095) & ~(uintptr_t)4095;
+    const size_t span = hi - lo, frames = img_bytes * (size_t)cnt;
+    if (span > frames + frames / 4 + (8u << 20)) return false; // the frames lie scattered: a range over them would pin memory that is not theirs
+    if (hipHostRegister((void *)lo, span, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    ctx->autoregs.push_back((void *)lo);
+    ctx->last_batch_autoreg_frames += cnt;
+    return true;
+}
+static void auto_unregister_all(tic_ctx *ctx) { // (after the call's last copy has completed)
+    for (void *r : ctx->autoregs) {
+        if (hipHostUnregister(r) != hipSuccess) (void)hipGetLastError();
+    }
+    ctx->autoregs.clear();
+}
+
 static hipError_t upload_chunk(tic_ctx *ctx, Slot &s, size_t img_bytes, size_t pitch, const uint8_t *const *images, int first, int cnt,
                                ptrdiff_t row_stride, int h, int w, hipStream_t st, int *direct) {
     *direct = 0;
@@ -923,6 +947,11 @@ static hipError_t upload_chunk(tic_ctx *ctx, Slot &s, size_t img_bytes, size_t p
     bool pinned = dense;
     for (int k = 0; k < cnt && pinned; k++)
         pinned = host_pointer_is_pinned(images[first + k]) && host_pointer_is_pinned(images[first + k] + img_bytes - 1);
+    if (!pinned && dense) {
+        BT_START();
+        pinned = auto_register_frames(ctx, images, first, cnt, img_bytes); // (chunk by chunk: the whole batch was tried at the call's start)
+        BT_STOP(0);
+    }
     if (!pinned) {
         BT_START();
         stage_chunk(ctx, s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w);
@@ -1025,7 +1054,13 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
     bool closing = false;
     std::atomic<int> first_err{TIC_OK};
 
-    ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = 0;
+    ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = ctx->last_batch_autoreg_frames = 0;
+    ctx->bt = BatchTrace();
+    if ((size_t)row_stride == pitch && pitch == (size_t)w && !host_pointer_is_pinned(images[0])) { // the whole batch as one range, if it is one
+        BT_START();
+        (void)auto_register_frames(ctx, images, 0, n, img_bytes);
+        BT_STOP(0);
+    }
     auto consumer = [&]() {
         bind_pipeline_thread(ctx);
         (void)hipSetDevice(ctx->device);
@@ -1110,6 +1145,7 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
     for (auto &t : pool) t.join();
     (void)hipStreamSynchronize(ctx->bstream[0]);
     (void)hipStreamSynchronize(ctx->bstream[1]);
+    auto_unregister_all(ctx);
     cleanup();
     if (result == TIC_OK && first_err.load() != TIC_OK)
         result = set_err(ctx, first_err.load(), "batch consumer failed with code %d", first_err.load());
@@ -1227,7 +1263,13 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     std::vector<char> busy(S, 0);   // slot submitted and not yet released by the hand-out thread
     bool stop_read = false, stop_hand = false;
     int fin_result = TIC_OK;
-    ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = 0;
+    ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = ctx->last_batch_autoreg_frames = 0;
+    ctx->bt = BatchTrace();
+    if ((size_t)row_stride == pitch && pitch == (size_t)w && !host_pointer_is_pinned(images[0])) { // the whole batch as one range, if it is one
+        BT_START();
+        (void)auto_register_frames(ctx, images, 0, n, img_bytes);
+        BT_STOP(0);
+    }
     std::thread reader([&]() {
         bind_pipeline_thread(ctx);
         (void)hipSetDevice(ctx->device);
@@ -1340,6 +1382,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     (void)hipStreamSynchronize(ctx->bstream[0]);
     (void)hipStreamSynchronize(ctx->bstream[1]);
     (void)hipStreamSynchronize(ctx->rstream);
+    auto_unregister_all(ctx);
     for (auto &sl : slots) sl.count = 0;
     return result;
 }

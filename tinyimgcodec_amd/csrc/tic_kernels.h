@@ -77,6 +77,10 @@ struct IdctArgs {
     double pow2 = 1.0; // 2 ** (quality field of the stream)
 };
 
+// C-ABI kernel selector (TIC_KERNEL_AUTO / _EXACT / _HYBRID) -> launch_dctq's variant (1 exact, 2 strip kernel), -1 for anything else.
+// Defined beside the kernels: the experiment build of tools/ compiles its own kernel file, whose definition also lets its
+// timing-only variants (>= 10) through - which is why tic_api.hip holds no switch for them.
+int dctq_kernel_id(int abi_variant);
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream);
 hipError_t launch_dctq_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_idct(const IdctArgs &a, hipStream_t stream);

@@ -907,6 +907,10 @@ static Tunables tunables() {
     return live ? read_tunables() : once;
 }
 
+int dctq_kernel_id(int abi_variant) { // (TIC_KERNEL_AUTO 0, TIC_KERNEL_EXACT 1, TIC_KERNEL_HYBRID 2: include/tinyimgcodec_hip.h)
+    return abi_variant == 1 ? 1 : ((abi_variant == 0 || abi_variant == 2) ? 2 : -1);
+}
+
 // variant 1: the exact kernel for every block; variant 2: the strip kernel on the rectangle of complete 64x8 strips with 8-byte
 // aligned rows, the exact kernel on what is left (right / bottom padding).
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {

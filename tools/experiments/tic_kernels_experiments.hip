@@ -2316,6 +2316,10 @@ static Tunables tunables() {
     return live ? read_tunables() : once;
 }
 
+int dctq_kernel_id(int abi_variant) { // the experiment build lets its timing-only / stamp variants (>= 10) through
+    return abi_variant >= 10 ? abi_variant : (abi_variant == 1 ? 1 : ((abi_variant == 0 || abi_variant == 2) ? 2 : -1));
+}
+
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
     if (a.ntiles <= 0) return hipSuccess;
     dim3 block(kWavesPerWG * 64);
