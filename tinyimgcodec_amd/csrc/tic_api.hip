@@ -914,6 +914,9 @@ static bool host_pointer_is_pinned(const void *p) {
 // are now pinned.
 static bool auto_register_frames(tic_ctx *ctx, const uint8_t *const *images, int first, int cnt, size_t img_bytes) {
     if (!ctx->auto_register || cnt < 1 || img_bytes < (256u << 10)) return false;
+    // (a range over frames of which some are pinned already would overlap the caller's own registration: such a set is left alone)
+    for (int k = 0; k < cnt; k++)
+        if (host_pointer_is_pinned(images[first + k]) || host_pointer_is_pinned(images[first + k] + img_bytes - 1)) return false;
     uintptr_t lo = UINTPTR_MAX, hi = 0;
     for (int k = 0; k < cnt; k++) {
         const uintptr_t p = (uintptr_t)images[first + k];
@@ -924,7 +927,7 @@ static bool auto_register_frames(tic_ctx *ctx, const uint8_t *const *images, int
     lo &= ~(uintptr_t)4095;
     hi = (hi + 4095) & ~(uintptr_t)4095;
     const size_t span = hi - lo, frames = img_bytes * (size_t)cnt;
-    if (span > frames + frames / 4 + (8u << 20)) return false; // the frames lie scattered: a range over them would pin memory that is not theirs
+    if (span > frames + frames / 4 + (1u << 20)) return false; // the frames lie scattered: a range over them would pin memory that is not theirs
     if (hipHostRegister((void *)lo, span, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();
         return false;
@@ -948,25 +951,34 @@ static hipError_t upload_chunk(tic_ctx *ctx, Slot &s, size_t img_bytes, size_t p
     for (int k = 0; k < cnt && pinned; k++)
         pinned = host_pointer_is_pinned(images[first + k]) && host_pointer_is_pinned(images[first + k] + img_bytes - 1);
     if (!pinned && dense) {
+        // a chunk of pageable frames (chunk by chunk: the whole batch was tried at the call's start)
         BT_START();
-        pinned = auto_register_frames(ctx, images, first, cnt, img_bytes); // (chunk by chunk: the whole batch was tried at the call's start)
+        pinned = auto_register_frames(ctx, images, first, cnt, img_bytes);
         BT_STOP(0);
     }
-    if (!pinned) {
-        BT_START();
-        stage_chunk(ctx, s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w);
-        BT_STOP(0);
-        return hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
+    if (pinned) {
+        // from where the frames lie: one copy for the chunk when they follow each other in memory, else one per frame.  A copy the
+        // runtime refuses (frames of one chunk in two separately registered ranges make a chunk-wide copy invalid) falls back to
+        // one copy per frame, and that to the staged route below - the device buffer is simply written again, in stream order
+        bool contiguous = true;
+        for (int k = 1; k < cnt && contiguous; k++) contiguous = images[first + k] == images[first] + (size_t)k * img_bytes;
+        hipError_t e = contiguous ? hipMemcpyAsync(s.d_img, images[first], img_bytes * cnt, hipMemcpyHostToDevice, st) : hipErrorInvalidValue;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipSuccess;
+            for (int k = 0; k < cnt && e == hipSuccess; k++)
+                e = hipMemcpyAsync((char *)s.d_img + (size_t)k * img_bytes, images[first + k], img_bytes, hipMemcpyHostToDevice, st);
+        }
+        if (e == hipSuccess) {
+            *direct = cnt;
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
     }
-    *direct = cnt;
-    bool contiguous = true;
-    for (int k = 1; k < cnt && contiguous; k++) contiguous = images[first + k] == images[first] + (size_t)k * img_bytes;
-    if (contiguous) return hipMemcpyAsync(s.d_img, images[first], img_bytes * cnt, hipMemcpyHostToDevice, st);
-    for (int k = 0; k < cnt; k++) {
-        const hipError_t e = hipMemcpyAsync((char *)s.d_img + (size_t)k * img_bytes, images[first + k], img_bytes, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+    BT_START();
+    stage_chunk(ctx, s.pin_in, img_bytes, pitch, images, first, cnt, row_stride, h, w);
+    BT_STOP(0);
+    return hipMemcpyAsync(s.d_img, s.pin_in, img_bytes * cnt, hipMemcpyHostToDevice, st);
 }
 
 static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
@@ -1056,7 +1068,7 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
 
     ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = ctx->last_batch_autoreg_frames = 0;
     ctx->bt = BatchTrace();
-    if ((size_t)row_stride == pitch && pitch == (size_t)w && !host_pointer_is_pinned(images[0])) { // the whole batch as one range, if it is one
+    if ((size_t)row_stride == pitch && pitch == (size_t)w) { // the whole batch as one range, if it is one
         BT_START();
         (void)auto_register_frames(ctx, images, 0, n, img_bytes);
         BT_STOP(0);
@@ -1265,7 +1277,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     int fin_result = TIC_OK;
     ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = ctx->last_batch_autoreg_frames = 0;
     ctx->bt = BatchTrace();
-    if ((size_t)row_stride == pitch && pitch == (size_t)w && !host_pointer_is_pinned(images[0])) { // the whole batch as one range, if it is one
+    if ((size_t)row_stride == pitch && pitch == (size_t)w) { // the whole batch as one range, if it is one
         BT_START();
         (void)auto_register_frames(ctx, images, 0, n, img_bytes);
         BT_STOP(0);
