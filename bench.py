@@ -337,7 +337,8 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
         "dtype": "f32+f64" if args.variant == "hybrid" else "f64",
         "data": "synthetic",
         "config": {
-            "workload": "single %dx%d random uint8 grayscale frame, quality=%d (BASELINE config 2), input resident in HBM" % (h, w, q),
+            "workload": "single %dx%d random uint8 grayscale frame, quality=%d (%s), input resident in HBM"
+            % (h, w, q, "BASELINE config 2" if (h, w) == (4096, 4096) else ("BASELINE config 5" if (h, w) == (16384, 16384) else "not a BASELINE size")),
             "kernel": args.variant,
             "frames_per_step_per_gpu": 1,
             "settle_ms": args.settle_ms,
@@ -364,7 +365,8 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             "traffic_source": traffic_source,
             "kernel_us": round(kernel_ms * 1e3, 3),
             "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels,
-            "note": "one frame and one coefficient buffer replayed: the 50 MB working set stays in the 256 MiB Infinity Cache (see cold)",
+            "note": "one frame and one coefficient buffer replayed: the 50 MB working set stays in the 256 MiB Infinity Cache (see cold)"
+            if 3 * h * w < (200 << 20) else "one frame and one coefficient buffer replayed; %d MB per launch do not fit the 256 MiB Infinity Cache" % ((3 * h * w) >> 20),
             "limiter": "priced against HBM as the contract asks; what actually bounds the loop is the CU's LDS pipeline (72 cycles per strip: "
             "transpose + zig-zag staging) together with vector issue (100 instructions per strip) - timing builds in DESIGN.md 5.5, "
             "profiles/r03_ablate_16384.txt - plus the launch's fill and tail at this size; only the cold stream of a 4096^2 frame sits on its memory floor",

@@ -2,7 +2,7 @@
 # Runs a list of GPU steps on the gpurun box, each under its own timeout; stops at the first step that is killed
 # by its timeout (never starts another GPU step after a hang).  Usage: tools/gpu_run.sh step1 step2 ...
 # Steps: microbench[2|3] | tests | tests_fast | tests_all | smoke | bench | bench_exact | bench16k | sweep | ablate | ab |
-#        stamps | prof | pmc_rd | pmc_wr | pmc_sq | pmc_sq2 | pmc_cal | pmc_cal_wr   (binaries: make -C tools)
+#        stamps | prof | pmc_rd | pmc_wr | pmc_sq | pmc_sq2 | pmc_cal | pmc_cal_wr | config5   (binaries: make -C tools)
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
@@ -56,6 +56,13 @@ for step in "$@"; do
     bench_cold) run bench_cold 300 python bench.py --steps 50 --warmup 10 --settle-ms 1 --no-cpu-baseline --no-config4 ;;
     bench_exact) run bench_exact 300 python bench.py --variant exact --no-cpu-baseline ;;
     bench16k)   run bench16k 300 python bench.py --height 16384 --width 16384 --steps 20 --warmup 3 --no-cpu-baseline ;;
+    config5)    for q in 10 50 90; do
+                  rm -rf gpurun_out/c5_prof_q$q gpurun_out/c5_rd_q$q gpurun_out/c5_wr_q$q
+                  C5="bench.py --height 16384 --width 16384 --quality $q --steps 20 --warmup 3 --no-cpu-baseline --no-config4 --no-cold"
+                  run c5_prof_q$q 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/c5_prof_q$q -- python $C5
+                  run c5_rd_q$q 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/c5_rd_q$q -- python bench.py --height 16384 --width 16384 --quality $q --steps 3 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-config4 --no-cold
+                  run c5_wr_q$q 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/c5_wr_q$q -- python bench.py --height 16384 --width 16384 --quality $q --steps 3 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-config4 --no-cold
+                done ;;
     sweep)      run sweep 600 python tools/sweep.py ;;
     prof)       rm -rf gpurun_out/prof; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --no-cpu-baseline --no-cold --no-config4 ;;
     prof_cold)  rm -rf gpurun_out/prof_cold; run prof_cold 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cold -- python bench.py --steps 50 --warmup 10 --settle-ms 1 --no-cpu-baseline --no-config4 ;;
