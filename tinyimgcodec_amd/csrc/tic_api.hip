@@ -44,6 +44,7 @@ struct BatchTrace {
 #define BT_START() ctx->bt.start()
 #define BT_STOP(K) ctx->bt.stop(K)
 
+constexpr size_t kDecTailEnd = 512, kDecTailCoef = 64 * 1024; // device decoder: bytes of stream end prefetched, bytes of tail coefficients (pinned)
 constexpr int kChunk = 16;
 struct Slot {
     uint8_t *pin_in = nullptr;
@@ -106,6 +107,10 @@ struct tic_ctx {
     DecLutsDev *d_dec_luts = nullptr;
     void *d_dec_work = nullptr;
     size_t dec_work_bytes = 0;
+    uint8_t *h_dec_tail = nullptr;                              // pinned: kDecTailEnd bytes of stream end + kDecTailCoef bytes of tail coefficients
+    unsigned long long *d_dec_desc = nullptr;                   // look-back words of the device decoder's single-launch scans (nothing else lives there)
+    size_t dec_desc_words = 0;
+    uint32_t dec_epoch = 0;                                     // calls of the device decoder on this workspace (its single-launch scans tell their words by it)
     DecStatus *h_dec_status = nullptr, *d_dec_status = nullptr; // host-mapped
     int last_decode_path = 0;                                  // 0 none, 1 device decoder, 2 host decoder (tic_last_decode_path)
     int last_decode_giveup = 0;                                // why the device decoder handed the last long stream to the host (DecStatus::giveup bits)
@@ -263,6 +268,8 @@ void tic_destroy(tic_ctx *ctx) {
     if (ctx->d_stream_buf) (void)hipFree(ctx->d_stream_buf);
     if (ctx->d_dec_luts) (void)hipFree(ctx->d_dec_luts);
     if (ctx->d_dec_work) (void)hipFree(ctx->d_dec_work);
+    if (ctx->d_dec_desc) (void)hipFree(ctx->d_dec_desc);
+    if (ctx->h_dec_tail) (void)hipHostFree(ctx->h_dec_tail);
     if (ctx->h_dec_status) (void)hipHostFree(ctx->h_dec_status);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1469,10 +1476,13 @@ static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int 
     return idct_from_device(ctx, h, w, quality, scaled_exp, out);
 }
 
-// Long streams: Huffman + run-length decode on the device (tic_entropy_dec_gpu.hip).  Returns TIC_OK with *done = true when the
-// coefficients of all N blocks are in ctx->d_coef; *done = false (and TIC_OK) when the device decoder met something unusual or does
-// not apply - the caller then decodes on the host, which reproduces the reference's behaviour on malformed streams.
-static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h, int w, bool *done, bool src_on_device = false) {
+// Long streams: Huffman + run-length decode AND the inverse stage on the device, fused (tic_entropy_dec_gpu.hip): the stream goes
+// in, pixels come out, no coefficient array in between.  `out` / `out_on_device` / `out_stride` as idct_from_device.  Returns TIC_OK
+// with *done = true when the image is complete in `out`; *done = false (and TIC_OK) when the device decoder met something unusual
+// or does not apply - the caller then decodes on the host, which reproduces the reference's behaviour on malformed streams (what
+// the device wrote to `out` until then is overwritten).
+static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h, int w, int quality, int scaled_exp, uint8_t *out,
+                            bool out_on_device, size_t out_stride, bool *done, bool src_on_device = false) {
     *done = false;
     const size_t n = num_blocks(h, w);
     // the host parallel decoder's own threshold: shorter streams are decoded serially in well under a millisecond
@@ -1491,13 +1501,22 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     const size_t pitch = align_up((size_t)w, 256);
     int rc = ensure_scratch(ctx, pitch * (size_t)h, n * 128);
     if (rc) return rc;
-    const size_t padded = align_up(len, 4) + 16;
-    if (padded > ctx->d_stream_cap) {
-        if (ctx->d_stream_buf) HIPCHK(ctx, hipFree(ctx->d_stream_buf));
-        ctx->d_stream_buf = nullptr;
-        ctx->d_stream_cap = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_stream_buf, padded));
-        ctx->d_stream_cap = padded;
+    // The stream is decoded where it lies when it is in device memory at a 4-byte aligned address (the kernels mask the bytes behind
+    // its end themselves); a host stream, or an odd address, goes through the context's stream buffer.
+    const bool in_place = src_on_device && ((uintptr_t)data & 3u) == 0;
+    if (!in_place) {
+        const size_t padded = align_up(len, 4) + 16;
+        if (padded > ctx->d_stream_cap) {
+            if (ctx->d_stream_buf) HIPCHK(ctx, hipFree(ctx->d_stream_buf));
+            ctx->d_stream_buf = nullptr;
+            ctx->d_stream_cap = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->d_stream_buf, padded));
+            ctx->d_stream_cap = padded;
+        }
+    }
+    const void *d_stream = in_place ? (const void *)data : (const void *)ctx->d_stream_buf;
+    if (!ctx->h_dec_tail) { // pinned: the stream's last bytes on their way down (device source), the tail's coefficients on their way up
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_dec_tail, kDecTailEnd + kDecTailCoef, hipHostMallocDefault));
     }
     const size_t wb = entropy_decode_gpu_work_bytes(len, n);
     if (wb > ctx->dec_work_bytes) {
@@ -1507,8 +1526,35 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
         HIPCHK(ctx, hipMalloc(&ctx->d_dec_work, wb));
         ctx->dec_work_bytes = wb;
     }
-    HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_stream_buf + (len & ~(size_t)3), 0, padded - (len & ~(size_t)3), ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stream_buf, data, len, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    size_t dw = entropy_decode_gpu_desc_words(len, n);
+    if (dw > ctx->dec_desc_words) { // the look-back words of the decoder's scans: an array of their own, zero or stamped with a past epoch
+        dw = dw < 8192 ? 8192 : 2 * dw;
+        if (ctx->d_dec_desc) HIPCHK(ctx, hipFree(ctx->d_dec_desc));
+        ctx->d_dec_desc = nullptr;
+        ctx->dec_desc_words = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_dec_desc, dw * 8));
+        HIPCHK(ctx, hipMemset(ctx->d_dec_desc, 0, dw * 8));
+        ctx->dec_desc_words = dw;
+        ctx->dec_epoch = 0;
+    }
+    if (!in_place) HIPCHK(ctx, hipMemcpyAsync(ctx->d_stream_buf, data, len, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    // The blocks that start in the stream's last 2048 bits are decoded on the host (below): with a device source their bytes - the
+    // last 256 of the stream, 512 taken - come down NOW, in front of the kernels, instead of in a synchronous copy behind them
+    const size_t end_bytes = len < kDecTailEnd ? len : kDecTailEnd;
+    if (src_on_device) HIPCHK(ctx, hipMemcpyAsync(ctx->h_dec_tail, (const char *)data + (len - end_bytes), end_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    // where the pixels go: a device destination whose rows are 8-byte aligned takes them straight from the kernels (row stores are
+    // cropped to w); anything else gets them from the context's image buffer with one strided copy at the end
+    const bool direct = out_on_device && out_stride % 8 == 0 && (uintptr_t)out % 8 == 0;
+    DecIdctArgs ia;
+    ia.out = direct ? out : (uint8_t *)ctx->d_img;
+    ia.h = h;
+    ia.w = w;
+    ia.stride = direct ? (long)out_stride : (long)pitch;
+    ia.bw = (w + 7) / 8;
+    ia.aligned8 = 1;
+    ia.consts = ctx->d_consts + (scaled_exp >= 0 ? 50 : quality); // codec.py:62: quality = 50 on the scaled branch
+    ia.scaled = scaled_exp >= 0;
+    ia.pow2 = scaled_exp >= 0 ? ldexp(1.0, scaled_exp) : 1.0;
     // stream bits per lane from the average block length (rounded up to 4 average blocks): noise at q=50 (220 bits per block) takes
     // 1024, natural images 512, noise at q >= 85 2048; a range without a synchronisation point (a block longer than the range) makes
     // the stitch give up with bit 4: one more try with 2048 before the host decoder takes over
@@ -1517,8 +1563,13 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     if (const char *e = test_hook("TIC_DECODE_RANGE")) range_bits = atoi(e);
     DecStatus st;
     for (;;) {
-        HIPCHK(ctx, entropy_decode_gpu(ctx->d_stream_buf, len, n, ctx->d_dec_luts, ctx->d_dec_work, ctx->dec_work_bytes, (int16_t *)ctx->d_coef,
-                                       ctx->d_dec_status, range_bits, ctx->stream));
+        memset(ctx->h_dec_status, 0, sizeof(DecStatus)); // (host-mapped; nothing of an earlier call is in flight: every call ends with a drained stream)
+        if (++ctx->dec_epoch >= (1u << 22)) { // (the scans carry 24 bits of 2 x epoch: start over on clean words long before a value could recur)
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_dec_desc, 0, ctx->dec_desc_words * 8, ctx->stream));
+            ctx->dec_epoch = 1;
+        }
+        HIPCHK(ctx, entropy_decode_idct_gpu(d_stream, len, n, ctx->d_dec_luts, ctx->d_dec_work, ctx->dec_work_bytes, ctx->d_dec_desc,
+                                            ctx->dec_desc_words, ctx->dec_epoch, ia, ctx->d_dec_status, range_bits, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(&st, ctx->h_dec_status, sizeof st); // (host-mapped: the stream has drained)
         if (st.giveup == 4 && range_bits < 2048) {
@@ -1529,18 +1580,48 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     }
     ctx->last_decode_giveup = st.giveup | ((st.m == 0 || st.m > n) ? 64 : 0);
     if (ctx->last_decode_giveup != 0) return TIC_OK; // the host decoder takes the whole stream
-    if (st.m < n) { // the blocks that start in the stream's last 2048 bits: serial on the host, a few KB uploaded behind the others
-        std::vector<int16_t> tail((n - (size_t)st.m) * 64);
-        if (src_on_device) { // the end of the stream comes down (a few hundred bytes), the bit positions move with it
-            const size_t off = (size_t)st.pos_out / 8;
-            std::vector<uint8_t> end(len - off);
-            HIPCHK(ctx, hipMemcpy(end.data(), (const char *)ctx->d_stream_buf + off, len - off, hipMemcpyDeviceToHost));
-            entropy_decode_tail(end.data(), len - off, h, w, (size_t)st.m, (size_t)st.pos_out - off * 8, st.dc_out, tail.data());
-        } else {
-            entropy_decode_tail(data, len, h, w, (size_t)st.m, (size_t)st.pos_out, st.dc_out, tail.data());
+    if (st.m < n) { // the blocks that start in the stream's last 2048 bits: serial on the host, a few KB uploaded, transformed by idct_kernel's block-range form
+        const size_t tail_bytes = (n - (size_t)st.m) * 128;
+        std::vector<int16_t> big; // (more tail blocks than the pinned buffer holds: cannot happen for a stream the device decoder accepts - 2048 bits are at most 341 blocks)
+        int16_t *tail = reinterpret_cast<int16_t *>(ctx->h_dec_tail + kDecTailEnd);
+        if (tail_bytes > kDecTailCoef) {
+            big.resize(tail_bytes / 2);
+            tail = big.data();
         }
-        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_coef + (size_t)st.m * 128, tail.data(), tail.size() * 2, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (`tail` leaves scope)
+        const size_t off = len - end_bytes; // the piece of the stream that came down in front of the kernels starts here
+        if (src_on_device && (size_t)st.pos_out / 8 >= off) { // (pos_out >= 8 len - 2048: always inside that piece)
+            entropy_decode_tail(ctx->h_dec_tail, end_bytes, h, w, (size_t)st.m, (size_t)st.pos_out - off * 8, st.dc_out, tail);
+        } else if (src_on_device) {
+            const size_t o2 = (size_t)st.pos_out / 8;
+            std::vector<uint8_t> end(len - o2);
+            HIPCHK(ctx, hipMemcpy(end.data(), (const char *)data + o2, len - o2, hipMemcpyDeviceToHost));
+            entropy_decode_tail(end.data(), len - o2, h, w, (size_t)st.m, (size_t)st.pos_out - o2 * 8, st.dc_out, tail);
+        } else {
+            entropy_decode_tail(data, len, h, w, (size_t)st.m, (size_t)st.pos_out, st.dc_out, tail);
+        }
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_coef + (size_t)st.m * 128, tail, tail_bytes, hipMemcpyHostToDevice, ctx->stream));
+        IdctArgs a;
+        a.coeffs = (const int16_t *)ctx->d_coef;
+        a.out = ia.out;
+        a.h = h;
+        a.w = w;
+        a.stride = ia.stride;
+        a.bw = ia.bw;
+        a.tiles_x = (a.bw + 7) / 8;
+        a.first_block = (long)st.m;
+        a.nblocks_sel = (long)(n - (size_t)st.m);
+        a.ntiles = (int)((a.nblocks_sel + 7) / 8);
+        a.aligned8 = 1;
+        a.consts = ia.consts;
+        a.scaled = ia.scaled;
+        a.pow2 = ia.pow2;
+        HIPCHK(ctx, launch_idct(a, ctx->stream));
+        if (direct || !big.empty()) HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (the caller's pixels are complete when this returns)
+    }
+    if (!direct) {
+        HIPCHK(ctx, hipMemcpy2DAsync(out, out_on_device ? out_stride : (size_t)w, ctx->d_img, pitch, (size_t)w, (size_t)h,
+                                     out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     *done = true;
     return TIC_OK;
@@ -1589,11 +1670,11 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
     if (!out || (size_t)h * (size_t)w > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
     {   // long streams: the Huffman decode runs on the device too; only the stream goes up and the pixels come down
         bool done = false;
-        const int rc = decode_on_device(ctx, data, len, h, w, &done);
+        const int rc = decode_on_device(ctx, data, len, h, w, scaled ? 50 : quality, scaled ? quality : -1, out, false, 0, &done);
         if (rc) return rc;
         if (done) {
             ctx->last_decode_path = 1;
-            return idct_from_device(ctx, h, w, scaled ? 50 : quality, scaled ? quality : -1, out);
+            return TIC_OK;
         }
     }
     // coefficients land in a pinned buffer kept on the context: no page faults on a fresh 32 MB vector per call, and the upload
@@ -1639,10 +1720,12 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
     if (out_stride < (ptrdiff_t)w) return set_err(ctx, TIC_E_ARG, "row stride %td smaller than the width %d", out_stride, w);
     if (!d_out || (size_t)(h - 1) * (size_t)out_stride + (size_t)w > out_cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
     bool done = false;
-    int rc = decode_on_device(ctx, (const uint8_t *)d_stream, len, h, w, &done, true);
+    int rc = decode_on_device(ctx, (const uint8_t *)d_stream, len, h, w, scaled ? 50 : quality, scaled ? quality : -1, (uint8_t *)d_out, true,
+                              (size_t)out_stride, &done, true);
     if (rc) return rc;
     if (done) {
         ctx->last_decode_path = 1;
+        return TIC_OK;
     } else {
         std::vector<uint8_t> host(len);
         HIPCHK(ctx, hipMemcpy(host.data(), d_stream, len, hipMemcpyDeviceToHost));

@@ -17,16 +17,33 @@ struct DecLutsDev {
 struct DecStatus {
     int giveup;                 // != 0: something unusual on the true chain - the caller decodes the whole stream on the host
     int dc_out;                 // running DC behind the last block produced here
-    unsigned long long m;       // blocks produced: [0, m) of the int16 [N][64] array are complete (entry 0 = integrated DC)
+    unsigned long long m;       // blocks produced: the pixels of blocks [0, m) have been written
     unsigned long long pos_out; // first stream bit behind block m - 1
 };
 
+// Where the pixels go and how the coefficients become pixels (the inverse stage of decode(), codec.py:46-70): the arguments of
+// idct_kernel, minus the coefficient array - the fused kernel never writes one.
+struct DecIdctArgs {
+    uint8_t *out;      // device, uint8 [h][stride]
+    int h, w;
+    long stride;
+    int bw;            // blocks per row
+    int aligned8;      // out and stride are multiples of 8: whole 8-byte row stores
+    const struct DctqConsts *consts; // constants of the stream's quality (quality 50 on the scaled_dct branch)
+    int scaled;        // decode()'s scaled_dct branch (codec.py:59-62)
+    double pow2;       // 2 ** (quality field of the stream) on that branch
+};
+
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks);
-// d_stream_words: the whole stream (header included) in device memory, 4-byte aligned, readable for 8 bytes past its end.
-// range_bits: 512, 1024 or 2048 stream bits per lane (shorter = more lanes = faster, but every range must hold a block start of
-// the true chain: giveup has bit 4 set when one did not - try 2048).  Asynchronous on `stream`; *d_status is complete when the
-// stream has drained.
-hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
-                              size_t work_bytes, int16_t *d_zz, DecStatus *d_status, int range_bits, hipStream_t stream);
+// d_stream_words: the whole stream (header included) in device memory, 4-byte aligned; the 4-byte word that holds its last byte is
+// read whole (the bytes behind the stream's end are masked off), nothing behind that word is touched.  range_bits: 512, 1024 or 2048 stream bits per lane (shorter = more lanes = faster, but every range must
+// hold a block start of the true chain: giveup has bit 4 set when one did not - try 2048).  d_work: zeroed when it was allocated;
+// `epoch`: a number never used before on this workspace (the single-launch scans recognise this call's words by it), != 0.
+// Writes the PIXELS of blocks [0, m) through `idct`; *d_status (zeroed by the caller) says how many that is and where the stream
+// and the running DC stand behind them.  Asynchronous on `stream`; *d_status is complete when the stream has drained.
+size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks);
+hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
+                                   size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, const DecIdctArgs &idct,
+                                   DecStatus *d_status, int range_bits, hipStream_t stream);
 
 } // namespace tic

@@ -16,10 +16,16 @@
 //             trace recorded; from that entry on the trace IS the true chain (a block start carries no state), so the trace's end is
 //             where the true chain enters range t+1 - which is the hypothesis for t+1.  Range 0 starts on a true block start, so if
 //             EVERY lane finds its synchronisation point inside its range, induction makes every hypothesis true.  Otherwise: give up.
-//   scan      exclusive prefix sum of the ranges' true block counts -> index of each range's first block.
+//   scan      exclusive prefix sum of the ranges' true block counts -> index of each range's first block (ONE launch: every tile
+//             publishes its own sum and adds up the sums of the tiles in front of it, scan_lookback below).
 //   bpos      a lane per range writes the first bit of each of its true blocks (by-hand ones, then the trace from the entry on).
-//   decode    a lane per BLOCK decodes it from its first bit into the (zeroed) int16 [N][64] coefficient array, DC differences aside.
-//   scan      inclusive prefix sum of the DC differences (np.cumsum), saturated into entry 0 of every block.
+//   dc scan   a lane per BLOCK decodes the block's DC symbol and the differences are summed inclusively over the blocks
+//             (np.cumsum, codec.py:53): one launch, the same look-back.
+//   decode + inverse transform   a workgroup per 256 consecutive blocks: a lane per block decodes it from its first bit into an LDS
+//             image of the block (natural order), then the workgroup dequantises and inverse-transforms its 256 images, 8 lanes per
+//             block, in the reference's float64 operation order, and stores PIXELS.  The coefficients never exist in memory.
+//             (Rounds 2-3: a decode kernel that scattered the non-zero coefficients into a zeroed int16 [N][64] array - 45 two-byte
+//             stores per lane to 64 different lines each - then idct_kernel read the array back: 68 + 24 us and a 33.5 MB fill.)
 // The walks are one dependent chain of look-ups per lane: stream words and tables are staged in LDS (the codewords of 12-16 bits
 // included: as look-ups in memory they stalled a whole wave in every second step), and the chain is kept short - a range for the
 // measure kernel, a block for the decode kernel.  7 MB stream (4096^2 noise, q=50), rocprofv3: measure 282 -> 125 us, decode
@@ -35,6 +41,7 @@
 #include <string.h>
 
 #include "tic_entropy_dec_gpu.h"
+#include "tic_math.h"
 
 namespace tic {
 namespace {
@@ -58,13 +65,22 @@ constexpr uint32_t kStageLds = kStageMax + kStageMax / 16 + 2;   // ... with pad
 struct Bits {
     const uint32_t *lds, *glob;
     uint32_t wbase, wcount, sh, nwords; // first word of the window, its length, log2(words per range); words of the stream
+    uint32_t last_mask;                 // big-endian mask of the stream's last word (the bytes behind the stream's end read as zero)
 };
+// word wi of the stream, big-endian; zero behind the end, and the bytes of the last word that lie behind the stream's last byte are
+// zero too - the stream is read where the caller holds it, not from a zero-padded copy
+__device__ __forceinline__ uint32_t stream_word(const uint32_t *__restrict__ words, uint32_t wi, uint32_t nwords, uint32_t last_mask) {
+    if (wi >= nwords) return 0u;
+    const uint32_t v = __builtin_bswap32(words[wi]);
+    return wi == nwords - 1u ? (v & last_mask) : v;
+}
 __device__ __forceinline__ uint32_t word_be(const Bits &s, uint32_t wi) {
     const uint32_t r = wi - s.wbase;
     if (r < s.wcount) return s.lds[r + (r >> s.sh)];
-    return wi < s.nwords ? __builtin_bswap32(s.glob[wi]) : 0u;
+    return stream_word(s.glob, wi, s.nwords, s.last_mask);
 }
-__device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_word, uint32_t wcount, uint32_t sh, uint32_t nwords) {
+__device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_word, uint32_t wcount, uint32_t sh, uint32_t nwords,
+                                            uint32_t last_mask) {
     Bits s;
     s.lds = lds;
     s.glob = words;
@@ -72,9 +88,10 @@ __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__res
     s.wcount = wcount;
     s.sh = sh;
     s.nwords = nwords;
+    s.last_mask = last_mask;
     for (uint32_t r = threadIdx.x; r < wcount; r += blockDim.x) {
         const uint32_t wi = first_word + r;
-        const uint32_t v = wi < nwords ? __builtin_bswap32(words[wi]) : 0u;
+        const uint32_t v = stream_word(words, wi, nwords, last_mask);
         lds[r + (r >> sh)] = v;
         if (r != 0u && (r & ((1u << sh) - 1u)) == 0u) lds[r + (r >> sh) - 1u] = v; // the padding word in front of a row repeats the row's
                                                                                    // first word: word r + 1 always sits right behind word r
@@ -83,8 +100,8 @@ __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__res
     return s;
 }
 // the window of 64 consecutive ranges from bit first_bit (128 + 64 k range: a multiple of 32)
-__device__ __forceinline__ Bits stage_bits(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_bit, uint32_t range, uint32_t nwords) {
-    return stage_words(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, range == 512u ? 4u : (range == 1024u ? 5u : 6u), nwords);
+__device__ __forceinline__ Bits stage_bits(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_bit, uint32_t range, uint32_t nwords, uint32_t last_mask) {
+    return stage_words(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, range == 512u ? 4u : (range == 1024u ? 5u : 6u), nwords, last_mask);
 }
 // 32 stream bits (MSB first) from bit `pos`; the two words around it are cached in registers and refetched when the position
 // leaves them (a symbol is 5-8 bits on average: one refetch per ~5 symbols).
@@ -162,13 +179,13 @@ __device__ __forceinline__ void load_lut(uint16_t *lds, const DecLutsDev *__rest
 // a wave then wait for each other at every block end (a wave-step lasts as long as its longest block) - 630 symbol steps per wave
 // where the longest lane has ~250 symbols.  In the measure kernel the position inside the block (k: 0 = the DC category comes next)
 // is lane state and a block end is just another step.  Same tables, same rules as block_dev().
-__global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, const DecLutsDev *__restrict__ L, uint32_t fast_end,
+__global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L, uint32_t fast_end,
                                                          uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts, uint32_t *__restrict__ nrec,
                                                          uint32_t *__restrict__ endpos, int *__restrict__ lastbrk, DecStatus *__restrict__ st) {
     __shared__ uint16_t lut[kLutLds];
     __shared__ uint32_t sbits[kStageLds];
     load_lut(lut, L);
-    const Bits words = stage_bits(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords);
+    const Bits words = stage_bits(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords, last_mask);
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= nranges) return;
     const uint32_t lo = 128u + t * range;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
     lastbrk[t] = brk;
 }
 
-__global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, const DecLutsDev *__restrict__ L, uint32_t fast_end,
+__global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L, uint32_t fast_end,
                                                         uint32_t range, uint32_t nranges, const uint16_t *__restrict__ starts, const uint32_t *__restrict__ nrec,
                                                         const uint32_t *__restrict__ endpos, const int *__restrict__ lastbrk,
                                                         uint32_t *__restrict__ nblk, uint16_t *__restrict__ hand,
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
     __shared__ uint16_t lut[kLutLds];
     __shared__ uint32_t sbits[kStageLds];
     load_lut(lut, L);
-    const Bits words = stage_bits(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords);
+    const Bits words = stage_bits(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords, last_mask);
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= nranges) return;
     entry[t] = nrec[t]; // (until the walk below meets the trace: no trace block belongs to the true chain)
@@ -292,7 +309,12 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
     }
 }
 
-// ---- prefix sums (three small kernels: per-tile sums, scan of the tile sums by one workgroup, per-tile scan + offset) -----------
+// ---- prefix sums in ONE launch ----------------------------------------------------------------------------------------------------
+// Every tile of kTile elements scans itself, PUBLISHES its own sum - one 8-byte agent-scope atomic store that carries the sum
+// and the launch's epoch, so that nothing has to be zeroed between launches and no fence is needed: the word is the whole message -
+// and then adds up the words of all tiles in front of it, thread j reading tile j's.  No tile waits for a RESULT of another tile,
+// only for its publication, which every tile makes before it looks back; workgroups are dispatched in index order, so the tiles
+// a tile waits for are running or done.  (Rounds 2-3: three launches per scan - tile sums, a one-workgroup scan of the sums, apply.)
 constexpr int kTile = 1024;
 __device__ __forceinline__ long long wg_inclusive_scan(long long v, long long *lds /* [16] */, long long &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -313,50 +335,50 @@ __device__ __forceinline__ long long wg_inclusive_scan(long long v, long long *l
     total = tot;
     return v + off;
 }
-__global__ __launch_bounds__(kTile) void scan_tile_sums_kernel(const int32_t *__restrict__ in, size_t n, long long *__restrict__ tile_sum) {
-    __shared__ long long lds[16];
-    const size_t i = (size_t)blockIdx.x * kTile + threadIdx.x;
-    long long tot;
-    (void)wg_inclusive_scan(i < n ? (long long)in[i] : 0ll, lds, tot);
-    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+// 24 bits of epoch, 40 bits of sum (two's complement): |sum| < 2^39 covers 2^32 blocks of +-2047 each... by a wide margin for every
+// frame the 32-bit bit positions of this file admit
+__device__ __forceinline__ unsigned long long scan_pack(uint32_t epoch, long long sum) {
+    return ((unsigned long long)(epoch & 0xffffffu) << 40) | ((unsigned long long)sum & 0xffffffffffull);
 }
-__global__ __launch_bounds__(kTile) void scan_of_sums_kernel(long long *__restrict__ tile_sum, size_t ntiles, long long *__restrict__ grand_total) {
-    __shared__ long long lds[16];
-    long long carry = 0;
-    for (size_t base = 0; base < ntiles; base += kTile) { // one workgroup: a few iterations at most (2 M ranges = 2 K tiles)
-        const size_t i = base + threadIdx.x;
-        long long tot;
-        const long long v = i < ntiles ? tile_sum[i] : 0ll;
-        const long long inc = wg_inclusive_scan(v, lds, tot);
-        if (i < ntiles) tile_sum[i] = carry + inc - v; // exclusive
-        carry += tot;
+__device__ __forceinline__ long long scan_sum_of(unsigned long long d) { return ((long long)(d << 24)) >> 24; }
+// sum of the tiles in front of this one (the caller has published its own `tot` through scan_publish)
+__device__ __forceinline__ void scan_publish(unsigned long long *desc, uint32_t epoch, long long tot) {
+    if (threadIdx.x == 0) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ long long scan_lookback(const unsigned long long *desc, uint32_t epoch, long long *lds /* [16] */, DecStatus *st) {
+    long long part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += blockDim.x) {
+        unsigned long long d;
+        uint32_t spins = 0;
+        do {
+            d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (an exit every wave reaches: a tile in front that never publishes - which the dispatch order rules out - ends the wait after
+            // about a second, and the flag sends the whole stream to the host decoder)
+            if (++spins == (1u << 20)) {
+                atomicOr(&st->giveup, 128);
+                d = scan_pack(epoch, 0);
+            }
+        } while ((uint32_t)(d >> 40) != (epoch & 0xffffffu));
+        part += scan_sum_of(d);
     }
-    if (threadIdx.x == 0) *grand_total = carry;
+    long long total;
+    (void)wg_inclusive_scan(part, lds, total);
+    return total;
 }
-// out[i] = (INCLUSIVE ? in[0..i] : in[0..i-1]) summed, as int64 narrowed to the output type by the caller's functor
-template <bool INCLUSIVE, typename Out>
-__global__ __launch_bounds__(kTile) void scan_apply_kernel(const int32_t *__restrict__ in, size_t n, const long long *__restrict__ tile_off, Out out) {
+// first_blk[t] = number of true blocks in the ranges in front of range t; *grand_total = all of them
+__global__ __launch_bounds__(kTile) void scan_counts_kernel(const uint32_t *__restrict__ nblk, uint32_t nranges, unsigned long long *__restrict__ desc,
+                                                            uint32_t epoch, uint32_t *__restrict__ first_blk, long long *__restrict__ grand_total,
+                                                            DecStatus *__restrict__ st) {
     __shared__ long long lds[16];
     const size_t i = (size_t)blockIdx.x * kTile + threadIdx.x;
     long long tot;
-    const long long v = i < n ? (long long)in[i] : 0ll;
+    const long long v = i < nranges ? (long long)nblk[i] : 0ll;
     const long long inc = wg_inclusive_scan(v, lds, tot);
-    if (i < n) out(i, tile_off[blockIdx.x] + (INCLUSIVE ? inc : inc - v));
+    scan_publish(desc, epoch, tot);
+    const long long off = scan_lookback(desc, epoch, lds, st);
+    if (i < nranges) first_blk[i] = (uint32_t)(off + inc - v);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grand_total = off + tot;
 }
-struct StoreU32 {
-    uint32_t *p;
-    __device__ void operator()(size_t i, long long v) const { p[i] = (uint32_t)v; }
-};
-struct StoreDc {
-    int16_t *zz;
-    size_t m;
-    DecStatus *st;
-    __device__ void operator()(size_t i, long long v) const { // c[0] = sat16(np.cumsum(dc)[i]) (the host decoder's sat16)
-        const long long s = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
-        zz[i * 64] = (int16_t)s;
-        if (i == m - 1) st->dc_out = (int)v; // (m = all blocks: the differences behind the last block produced are 0)
-    }
-};
 
 // First bit of every block of the true chain: range t's blocks are the ones its stitch walked by hand, then its trace from the entry
 // on; first_blk[t] (the scan of the counts) is the index of the first of them.
@@ -373,43 +395,256 @@ __global__ __launch_bounds__(64) void dec_bpos_kernel(uint32_t range, uint32_t n
     for (uint32_t j = 0; j < from_trace && first + by_hand + j < nblocks; j++) bpos[first + by_hand + j] = lo + (uint32_t)starts[(size_t)t * cap + a + j];
 }
 
-// A lane per BLOCK: lane b decodes the block at bpos[b] straight into the (zeroed) int16 [N][64] array: non-zero coefficients only,
-// entry 0 is written by the DC pass.  The 256 consecutive blocks of a workgroup are one contiguous piece of the stream, staged in LDS
-// (up to kBlkWin words: 500 bits per block on average; what lies behind is read from memory).  History: the first version decoded a
-// RANGE per lane, the blocks of its range one after the other through an LDS image - 880 waves for a 7 MB stream, one per SIMD, each
-// a chain of ~500 dependent symbol steps: 102-148 us.  A wave per 64 blocks with an image per lane (26 KB of LDS per wave, six waves
-// per CU): 108 us.  Without the image, four waves sharing tables and window: 24 waves per CU.
+// np.cumsum of the DC differences (codec.py:53), one launch: lane b decodes the DC symbol of block b (the first symbol at bpos[b]:
+// one table look-up) and the differences are summed inclusively over the blocks, tile by tile with the look-back above.
+// dcsum[b] = sum of the differences of blocks 0..b (int32: at most 2^32 blocks of +-2047... the host decoder's long long, narrowed
+// where it is used: sat16).  Blocks past the m produced here contribute nothing.
+__global__ __launch_bounds__(kTile) void dec_dc_scan_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+                                                            const uint32_t *__restrict__ bpos, const long long *__restrict__ total_blocks,
+                                                            unsigned long long n_want, unsigned long long *__restrict__ desc, uint32_t epoch,
+                                                            int32_t *__restrict__ dcsum, DecStatus *__restrict__ st) {
+    __shared__ long long lds[16];
+    __shared__ uint16_t dc11[2048];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) reinterpret_cast<uint32_t *>(dc11)[i] = reinterpret_cast<const uint32_t *>(L->dc11)[i];
+    __syncthreads();
+    const unsigned long long total = (unsigned long long)*total_blocks;
+    const unsigned long long m = total < n_want ? total : n_want;
+    const unsigned long long b = (unsigned long long)blockIdx.x * kTile + threadIdx.x;
+    long long v = 0;
+    if (b < m) {
+        const uint32_t pos = bpos[b], wi = pos >> 5, sh = pos & 31u;
+        const uint32_t wa = stream_word(gwords, wi, nwords, last_mask), wb = stream_word(gwords, wi + 1u, nwords, last_mask);
+        const uint32_t pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa;
+        const uint32_t e = dc11[pk >> 21]; // (measure or stitch walked this block: a DC codeword is there)
+        v = (long long)value_of(pk, (int)(e >> 8), (int)(e & 15u));
+    }
+    long long tot;
+    const long long inc = wg_inclusive_scan(v, lds, tot);
+    scan_publish(desc, epoch, tot);
+    const long long off = scan_lookback(desc, epoch, lds, st);
+    if (b < m) {
+        dcsum[b] = (int32_t)(off + inc);
+        if (b == m - 1) st->dc_out = (int)(off + inc); // running DC behind the last block produced here (the host's tail continues from it)
+    }
+}
+
+// ---- decode + inverse transform, fused --------------------------------------------------------------------------------------------
+// A workgroup per kDecodeWG consecutive blocks (one contiguous piece of the stream, staged in LDS: up to kBlkWin words, 500 bits
+// per block on average; what lies behind is read from memory).  Phase 1, a lane per BLOCK: lane b decodes the block at bpos[b] into
+// its LDS image - 64 int16 in NATURAL order (the zig-zag walk is undone by the store address), entry 0 = the integrated DC, saturated
+// as the host decoder saturates it.  Phase 2, 8 lanes per block, 8 blocks per wave and round: dequantise (coef x div, one rounding;
+// the scaled_dct branch's three), exact DCT-III down the columns, 8x8 float64 transpose through the wave's LDS buffer, exact DCT-III
+// along the rows, + 128, clip, truncating cast (codec.py:46-70, utils.py:40-45): idct_kernel's arithmetic, statement for statement.
+// LDS: tables 8.6 KB + window 16.9 KB + images 36 KB (144 B apart: the phase-2 reads of a wave's 8 blocks fall on 8 x 4 distinct
+// banks) + 4 x 2.2 KB of transpose buffers = 70 KB, two workgroups per CU.  The decode phase is a chain of LDS look-ups per lane
+// (~100 cycles per symbol), which two waves per SIMD already overlap; what made the separate decode kernel slow were its 45
+// two-byte global stores per lane.
 constexpr int kDecodeWG = 256;
 constexpr uint32_t kBlkWin = 4096 + kOver;
 constexpr uint32_t kBlkLds = kBlkWin + kBlkWin / 32 + 2;
-__global__ __launch_bounds__(kDecodeWG) void dec_decode_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, const DecLutsDev *__restrict__ L,
-                                                               const uint32_t *__restrict__ bpos, const long long *__restrict__ total_blocks,
-                                                               unsigned long long n_want, int16_t *__restrict__ zz /* zeroed */, int32_t *__restrict__ dcdiff,
-                                                               DecStatus *__restrict__ st) {
-    __shared__ uint16_t lut[kLutLds];
-    __shared__ uint32_t sbits[kBlkLds];
+constexpr int kImgStrideB = 144;  // bytes between the images of two blocks
+constexpr int kTrStrideDw = 68;   // dwords per block in a wave's transpose buffer (64 + 4 pad)
+__constant__ int kAnnScalesDec[64] = { // ANNSCALES of the reference's scaled_dct branch (constants.py; utils.py:59-62), as integers x 2048
+    16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
+    21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906,  19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
+    16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  12873, 17855, 16819, 15137, 12873, 10114, 6967,  3552,
+    8867,  12299, 11585, 10426, 8867,  6967,  4799,  2446,  4520,  6270,  5906,  5315,  4520,  3552,  2446,  1247};
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// 8 dwords per lane transposed across the 8 lanes of each block through the wave's buffer: in lane (g,c) v[u] = M[u][c]; out lane (g,u) v[c]
+__device__ __forceinline__ void tr8x8_dwords(uint32_t *buf, int g, int i, uint32_t v[8]) {
+    uint32_t *blk = buf + g * kTrStrideDw;
+#pragma unroll
+    for (int u = 0; u < 8; u++) blk[u * 8 + i] = v[u];
+    wave_fence();
+    const uint4 *rp = reinterpret_cast<const uint4 *>(blk + i * 8);
+    const uint4 a = rp[0], c = rp[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    wave_fence();
+}
+
+__global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+                                                                    const uint32_t *__restrict__ bpos, const int32_t *__restrict__ dcsum,
+                                                                    const long long *__restrict__ total_blocks, unsigned long long n_want,
+                                                                    DecIdctArgs a, DecStatus *__restrict__ st) {
+    // phase 1: tables + stream window; phase 2 (behind the barrier): the waves' transpose buffers, two per wave
+    constexpr int kLutDw = (kLutLds * 2 + 15) / 16 * 4;
+    constexpr int kTrDw = (kDecodeWG / 64) * 2 * 8 * kTrStrideDw;
+    constexpr int kScratchDw = kLutDw + (int)kBlkLds > kTrDw ? kLutDw + (int)kBlkLds : kTrDw;
+    __shared__ __attribute__((aligned(16))) uint32_t scratch[kScratchDw];
+    __shared__ __attribute__((aligned(16))) unsigned char img[kDecodeWG * kImgStrideB];
+    __shared__ uint8_t zznat[64];
+    uint16_t *lut = reinterpret_cast<uint16_t *>(scratch);
+    uint32_t *sbits = scratch + kLutDw;
     const unsigned long long total = (unsigned long long)*total_blocks;
     const unsigned long long m = total < n_want ? total : n_want; // blocks produced here
     const unsigned long long b0 = (unsigned long long)blockIdx.x * kDecodeWG, b = b0 + threadIdx.x;
     if (b0 >= m) return; // (the whole workgroup)
+    if (threadIdx.x < 64) zznat[threadIdx.x] = a.consts->zznat[threadIdx.x];
+    { // the images start as zeros: the decoder writes the non-zero coefficients only
+        uint4 *z = reinterpret_cast<uint4 *>(img);
+        for (int k = threadIdx.x; k < kDecodeWG * kImgStrideB / 16; k += kDecodeWG) z[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     load_lut(lut, L);
     const unsigned long long last = b0 + kDecodeWG - 1 < m - 1 ? b0 + kDecodeWG - 1 : m - 1;
     const uint32_t w0 = bpos[b0] >> 5, w1 = bpos[last] >> 5;
     const uint32_t want = w1 >= w0 ? w1 - w0 + kOver : kOver;
-    const Bits words = stage_words(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords);
-    if (b >= m) return;
-    BitWin win = {0xffffffffu, 0u, 0u};
-    const uint32_t pos = bpos[b];
-    int d;
-    uint32_t used;
-    if (!block_dev<true>(words, L, lut, pos, win, zz + b * 64ull, d, used)) { // (measure or stitch walked this block: cannot fail)
-        atomicOr(&st->giveup, 32);
-        return;
+    const Bits words = stage_words(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords, last_mask); // (ends with a barrier: tables, window, zeros, zznat)
+#ifndef TIC_EXP
+#define TIC_EXP 0
+#endif
+    // ---- phase 1: a lane per block, one SYMBOL per step as in the measure kernel: the stream words under the read position sit
+    // in registers (wa, wb) and the word behind them (wc) is fetched a step ahead, so that the table look-up is the only LDS access
+    // on the lane's dependent chain; the coefficient's store (its address comes through the zig-zag table) is off that chain.
+    if (b < m && (!(TIC_EXP & 2) || b == m - 1)) {
+        int16_t *c = reinterpret_cast<int16_t *>(img + (size_t)threadIdx.x * kImgStrideB);
+        const uint16_t *ac11 = lut + 2048;
+        uint32_t pos = bpos[b];
+        uint32_t wi = pos >> 5;
+        uint32_t wa = word_be(words, wi), wb = word_be(words, wi + 1u), wc = word_be(words, wi + 2u);
+        auto advance = [&](uint32_t bits) { // a symbol consumes at most 27 bits: at most one word boundary is crossed
+            pos += bits;
+            const bool crossed = (pos >> 5) != wi;
+            wa = crossed ? wb : wa;
+            wb = crossed ? wc : wb;
+            wi += crossed ? 1u : 0u;
+            wc = word_be(words, wi + 2u); // (not needed before the next boundary)
+        };
+        uint32_t sh = pos & 31u;
+        uint32_t pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa;
+        uint32_t e = lut[pk >> 21];
+        bool ok = e != 0u; // DC categories are at most 9 bits long
+        if (ok) {
+            advance((e >> 8) + (e & 15u)); // the DC difference itself went through the scan
+            const int32_t dc = dcsum[b];
+            c[0] = (int16_t)(dc < -32768 ? -32768 : (dc > 32767 ? 32767 : dc)); // the host decoder's sat16
+            int k = 1;
+            bool live = true;
+            while (live) {
+                sh = pos & 31u;
+                pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa;
+                e = ac11[pk >> 21];
+                if (__any(e == 0u)) { // a codeword of 12 to 16 bits somewhere in the wave
+                    const uint32_t e2 = long_code(lut, pk);
+                    e = e == 0u ? e2 : e;
+                }
+                const bool nocode = e == 0u;
+                const bool eob = !nocode && (e & 0xffu) == 0u;
+                const int len = (int)(e >> 8), size = (int)(e & 15u);
+                const int k_at = k + (int)((e >> 4) & 15u);
+                const bool bad = nocode || (!eob && k_at > 63);
+#if TIC_EXP & 8
+                if (!eob && !bad && k_at == 77) c[zznat[k_at]] = (int16_t)value_of(pk, len, size);
+#else
+                if (!eob && !bad) c[zznat[k_at]] = (int16_t)value_of(pk, len, size);
+#endif
+                if (!nocode) advance((uint32_t)(len + size));
+                k = k_at + 1;
+                ok = ok && !bad;
+                live = !eob && !bad;
+            }
+        }
+        if (!ok) atomicOr(&st->giveup, 32); // (measure or stitch walked this block: cannot fail)
+        if (b == m - 1) {
+            st->pos_out = pos;
+            st->m = m;
+        }
     }
-    dcdiff[b] = d;
-    if (b == m - 1) {
-        st->pos_out = pos + used;
-        st->m = m;
+    __syncthreads();
+    // ---- phase 2: 8 lanes per block; a wave takes 2 x 8 consecutive blocks per round - two independent chains of float64 work per
+    // lane, which is what keeps the vector unit busy at two waves per SIMD (one chain per lane: 68 us for this phase, two: see DESIGN)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 3, i = lane & 7;
+    const DctqConsts *__restrict__ C = a.consts;
+    uint32_t *tbA = scratch + wave * (2 * 8 * kTrStrideDw), *tbB = tbA + 8 * kTrStrideDw; // (tables and window are dead: behind the barrier)
+    double dq[8]; // the lane's eight dequantisation constants (column v = i): read once, not once per round
+#pragma unroll
+    for (int u = 0; u < 8; u++) dq[u] = C->div[u * 8 + i];
+    auto load_col = [&](int lb, double (&c)[8]) { // lane i takes column v = i of the natural 8x8 coefficient matrix of block lb
+        const int16_t *c16 = reinterpret_cast<const int16_t *>(img + (size_t)lb * kImgStrideB);
+        int cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) cv[u] = (int)c16[u * 8 + i]; // (eight reads in flight: with the branch below inside this loop the
+                                                                  // compiler waited for every one of them before issuing the next)
+        if (a.scaled) { // codec.py:60-62: (coeffs / ANNSCALES) * 2**quality, then the inverse quantiser of quality 50: three roundings
+#pragma unroll
+            for (int u = 0; u < 8; u++) c[u] = (((double)cv[u] / ((double)kAnnScalesDec[u * 8 + i] / 2048.0)) * a.pow2) * dq[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; u++) c[u] = (double)cv[u] * dq[u]; // coeffs * (Q*factor/100)
+        }
+    };
+    auto store_rows = [&](int lb, const double (&c)[8]) { // lane i holds pixel row i of block lb
+        uint32_t px[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            double v = c[k] + 128.0;
+            v = v < 0.0 ? 0.0 : v;
+            v = v > 255.0 ? 255.0 : v;
+            px[k] = (uint32_t)(int)v; // truncation toward zero, as astype(np.uint8) on a clipped value
+        }
+        const unsigned long long blk = b0 + (unsigned long long)lb;
+#if TIC_EXP & 16
+        asm volatile("" : : "v"(px[0] + px[1] + px[2] + px[3] + px[4] + px[5] + px[6] + px[7]));
+        if (blk >= m || a.h != 123457) return;
+#endif
+        if (blk >= m) return;
+        const unsigned long long by = blk / (unsigned long long)a.bw, bx = blk - by * (unsigned long long)a.bw;
+        const long y = (long)by * 8 + i;
+        const int x0 = (int)bx * 8;
+        if (y >= a.h) return;
+        uint8_t *p = a.out + y * a.stride + x0;
+        if (a.aligned8 && x0 + 8 <= a.w) {
+            uint2 o;
+            o.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+            o.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+            *reinterpret_cast<uint2 *>(p) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (x0 + k < a.w) p[k] = (uint8_t)px[k];
+        }
+    };
+    // two 8x8 dword transposes side by side (blocks A and B of the lane group), one pair of fences for both
+    auto tr2 = [&](uint32_t (&va)[8], uint32_t (&vb)[8]) {
+        uint32_t *pa = tbA + g * kTrStrideDw, *pb = tbB + g * kTrStrideDw;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { pa[u * 8 + i] = va[u]; pb[u * 8 + i] = vb[u]; }
+        wave_fence();
+        const uint4 *ra = reinterpret_cast<const uint4 *>(pa + i * 8), *rb = reinterpret_cast<const uint4 *>(pb + i * 8);
+        const uint4 a0 = ra[0], a1 = ra[1], b0v = rb[0], b1v = rb[1];
+        va[0] = a0.x; va[1] = a0.y; va[2] = a0.z; va[3] = a0.w; va[4] = a1.x; va[5] = a1.y; va[6] = a1.z; va[7] = a1.w;
+        vb[0] = b0v.x; vb[1] = b0v.y; vb[2] = b0v.z; vb[3] = b0v.w; vb[4] = b1v.x; vb[5] = b1v.y; vb[6] = b1v.z; vb[7] = b1v.w;
+        wave_fence();
+    };
+    for (int round = 0; round < ((TIC_EXP & 1) ? 0 : kDecodeWG / 64); round++) {
+        const int lbA = round * 64 + wave * 16 + g, lbB = lbA + 8; // the two blocks of this lane group inside the workgroup
+        double cA[8], cB[8];
+        load_col(lbA, cA);
+        load_col(lbB, cB);
+#if !(TIC_EXP & 4)
+        idct8_exact(cA[0], cA[1], cA[2], cA[3], cA[4], cA[5], cA[6], cA[7]); // axis -2
+        idct8_exact(cB[0], cB[1], cB[2], cB[3], cB[4], cB[5], cB[6], cB[7]);
+#endif
+        uint32_t wA[8], hA[8], wB[8], hB[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { wA[k] = (uint32_t)__double2loint(cA[k]); wB[k] = (uint32_t)__double2loint(cB[k]); }
+        tr2(wA, wB);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { hA[k] = (uint32_t)__double2hiint(cA[k]); hB[k] = (uint32_t)__double2hiint(cB[k]); }
+        tr2(hA, hB);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { cA[k] = __hiloint2double((int)hA[k], (int)wA[k]); cB[k] = __hiloint2double((int)hB[k], (int)wB[k]); }
+#if !(TIC_EXP & 4)
+        idct8_exact(cA[0], cA[1], cA[2], cA[3], cA[4], cA[5], cA[6], cA[7]); // axis -1: lane i holds pixel row i
+        idct8_exact(cB[0], cB[1], cB[2], cB[3], cB[4], cB[5], cB[6], cB[7]);
+#endif
+        store_rows(lbA, cA);
+        store_rows(lbB, cB);
     }
 }
 
@@ -419,11 +654,18 @@ size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
     const size_t nbits = stream_bytes * 8;
     const size_t nranges = nbits / 512 + 2; // (the smallest range: most ranges, and the most room per stream bit)
     const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
-    return nranges * ((size_t)cap_of(512) * 2 * 2 + 9 * 4) + nblocks * 8 + ntiles * 8 * 2 + 16384; // (two traces and seven 4-byte arrays per range, two per block; every piece is rounded up to 256 B)
+    return nranges * ((size_t)cap_of(512) * 2 * 2 + 9 * 4) + nblocks * 8 + ntiles * 8 * 2 + 16384; // (two traces and seven 4-byte arrays per range, two per block, two look-back words per tile; every piece is rounded up to 256 B)
 }
 
-hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
-                              size_t work_bytes, int16_t *d_zz, DecStatus *d_status, int range_bits, hipStream_t stream) {
+size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks) { // look-back words of the two scans (half of the array each)
+    const size_t nranges = stream_bytes * 8 / 512 + 2;
+    const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
+    return 2 * ntiles;
+}
+
+hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
+                                   size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, const DecIdctArgs &idct,
+                                   DecStatus *d_status, int range_bits, hipStream_t stream) {
     const size_t nbits = stream_bytes * 8;
     if (range_bits != 512 && range_bits != 1024 && range_bits != 2048) return hipErrorInvalidValue;
     const uint32_t range = (uint32_t)range_bits;
@@ -434,44 +676,37 @@ hipError_t entropy_decode_gpu(const void *d_stream_words, size_t stream_bytes, s
     const uint32_t fast_end = (uint32_t)(nbits - 2048); // a block may START on the fast path up to here (as in the host decoder)
     const uint32_t nranges = (uint32_t)((fast_end - 128 + kRange - 1) / kRange);
     const size_t ntiles_r = ((size_t)nranges + kTile - 1) / kTile, ntiles_b = (nblocks + kTile - 1) / kTile;
+    // The look-back words of the two scans live in an array of their own that holds nothing else, ever: a word there either is zero
+    // (since allocation) or carries the epoch of the launch that wrote it, and the caller never reuses an epoch on it.  (Inside the
+    // workspace the pieces move with the sizes of the call: a stale trace entry could pass for a published sum.)
+    if (!d_desc || desc_words < 2 * (ntiles_r > ntiles_b ? ntiles_r : ntiles_b) || epoch == 0 || epoch >= (1u << 22)) return hipErrorInvalidValue;
+    unsigned long long *desc_r = d_desc, *desc_b = d_desc + desc_words / 2;
     // workspace carve-up
     char *w = (char *)d_work;
     auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) / 256 * 256; return (void *)p; };
+    long long *totals = (long long *)take(16);
     uint16_t *starts = (uint16_t *)take((size_t)nranges * kCap * 2), *hand = (uint16_t *)take((size_t)nranges * kCap * 2);
     uint32_t *entry = (uint32_t *)take((size_t)nranges * 4), *bpos = (uint32_t *)take(nblocks * 4);
     uint32_t *nrec = (uint32_t *)take((size_t)nranges * 4), *endpos = (uint32_t *)take((size_t)nranges * 4);
     int *lastbrk = (int *)take((size_t)nranges * 4);
     uint32_t *nblk = (uint32_t *)take((size_t)nranges * 4);
     uint32_t *first_blk = (uint32_t *)take((size_t)nranges * 4);
-    int32_t *dcdiff = (int32_t *)take(nblocks * 4);
-    long long *tiles_r = (long long *)take((ntiles_r + 1) * 8), *tiles_b = (long long *)take((ntiles_b + 1) * 8);
-    long long *totals = (long long *)take(16);
+    int32_t *dcsum = (int32_t *)take(nblocks * 4);
     if ((size_t)(w - (char *)d_work) > work_bytes) return hipErrorInvalidValue;
     const uint32_t *words = (const uint32_t *)d_stream_words;
-    hipError_t e = hipMemsetAsync(d_status, 0, sizeof(DecStatus), stream);
-    if (e != hipSuccess) return e;
     const dim3 gr((nranges + 63) / 64), bl(64);
-    const uint32_t nwords = (uint32_t)((stream_bytes + 3) / 4); // (the caller zero-pads the last word and keeps 16 bytes behind it)
-    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, nwords, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, d_status);
-    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, nwords, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, nblk, hand, entry, d_status);
-    // first block of every range: exclusive scan of the true block counts
-    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const int32_t *)nblk, (size_t)nranges, tiles_r);
-    hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(kTile), 0, stream, tiles_r, ntiles_r, totals);
-    hipLaunchKernelGGL((scan_apply_kernel<false, StoreU32>), dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const int32_t *)nblk, (size_t)nranges,
-                       (const long long *)tiles_r, StoreU32{first_blk});
-    e = hipMemsetAsync(dcdiff, 0, nblocks * 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_zz, 0, nblocks * 128, stream); // the decode kernel writes the non-zero coefficients only
-    if (e != hipSuccess) return e;
+    const uint32_t nwords = (uint32_t)((stream_bytes + 3) / 4);
+    const uint32_t last_mask = (stream_bytes & 3) ? 0xffffffffu << (8u * (4u - (uint32_t)(stream_bytes & 3))) : 0xffffffffu; // (big-endian: the stream's bytes are the word's high bytes)
+    // (*d_status is zeroed by the caller: it is host-mapped memory)
+    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, d_status);
+    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, nblk, hand, entry, d_status);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const uint32_t *)nblk, nranges, desc_r, 2u * epoch, first_blk, totals, d_status);
     hipLaunchKernelGGL(dec_bpos_kernel, gr, bl, 0, stream, range, nranges, (const uint16_t *)starts, (const uint16_t *)hand, (const uint32_t *)nrec,
                        (const uint32_t *)entry, (const uint32_t *)nblk, (const uint32_t *)first_blk, (unsigned long long)nblocks, bpos);
-    hipLaunchKernelGGL(dec_decode_kernel, dim3((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG)), dim3(kDecodeWG), 0, stream, words, nwords, d_luts, (const uint32_t *)bpos,
-                       (const long long *)totals, (unsigned long long)nblocks, d_zz, dcdiff, d_status);
-    // np.cumsum of the DC differences over the blocks (blocks past the ones produced here hold 0 differences: their entry 0 is
-    // overwritten by the host's tail, which continues from dc_out)
-    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, (const int32_t *)dcdiff, nblocks, tiles_b);
-    hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(kTile), 0, stream, tiles_b, ntiles_b, totals + 1);
-    hipLaunchKernelGGL((scan_apply_kernel<true, StoreDc>), dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, (const int32_t *)dcdiff, nblocks,
-                       (const long long *)tiles_b, StoreDc{d_zz, nblocks, d_status});
+    hipLaunchKernelGGL(dec_dc_scan_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const long long *)totals,
+                       (unsigned long long)nblocks, desc_b, 2u * epoch + 1u, dcsum, d_status);
+    hipLaunchKernelGGL(dec_decode_idct_kernel, dim3((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG)), dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts,
+                       (const uint32_t *)bpos, (const int32_t *)dcsum, (const long long *)totals, (unsigned long long)nblocks, idct, d_status);
     return hipGetLastError();
 }
 

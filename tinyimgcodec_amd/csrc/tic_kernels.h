@@ -75,6 +75,11 @@ struct IdctArgs {
     const DctqConsts *consts;
     int scaled = 0;    // decode()'s scaled_dct branch (codec.py:59-62): coefficients / ANNSCALES * pow2, consts = quality 50
     double pow2 = 1.0; // 2 ** (quality field of the stream)
+    // Block-range form (first_block >= 0): the kernel transforms blocks [first_block, first_block + nblocks_sel) in raster order,
+    // 8 per wave, instead of the frame's strips - the few blocks the host decodes at the end of a long stream (their coefficients
+    // sit at their places in `coeffs`; every other block's pixels come from the fused decode kernel).
+    long first_block = -1;
+    long nblocks_sel = 0;
 };
 
 // C-ABI kernel selector (TIC_KERNEL_AUTO / _EXACT / _HYBRID) -> launch_dctq's variant (1 exact, 2 strip kernel), -1 for anything else.

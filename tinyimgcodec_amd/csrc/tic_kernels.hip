@@ -797,6 +797,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void idct_kernel(IdctArgs a) {
     const int tile = blockIdx.x * kWavesPerWG + wave;
     const DctqConsts *__restrict__ C = a.consts;
     Strip s = make_strip(tile, a.ntiles, a.tiles_x, a.bw, b);
+    if (a.first_block >= 0) { // block-range form: 8 consecutive blocks of the raster order per wave
+        const long blk = a.first_block + (long)tile * 8 + b;
+        s.valid = blk < a.first_block + a.nblocks_sel;
+        s.by = (int)(blk / a.bw);
+        s.bx = (int)(blk - (long)s.by * a.bw);
+        s.oblk = (size_t)blk;
+    }
 
     // lane i of block b loads zig-zag entries 8i..8i+7 (16 B), scatters them to natural order in LDS
     uint4 val = make_uint4(0, 0, 0, 0);
