@@ -16,9 +16,9 @@
 //             trace recorded; from that entry on the trace IS the true chain (a block start carries no state), so the trace's end is
 //             where the true chain enters range t+1 - which is the hypothesis for t+1.  Range 0 starts on a true block start, so if
 //             EVERY lane finds its synchronisation point inside its range, induction makes every hypothesis true.  Otherwise: give up.
-//   scan      exclusive prefix sum of the ranges' true block counts -> index of each range's first block (ONE launch: every tile
-//             publishes its own sum and adds up the sums of the tiles in front of it, scan_lookback below).
-//   bpos      a lane per range writes the first bit of each of its true blocks (by-hand ones, then the trace from the entry on).
+//   scan + bpos   exclusive prefix sum of the ranges' true block counts -> index of each range's first block (ONE launch: every tile
+//             publishes its own sum and adds up the sums of the tiles in front of it, scan_lookback below); the lane of a range then
+//             writes the first bit of each of its true blocks (by-hand ones, then the trace from the entry on).
 //   dc scan   a lane per BLOCK decodes the block's DC symbol and the differences are summed inclusively over the blocks
 //             (np.cumsum, codec.py:53): one launch, the same look-back.
 //   decode + inverse transform   a workgroup per 256 consecutive blocks: a lane per block decodes it from its first bit into an LDS
@@ -365,34 +365,28 @@ __device__ __forceinline__ long long scan_lookback(const unsigned long long *des
     (void)wg_inclusive_scan(part, lds, total);
     return total;
 }
-// first_blk[t] = number of true blocks in the ranges in front of range t; *grand_total = all of them
-__global__ __launch_bounds__(kTile) void scan_counts_kernel(const uint32_t *__restrict__ nblk, uint32_t nranges, unsigned long long *__restrict__ desc,
-                                                            uint32_t epoch, uint32_t *__restrict__ first_blk, long long *__restrict__ grand_total,
-                                                            DecStatus *__restrict__ st) {
+// Index of every range's first true block (exclusive scan of the ranges' block counts; *grand_total = all of them) and, with it, the
+// first bit of every block of the true chain: range t's blocks are the ones its stitch walked by hand, then its trace from the entry
+// on.  (Rounds 2-3: three scan launches and a bpos launch.)
+__global__ __launch_bounds__(kTile) void scan_counts_bpos_kernel(const uint32_t *__restrict__ nblk, uint32_t range, uint32_t nranges, unsigned long long *__restrict__ desc,
+                                                                 uint32_t epoch, const uint16_t *__restrict__ starts, const uint16_t *__restrict__ hand,
+                                                                 const uint32_t *__restrict__ nrec, const uint32_t *__restrict__ entry, unsigned long long nblocks,
+                                                                 uint32_t *__restrict__ bpos, long long *__restrict__ grand_total, DecStatus *__restrict__ st) {
     __shared__ long long lds[16];
-    const size_t i = (size_t)blockIdx.x * kTile + threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * kTile + threadIdx.x;
     long long tot;
-    const long long v = i < nranges ? (long long)nblk[i] : 0ll;
+    const long long v = t < nranges ? (long long)nblk[t] : 0ll;
     const long long inc = wg_inclusive_scan(v, lds, tot);
     scan_publish(desc, epoch, tot);
     const long long off = scan_lookback(desc, epoch, lds, st);
-    if (i < nranges) first_blk[i] = (uint32_t)(off + inc - v);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grand_total = off + tot;
-}
-
-// First bit of every block of the true chain: range t's blocks are the ones its stitch walked by hand, then its trace from the entry
-// on; first_blk[t] (the scan of the counts) is the index of the first of them.
-__global__ __launch_bounds__(64) void dec_bpos_kernel(uint32_t range, uint32_t nranges, const uint16_t *__restrict__ starts, const uint16_t *__restrict__ hand,
-                                                      const uint32_t *__restrict__ nrec, const uint32_t *__restrict__ entry, const uint32_t *__restrict__ nblk,
-                                                      const uint32_t *__restrict__ first_blk, unsigned long long nblocks, uint32_t *__restrict__ bpos) {
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= nranges) return;
-    const uint32_t lo = 128u + t * range, cap = cap_of(range);
+    const unsigned long long first = (unsigned long long)(off + inc - v);
+    const uint32_t lo = 128u + (uint32_t)t * range, cap = cap_of(range);
     const uint32_t nr = nrec[t] < cap ? nrec[t] : cap, a = entry[t] < nr ? entry[t] : nr;
-    const uint32_t nb = nblk[t], from_trace = nr - a < nb ? nr - a : nb, by_hand = nb - from_trace;
-    const unsigned long long first = first_blk[t];
-    for (uint32_t i = 0; i < by_hand && i < cap && first + i < nblocks; i++) bpos[first + i] = lo + (uint32_t)hand[(size_t)t * cap + i];
-    for (uint32_t j = 0; j < from_trace && first + by_hand + j < nblocks; j++) bpos[first + by_hand + j] = lo + (uint32_t)starts[(size_t)t * cap + a + j];
+    const uint32_t nb = (uint32_t)v, from_trace = nr - a < nb ? nr - a : nb, by_hand = nb - from_trace;
+    for (uint32_t i = 0; i < by_hand && i < cap && first + i < nblocks; i++) bpos[first + i] = lo + (uint32_t)hand[t * cap + i];
+    for (uint32_t j = 0; j < from_trace && first + by_hand + j < nblocks; j++) bpos[first + by_hand + j] = lo + (uint32_t)starts[t * cap + a + j];
 }
 
 // np.cumsum of the DC differences (codec.py:53), one launch: lane b decodes the DC symbol of block b (the first symbol at bpos[b]:
@@ -402,7 +396,7 @@ __global__ __launch_bounds__(64) void dec_bpos_kernel(uint32_t range, uint32_t n
 __global__ __launch_bounds__(kTile) void dec_dc_scan_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                             const uint32_t *__restrict__ bpos, const long long *__restrict__ total_blocks,
                                                             unsigned long long n_want, unsigned long long *__restrict__ desc, uint32_t epoch,
-                                                            int32_t *__restrict__ dcsum, DecStatus *__restrict__ st) {
+                                                            int32_t *__restrict__ dcsum, uint8_t *__restrict__ dclen, DecStatus *__restrict__ st) {
     __shared__ long long lds[16];
     __shared__ uint16_t dc11[2048];
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) reinterpret_cast<uint32_t *>(dc11)[i] = reinterpret_cast<const uint32_t *>(L->dc11)[i];
@@ -416,7 +410,9 @@ __global__ __launch_bounds__(kTile) void dec_dc_scan_kernel(const uint32_t *__re
         const uint32_t wa = stream_word(gwords, wi, nwords, last_mask), wb = stream_word(gwords, wi + 1u, nwords, last_mask);
         const uint32_t pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa;
         const uint32_t e = dc11[pk >> 21]; // (measure or stitch walked this block: a DC codeword is there)
+        if (!e) atomicOr(&st->giveup, 32);
         v = (long long)value_of(pk, (int)(e >> 8), (int)(e & 15u));
+        dclen[b] = (uint8_t)((e >> 8) + (e & 15u)); // bits of the DC symbol: the fused kernel starts behind it and needs no DC table
     }
     long long tot;
     const long long inc = wg_inclusive_scan(v, lds, tot);
@@ -440,8 +436,16 @@ __global__ __launch_bounds__(kTile) void dec_dc_scan_kernel(const uint32_t *__re
 // (~100 cycles per symbol), which two waves per SIMD already overlap; what made the separate decode kernel slow were its 45
 // two-byte global stores per lane.
 constexpr int kDecodeWG = 256;
-constexpr uint32_t kBlkWin = 4096 + kOver;
-constexpr uint32_t kBlkLds = kBlkWin + kBlkWin / 32 + 2;
+constexpr int kAcLutLds = 2048 + kLongCodes; // ac11 + the long codewords (the DC symbol's length comes from the DC scan: no dc11 here)
+// ac11 and the long AC codewords into LDS: lut[0..2047] = ac11, lut[2048..] = long codewords (long_code_ac)
+__device__ __forceinline__ void load_ac_lut(uint16_t *lds, const DecLutsDev *__restrict__ L) {
+    for (int i = threadIdx.x; i < 2048 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(L->ac11)[i];
+    for (int i = threadIdx.x; i < kLongCodes; i += blockDim.x) lds[2048 + i] = L->ac16[kLongFirst + i];
+}
+__device__ __forceinline__ uint32_t long_code_ac(const uint16_t *lut, uint32_t pk) {
+    const uint32_t i = (pk >> 16) - (uint32_t)kLongFirst;
+    return i < (uint32_t)kLongCodes ? lut[2048u + i] : 0u;
+}
 constexpr int kImgStrideB = 144;  // bytes between the images of two blocks
 constexpr int kTrStrideDw = 68;   // dwords per block in a wave's transpose buffer (64 + 4 pad)
 __constant__ int kAnnScalesDec[64] = { // ANNSCALES of the reference's scaled_dct branch (constants.py; utils.py:59-62), as integers x 2048
@@ -467,13 +471,18 @@ __device__ __forceinline__ void tr8x8_dwords(uint32_t *buf, int g, int i, uint32
     wave_fence();
 }
 
+// kWinWords: stream words of the workgroup's window: 2048 (+ kOver) hold 256 blocks of up to 256 bits on average - three workgroups
+// per CU - 4096 of up to 512 - two; what lies behind the window is read from memory
+template <uint32_t kWinWords>
 __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
-                                                                    const uint32_t *__restrict__ bpos, const int32_t *__restrict__ dcsum,
+                                                                    const uint32_t *__restrict__ bpos, const int32_t *__restrict__ dcsum, const uint8_t *__restrict__ dclen,
                                                                     const long long *__restrict__ total_blocks, unsigned long long n_want,
                                                                     DecIdctArgs a, DecStatus *__restrict__ st) {
-    // phase 1: tables + stream window; phase 2 (behind the barrier): the waves' transpose buffers, two per wave
-    constexpr int kLutDw = (kLutLds * 2 + 15) / 16 * 4;
-    constexpr int kTrDw = (kDecodeWG / 64) * 2 * 8 * kTrStrideDw;
+    // phase 1: tables + stream window; phase 2 (behind the barrier): the waves' transpose buffers
+    constexpr uint32_t kBlkWin = kWinWords + kOver;
+    constexpr uint32_t kBlkLds = kBlkWin + kBlkWin / 32 + 2;
+    constexpr int kLutDw = (kAcLutLds * 2 + 15) / 16 * 4;
+    constexpr int kTrDw = (kDecodeWG / 64) * 8 * kTrStrideDw;
     constexpr int kScratchDw = kLutDw + (int)kBlkLds > kTrDw ? kLutDw + (int)kBlkLds : kTrDw;
     __shared__ __attribute__((aligned(16))) uint32_t scratch[kScratchDw];
     __shared__ __attribute__((aligned(16))) unsigned char img[kDecodeWG * kImgStrideB];
@@ -489,20 +498,17 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
         uint4 *z = reinterpret_cast<uint4 *>(img);
         for (int k = threadIdx.x; k < kDecodeWG * kImgStrideB / 16; k += kDecodeWG) z[k] = make_uint4(0u, 0u, 0u, 0u);
     }
-    load_lut(lut, L);
+    load_ac_lut(lut, L);
     const unsigned long long last = b0 + kDecodeWG - 1 < m - 1 ? b0 + kDecodeWG - 1 : m - 1;
     const uint32_t w0 = bpos[b0] >> 5, w1 = bpos[last] >> 5;
     const uint32_t want = w1 >= w0 ? w1 - w0 + kOver : kOver;
     const Bits words = stage_words(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords, last_mask); // (ends with a barrier: tables, window, zeros, zznat)
-#ifndef TIC_EXP
-#define TIC_EXP 0
-#endif
     // ---- phase 1: a lane per block, one SYMBOL per step as in the measure kernel: the stream words under the read position sit
     // in registers (wa, wb) and the word behind them (wc) is fetched a step ahead, so that the table look-up is the only LDS access
     // on the lane's dependent chain; the coefficient's store (its address comes through the zig-zag table) is off that chain.
-    if (b < m && (!(TIC_EXP & 2) || b == m - 1)) {
+    if (b < m) {
         int16_t *c = reinterpret_cast<int16_t *>(img + (size_t)threadIdx.x * kImgStrideB);
-        const uint16_t *ac11 = lut + 2048;
+        const uint16_t *ac11 = lut;
         uint32_t pos = bpos[b];
         uint32_t wi = pos >> 5;
         uint32_t wa = word_be(words, wi), wb = word_be(words, wi + 1u), wc = word_be(words, wi + 2u);
@@ -514,12 +520,10 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
             wi += crossed ? 1u : 0u;
             wc = word_be(words, wi + 2u); // (not needed before the next boundary)
         };
-        uint32_t sh = pos & 31u;
-        uint32_t pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa;
-        uint32_t e = lut[pk >> 21];
-        bool ok = e != 0u; // DC categories are at most 9 bits long
-        if (ok) {
-            advance((e >> 8) + (e & 15u)); // the DC difference itself went through the scan
+        uint32_t sh, pk, e;
+        bool ok = true;
+        {
+            advance((uint32_t)dclen[b]); // the DC symbol went through the scan, which left its length and the integrated DC
             const int32_t dc = dcsum[b];
             c[0] = (int16_t)(dc < -32768 ? -32768 : (dc > 32767 ? 32767 : dc)); // the host decoder's sat16
             int k = 1;
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
                 pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa;
                 e = ac11[pk >> 21];
                 if (__any(e == 0u)) { // a codeword of 12 to 16 bits somewhere in the wave
-                    const uint32_t e2 = long_code(lut, pk);
+                    const uint32_t e2 = long_code_ac(lut, pk);
                     e = e == 0u ? e2 : e;
                 }
                 const bool nocode = e == 0u;
@@ -537,11 +541,7 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
                 const int len = (int)(e >> 8), size = (int)(e & 15u);
                 const int k_at = k + (int)((e >> 4) & 15u);
                 const bool bad = nocode || (!eob && k_at > 63);
-#if TIC_EXP & 8
-                if (!eob && !bad && k_at == 77) c[zznat[k_at]] = (int16_t)value_of(pk, len, size);
-#else
                 if (!eob && !bad) c[zznat[k_at]] = (int16_t)value_of(pk, len, size);
-#endif
                 if (!nocode) advance((uint32_t)(len + size));
                 k = k_at + 1;
                 ok = ok && !bad;
@@ -555,12 +555,13 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
         }
     }
     __syncthreads();
-    // ---- phase 2: 8 lanes per block; a wave takes 2 x 8 consecutive blocks per round - two independent chains of float64 work per
-    // lane, which is what keeps the vector unit busy at two waves per SIMD (one chain per lane: 68 us for this phase, two: see DESIGN)
+    // ---- phase 2: 8 lanes per block, a wave takes 8 consecutive blocks per round.  (Two blocks per lane group and round - two
+    // independent float64 chains per lane - measured no faster and cost a second transpose buffer per wave, i.e. the third workgroup
+    // per CU.)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 3, i = lane & 7;
     const DctqConsts *__restrict__ C = a.consts;
-    uint32_t *tbA = scratch + wave * (2 * 8 * kTrStrideDw), *tbB = tbA + 8 * kTrStrideDw; // (tables and window are dead: behind the barrier)
+    uint32_t *tb = scratch + wave * (8 * kTrStrideDw); // (tables and window are dead: behind the barrier)
     double dq[8]; // the lane's eight dequantisation constants (column v = i): read once, not once per round
 #pragma unroll
     for (int u = 0; u < 8; u++) dq[u] = C->div[u * 8 + i];
@@ -588,10 +589,6 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
             px[k] = (uint32_t)(int)v; // truncation toward zero, as astype(np.uint8) on a clipped value
         }
         const unsigned long long blk = b0 + (unsigned long long)lb;
-#if TIC_EXP & 16
-        asm volatile("" : : "v"(px[0] + px[1] + px[2] + px[3] + px[4] + px[5] + px[6] + px[7]));
-        if (blk >= m || a.h != 123457) return;
-#endif
         if (blk >= m) return;
         const unsigned long long by = blk / (unsigned long long)a.bw, bx = blk - by * (unsigned long long)a.bw;
         const long y = (long)by * 8 + i;
@@ -609,42 +606,22 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
                 if (x0 + k < a.w) p[k] = (uint8_t)px[k];
         }
     };
-    // two 8x8 dword transposes side by side (blocks A and B of the lane group), one pair of fences for both
-    auto tr2 = [&](uint32_t (&va)[8], uint32_t (&vb)[8]) {
-        uint32_t *pa = tbA + g * kTrStrideDw, *pb = tbB + g * kTrStrideDw;
+    for (int round = 0; round < kDecodeWG / 32; round++) {
+        const int lb = round * 32 + wave * 8 + g; // block of this lane group inside the workgroup
+        double c[8];
+        load_col(lb, c);
+        idct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -2
+        uint32_t w[8], wh[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { pa[u * 8 + i] = va[u]; pb[u * 8 + i] = vb[u]; }
-        wave_fence();
-        const uint4 *ra = reinterpret_cast<const uint4 *>(pa + i * 8), *rb = reinterpret_cast<const uint4 *>(pb + i * 8);
-        const uint4 a0 = ra[0], a1 = ra[1], b0v = rb[0], b1v = rb[1];
-        va[0] = a0.x; va[1] = a0.y; va[2] = a0.z; va[3] = a0.w; va[4] = a1.x; va[5] = a1.y; va[6] = a1.z; va[7] = a1.w;
-        vb[0] = b0v.x; vb[1] = b0v.y; vb[2] = b0v.z; vb[3] = b0v.w; vb[4] = b1v.x; vb[5] = b1v.y; vb[6] = b1v.z; vb[7] = b1v.w;
-        wave_fence();
-    };
-    for (int round = 0; round < ((TIC_EXP & 1) ? 0 : kDecodeWG / 64); round++) {
-        const int lbA = round * 64 + wave * 16 + g, lbB = lbA + 8; // the two blocks of this lane group inside the workgroup
-        double cA[8], cB[8];
-        load_col(lbA, cA);
-        load_col(lbB, cB);
-#if !(TIC_EXP & 4)
-        idct8_exact(cA[0], cA[1], cA[2], cA[3], cA[4], cA[5], cA[6], cA[7]); // axis -2
-        idct8_exact(cB[0], cB[1], cB[2], cB[3], cB[4], cB[5], cB[6], cB[7]);
-#endif
-        uint32_t wA[8], hA[8], wB[8], hB[8];
+        for (int k = 0; k < 8; k++) w[k] = (uint32_t)__double2loint(c[k]);
+        tr8x8_dwords(tb, g, i, w);
 #pragma unroll
-        for (int k = 0; k < 8; k++) { wA[k] = (uint32_t)__double2loint(cA[k]); wB[k] = (uint32_t)__double2loint(cB[k]); }
-        tr2(wA, wB);
+        for (int k = 0; k < 8; k++) wh[k] = (uint32_t)__double2hiint(c[k]);
+        tr8x8_dwords(tb, g, i, wh);
 #pragma unroll
-        for (int k = 0; k < 8; k++) { hA[k] = (uint32_t)__double2hiint(cA[k]); hB[k] = (uint32_t)__double2hiint(cB[k]); }
-        tr2(hA, hB);
-#pragma unroll
-        for (int k = 0; k < 8; k++) { cA[k] = __hiloint2double((int)hA[k], (int)wA[k]); cB[k] = __hiloint2double((int)hB[k], (int)wB[k]); }
-#if !(TIC_EXP & 4)
-        idct8_exact(cA[0], cA[1], cA[2], cA[3], cA[4], cA[5], cA[6], cA[7]); // axis -1: lane i holds pixel row i
-        idct8_exact(cB[0], cB[1], cB[2], cB[3], cB[4], cB[5], cB[6], cB[7]);
-#endif
-        store_rows(lbA, cA);
-        store_rows(lbB, cB);
+        for (int k = 0; k < 8; k++) c[k] = __hiloint2double((int)wh[k], (int)w[k]);
+        idct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -1: lane i holds pixel row i
+        store_rows(lb, c);
     }
 }
 
@@ -654,7 +631,7 @@ size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
     const size_t nbits = stream_bytes * 8;
     const size_t nranges = nbits / 512 + 2; // (the smallest range: most ranges, and the most room per stream bit)
     const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
-    return nranges * ((size_t)cap_of(512) * 2 * 2 + 9 * 4) + nblocks * 8 + ntiles * 8 * 2 + 16384; // (two traces and seven 4-byte arrays per range, two per block, two look-back words per tile; every piece is rounded up to 256 B)
+    return nranges * ((size_t)cap_of(512) * 2 * 2 + 9 * 4) + nblocks * 9 + ntiles * 8 * 2 + 16384; // (two traces and seven 4-byte arrays per range, two 4-byte arrays and a byte per block; every piece is rounded up to 256 B)
 }
 
 size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks) { // look-back words of the two scans (half of the array each)
@@ -690,8 +667,8 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     uint32_t *nrec = (uint32_t *)take((size_t)nranges * 4), *endpos = (uint32_t *)take((size_t)nranges * 4);
     int *lastbrk = (int *)take((size_t)nranges * 4);
     uint32_t *nblk = (uint32_t *)take((size_t)nranges * 4);
-    uint32_t *first_blk = (uint32_t *)take((size_t)nranges * 4);
     int32_t *dcsum = (int32_t *)take(nblocks * 4);
+    uint8_t *dclen = (uint8_t *)take(nblocks);
     if ((size_t)(w - (char *)d_work) > work_bytes) return hipErrorInvalidValue;
     const uint32_t *words = (const uint32_t *)d_stream_words;
     const dim3 gr((nranges + 63) / 64), bl(64);
@@ -700,13 +677,17 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     // (*d_status is zeroed by the caller: it is host-mapped memory)
     hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, d_status);
     hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, nblk, hand, entry, d_status);
-    hipLaunchKernelGGL(scan_counts_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const uint32_t *)nblk, nranges, desc_r, 2u * epoch, first_blk, totals, d_status);
-    hipLaunchKernelGGL(dec_bpos_kernel, gr, bl, 0, stream, range, nranges, (const uint16_t *)starts, (const uint16_t *)hand, (const uint32_t *)nrec,
-                       (const uint32_t *)entry, (const uint32_t *)nblk, (const uint32_t *)first_blk, (unsigned long long)nblocks, bpos);
+    hipLaunchKernelGGL(scan_counts_bpos_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const uint32_t *)nblk, range, nranges, desc_r, 2u * epoch,
+                       (const uint16_t *)starts, (const uint16_t *)hand, (const uint32_t *)nrec, (const uint32_t *)entry, (unsigned long long)nblocks, bpos, totals, d_status);
     hipLaunchKernelGGL(dec_dc_scan_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const long long *)totals,
-                       (unsigned long long)nblocks, desc_b, 2u * epoch + 1u, dcsum, d_status);
-    hipLaunchKernelGGL(dec_decode_idct_kernel, dim3((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG)), dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts,
-                       (const uint32_t *)bpos, (const int32_t *)dcsum, (const long long *)totals, (unsigned long long)nblocks, idct, d_status);
+                       (unsigned long long)nblocks, desc_b, 2u * epoch + 1u, dcsum, dclen, d_status);
+    const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
+    if (nbits / nblocks <= 240) // sparse enough for the small window: one workgroup more per CU
+        hipLaunchKernelGGL(dec_decode_idct_kernel<2048>, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos,
+                           (const int32_t *)dcsum, (const uint8_t *)dclen, (const long long *)totals, (unsigned long long)nblocks, idct, d_status);
+    else
+        hipLaunchKernelGGL(dec_decode_idct_kernel<4096>, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos,
+                           (const int32_t *)dcsum, (const uint8_t *)dclen, (const long long *)totals, (unsigned long long)nblocks, idct, d_status);
     return hipGetLastError();
 }
 
