@@ -1572,7 +1572,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
                                             ctx->dec_desc_words, ctx->dec_epoch, ia, ctx->d_dec_status, range_bits, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(&st, ctx->h_dec_status, sizeof st); // (host-mapped: the stream has drained)
-        if (st.giveup == 4 && range_bits < 2048) {
+        if ((st.giveup & 4) && range_bits < 2048) { // (a range without a synchronisation point breaks the chain: whatever else was flagged follows from it)
             range_bits = 2048;
             continue;
         }

@@ -181,7 +181,7 @@ __device__ __forceinline__ void load_lut(uint16_t *lds, const DecLutsDev *__rest
 // is lane state and a block end is just another step.  Same tables, same rules as block_dev().
 __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L, uint32_t fast_end,
                                                          uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts, uint32_t *__restrict__ nrec,
-                                                         uint32_t *__restrict__ endpos, int *__restrict__ lastbrk, DecStatus *__restrict__ st) {
+                                                         uint32_t *__restrict__ endpos, DecStatus *__restrict__ st) {
     __shared__ uint16_t lut[kLutLds];
     __shared__ uint32_t sbits[kStageLds];
     load_lut(lut, L);
@@ -194,10 +194,18 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
     // step: 40 vector + 40 scalar instructions).  Every read stays inside the staged window: a block that starts in front of `hi`
     // ends within 1,728 bits of it, a walk that goes on after an incident is cut at hi + 1,800, and the window reaches 2,112 bits
     // (kOver words) behind the workgroup's last range.
+    //
+    // Round 4: the walk keeps NO record of incidents.  An invalid prefix skips a bit, a block of more than 63 coefficients simply goes
+    // on to its EOB, and every EOB records the first bit of the block it ends - whether that block was well-formed or not.  A recorded
+    // position is a bit at which this lane stood with a block about to start; from such a bit the walk is a function of the stream
+    // alone, so a position the TRUE chain shares with the trace has the true chain's future behind it, incident or not.  Whether the
+    // blocks of the true chain are well-formed and follow each other without a gap is checked where they are decoded (the fused
+    // kernel: an invalid prefix, a 64th coefficient, or a block that does not end where the next one starts raises the give-up flag).
+    // Rounds 2-3 tracked the scan position, a clean flag and the last incident per lane here: 100 instructions per symbol, of which this
+    // bookkeeping was the larger half - and the kernel is bound by instruction issue (profiles/r04_decoder.txt).
     const uint32_t stop = hi + 1800u;
     uint32_t pos = lo, bstart = lo, cnt = 0; // a block that STARTS in front of `hi` is measured to its end
-    int k = 0, brk = -1;   // k: scan position the next AC symbol starts from; 0 = the DC category comes next
-    bool clean = true;     // the block in work began at a block-start guess and has decoded without an incident so far
+    bool at_dc = true;     // the DC category comes next (a block starts here)
     bool live = pos < hi;
     // The stream words under the read position sit in registers (wa, wb) and the word behind them (wc) is fetched a step ahead: the
     // walk is sequential, so the only LDS access left on the lane's dependent chain is the table look-up.
@@ -205,24 +213,14 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
     uint32_t wi = (pos >> 5) - words.wbase; // window-relative index of the word `pos` lies in
     uint32_t wa = word_at(wi), wb = word_at(wi + 1u), wc = word_at(wi + 2u);
     while (live) {
-        const uint32_t sh = pos & 31u;
-        const uint32_t pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa; // 32 stream bits from `pos`
-        uint32_t e = lut[(k ? 2048u : 0u) + (pk >> 21)];
-        if (__any(e == 0u && k != 0)) { // a codeword of 12 to 16 bits somewhere in the wave
+        const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32); // 32 stream bits from `pos`
+        uint32_t e = lut[(at_dc ? 0u : 2048u) + (pk >> 21)];
+        if (__any(e == 0u && !at_dc)) { // a codeword of 12 to 16 bits somewhere in the wave
             const uint32_t e2 = long_code(lut, pk);
-            e = (e == 0u && k != 0) ? e2 : e;
+            e = (e == 0u && !at_dc) ? e2 : e;
         }
-        const bool nocode = e == 0u, dc = k == 0;
-        const bool eob = !dc && !nocode && (e & 0xffu) == 0u;
-        const int k_at = k + (int)((e >> 4) & 15u);
-        // An incident: an invalid prefix, or more than 63 coefficients in the block.  The walk is a guess that led nowhere (or, behind
-        // the point of synchronisation, the stream is malformed).  It goes on from here IN THE AC STATE: most of a block is AC symbols, a
-        // walk that has fallen into step with the true symbols stays in step (an overflowing symbol is consumed, an invalid prefix
-        // skips a bit), and the next true EOB then ends on a true block start.  The block in work is not recorded; the one behind its
-        // EOB is a fresh guess.  (The first version went back to the failed block's first bit + 1 and took that for a block start:
-        // every incident threw away up to 63 symbols of walking and the alignment they had reached - the unluckiest lane of a wave
-        // walked 750 symbols for the 210 of its range.)
-        const bool bad = nocode || (!dc && !eob && k_at > 63);
+        const bool nocode = e == 0u;
+        const bool eob = !at_dc && !nocode && (e & 0xffu) == 0u;
         pos += nocode ? 1u : (e >> 8) + (e & 15u);
         { // a step consumes at most 27 bits: at most one word boundary is crossed
             const bool crossed = ((pos >> 5) - words.wbase) != wi;
@@ -231,25 +229,20 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
             wi += crossed ? 1u : 0u;
             wc = word_at(wi + 2u); // (not needed before the next boundary: off the dependent chain)
         }
-        const bool rec = eob && clean;
-        if (rec && cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(bstart - lo);
-        cnt += rec ? 1u : 0u;
-        brk = bad ? (int)cnt : brk;
-        clean = bad ? false : (eob ? true : clean);
+        if (eob && cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(bstart - lo);
+        cnt += eob ? 1u : 0u;
         bstart = eob ? pos : bstart;
-        k = bad ? 1 : (eob ? 0 : (dc ? 1 : k_at + 1));
+        at_dc = nocode ? at_dc : eob;
         live = (eob ? pos < hi : true) && pos < stop;
     }
-    if (t == 0u && brk >= 0) atomicOr(&st->giveup, 1); // an incident on the true chain itself: unusual
     if (cnt > cap_of(range)) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
     nrec[t] = cnt;
     endpos[t] = pos;
-    lastbrk[t] = brk;
 }
 
 __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L, uint32_t fast_end,
                                                         uint32_t range, uint32_t nranges, const uint16_t *__restrict__ starts, const uint32_t *__restrict__ nrec,
-                                                        const uint32_t *__restrict__ endpos, const int *__restrict__ lastbrk,
+                                                        const uint32_t *__restrict__ endpos,
                                                         uint32_t *__restrict__ nblk, uint16_t *__restrict__ hand,
                                                         uint32_t *__restrict__ entry, DecStatus *__restrict__ st) {
     __shared__ uint16_t lut[kLutLds];
@@ -290,8 +283,7 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
             else b = mid;
         }
         if (a < n && (uint32_t)tr[a] == want) {
-            // from here on the trace walked the true chain: a failed measurement behind this point is the stream's fault
-            if (lastbrk[t] > (int)a) atomicOr(&st->giveup, 8);
+            // from here on the trace walked the true chain (whether its blocks are well-formed is checked where they are decoded)
             nblk[t] = by_hand + (nrec[t] - a);
             entry[t] = a;
             return;
@@ -548,7 +540,9 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
                 live = !eob && !bad;
             }
         }
-        if (!ok) atomicOr(&st->giveup, 32); // (measure or stitch walked this block: cannot fail)
+        // the block is well-formed, and the next block of the chain starts where this one ends (the measure kernel vouches for
+        // neither: its walk goes on through incidents)
+        if (!ok || (b + 1 < m && bpos[b + 1] != pos)) atomicOr(&st->giveup, 32);
         if (b == m - 1) {
             st->pos_out = pos;
             st->m = m;
@@ -665,7 +659,6 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     uint16_t *starts = (uint16_t *)take((size_t)nranges * kCap * 2), *hand = (uint16_t *)take((size_t)nranges * kCap * 2);
     uint32_t *entry = (uint32_t *)take((size_t)nranges * 4), *bpos = (uint32_t *)take(nblocks * 4);
     uint32_t *nrec = (uint32_t *)take((size_t)nranges * 4), *endpos = (uint32_t *)take((size_t)nranges * 4);
-    int *lastbrk = (int *)take((size_t)nranges * 4);
     uint32_t *nblk = (uint32_t *)take((size_t)nranges * 4);
     int32_t *dcsum = (int32_t *)take(nblocks * 4);
     uint8_t *dclen = (uint8_t *)take(nblocks);
@@ -675,8 +668,8 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const uint32_t nwords = (uint32_t)((stream_bytes + 3) / 4);
     const uint32_t last_mask = (stream_bytes & 3) ? 0xffffffffu << (8u * (4u - (uint32_t)(stream_bytes & 3))) : 0xffffffffu; // (big-endian: the stream's bytes are the word's high bytes)
     // (*d_status is zeroed by the caller: it is host-mapped memory)
-    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, d_status);
-    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, lastbrk, nblk, hand, entry, d_status);
+    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, d_status);
+    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, nblk, hand, entry, d_status);
     hipLaunchKernelGGL(scan_counts_bpos_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const uint32_t *)nblk, range, nranges, desc_r, 2u * epoch,
                        (const uint16_t *)starts, (const uint16_t *)hand, (const uint32_t *)nrec, (const uint32_t *)entry, (unsigned long long)nblocks, bpos, totals, d_status);
     hipLaunchKernelGGL(dec_dc_scan_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const long long *)totals,
