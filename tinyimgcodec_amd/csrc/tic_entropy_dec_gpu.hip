@@ -268,21 +268,23 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
     const uint32_t n = nrec[t] < cap_of(range) ? nrec[t] : cap_of(range);
     BitWin win = {0xffffffffu, 0u, 0u};
     uint32_t by_hand = 0;
+    // the trace is sorted and the walk only moves forward: ONE pointer into the trace, advanced past the entries in front of the
+    // walk (rounds 2-3 searched the trace from scratch at every block: eight dependent loads from memory where this takes one or two)
+    uint32_t a = 0;
+    uint32_t ta = n ? (uint32_t)tr[0] : 0xffffffffu;
     for (;;) {
         if (pos >= hi) { // walked through the whole range without meeting its trace: the hypothesis for the next range fails
             atomicOr(&st->giveup, 4);
             nblk[t] = by_hand;
             return;
         }
-        // is `pos` a block start this range's trace recorded?  (sorted)
+        // is `pos` a block start this range's trace recorded?
         const uint32_t want = pos - lo;
-        uint32_t a = 0, b = n;
-        while (a < b) {
-            const uint32_t mid = (a + b) >> 1;
-            if ((uint32_t)tr[mid] < want) a = mid + 1;
-            else b = mid;
+        while (ta < want) {
+            a++;
+            ta = a < n ? (uint32_t)tr[a] : 0xffffffffu;
         }
-        if (a < n && (uint32_t)tr[a] == want) {
+        if (ta == want) {
             // from here on the trace walked the true chain (whether its blocks are well-formed is checked where they are decoded)
             nblk[t] = by_hand + (nrec[t] - a);
             entry[t] = a;
