@@ -52,6 +52,7 @@ struct Slot {
     void *d_img = nullptr;
     void *d_coef = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t rb_done = nullptr; // the chunk's streams have arrived in pin_out (recorded behind the read-back copy)
     // device entropy stage of the chunk
     void *d_work = nullptr;  // workspace of the fused entropy pass
     size_t work_bytes = 0;
@@ -1001,6 +1002,7 @@ static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
             if (sl.d_img) (void)hipFree(sl.d_img);
             if (sl.d_coef) (void)hipFree(sl.d_coef);
             if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.rb_done) (void)hipEventDestroy(sl.rb_done);
             if (sl.d_work) (void)hipFree(sl.d_work);
             if (sl.d_lens) (void)hipFree(sl.d_lens);
             if (sl.h_lens) (void)hipHostFree(sl.h_lens);
@@ -1017,7 +1019,8 @@ static int ensure_batch_slots(tic_ctx *ctx, int h, int w, int chunk) {
             if ((e = hipHostMalloc((void **)&sl.pin_in, need_img, hipHostMallocDefault)) != hipSuccess ||
                 (e = hipHostMalloc((void **)&sl.pin_out, need_coef, hipHostMallocDefault)) != hipSuccess ||
                 (e = hipMalloc(&sl.d_img, need_img)) != hipSuccess || (e = hipMalloc(&sl.d_coef, need_coef)) != hipSuccess ||
-                (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
+                (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess ||
+                (e = hipEventCreateWithFlags(&sl.rb_done, hipEventDisableTiming)) != hipSuccess)
                 return set_err(ctx, TIC_E_HIP, "batch buffer allocation failed: %s", hipGetErrorString(e));
             sl.work_bytes = entropy_fused_work_bytes((nblk + 8) * (size_t)chunk); // (every frame's partitions are rounded up)
             sl.parity = 0;
@@ -1234,7 +1237,9 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
                 if (e != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed: %s", hipGetErrorString(e));
             }
         }
-        const hipError_t rb = hipStreamSynchronize(st);
+        // (the reading thread does not wait for the copy: it records an event behind it and turns to the next chunk, so that the
+        // read-backs follow each other on their stream without a host round trip in between; the hand-out thread waits for the event)
+        const hipError_t rb = hipEventRecord(s.rb_done, st);
         BT_STOP(3);
         if (rb != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed");
         s.rb_row = packed ? row : 0;
@@ -1246,6 +1251,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         const size_t row = s.rb_row;
         const bool packed = row != 0;
         BT_START();
+        if (hipEventSynchronize(s.rb_done) != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed");
         if (packed) {
             const int cnt = s.count, first = s.first;
             const char *src = (const char *)s.pin_out;
