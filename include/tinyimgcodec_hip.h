@@ -33,6 +33,7 @@ extern "C" {
 #define TIC_E_NODEVICE -7 /* no gfx950 device / extension unusable */
 
 /* kernel variants of the transform stage (all bit-identical in output) */
+#define TIC_QUALITY_CUSTOM 0 /* the quality installed with tic_set_custom_quality (any number in [1, 99]) */
 #define TIC_KERNEL_AUTO 0
 #define TIC_KERNEL_EXACT 1  /* every coefficient in pocketfft float64 operation order */
 #define TIC_KERNEL_HYBRID 2 /* fp32 AAN fast path + guard band + exact rational coefficients + exact fallback */
@@ -74,6 +75,10 @@ int tic_encode(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_s
  * coefficients.  A drop-in edge, not a hot path. */
 int tic_encode_wide(tic_ctx *ctx, const int32_t *image, int h, int w, ptrdiff_t row_stride_elems, int quality, int32_t *dc,
                     int32_t *ac);
+/* encode() / decode() with a non-integral quality (utils.py:50-53 computes with any number; the device holds one constant block
+ * per integer quality): installs the constants of `quality`, any number in [1, 99], in the context's spare slot; tic_dctq,
+ * tic_encode, tic_encode_wide, tic_dctq_dev and tic_idctq then take quality = TIC_QUALITY_CUSTOM to mean it. */
+int tic_set_custom_quality(tic_ctx *ctx, double quality);
 
 /* Device-resident form (what bench.py times): d_image / d_coeffs are device pointers from tic_dev_alloc.
  * Asynchronous on the context's stream; `variant` is one of TIC_KERNEL_*. */

@@ -111,7 +111,12 @@ def encode(image, quality=50):
     n = nblocks(h, w)
     dc = np.zeros(max(n, 1), dtype=np.int32)
     ac = np.zeros((max(n, 1), 63), dtype=np.int32)
-    rc = lib().tico_encode(_p(a, C.c_uint8), h, w, a.strides[0] if a.size else w, int(quality), _p(dc, C.c_int32), _p(ac, C.c_int32))
+    if isinstance(quality, float) and quality != int(quality):  # utils.py:50-53 on a float that is not an integer
+        L = lib()
+        L.tico_encode_f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_ssize_t, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        rc = L.tico_encode_f(_p(a, C.c_uint8), h, w, a.strides[0] if a.size else w, float(quality), _p(dc, C.c_int32), _p(ac, C.c_int32))
+    else:
+        rc = lib().tico_encode(_p(a, C.c_uint8), h, w, a.strides[0] if a.size else w, int(quality), _p(dc, C.c_int32), _p(ac, C.c_int32))
     if rc:
         raise OracleError(rc)
     return dc[:n], ac[:n]

@@ -260,6 +260,17 @@ int tico_divisors(int quality, double div[64]) {
     }
     return TICO_OK;
 }
+/* The same for a quality that is not an integer (utils.py:50-53 computes with whatever number it is given: a float quality makes
+ * `200 - 2 * quality` a float too, and `table * factor / 100` is evaluated left to right in float64). */
+int tico_divisors_f(double quality, double div[64]) {
+    if (!(quality >= 1.0 && quality <= 99.0)) return TICO_E_QUALITY;
+    double factor = quality < 50.0 ? 5000.0 / quality : 200.0 - 2.0 * quality;
+    for (int i = 0; i < 64; i++) {
+        double p = (double)QTABLE[i] * factor;
+        div[i] = p / 100.0;
+    }
+    return TICO_OK;
+}
 
 /* utils.py:56-61: np.pad(..., "reflect") index map for right/bottom padding (edge sample not repeated;
  * a length-1 axis degenerates to edge replication, as numpy does). */
@@ -273,10 +284,14 @@ static int reflect_index(int i, int n) {
 /* Transform stage up to and including zig-zag; zz: int32 [N][64], zz[.][0] = un-differenced DC.
  * Pixels come as uint8 (image) or, for integer images outside 0..255, as int32 (image32; codec.py:29 casts with astype(int32)
  * and transforms whatever it finds); stride in elements. */
+static int transform_zz_div(const uint8_t *image, const int32_t *image32, int h, int w, ptrdiff_t stride, const double div[64], int32_t *zz);
 static int transform_zz_any(const uint8_t *image, const int32_t *image32, int h, int w, ptrdiff_t stride, int quality, int32_t *zz) {
     double div[64];
     int rc = tico_divisors(quality, div);
     if (rc) return rc;
+    return transform_zz_div(image, image32, h, w, stride, div, zz);
+}
+static int transform_zz_div(const uint8_t *image, const int32_t *image32, int h, int w, ptrdiff_t stride, const double div[64], int32_t *zz) {
     int bh = (h + 7) / 8, bw = (w + 7) / 8;
     if (h == 0 || w == 0) return TICO_OK;
     for (int by = 0; by < bh; by++) {
@@ -316,6 +331,29 @@ static int encode_any(const uint8_t *image, const int32_t *image32, int h, int w
     if (rc == TICO_OK) {
         int32_t prev = 0;
         for (size_t b = 0; b < n; b++) { /* codec.py:34-36: DPCM over all blocks in raster order */
+            int32_t cur = zz[b * 64];
+            dc[b] = b ? cur - prev : cur;
+            prev = cur;
+            memcpy(ac + b * 63, zz + b * 64 + 1, 63 * sizeof(int32_t));
+        }
+    }
+    free(zz);
+    return rc;
+}
+
+/* encode() with a non-integral quality (codec.py:26-43 with utils.py:50-53 on a float): dc (DPCM'd), ac as tico_encode */
+int tico_encode_f(const uint8_t *image, int h, int w, ptrdiff_t stride, double quality, int32_t *dc, int32_t *ac) {
+    double div[64];
+    int rc = tico_divisors_f(quality, div);
+    if (rc) return rc;
+    size_t n = (size_t)((h + 7) / 8) * (size_t)((w + 7) / 8);
+    if (h == 0 || w == 0) n = 0;
+    int32_t *zz = (int32_t *)malloc((n ? n : 1) * 64 * sizeof(int32_t));
+    if (!zz) return TICO_E_SPACE;
+    rc = transform_zz_div(image, NULL, h, w, stride, div, zz);
+    if (rc == TICO_OK) {
+        int32_t prev = 0;
+        for (size_t b = 0; b < n; b++) { /* codec.py:34-36 */
             int32_t cur = zz[b * 64];
             dc[b] = b ? cur - prev : cur;
             prev = cur;

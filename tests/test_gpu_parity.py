@@ -773,7 +773,51 @@ def test_wide_pixels_round2(ctx, golden):
     with pytest.raises(struct.error):
         T.compress(img, 50.0, ctx=ctx)
     with pytest.raises(ValueError):
-        T.encode(img, 37.5, ctx=ctx)
+        T.encode(img, 0.5, ctx=ctx)  # (non-integral qualities in [1, 99] work since round 4: test_non_integral_qualities_round4)
+
+
+def test_non_integral_qualities_round4(ctx, golden, oracle):
+    """encode() / decode() / dctq() with a quality that is not an integer - the reference computes with whatever number it is given
+    (utils.py:50-53) - against the reference's own outputs (float_quality.npz: eight qualities x four images, incl. ragged shapes and
+    flat blocks): coefficients and decoded pixels, both kernels; compress() raises struct.error for a float as the reference does; an
+    integer call right after a float one uses the integer's constants again."""
+    import struct
+
+    L = N.load()
+    d = golden("float_quality")
+    for name in d["names"]:
+        img = d["img_" + str(name)]
+        for k, q in enumerate(d["qualities"]):
+            q = float(q)
+            e = T.encode(img, q, ctx=ctx)
+            assert e["quality"] == q
+            assert np.array_equal(e["dc"], d["dc_%s_%d" % (name, k)]) and np.array_equal(e["ac"], d["ac_%s_%d" % (name, k)]), (name, q)
+            e["scaled_dct"] = False
+            assert np.array_equal(T.decode(e, ctx=ctx), d["px_%s_%d" % (name, k)]), (name, q)
+            zz = T.dctq(img, q, ctx=ctx)
+            dc, ac = zz_to_dc_ac(zz)
+            assert np.array_equal(dc, d["dc_%s_%d" % (name, k)]) and np.array_equal(ac, d["ac_%s_%d" % (name, k)]), (name, q, "dctq")
+    # both kernels on a resident frame with the custom slot (TIC_QUALITY_CUSTOM), a larger random frame against the oracle
+    img = rand_frame(4242, 264, 328)
+    for q in (33.3, 71.9):
+        ctx.check(L.tic_set_custom_quality(ctx.handle, q))
+        f = DevFrame(ctx, img)
+        want_dc, want_ac = oracle.encode(img, q)
+        for variant in (N.KERNEL_EXACT, N.KERNEL_HYBRID):
+            dc, ac = zz_to_dc_ac(f.run(N.QUALITY_CUSTOM, variant))
+            assert np.array_equal(dc, want_dc) and np.array_equal(ac, want_ac), (q, variant)
+        f.free()
+    # the integer qualities are untouched by the custom slot
+    assert np.array_equal(T.dctq(img, 50, ctx=ctx), oracle.encode_zz16(img, 50))
+    with pytest.raises(struct.error):
+        T.compress(img, 37.5, ctx=ctx)
+    for bad in (0.5, 99.5, -3.5, float("nan")):
+        with pytest.raises((ValueError, ZeroDivisionError)):
+            T.encode(img, bad, ctx=ctx)
+    lens = C.c_size_t()
+    out = np.empty(L.tic_compress_bound(264, 328), np.uint8)
+    assert L.tic_compress(ctx.handle, img.ctypes.data, 264, 328, 328, N.QUALITY_CUSTOM, out.ctypes.data, out.size, C.byref(lens)) == N.TIC_E_QUALITY
+    assert L.tic_set_custom_quality(ctx.handle, 100.0) == N.TIC_E_QUALITY
 
 
 def test_rccl_single_rank_smoke(ctx, monkeypatch, tmp_path):

@@ -282,3 +282,18 @@ def test_oracle_against_full_size_manifest_r4(oracle):
     for k in sorted(set([0, 1, 100, 255, 256, len(fr) // 2, len(fr) - 1]) & set(range(len(fr)))):
         bs = oracle.compress(rand_frame(fr[k]["seed"], 1080, 1920), 50)
         assert len(bs) == fr[k]["bytes"] and hashlib.sha256(bs).hexdigest() == fr[k]["sha256"], fr[k]["seed"]
+
+
+def test_oracle_non_integral_qualities(oracle, golden):
+    """Round 4: encode() with a quality that is not an integer (utils.py:50-53 computes with any number): the oracle's divisors and
+    coefficients equal the reference's on float_quality.npz (make_goldens_r4b.py: eight qualities x four images)."""
+    d = golden("float_quality")
+    for name in d["names"]:
+        img = d["img_" + str(name)]
+        for k, q in enumerate(d["qualities"]):
+            dc, ac = oracle.encode(img, float(q))
+            assert np.array_equal(dc, d["dc_%s_%d" % (name, k)]) and np.array_equal(ac, d["ac_%s_%d" % (name, k)]), (name, q)
+    # an integral float is the integer quality
+    img = d["img_rand_40x56"]
+    a, b = oracle.encode(img, 37.0), oracle.encode(img, 37)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libtinyimgcodec_hip.so")
 TIC_OK = 0
 TIC_E_ARG, TIC_E_QUALITY, TIC_E_RANGE, TIC_E_SPACE, TIC_E_STREAM, TIC_E_HIP, TIC_E_NODEVICE = -1, -2, -3, -4, -5, -6, -7
 KERNEL_AUTO, KERNEL_EXACT, KERNEL_HYBRID = 0, 1, 2
+QUALITY_CUSTOM = 0  # TIC_QUALITY_CUSTOM: the quality installed with tic_set_custom_quality
 
 
 class NativeUnavailable(RuntimeError):
@@ -41,6 +42,7 @@ SIGNATURES = {
     "tic_dctq": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p]),
     "tic_encode": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_void_p]),
     "tic_encode_wide": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "tic_set_custom_quality": (C.c_int, [_ctxp, C.c_double]),
     "tic_dev_alloc": (C.c_int, [_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),
     "tic_dev_free": (C.c_int, [_ctxp, C.c_void_p]),
     "tic_host_alloc_pinned": (C.c_int, [_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -14,8 +14,9 @@ functions raise tinyimgcodec_amd.NativeUnavailable.
 Documented differences from the reference (all outside its working domain):
   * integer pixel values outside 0..255 are transformed as the reference does (exact float64 path on the device) by
     encode() and compress(); the batch and device-layout helpers (compress_batch, dctq) are 8-bit only;
-  * encode()/decode() accept integral float qualities like the reference; non-integral or negative qualities (for which the
-    reference computes with fractional or negative divisors) raise ValueError;
+  * encode()/decode() accept float qualities like the reference, integral or not (utils.py:50-53 computes with any number: the
+    constants of a non-integral quality in [1, 99] are built per call, tic_set_custom_quality); qualities below 1 or negative (for
+    which the reference computes with huge or negative divisors) raise ValueError;
   * auto_generate_huffman_table=True raises NotImplementedError (that path is broken in the reference:
     the table flag is written big-endian and read little-endian, codec.py:111/119);
   * quality > 100 raises ValueError (the reference produces streams with negative divisors);
@@ -41,8 +42,9 @@ def _check_quality(quality, packs_header):
     packs_header=True  (compress): the reference evaluates `5000 / quality` in encode() and then struct.pack("III", ...) in
                        make_header (codec.py:103-108): floats and negatives end in struct.error.
     packs_header=False (encode, dctq, decode): nothing is packed; the reference computes with whatever number it gets.
-                       Integral floats give the same divisors as the int and are accepted; what the per-quality device
-                       tables cannot express (non-integral or negative values) raises ValueError - a documented difference."""
+                       Integral floats give the same divisors as the int and are returned as the int; a non-integral quality
+                       in [1, 99] is returned as the float it is (the caller installs its constants: _q_arg); negative values
+                       and values below 1 raise ValueError - a documented difference."""
     if isinstance(quality, (bool, np.bool_)):
         quality = int(quality)
     if isinstance(quality, (float, np.floating)):
@@ -50,8 +52,12 @@ def _check_quality(quality, packs_header):
             raise ZeroDivisionError("float division by zero")  # utils.py:50
         if packs_header:
             struct.pack("I", quality)  # raises struct.error: required argument is not an integer
+        if quality != quality:
+            raise ValueError("quality is not a number")
         if quality != int(quality):
-            raise ValueError("non-integral quality %r is not supported by the MI355X path" % (quality,))
+            if not (1.0 <= quality <= 99.0):
+                raise ValueError("non-integral quality %r outside 1..99 is not supported by the MI355X path" % (quality,))
+            return float(quality)
         quality = int(quality)
     elif not isinstance(quality, (int, np.integer)):
         raise TypeError("quality must be a number")
@@ -69,6 +75,15 @@ def _check_quality(quality, packs_header):
     if quality > 100:
         raise ValueError("quality must be in 1..99")
     return quality
+
+
+def _q_arg(ctx, q):
+    """The quality argument of a transform / inverse entry point: the integer itself, or - for a non-integral quality, whose
+    constants are installed in the context's spare slot first - TIC_QUALITY_CUSTOM.  Call with ctx.lock held."""
+    if isinstance(q, float):
+        ctx.check(N.load().tic_set_custom_quality(ctx.handle, q))
+        return N.QUALITY_CUSTOM
+    return q
 
 
 def _as_image(image):
@@ -98,7 +113,7 @@ def _encode_wide(img, h, w, q, ctx):
     ac = np.zeros((n, 63), dtype=np.int32)
     if n:
         with ctx.lock:
-            ctx.check(L.tic_encode_wide(ctx.handle, img.ctypes.data, h, w, img.strides[0] // 4, q, dc.ctypes.data, ac.ctypes.data))
+            ctx.check(L.tic_encode_wide(ctx.handle, img.ctypes.data, h, w, img.strides[0] // 4, _q_arg(ctx, q), dc.ctypes.data, ac.ctypes.data))
     return dc, ac
 
 
@@ -111,7 +126,7 @@ def dctq(image, quality=50, ctx=None):
     zz = np.zeros((n, 64), dtype=np.int16)
     if n:
         with ctx.lock:
-            ctx.check(N.load().tic_dctq(ctx.handle, img.ctypes.data, h, w, img.strides[0], quality, zz.ctypes.data))
+            ctx.check(N.load().tic_dctq(ctx.handle, img.ctypes.data, h, w, img.strides[0], _q_arg(ctx, quality), zz.ctypes.data))
     return zz
 
 
@@ -127,7 +142,7 @@ def encode(image, quality=50, ctx=None):
     ac = np.zeros((n, 63), dtype=np.int32)
     if n:
         with ctx.lock:
-            ctx.check(N.load().tic_encode(ctx.handle, img.ctypes.data, h, w, img.strides[0], q, dc.ctypes.data, ac.ctypes.data))
+            ctx.check(N.load().tic_encode(ctx.handle, img.ctypes.data, h, w, img.strides[0], _q_arg(ctx, q), dc.ctypes.data, ac.ctypes.data))
     return {"height": h, "width": w, "quality": quality, "dc": dc, "ac": ac}
 
 
@@ -272,5 +287,5 @@ def decode(data, ctx=None):
     q = _check_quality(quality, packs_header=False)
     if n:
         with ctx.lock:
-            ctx.check(N.load().tic_idctq(ctx.handle, zz.ctypes.data, int(height), int(width), q, out.ctypes.data, out.size))
+            ctx.check(N.load().tic_idctq(ctx.handle, zz.ctypes.data, int(height), int(width), _q_arg(ctx, q), out.ctypes.data, out.size))
     return out

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -77,7 +78,8 @@ struct tic_ctx {
     hipStream_t rstream = nullptr;               // read-back of finished streams: never queued behind a later chunk's work
     int16_t *h_zz = nullptr;                     // pinned landing buffer of the host Huffman decoder (tic_decompress)
     size_t h_zz_bytes = 0;
-    DctqConsts *d_consts = nullptr;   // [100], index = quality
+    DctqConsts *d_consts = nullptr;   // [100], index = quality; slot 0 = the custom (non-integral) quality of tic_set_custom_quality
+    double custom_quality = 0.0;      // what slot 0 holds (0: nothing yet)
     unsigned long long *d_fallback = nullptr;
     bool stats = false; // count guard-band fallbacks with a global atomic (diagnostic; serialises at ~12 ns per wave)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -472,11 +474,17 @@ static hipError_t wait_stream(tic_ctx *ctx) {
 static int check_geometry(tic_ctx *ctx, int h, int w, ptrdiff_t stride, int quality) {
     if (!ctx) return TIC_E_ARG;
     if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size %dx%d", h, w);
-    if (quality < 1 || quality > 99)
+    if ((quality < 1 || quality > 99) && !(quality == TIC_QUALITY_CUSTOM && ctx->custom_quality != 0.0))
         return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99 (the reference fails for 0, 100 and negatives)",
                        quality);
     if (h > 0 && w > 0 && stride < (ptrdiff_t)w) return set_err(ctx, TIC_E_ARG, "row stride %td < width %d", stride, w);
     return TIC_OK;
+}
+
+// ... for the entry points that write a stream: its header holds the quality as an integer (codec.py:102-114), the custom slot has none
+static int check_stream_geometry(tic_ctx *ctx, int h, int w, ptrdiff_t stride, int quality) {
+    if (ctx && quality == TIC_QUALITY_CUSTOM) return set_err(ctx, TIC_E_QUALITY, "a stream needs an integer quality 1..99 in its header");
+    return check_geometry(ctx, h, w, stride, quality);
 }
 
 static DctqArgs make_args(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t stride, int quality, void *d_out) {
@@ -630,6 +638,23 @@ int tic_set_entropy_lane_kernel(tic_ctx *ctx, int max_quality) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     ctx->ent_lane_max_quality = max_quality < 1 ? -1 : (max_quality > 99 ? 99 : max_quality);
+    return TIC_OK;
+}
+
+// Non-integral qualities.  The reference's encode() / decode() compute with whatever number they are given (utils.py:50-53:
+// factor = 5000 / q or 200 - 2 q, divisor = Q * factor / 100); the device keeps one constant block per INTEGER quality.  This
+// installs the block of any number in [1, 99] in the context's spare slot; the transform and inverse entry points (tic_dctq,
+// tic_encode, tic_encode_wide, tic_dctq_dev, tic_idctq) then take quality = TIC_QUALITY_CUSTOM to mean it.  (compress() packs the
+// quality into the header as an integer - struct.error for a float in the reference - so the stream entry points have no use for it.)
+int tic_set_custom_quality(tic_ctx *ctx, double quality) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    std::unique_ptr<DctqConsts> c(new DctqConsts());
+    if (!build_consts(quality, c.get())) return set_err(ctx, TIC_E_QUALITY, "quality %g outside 1..99", quality);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (nothing in flight reads the slot: every entry point that uses it ends drained)
+    HIPCHK(ctx, hipMemcpy(ctx->d_consts, c.get(), sizeof(DctqConsts), hipMemcpyHostToDevice));
+    ctx->custom_quality = quality;
     return TIC_OK;
 }
 
@@ -816,7 +841,7 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
 int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out,
                      size_t cap, size_t *out_len) {
     TIC_LOCK(ctx);
-    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    int rc = check_stream_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     const size_t n = num_blocks(h, w);
     rc = ensure_scratch(ctx, 0, n * 128 + 16);
@@ -829,7 +854,7 @@ int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t 
 int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, uint8_t *out,
                  size_t cap, size_t *out_len) {
     TIC_LOCK(ctx);
-    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    int rc = check_stream_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (!out || !out_len) return set_err(ctx, TIC_E_ARG, "null output pointer");
     const size_t n = num_blocks(h, w);
@@ -1179,7 +1204,7 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
 constexpr int kRetryEightLanes = -1000; // internal: compress_batch_gpu asks tic_compress_batch for another run with the 8-lane packing kernel
 static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
                               int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
-    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    int rc = check_stream_geometry(ctx, h, w, row_stride, quality);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!images || !outs || !caps || !out_lens))) return set_err(ctx, TIC_E_ARG, "bad batch arguments");
     if (n == 0) return TIC_OK;
@@ -1468,7 +1493,8 @@ static int idct_from_device(tic_ctx *ctx, int h, int w, int quality, int scaled_
 static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int quality, int scaled_exp, uint8_t *out, size_t cap) {
     if (!ctx) return TIC_E_ARG;
     if (h < 0 || w < 0) return set_err(ctx, TIC_E_ARG, "negative image size");
-    if (scaled_exp < 0 && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
+    if (scaled_exp < 0 && (quality < 1 || quality > 99) && !(quality == TIC_QUALITY_CUSTOM && ctx->custom_quality != 0.0))
+        return set_err(ctx, TIC_E_QUALITY, "quality %d outside 1..99", quality);
     if (scaled_exp > 62) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d outside 0..62", scaled_exp);
     const size_t n = num_blocks(h, w);
     if (n == 0) return TIC_OK;

@@ -214,19 +214,17 @@ inline float thr_below(double tau) {
     return nextafterf(f, 0.0f);
 }
 
-// utils.py:50-53 divisor recipe.  Returns false when quality is outside 1..99.
-inline bool build_consts(int quality, DctqConsts *c) {
+// utils.py:50-53 divisor recipe: factor = 5000 / q if q < 50 else 200 - 2 q; divisor = (Q * factor) / 100, in
+// that order, in float64.  `quality` is any number in [1, 99] - the reference computes with whatever it is given (an int quality gives
+// an int factor for q >= 50, whose product with the table entry is the same number as the float64 product here: both are exact).
+// Returns false when quality is outside 1..99 (or not a number).
+inline bool build_consts(double quality, DctqConsts *c) {
 #pragma clang fp contract(off)
-    if (quality < 1 || quality > 99) return false;
+    if (!(quality >= 1.0 && quality <= 99.0)) return false;
+    const double factor = quality < 50.0 ? 5000.0 / quality : 200.0 - 2.0 * quality;
     for (int i = 0; i < 64; i++) {
-        if (quality < 50) {
-            double factor = 5000.0 / (double)quality;
-            double p = (double)kQTable[i] * factor;
-            c->div[i] = p / 100.0;
-        } else {
-            int factor = 200 - 2 * quality;
-            c->div[i] = (double)(kQTable[i] * factor) / 100.0;
-        }
+        const double p = (double)kQTable[i] * factor;
+        c->div[i] = p / 100.0;
         c->rdiv[i] = 1.0 / c->div[i];
     }
     double aan[8];
@@ -302,5 +300,7 @@ inline bool build_consts(int quality, DctqConsts *c) {
     }
     return true;
 }
+inline bool build_consts(int quality, DctqConsts *c) { return build_consts((double)quality, c); }
+
 
 } // namespace tic
