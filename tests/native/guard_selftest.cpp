@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../tinyimgcodec_amd/csrc/tic_math.h"
 
@@ -103,6 +104,19 @@ static void check_block(const uint8_t px[64]) {
 int main(int argc, char **argv) {
     const char *file = argc > 1 ? argv[1] : "";
     const long n_random = argc > 2 ? atol(argv[2]) : 2000000;
+    { // round 4: build_consts takes any number in [1, 99].  For every INTEGER quality its divisors must be bit-identical to the
+      // reference's integer recipe (utils.py:50-53: an int factor 200 - 2 q for q >= 50), whether the quality arrives as int or double
+        static DctqConsts a, b;
+        for (int q = 1; q <= 99; q++) {
+            if (!build_consts(q, &a) || !build_consts((double)q, &b)) { printf("FAIL build_consts(%d)\n", q); return 1; }
+            for (int i = 0; i < 64; i++) {
+                const double want = q < 50 ? ((double)kQTable[i] * (5000.0 / (double)q)) / 100.0 : (double)(kQTable[i] * (200 - 2 * q)) / 100.0;
+                if (a.div[i] != want || b.div[i] != want || a.mulT[i] != b.mulT[i] || a.thrG[i & 31] != b.thrG[i & 31]) { printf("FAIL divisors of quality %d\n", q); return 1; }
+            }
+            if (memcmp(a.dcflat, b.dcflat, sizeof a.dcflat) != 0) { printf("FAIL dcflat of quality %d\n", q); return 1; }
+        }
+        if (build_consts(0.999, &a) || build_consts(99.001, &a) || build_consts(nan(""), &a) || !build_consts(37.5, &a)) { printf("FAIL range of build_consts\n"); return 1; }
+    }
     build_consts(1, &C1);
     build_consts(99, &C99);
     build_consts(10, &C10);
