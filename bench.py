@@ -367,9 +367,11 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels,
             "note": "one frame and one coefficient buffer replayed: the 50 MB working set stays in the 256 MiB Infinity Cache (see cold)"
             if 3 * h * w < (200 << 20) else "one frame and one coefficient buffer replayed; %d MB per launch do not fit the 256 MiB Infinity Cache" % ((3 * h * w) >> 20),
-            "limiter": "priced against HBM as the contract asks; what actually bounds the loop is the CU's LDS pipeline (72 cycles per strip: "
-            "transpose + zig-zag staging) together with vector issue (100 instructions per strip) - timing builds in DESIGN.md 5.5, "
-            "profiles/r03_ablate_16384.txt - plus the launch's fill and tail at this size; only the cold stream of a 4096^2 frame sits on its memory floor",
+            "limiter": "priced against HBM as the contract asks.  The kernel moves 1.005 x the algorithmic bytes and streams them at 5.7 TB/s from and to "
+            "HBM on frames beyond the caches (0.72 of 8 TB/s: the 531-Mpixel config-4 shard, twelve 16384^2 pairs in rotation - DESIGN.md 5.5, "
+            "profiles/r04_shape_ab.txt); what a 4096^2 launch adds to that stream is its fill (first pixels ~0.8 us after the first wave) and its tail: the "
+            "batch pass that settles the tripped blocks costs 1.0-1.3 us warm and cold, and the launch ends with the slowest of 6,144 waves "
+            "(profiles/r04_tail_experiments.txt: a per-workgroup pooled pass was built and does not shorten it)",
         },
     }
     if cold is not None:
