@@ -1240,9 +1240,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, OCC) __attribute__((amdgpu_num_vg
             return;
         }
         if (ABL == 8 && a.dbg != nullptr && lane == 0) a.dbg[(((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * kWavesPerWG + wave) * 8 + 3] = __builtin_amdgcn_s_memtime(); // loop left
-        // loads past the end of the walk (clamped addresses) may still be in flight: their registers stay reserved until
-        // only the wave's last store is outstanding
-        asm volatile("s_waitcnt vmcnt(1)" : : : TIC_RSV_CLOBBER);
+        // (round 4, as in the product: nothing waits here - the loads past the end of the walk land in v72..v79, which nothing behind
+        // the loop names; rounds 1-3 waited for vmcnt(1), i.e. for the acknowledgement of the second-to-last strip store)
+        asm volatile("; end of the strip walk" : : : TIC_RSV_CLOBBER);
 #undef TIC_LOAD
 #undef TIC_TAKE
 #undef TIC_RSV_CLOBBER
