@@ -116,6 +116,7 @@ struct tic_ctx {
     uint32_t dec_epoch = 0;                                     // calls of the device decoder on this workspace (its single-launch scans tell their words by it)
     DecStatus *h_dec_status = nullptr, *d_dec_status = nullptr; // host-mapped
     int last_decode_path = 0;                                  // 0 none, 1 device decoder, 2 host decoder (tic_last_decode_path)
+    int last_decode_range = 0, last_decode_tries = 0;          // stream bits per lane of the device decoder's last run, and how many runs the last long stream took
     int last_decode_giveup = 0;                                // why the device decoder handed the last long stream to the host (DecStatus::giveup bits)
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
     std::vector<Slot> bslots;
@@ -1587,12 +1588,26 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     ia.consts = ctx->d_consts + (scaled_exp >= 0 ? 50 : quality); // codec.py:62: quality = 50 on the scaled branch
     ia.scaled = scaled_exp >= 0;
     ia.pow2 = scaled_exp >= 0 ? ldexp(1.0, scaled_exp) : 1.0;
-    // stream bits per lane from the average block length (rounded up to 4 average blocks): noise at q=50 (220 bits per block) takes
-    // 1024, natural images 512, noise at q >= 85 2048; a range without a synchronisation point (a block longer than the range) makes
-    // the stitch give up with bit 4: one more try with 2048 before the host decoder takes over
-    int range_bits = 512;
-    while (range_bits < 2048 && (size_t)range_bits * n < 4 * (len * 8)) range_bits *= 2;
+    // stream bits per lane: 3 average blocks, at least 544 bits, as an odd number of 32-bit words up to 63 (noise at q = 50, 220 bits
+    // per block: 672; tiled Lenna, 41, and noise at q = 10, 70: 544; noise at q = 90, 404: 1,248).  The decoder's kernels are one
+    // dependent chain per lane, so their time goes with this number (profiles/r04_decoder.txt: the measure kernel 57 us at 672 bits,
+    // 76 at 1,024).  A range in which the range's own walk does not fall in step with the true chain - a block longer than the range,
+    // or, below ~400 bits, a walk that stays out of step for all of it (noise at q = 10 at 288 bits: one range in 20,000) - makes the
+    // stitch give up with bit 4: one more try with the longest range, then the host decoder takes over
+    size_t mult = 3, floor_words = 17;
+    if (const char *e = test_hook("TIC_DECODE_RULE")) { // "<average blocks per range>,<least words per range>": measurements of the rule itself
+        unsigned a = 0, b = 0;
+        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 64 && b >= 9 && b <= 63) mult = a, floor_words = b | 1;
+    }
+    auto odd_words = [floor_words](size_t bits) {
+        size_t k = (bits + 31) / 32;
+        k |= 1;
+        return (int)(k < floor_words ? floor_words : (k > 63 ? 63 : k)) * 32;
+    };
+    int range_bits = odd_words(mult * (len * 8) / n);
+    ctx->last_decode_tries = 0;
     if (const char *e = test_hook("TIC_DECODE_RANGE")) range_bits = atoi(e);
+    if (!entropy_decode_gpu_range_ok(range_bits)) return set_err(ctx, TIC_E_ARG, "TIC_DECODE_RANGE=%d: not a range the device decoder takes", range_bits);
     DecStatus st;
     for (;;) {
         memset(ctx->h_dec_status, 0, sizeof(DecStatus)); // (host-mapped; nothing of an earlier call is in flight: every call ends with a drained stream)
@@ -1600,12 +1615,14 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
             HIPCHK(ctx, hipMemsetAsync(ctx->d_dec_desc, 0, ctx->dec_desc_words * 8, ctx->stream));
             ctx->dec_epoch = 1;
         }
+        ctx->last_decode_tries++;
+        ctx->last_decode_range = range_bits;
         HIPCHK(ctx, entropy_decode_idct_gpu(d_stream, len, n, ctx->d_dec_luts, ctx->d_dec_work, ctx->dec_work_bytes, ctx->d_dec_desc,
                                             ctx->dec_desc_words, ctx->dec_epoch, ia, ctx->d_dec_status, range_bits, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(&st, ctx->h_dec_status, sizeof st); // (host-mapped: the stream has drained)
-        if ((st.giveup & 4) && range_bits < 2048) { // (a range without a synchronisation point breaks the chain: whatever else was flagged follows from it)
-            range_bits = 2048;
+        if ((st.giveup & 4) && range_bits < 2016) { // (a range without a synchronisation point breaks the chain: whatever else was flagged follows from it)
+            range_bits = 2016; // (one retry, with the longest range: a stream that trips the first choice has blocks far above its average)
             continue;
         }
         break;
@@ -1684,10 +1701,21 @@ int tic_last_decode_giveup(tic_ctx *ctx) {
     return ctx ? ctx->last_decode_giveup : TIC_E_ARG;
 }
 
+// ... and the stream bits per lane its last run worked with, and how many runs the last long stream took (2: the first choice of
+// range met a range without a synchronisation point and the longest range was tried).  Either pointer may be null.
+int tic_last_decode_range(tic_ctx *ctx, int *range_bits, int *tries) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    if (range_bits) *range_bits = ctx->last_decode_range;
+    if (tries) *tries = ctx->last_decode_tries;
+    return TIC_OK;
+}
+
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     ctx->last_decode_giveup = 0;
+    ctx->last_decode_tries = 0;
     int h, w, quality;
     uint32_t flag;
     if (parse_header(data, len, &h, &w, &quality, &flag) != TIC_OK)
@@ -1732,6 +1760,7 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
     ctx->last_decode_giveup = 0;
+    ctx->last_decode_tries = 0;
     if (!d_stream && len) return set_err(ctx, TIC_E_ARG, "null stream pointer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     uint8_t head[16] = {0};

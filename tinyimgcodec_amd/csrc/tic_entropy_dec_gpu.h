@@ -36,12 +36,14 @@ struct DecIdctArgs {
 
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks);
 // d_stream_words: the whole stream (header included) in device memory, 4-byte aligned; the 4-byte word that holds its last byte is
-// read whole (the bytes behind the stream's end are masked off), nothing behind that word is touched.  range_bits: 512, 1024 or 2048 stream bits per lane (shorter = more lanes = faster, but every range must
-// hold a block start of the true chain: giveup has bit 4 set when one did not - try 2048).  d_work: zeroed when it was allocated;
+// read whole (the bytes behind the stream's end are masked off), nothing behind that word is touched.  range_bits: stream bits per lane, a value entropy_decode_gpu_range_ok() accepts - an odd
+// number of 32-bit words from 288 to 2,016 bits, or 512 / 1024 / 2048 (shorter = shorter chains = faster, but every range must
+// hold a block start of the true chain: giveup has bit 4 set when one did not - try a longer range).  d_work: zeroed when it was allocated;
 // `epoch`: a number never used before on this workspace (the single-launch scans recognise this call's words by it), != 0.
 // Writes the PIXELS of blocks [0, m) through `idct`; *d_status (zeroed by the caller) says how many that is and where the stream
 // and the running DC stand behind them.  Asynchronous on `stream`; *d_status is complete when the stream has drained.
 size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks);
+bool entropy_decode_gpu_range_ok(int range_bits);
 hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
                                    size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, const DecIdctArgs &idct,
                                    DecStatus *d_status, int range_bits, hipStream_t stream);

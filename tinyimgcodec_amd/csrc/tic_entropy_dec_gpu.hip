@@ -46,11 +46,13 @@
 namespace tic {
 namespace {
 
-// Stream bits per range: 512, 1024 or 2048 (a block is at most 64 x 27 = 1,728 bits long), chosen by the caller from the stream's
-// average block length: the kernels are latency-bound per lane (one dependent chain of table look-ups), so their time goes with the
-// bits a lane walks, and a 7 MB stream cut into 2048-bit ranges is only 440 waves for 1,024 SIMDs.  The stitch needs every range
-// to hold a synchronisation point: a range shorter than the stream's long blocks makes it give up (the caller then tries 2048).
-constexpr int kRangeMax = 2048;
+// Stream bits per range: a multiple of 32 - an ODD number of words between 9 and 63 (288 ... 2,016 bits), or 512 / 1024 / 2048 -
+// chosen by the caller from the stream's average block length (a block is at most 64 x 27 = 1,728 bits long).  The kernels are
+// latency-bound per lane (one dependent chain of table look-ups; the measure kernel takes the same time with a quarter of its grid,
+// profiles/r04_decoder.txt), so their time goes with the bits a lane walks - hence ranges as short as the stitch tolerates: it needs
+// every range to hold a block start of the true chain that the range's own walk recorded, and a range shorter than the stream's
+// long blocks makes it give up (the caller then tries the longest range).
+constexpr int kRangeMin = 288, kRangeMax = 2048;
 __host__ __device__ constexpr uint32_t cap_of(uint32_t range) { return range / 6u + 2u; } // block starts a range can hold (a block has at least 6 bits: 2-bit DC code + EOB)
 
 // The stream bits a workgroup walks, staged in LDS.  A workgroup is one wave, its lanes own 64 consecutive ranges: one contiguous
@@ -60,8 +62,13 @@ __host__ __device__ constexpr uint32_t cap_of(uint32_t range) { return range / 6
 // staged byte-swapped (the stream is big-endian) with coalesced loads, one padding word per range so that the lanes - a range apart -
 // fall on different banks.  A word outside the window (cannot happen by the bounds in the kernels) is read from memory.
 constexpr uint32_t kOver = 66;                                   // 1,728 bits of the longest block + the 64-bit window, in words
-constexpr uint32_t kStageMax = 64 * (kRangeMax / 32) + kOver;    // window words of the longest range
-constexpr uint32_t kStageLds = kStageMax + kStageMax / 16 + 2;   // ... with padding (the shortest range pads most)
+// (An odd number of words per range needs no padding: the lanes' words are an odd stride apart.)
+__host__ __device__ constexpr uint32_t range_shift(uint32_t range) { // log2(words per range) for the padded layout; 31 = no padding
+    return range == 512u ? 4u : (range == 1024u ? 5u : (range == 2048u ? 6u : 31u));
+}
+__host__ __device__ constexpr uint32_t stage_lds_words(uint32_t range) { // LDS words of a workgroup's window
+    return 64u * (range >> 5) + kOver + ((64u * (range >> 5) + kOver) >> range_shift(range)) + 2u;
+}
 struct Bits {
     const uint32_t *lds, *glob;
     uint32_t wbase, wcount, sh, nwords; // first word of the window, its length, log2(words per range); words of the stream
@@ -79,6 +86,10 @@ __device__ __forceinline__ uint32_t word_be(const Bits &s, uint32_t wi) {
     if (r < s.wcount) return s.lds[r + (r >> s.sh)];
     return stream_word(s.glob, wi, s.nwords, s.last_mask);
 }
+// T = threads of the workgroup (compile time: with blockDim.x as the stride the compiler emitted one load, one wait, one LDS
+// write per trip - 33 dependent trips to memory per lane for a 1,024-bit range, ~13 us of a kernel's start).  Eight words per lane
+// are requested before the first is written; the loads are unconditional (the index is clamped, the value masked afterwards).
+template <int T>
 __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_word, uint32_t wcount, uint32_t sh, uint32_t nwords,
                                             uint32_t last_mask) {
     Bits s;
@@ -89,19 +100,34 @@ __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__res
     s.sh = sh;
     s.nwords = nwords;
     s.last_mask = last_mask;
-    for (uint32_t r = threadIdx.x; r < wcount; r += blockDim.x) {
-        const uint32_t wi = first_word + r;
-        const uint32_t v = stream_word(words, wi, nwords, last_mask);
-        lds[r + (r >> sh)] = v;
-        if (r != 0u && (r & ((1u << sh) - 1u)) == 0u) lds[r + (r >> sh) - 1u] = v; // the padding word in front of a row repeats the row's
-                                                                                   // first word: word r + 1 always sits right behind word r
+    constexpr int kBatch = 8;
+    const uint32_t lastw = nwords - 1u; // (a stream has its 16-byte header: nwords >= 4)
+    for (uint32_t r0 = threadIdx.x; r0 < wcount; r0 += kBatch * T) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t wi = first_word + r0 + (uint32_t)(k * T);
+            v[k] = words[wi < lastw ? wi : lastw];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t r = r0 + (uint32_t)(k * T), wi = first_word + r;
+            uint32_t x = __builtin_bswap32(v[k]);
+            x = wi < lastw ? x : (wi == lastw ? (x & last_mask) : 0u);
+            if (r < wcount) {
+                lds[r + (r >> sh)] = x;
+                if (r != 0u && (r & ((1u << sh) - 1u)) == 0u) lds[r + (r >> sh) - 1u] = x; // the padding word in front of a row repeats the
+                                                                                           // row's first word: word r + 1 always sits right behind word r
+            }
+        }
     }
     __syncthreads();
     return s;
 }
 // the window of 64 consecutive ranges from bit first_bit (128 + 64 k range: a multiple of 32)
+template <int T>
 __device__ __forceinline__ Bits stage_bits(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_bit, uint32_t range, uint32_t nwords, uint32_t last_mask) {
-    return stage_words(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, range == 512u ? 4u : (range == 1024u ? 5u : 6u), nwords, last_mask);
+    return stage_words<T>(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, range_shift(range), nwords, last_mask);
 }
 // 32 stream bits (MSB first) from bit `pos`; the two words around it are cached in registers and refetched when the position
 // leaves them (a symbol is 5-8 bits on average: one refetch per ~5 symbols).
@@ -126,7 +152,7 @@ __device__ __forceinline__ int value_of(uint32_t pk, int len, int size) {
 }
 
 constexpr int kLongFirst = 0xff40, kLongCodes = 0x10000 - kLongFirst; // ac16 entries of the 11-bit prefixes 0x7fa..0x7ff
-constexpr int kLutLds = 4096 + kLongCodes;
+constexpr int kLutLds = 4096 + kLongCodes + 8; // (+ a zero entry behind the long codewords: the slot of an index out of their range)
 __device__ __forceinline__ uint32_t long_code(const uint16_t *lut, uint32_t pk) {
     const uint32_t i = (pk >> 16) - (uint32_t)kLongFirst;
     return i < (uint32_t)kLongCodes ? lut[4096u + i] : 0u;
@@ -164,14 +190,36 @@ __device__ __forceinline__ bool block_dev(const Bits &words, const DecLutsDev *_
     return true;
 }
 
+// `n16` 16-byte pieces from memory to LDS with T threads: all of a lane's loads are in flight before its first LDS write
+template <int T, int n16>
+__device__ __forceinline__ void copy16_to_lds(void *lds, const void *__restrict__ src) {
+    constexpr int kPer = (n16 + T - 1) / T;
+    uint4 v[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const int j = (int)threadIdx.x + k * T;
+        v[k] = reinterpret_cast<const uint4 *>(src)[j < n16 ? j : n16 - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const int j = (int)threadIdx.x + k * T;
+        if (j < n16) reinterpret_cast<uint4 *>(lds)[j] = v[k];
+    }
+}
+static_assert(offsetof(DecLutsDev, dc11) % 16 == 0 && offsetof(DecLutsDev, ac11) % 16 == 0 && (offsetof(DecLutsDev, ac16) + 2 * kLongFirst) % 16 == 0 &&
+                  (2 * kLongCodes) % 16 == 0,
+              "the tables are copied in 16-byte pieces (the structure itself comes from hipMalloc)");
 // dc11 and ac11 (adjacent in DecLutsDev) into LDS: lut[0..2047] = DC, lut[2048..4095] = AC, lut[4096..4287] = long AC codewords
+// (`lds` 16-byte aligned)
+template <int T>
 __device__ __forceinline__ void load_lut(uint16_t *lds, const DecLutsDev *__restrict__ L) {
     static_assert(offsetof(DecLutsDev, ac11) == offsetof(DecLutsDev, dc11) + 4096, "dc11 and ac11 are adjacent");
-    for (int i = threadIdx.x; i < 4096 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(L->dc11)[i];
+    copy16_to_lds<T, 8192 / 16>(lds, L->dc11);
     // ... and the AC codewords of 12 to 16 bits: their 11-bit prefixes are 0x7fa..0x7ff (the fixed AC table is a complete prefix code:
     // every other prefix resolves in ac11), i.e. entries 0xff40..0xffff of ac16.  One symbol in a hundred at q = 50 - but with 64 lanes
     // side by side every second step has one, and as a look-up in the 128 KB table in memory it stalled the whole wave for a microsecond.
-    for (int i = threadIdx.x; i < kLongCodes; i += blockDim.x) lds[4096 + i] = L->ac16[kLongFirst + i];
+    copy16_to_lds<T, 2 * kLongCodes / 16>(lds + 4096, L->ac16 + kLongFirst);
+    if (threadIdx.x == 0) lds[4096 + kLongCodes] = 0;
     __syncthreads();
 }
 
@@ -182,10 +230,10 @@ __device__ __forceinline__ void load_lut(uint16_t *lds, const DecLutsDev *__rest
 __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L, uint32_t fast_end,
                                                          uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts, uint32_t *__restrict__ nrec,
                                                          uint32_t *__restrict__ endpos, DecStatus *__restrict__ st) {
-    __shared__ uint16_t lut[kLutLds];
-    __shared__ uint32_t sbits[kStageLds];
-    load_lut(lut, L);
-    const Bits words = stage_bits(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords, last_mask);
+    __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLds];
+    extern __shared__ uint32_t sbits[]; // stage_lds_words(range), the launch's dynamic LDS
+    load_lut<64>(lut, L);
+    const Bits words = stage_bits<64>(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords, last_mask);
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= nranges) return;
     const uint32_t lo = 128u + t * range;
@@ -206,33 +254,41 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
     const uint32_t stop = hi + 1800u;
     uint32_t pos = lo, bstart = lo, cnt = 0; // a block that STARTS in front of `hi` is measured to its end
     bool at_dc = true;     // the DC category comes next (a block starts here)
+    bool in_long = false;  // the step before met an AC prefix of a 12..16-bit codeword: this step looks it up in the long table
     bool live = pos < hi;
-    // The stream words under the read position sit in registers (wa, wb) and the word behind them (wc) is fetched a step ahead: the
-    // walk is sequential, so the only LDS access left on the lane's dependent chain is the table look-up.
+    // The stream words under the read position sit in registers (wa, wb, wc); the word that becomes wc when a step crosses a word
+    // boundary is requested together with the table entry, at the top of the step, so that one wait covers both and the only LDS
+    // access on the lane's dependent chain is the table look-up.
+    //
+    // One look-up per step, always: a lane whose AC prefix resolves in the long table (one symbol in a hundred at q = 50) spends a
+    // second STEP on it instead of a second look-up inside the step.  With 64 lanes side by side every second step had such a lane,
+    // and the whole wave went through a branch, a second LDS round trip and a second wait for it.
     auto word_at = [&](uint32_t r) { return sbits[r + (r >> words.sh)]; };
     uint32_t wi = (pos >> 5) - words.wbase; // window-relative index of the word `pos` lies in
     uint32_t wa = word_at(wi), wb = word_at(wi + 1u), wc = word_at(wi + 2u);
     while (live) {
+        const uint32_t wn = word_at(wi + 3u);
+        asm volatile("" ::: "memory"); // (keeps the request in front of the table look-up: it has returned when the entry has)
         const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32); // 32 stream bits from `pos`
-        uint32_t e = lut[(at_dc ? 0u : 2048u) + (pk >> 21)];
-        if (__any(e == 0u && !at_dc)) { // a codeword of 12 to 16 bits somewhere in the wave
-            const uint32_t e2 = long_code(lut, pk);
-            e = (e == 0u && !at_dc) ? e2 : e;
-        }
-        const bool nocode = e == 0u;
-        const bool eob = !at_dc && !nocode && (e & 0xffu) == 0u;
-        pos += nocode ? 1u : (e >> 8) + (e & 15u);
+        const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
+        const uint32_t idx = in_long ? 4096u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : (at_dc ? 0u : 2048u) + (pk >> 21);
+        const uint32_t e = lut[idx];
+        const bool none = e == 0u;
+        const bool esc = none && !in_long && !at_dc; // an AC prefix of a long codeword: the next step resolves it
+        const bool eob = !at_dc && !none && (e & 0xffu) == 0u;
+        pos += esc ? 0u : (none ? 1u : (e >> 8) + (e & 15u)); // (no codeword here: skip a bit)
         { // a step consumes at most 27 bits: at most one word boundary is crossed
             const bool crossed = ((pos >> 5) - words.wbase) != wi;
             wa = crossed ? wb : wa;
             wb = crossed ? wc : wb;
+            wc = crossed ? wn : wc;
             wi += crossed ? 1u : 0u;
-            wc = word_at(wi + 2u); // (not needed before the next boundary: off the dependent chain)
         }
         if (eob && cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(bstart - lo);
         cnt += eob ? 1u : 0u;
         bstart = eob ? pos : bstart;
-        at_dc = nocode ? at_dc : eob;
+        at_dc = none ? at_dc : eob;
+        in_long = esc;
         live = (eob ? pos < hi : true) && pos < stop;
     }
     if (cnt > cap_of(range)) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
@@ -245,36 +301,46 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ endpos,
                                                         uint32_t *__restrict__ nblk, uint16_t *__restrict__ hand,
                                                         uint32_t *__restrict__ entry, DecStatus *__restrict__ st) {
-    __shared__ uint16_t lut[kLutLds];
-    __shared__ uint32_t sbits[kStageLds];
-    load_lut(lut, L);
-    const Bits words = stage_bits(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords, last_mask);
+    __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLds];
+    extern __shared__ uint32_t sbits[]; // stage_lds_words(range), the launch's dynamic LDS
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    if (t >= nranges) return;
-    entry[t] = nrec[t]; // (until the walk below meets the trace: no trace block belongs to the true chain)
+    const bool mine = t < nranges;
+    // what the walk starts from - the exit of the range in front, this range's record count and the head of its trace - is requested
+    // in front of the staging: behind it each would be a trip to memory of its own
+    const uint16_t *tr = starts + (size_t)(mine ? t : 0u) * cap_of(range);
+    const uint32_t n_rec = mine ? nrec[t] : 0u;
+    const uint32_t pos_in = mine && t != 0u ? endpos[t - 1] : 0u;
+    const uint32_t tr0 = tr[0], tr1 = tr[1]; // (entries behind n_rec are never looked at)
+    load_lut<64>(lut, L);
+    const Bits words = stage_bits<64>(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords, last_mask);
+    if (!mine) return;
+    entry[t] = n_rec; // (until the walk below meets the trace: no trace block belongs to the true chain)
     if (t == 0u) {
-        nblk[0] = nrec[0];
+        nblk[0] = n_rec;
         entry[0] = 0u;
         return;
     }
     const uint32_t lo = 128u + t * range;
     const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
-    uint32_t pos = endpos[t - 1]; // hypothesis: where the true chain enters this range
+    uint32_t pos = pos_in; // hypothesis: where the true chain enters this range
     if (pos >= fast_end) { // the chain left the fast part of the stream in front of this range
         nblk[t] = 0u;
         return;
     }
-    const uint16_t *tr = starts + (size_t)t * cap_of(range);
-    const uint32_t n = nrec[t] < cap_of(range) ? nrec[t] : cap_of(range);
+    const uint32_t n = n_rec < cap_of(range) ? n_rec : cap_of(range);
+    auto trace_at = [&](uint32_t k) { return k >= n ? 0xffffffffu : (k == 0u ? tr0 : (k == 1u ? tr1 : (uint32_t)tr[k])); };
     BitWin win = {0xffffffffu, 0u, 0u};
     uint32_t by_hand = 0;
     // the trace is sorted and the walk only moves forward: ONE pointer into the trace, advanced past the entries in front of the
     // walk (rounds 2-3 searched the trace from scratch at every block: eight dependent loads from memory where this takes one or two)
     uint32_t a = 0;
-    uint32_t ta = n ? (uint32_t)tr[0] : 0xffffffffu;
+    uint32_t ta = trace_at(0u);
     for (;;) {
         if (pos >= hi) { // walked through the whole range without meeting its trace: the hypothesis for the next range fails
-            atomicOr(&st->giveup, 4);
+            // (... unless there is no next range: the last one may be a few bits long, its own walk then has no time to fall in step,
+            // and nothing depends on where that walk ended - its blocks are the ones walked by hand here.  Rounds 2-3 gave up on
+            // such a stream and decoded it a second time with the longest range.)
+            if (t + 1u != nranges) atomicOr(&st->giveup, 4);
             nblk[t] = by_hand;
             return;
         }
@@ -282,11 +348,11 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
         const uint32_t want = pos - lo;
         while (ta < want) {
             a++;
-            ta = a < n ? (uint32_t)tr[a] : 0xffffffffu;
+            ta = trace_at(a);
         }
         if (ta == want) {
             // from here on the trace walked the true chain (whether its blocks are well-formed is checked where they are decoded)
-            nblk[t] = by_hand + (nrec[t] - a);
+            nblk[t] = by_hand + (n_rec - a);
             entry[t] = a;
             return;
         }
@@ -368,19 +434,32 @@ __global__ __launch_bounds__(kTile) void scan_counts_bpos_kernel(const uint32_t 
                                                                  uint32_t *__restrict__ bpos, long long *__restrict__ grand_total, DecStatus *__restrict__ st) {
     __shared__ long long lds[16];
     const size_t t = (size_t)blockIdx.x * kTile + threadIdx.x;
+    const bool mine = t < nranges;
     long long tot;
-    const long long v = t < nranges ? (long long)nblk[t] : 0ll;
+    const long long v = mine ? (long long)nblk[t] : 0ll;
+    const uint32_t nrec_t = mine ? nrec[t] : 0u, entry_t = mine ? entry[t] : 0u; // (requested in front of the scan's barriers)
     const long long inc = wg_inclusive_scan(v, lds, tot);
     scan_publish(desc, epoch, tot);
     const long long off = scan_lookback(desc, epoch, lds, st);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grand_total = off + tot;
-    if (t >= nranges) return;
+    if (!mine) return;
     const unsigned long long first = (unsigned long long)(off + inc - v);
     const uint32_t lo = 128u + (uint32_t)t * range, cap = cap_of(range);
-    const uint32_t nr = nrec[t] < cap ? nrec[t] : cap, a = entry[t] < nr ? entry[t] : nr;
+    const uint32_t nr = nrec_t < cap ? nrec_t : cap, a = entry_t < nr ? entry_t : nr;
     const uint32_t nb = (uint32_t)v, from_trace = nr - a < nb ? nr - a : nb, by_hand = nb - from_trace;
-    for (uint32_t i = 0; i < by_hand && i < cap && first + i < nblocks; i++) bpos[first + i] = lo + (uint32_t)hand[t * cap + i];
-    for (uint32_t j = 0; j < from_trace && first + by_hand + j < nblocks; j++) bpos[first + by_hand + j] = lo + (uint32_t)starts[t * cap + a + j];
+    // a range has five blocks or so: four offsets are requested before the first position is written
+    auto emit = [&](const uint16_t *__restrict__ src, uint32_t cnt, unsigned long long dst0) {
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 4u) {
+            uint32_t x[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) x[k] = (uint32_t)src[j0 + k < cnt ? j0 + k : cnt - 1u];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++)
+                if (j0 + k < cnt && dst0 + j0 + k < nblocks) bpos[dst0 + j0 + k] = lo + x[k];
+        }
+    };
+    emit(hand + t * cap, by_hand < cap ? by_hand : cap, first);
+    emit(starts + t * cap + a, from_trace, first + by_hand);
 }
 
 // np.cumsum of the DC differences (codec.py:53), one launch: lane b decodes the DC symbol of block b (the first symbol at bpos[b]:
@@ -392,8 +471,8 @@ __global__ __launch_bounds__(kTile) void dec_dc_scan_kernel(const uint32_t *__re
                                                             unsigned long long n_want, unsigned long long *__restrict__ desc, uint32_t epoch,
                                                             int32_t *__restrict__ dcsum, uint8_t *__restrict__ dclen, DecStatus *__restrict__ st) {
     __shared__ long long lds[16];
-    __shared__ uint16_t dc11[2048];
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) reinterpret_cast<uint32_t *>(dc11)[i] = reinterpret_cast<const uint32_t *>(L->dc11)[i];
+    __shared__ __attribute__((aligned(16))) uint16_t dc11[2048];
+    copy16_to_lds<kTile, 4096 / 16>(dc11, L->dc11);
     __syncthreads();
     const unsigned long long total = (unsigned long long)*total_blocks;
     const unsigned long long m = total < n_want ? total : n_want;
@@ -430,15 +509,13 @@ __global__ __launch_bounds__(kTile) void dec_dc_scan_kernel(const uint32_t *__re
 // (~100 cycles per symbol), which two waves per SIMD already overlap; what made the separate decode kernel slow were its 45
 // two-byte global stores per lane.
 constexpr int kDecodeWG = 256;
-constexpr int kAcLutLds = 2048 + kLongCodes; // ac11 + the long codewords (the DC symbol's length comes from the DC scan: no dc11 here)
-// ac11 and the long AC codewords into LDS: lut[0..2047] = ac11, lut[2048..] = long codewords (long_code_ac)
+constexpr int kAcLutLds = 2048 + kLongCodes + 8; // (+ a zero entry) ac11 + the long codewords (the DC symbol's length comes from the DC scan: no dc11 here)
+// ac11 and the long AC codewords into LDS: lut[0..2047] = ac11, lut[2048..] = long codewords, then a zero entry
+template <int T>
 __device__ __forceinline__ void load_ac_lut(uint16_t *lds, const DecLutsDev *__restrict__ L) {
-    for (int i = threadIdx.x; i < 2048 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(L->ac11)[i];
-    for (int i = threadIdx.x; i < kLongCodes; i += blockDim.x) lds[2048 + i] = L->ac16[kLongFirst + i];
-}
-__device__ __forceinline__ uint32_t long_code_ac(const uint16_t *lut, uint32_t pk) {
-    const uint32_t i = (pk >> 16) - (uint32_t)kLongFirst;
-    return i < (uint32_t)kLongCodes ? lut[2048u + i] : 0u;
+    copy16_to_lds<T, 4096 / 16>(lds, L->ac11);
+    copy16_to_lds<T, 2 * kLongCodes / 16>(lds + 2048, L->ac16 + kLongFirst);
+    if (threadIdx.x == 0) lds[2048 + kLongCodes] = 0; // the slot of an index outside the long codewords
 }
 constexpr int kImgStrideB = 144;  // bytes between the images of two blocks
 constexpr int kTrStrideDw = 68;   // dwords per block in a wave's transpose buffer (64 + 4 pad)
@@ -492,59 +569,65 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
         uint4 *z = reinterpret_cast<uint4 *>(img);
         for (int k = threadIdx.x; k < kDecodeWG * kImgStrideB / 16; k += kDecodeWG) z[k] = make_uint4(0u, 0u, 0u, 0u);
     }
-    load_ac_lut(lut, L);
+    // this lane's block: position, the position of the block behind it, and what the DC scan left - requested here, in front of the
+    // staging, so that they arrive while the tables and the window do (behind the barrier each would be a trip to memory of its own)
+    const uint32_t my_pos = b < m ? bpos[b] : 0u, next_pos = b + 1 < m ? bpos[b + 1] : 0u;
+    const uint32_t my_dclen = b < m ? (uint32_t)dclen[b] : 0u;
+    const int32_t my_dc = b < m ? dcsum[b] : 0;
+    load_ac_lut<kDecodeWG>(lut, L);
     const unsigned long long last = b0 + kDecodeWG - 1 < m - 1 ? b0 + kDecodeWG - 1 : m - 1;
     const uint32_t w0 = bpos[b0] >> 5, w1 = bpos[last] >> 5;
     const uint32_t want = w1 >= w0 ? w1 - w0 + kOver : kOver;
-    const Bits words = stage_words(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords, last_mask); // (ends with a barrier: tables, window, zeros, zznat)
+    const Bits words = stage_words<kDecodeWG>(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords, last_mask); // (ends with a barrier: tables, window, zeros, zznat)
     // ---- phase 1: a lane per block, one SYMBOL per step as in the measure kernel: the stream words under the read position sit
     // in registers (wa, wb) and the word behind them (wc) is fetched a step ahead, so that the table look-up is the only LDS access
     // on the lane's dependent chain; the coefficient's store (its address comes through the zig-zag table) is off that chain.
     if (b < m) {
         int16_t *c = reinterpret_cast<int16_t *>(img + (size_t)threadIdx.x * kImgStrideB);
         const uint16_t *ac11 = lut;
-        uint32_t pos = bpos[b];
+        uint32_t pos = my_pos;
         uint32_t wi = pos >> 5;
         uint32_t wa = word_be(words, wi), wb = word_be(words, wi + 1u), wc = word_be(words, wi + 2u);
-        auto advance = [&](uint32_t bits) { // a symbol consumes at most 27 bits: at most one word boundary is crossed
+        auto advance = [&](uint32_t bits, uint32_t wn) { // a symbol consumes at most 27 bits: at most one word boundary is crossed
             pos += bits;
             const bool crossed = (pos >> 5) != wi;
             wa = crossed ? wb : wa;
             wb = crossed ? wc : wb;
+            wc = crossed ? wn : wc;
             wi += crossed ? 1u : 0u;
-            wc = word_be(words, wi + 2u); // (not needed before the next boundary)
         };
-        uint32_t sh, pk, e;
         bool ok = true;
         {
-            advance((uint32_t)dclen[b]); // the DC symbol went through the scan, which left its length and the integrated DC
-            const int32_t dc = dcsum[b];
+            advance(my_dclen, word_be(words, wi + 3u)); // the DC symbol went through the scan, which left its length and the integrated DC
+            const int32_t dc = my_dc;
             c[0] = (int16_t)(dc < -32768 ? -32768 : (dc > 32767 ? 32767 : dc)); // the host decoder's sat16
             int k = 1;
-            bool live = true;
+            bool live = true, in_long = false;
+            // one table look-up per step, as in the measure kernel: a long codeword takes a second step, not a second look-up
             while (live) {
-                sh = pos & 31u;
-                pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa;
-                e = ac11[pk >> 21];
-                if (__any(e == 0u)) { // a codeword of 12 to 16 bits somewhere in the wave
-                    const uint32_t e2 = long_code_ac(lut, pk);
-                    e = e == 0u ? e2 : e;
-                }
-                const bool nocode = e == 0u;
-                const bool eob = !nocode && (e & 0xffu) == 0u;
+                const uint32_t wn = word_be(words, wi + 3u);
+                asm volatile("" ::: "memory"); // (the request stays in front of the table look-up)
+                const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32);
+                const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
+                const uint32_t e = ac11[in_long ? 2048u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : pk >> 21];
+                const bool none = e == 0u;
+                const bool esc = none && !in_long;  // the prefix of a long codeword: the next step resolves it
+                const bool nocode = none && in_long; // no codeword at all
+                const bool eob = !none && (e & 0xffu) == 0u;
                 const int len = (int)(e >> 8), size = (int)(e & 15u);
                 const int k_at = k + (int)((e >> 4) & 15u);
-                const bool bad = nocode || (!eob && k_at > 63);
-                if (!eob && !bad) c[zznat[k_at]] = (int16_t)value_of(pk, len, size);
-                if (!nocode) advance((uint32_t)(len + size));
-                k = k_at + 1;
+                const bool bad = nocode || (!none && !eob && k_at > 63);
+                if (!none && !eob && !bad) c[zznat[k_at]] = (int16_t)value_of(pk, len, size);
+                advance(none ? 0u : (uint32_t)(len + size), wn);
+                k = none ? k : k_at + 1;
+                in_long = esc;
                 ok = ok && !bad;
                 live = !eob && !bad;
             }
         }
         // the block is well-formed, and the next block of the chain starts where this one ends (the measure kernel vouches for
         // neither: its walk goes on through incidents)
-        if (!ok || (b + 1 < m && bpos[b + 1] != pos)) atomicOr(&st->giveup, 32);
+        if (!ok || (b + 1 < m && next_pos != pos)) atomicOr(&st->giveup, 32);
         if (b == m - 1) {
             st->pos_out = pos;
             st->m = m;
@@ -623,15 +706,20 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
 
 } // namespace
 
+bool entropy_decode_gpu_range_ok(int range_bits) {
+    if (range_bits == 512 || range_bits == 1024 || range_bits == 2048) return true;
+    return range_bits >= kRangeMin && range_bits <= kRangeMax && range_bits % 64 == 32; // an odd number of words
+}
+
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
     const size_t nbits = stream_bytes * 8;
-    const size_t nranges = nbits / 512 + 2; // (the smallest range: most ranges, and the most room per stream bit)
+    const size_t nranges = nbits / kRangeMin + 2; // (the smallest range: most ranges, and the most room per stream bit)
     const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
-    return nranges * ((size_t)cap_of(512) * 2 * 2 + 9 * 4) + nblocks * 9 + ntiles * 8 * 2 + 16384; // (two traces and seven 4-byte arrays per range, two 4-byte arrays and a byte per block; every piece is rounded up to 256 B)
+    return nranges * ((size_t)cap_of(kRangeMin) * 2 * 2 + 9 * 4) + nblocks * 9 + ntiles * 8 * 2 + 16384; // (two traces and seven 4-byte arrays per range, two 4-byte arrays and a byte per block; every piece is rounded up to 256 B)
 }
 
 size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks) { // look-back words of the two scans (half of the array each)
-    const size_t nranges = stream_bytes * 8 / 512 + 2;
+    const size_t nranges = stream_bytes * 8 / kRangeMin + 2;
     const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
     return 2 * ntiles;
 }
@@ -640,7 +728,7 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
                                    size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, const DecIdctArgs &idct,
                                    DecStatus *d_status, int range_bits, hipStream_t stream) {
     const size_t nbits = stream_bytes * 8;
-    if (range_bits != 512 && range_bits != 1024 && range_bits != 2048) return hipErrorInvalidValue;
+    if (!entropy_decode_gpu_range_ok(range_bits)) return hipErrorInvalidValue;
     const uint32_t range = (uint32_t)range_bits;
     const uint32_t kCap = cap_of(range);
     const int kRange = range_bits;
@@ -670,8 +758,9 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const uint32_t nwords = (uint32_t)((stream_bytes + 3) / 4);
     const uint32_t last_mask = (stream_bytes & 3) ? 0xffffffffu << (8u * (4u - (uint32_t)(stream_bytes & 3))) : 0xffffffffu; // (big-endian: the stream's bytes are the word's high bytes)
     // (*d_status is zeroed by the caller: it is host-mapped memory)
-    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, d_status);
-    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, 0, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, nblk, hand, entry, d_status);
+    const unsigned win_lds = stage_lds_words(range) * 4u;
+    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, d_status);
+    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, nblk, hand, entry, d_status);
     hipLaunchKernelGGL(scan_counts_bpos_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const uint32_t *)nblk, range, nranges, desc_r, 2u * epoch,
                        (const uint16_t *)starts, (const uint16_t *)hand, (const uint32_t *)nrec, (const uint32_t *)entry, (unsigned long long)nblocks, bpos, totals, d_status);
     hipLaunchKernelGGL(dec_dc_scan_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const long long *)totals,
