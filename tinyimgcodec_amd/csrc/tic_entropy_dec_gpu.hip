@@ -6,12 +6,13 @@
 // re-synchronise: a decoder started at an arbitrary bit as if a block began there lands on true block starts within a block or two.
 // The host decoder uses that on 16 threads (tic_entropy.cpp decode_parallel: 7.7 ms for a 4096^2 stream); this is the same idea on
 // tens of thousands of lanes, and the coefficients never leave the device:
-//   measure   a lane per RANGE of kRange stream bits: walks the symbols from the range's first bit as if a block started there (a
-//             guess for every range but the first), one symbol per step, recording the first bit of every block that decoded cleanly
-//             from a block-start guess to its EOB; an invalid prefix or a block of more than 63 coefficients does not restart the
-//             walk: it goes on in the AC state (a walk in step with the true symbols stays in step; the next true EOB ends on a true
-//             block start) and the block in work is not recorded.
-//   stitch    a lane per range, all in parallel: HYPOTHESIS: the true chain enters range t where range t-1's trace ended.  From there
+//   measure   a lane per RANGE of stream bits (3 average blocks, 544 ... 2,016): walks the symbols from the range's first bit as if a
+//             block started there (a guess for every range but the first), one symbol per step, recording the first bit of every
+//             block it walked from a block-start guess to its EOB; an invalid prefix or a block of more than 63 coefficients does not
+//             restart the walk: it goes on (a walk in step with the true symbols stays in step; the next true EOB ends on a true
+//             block start).
+//   stitch    the same lanes, the same kernel, all in parallel: HYPOTHESIS: the true chain enters range t where range t-1's walk
+//             ended (the lane next door walked it; lane 0 of a workgroup shadows the last range of the workgroup in front).  From there
 //             the lane measures blocks "by hand" (recording their first bits too) until it lands on a block start the range's own
 //             trace recorded; from that entry on the trace IS the true chain (a block start carries no state), so the trace's end is
 //             where the true chain enters range t+1 - which is the hypothesis for t+1.  Range 0 starts on a true block start, so if
@@ -28,8 +29,8 @@
 //             stores per lane to 64 different lines each - then idct_kernel read the array back: 68 + 24 us and a 33.5 MB fill.)
 // The walks are one dependent chain of look-ups per lane: stream words and tables are staged in LDS (the codewords of 12-16 bits
 // included: as look-ups in memory they stalled a whole wave in every second step), and the chain is kept short - a range for the
-// measure kernel, a block for the decode kernel.  7 MB stream (4096^2 noise, q=50), rocprofv3: measure 282 -> 125 us, decode
-// 102 -> 67 us against the first version of this file (profiles/r03_decoder.txt).
+// measure walk, a block for the decode phase.  7 MB stream (4096^2 noise, q=50), rocprofv3: measure 282 -> 125 us, decode
+// 102 -> 67 us against the first version of this file (profiles/r03_decoder.txt); round 4: profiles/r04_decoder.txt.
 // Anything unusual ON THE TRUE CHAIN - an invalid prefix, more than 63 coefficients in a block, a range without a synchronisation
 // point, a measurement that failed behind the synchronisation point - raises a flag and the caller decodes the whole stream on the
 // host, whose bit-serial path reproduces the reference's behaviour on malformed streams (exactly the host parallel decoder's rule).
@@ -223,39 +224,52 @@ __device__ __forceinline__ void load_lut(uint16_t *lds, const DecLutsDev *__rest
     __syncthreads();
 }
 
-// The measure kernel walks one SYMBOL per step, the lanes of a wave side by side.  block_dev() above is a loop per block: the lanes of
-// a wave then wait for each other at every block end (a wave-step lasts as long as its longest block) - 630 symbol steps per wave
-// where the longest lane has ~250 symbols.  In the measure kernel the position inside the block (k: 0 = the DC category comes next)
-// is lane state and a block end is just another step.  Same tables, same rules as block_dev().
-__global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L, uint32_t fast_end,
-                                                         uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts, uint32_t *__restrict__ nrec,
-                                                         uint32_t *__restrict__ endpos, DecStatus *__restrict__ st) {
+// Measure and stitch, one kernel.  The walk goes one SYMBOL per step, the lanes of a wave side by side.  block_dev() above is a loop
+// per block: the lanes of a wave then wait for each other at every block end (a wave-step lasts as long as its longest block) - 630
+// symbol steps per wave where the longest lane has ~250 symbols.  Here the position inside the block (is the DC category next?) is
+// lane state and a block end is just another step.  Same tables, same rules as block_dev().
+//
+// A workgroup is one wave.  Lanes 1..63 own 63 consecutive ranges; lane 0 SHADOWS the range in front of them - it walks it exactly as
+// its owner (lane 63 of the workgroup before) does and writes nothing - so that every owner finds the exit of the range in front of
+// its own in the lane next to it: the stitch needs no second launch (its start, tables and window staged again, was a third of
+// it) and no workgroup waits for another.  1/63 more waves.
+constexpr uint32_t kOwned = 63; // ranges a workgroup owns
+__global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+                                                                uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
+                                                                uint32_t *__restrict__ nrec, uint32_t *__restrict__ nblk, uint16_t *__restrict__ hand,
+                                                                uint32_t *__restrict__ entry, DecStatus *__restrict__ st) {
     __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLds];
     extern __shared__ uint32_t sbits[]; // stage_lds_words(range), the launch's dynamic LDS
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t_first = blockIdx.x ? blockIdx.x * kOwned - 1u : 0u; // the window's first range
     load_lut<64>(lut, L);
-    const Bits words = stage_bits<64>(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords, last_mask);
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    if (t >= nranges) return;
-    const uint32_t lo = 128u + t * range;
+    const Bits words = stage_bits<64>(sbits, gwords, 128u + t_first * range, range, nwords, last_mask);
+    const bool shadow = lane == 0u;
+    const uint32_t t = blockIdx.x * kOwned + lane - 1u; // (lane 0 of workgroup 0: no such range)
+    const bool walks = (blockIdx.x != 0u || !shadow) && t < nranges;
+    const bool mine = walks && !shadow;
+    const uint32_t lo = 128u + (walks ? t : 0u) * range;
     const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
-    // One symbol per step, state updated by selects (the compiler's version of the same loop with if / else had ~25 branches per
-    // step: 40 vector + 40 scalar instructions).  Every read stays inside the staged window: a block that starts in front of `hi`
-    // ends within 1,728 bits of it, a walk that goes on after an incident is cut at hi + 1,800, and the window reaches 2,112 bits
-    // (kOver words) behind the workgroup's last range.
+    // ---- measure.  One symbol per step, state updated by selects (the compiler's version of the same loop with if / else had ~25
+    // branches per step: 40 vector + 40 scalar instructions).  Every read stays inside the staged window: a block that starts in
+    // front of `hi` ends within 1,728 bits of it, a walk that goes on after an incident is cut at hi + 1,800, and the window reaches
+    // 2,112 bits (kOver words) behind the workgroup's last range.
     //
-    // Round 4: the walk keeps NO record of incidents.  An invalid prefix skips a bit, a block of more than 63 coefficients simply goes
-    // on to its EOB, and every EOB records the first bit of the block it ends - whether that block was well-formed or not.  A recorded
-    // position is a bit at which this lane stood with a block about to start; from such a bit the walk is a function of the stream
-    // alone, so a position the TRUE chain shares with the trace has the true chain's future behind it, incident or not.  Whether the
-    // blocks of the true chain are well-formed and follow each other without a gap is checked where they are decoded (the fused
-    // kernel: an invalid prefix, a 64th coefficient, or a block that does not end where the next one starts raises the give-up flag).
-    // Rounds 2-3 tracked the scan position, a clean flag and the last incident per lane here: 100 instructions per symbol, of which this
-    // bookkeeping was the larger half - and the kernel is bound by instruction issue (profiles/r04_decoder.txt).
-    const uint32_t stop = hi + 1800u;
+    // The walk keeps NO record of incidents.  An invalid prefix skips a bit, a block of more than 63 coefficients simply goes on to its
+    // EOB, and every EOB records the first bit of the block it ends - whether that block was well-formed or not.  A recorded position is
+    // a bit at which this lane stood with a block about to start; from such a bit the walk is a function of the stream alone, so a
+    // position the TRUE chain shares with the trace has the true chain's future behind it, incident or not.  Whether the blocks of the
+    // true chain are well-formed and follow each other without a gap is checked where they are decoded (the fused kernel: an invalid
+    // prefix, a 64th coefficient, or a block that does not end where the next one starts raises the give-up flag).  (Rounds 2-3 tracked
+    // the scan position, a clean flag and the last incident per lane here: the larger half of 100 instructions per symbol.)
+    const uint32_t stop = hi + 1800u < stream_bits ? hi + 1800u : stream_bits; // (behind the stream's end there is nothing to walk: with margin_bits = 0 the last
+                                                                                // range's walk would go through 1,800 zero bits there, 600 steps with the whole launch waiting)
+    const uint32_t cap = cap_of(range);
+    uint16_t *tr = starts + (size_t)(mine ? t : 0u) * cap;
     uint32_t pos = lo, bstart = lo, cnt = 0; // a block that STARTS in front of `hi` is measured to its end
     bool at_dc = true;     // the DC category comes next (a block starts here)
     bool in_long = false;  // the step before met an AC prefix of a 12..16-bit codeword: this step looks it up in the long table
-    bool live = pos < hi;
+    bool live = walks && pos < hi;
     // The stream words under the read position sit in registers (wa, wb, wc); the word that becomes wc when a step crosses a word
     // boundary is requested together with the table entry, at the top of the step, so that one wait covers both and the only LDS
     // access on the lane's dependent chain is the table look-up.
@@ -284,51 +298,34 @@ __global__ __launch_bounds__(64) void dec_measure_kernel(const uint32_t *__restr
             wc = crossed ? wn : wc;
             wi += crossed ? 1u : 0u;
         }
-        if (eob && cnt < cap_of(range)) starts[(size_t)t * cap_of(range) + cnt] = (uint16_t)(bstart - lo);
+        if (eob && mine && cnt < cap) tr[cnt] = (uint16_t)(bstart - lo);
         cnt += eob ? 1u : 0u;
         bstart = eob ? pos : bstart;
         at_dc = none ? at_dc : eob;
         in_long = esc;
         live = (eob ? pos < hi : true) && pos < stop;
     }
-    if (cnt > cap_of(range)) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
-    nrec[t] = cnt;
-    endpos[t] = pos;
-}
-
-__global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L, uint32_t fast_end,
-                                                        uint32_t range, uint32_t nranges, const uint16_t *__restrict__ starts, const uint32_t *__restrict__ nrec,
-                                                        const uint32_t *__restrict__ endpos,
-                                                        uint32_t *__restrict__ nblk, uint16_t *__restrict__ hand,
-                                                        uint32_t *__restrict__ entry, DecStatus *__restrict__ st) {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLds];
-    extern __shared__ uint32_t sbits[]; // stage_lds_words(range), the launch's dynamic LDS
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    const bool mine = t < nranges;
-    // what the walk starts from - the exit of the range in front, this range's record count and the head of its trace - is requested
-    // in front of the staging: behind it each would be a trip to memory of its own
-    const uint16_t *tr = starts + (size_t)(mine ? t : 0u) * cap_of(range);
-    const uint32_t n_rec = mine ? nrec[t] : 0u;
-    const uint32_t pos_in = mine && t != 0u ? endpos[t - 1] : 0u;
-    const uint32_t tr0 = tr[0], tr1 = tr[1]; // (entries behind n_rec are never looked at)
-    load_lut<64>(lut, L);
-    const Bits words = stage_bits<64>(sbits, gwords, 128u + blockIdx.x * 64u * range, range, nwords, last_mask);
+    if (mine && cnt > cap) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
+    // ---- stitch: does the true chain, entering where the walk of the range in front ended, meet this range's trace?
+    const uint32_t pos_in = (uint32_t)__shfl_up((int)pos, 1, 64); // (all 64 lanes are here: nobody has returned)
     if (!mine) return;
+    const uint32_t n_rec = cnt;
+    nrec[t] = n_rec;
     entry[t] = n_rec; // (until the walk below meets the trace: no trace block belongs to the true chain)
     if (t == 0u) {
         nblk[0] = n_rec;
         entry[0] = 0u;
         return;
     }
-    const uint32_t lo = 128u + t * range;
-    const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
-    uint32_t pos = pos_in; // hypothesis: where the true chain enters this range
+    pos = pos_in; // hypothesis: where the true chain enters this range
     if (pos >= fast_end) { // the chain left the fast part of the stream in front of this range
         nblk[t] = 0u;
         return;
     }
-    const uint32_t n = n_rec < cap_of(range) ? n_rec : cap_of(range);
-    auto trace_at = [&](uint32_t k) { return k >= n ? 0xffffffffu : (k == 0u ? tr0 : (k == 1u ? tr1 : (uint32_t)tr[k])); };
+    const uint32_t n = n_rec < cap ? n_rec : cap;
+    // the head of the trace, back from memory in one trip (this lane's own stores); entry 0 is the range's first bit
+    const uint32_t tr1 = tr[1], tr2 = tr[2]; // (entries behind n are never looked at; cap >= 3)
+    auto trace_at = [&](uint32_t k) { return k >= n ? 0xffffffffu : (k == 0u ? 0u : (k == 1u ? tr1 : (k == 2u ? tr2 : (uint32_t)tr[k]))); };
     BitWin win = {0xffffffffu, 0u, 0u};
     uint32_t by_hand = 0;
     // the trace is sorted and the walk only moves forward: ONE pointer into the trace, advanced past the entries in front of the
@@ -341,6 +338,10 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
             // and nothing depends on where that walk ended - its blocks are the ones walked by hand here.  Rounds 2-3 gave up on
             // such a stream and decoded it a second time with the longest range.)
             if (t + 1u != nranges) atomicOr(&st->giveup, 4);
+            nblk[t] = by_hand;
+            return;
+        }
+        if (pos + 6u > stream_bits) { // fewer bits than a block has: the chain has arrived at the stream's end (its padding)
             nblk[t] = by_hand;
             return;
         }
@@ -358,9 +359,13 @@ __global__ __launch_bounds__(64) void dec_stitch_kernel(const uint32_t *__restri
         }
         int d;
         uint32_t used;
-        if (by_hand < cap_of(range)) hand[(size_t)t * cap_of(range) + by_hand] = (uint16_t)want; // first bit of the by-hand block (pos >= lo: the walk enters behind the range before)
-        if (!block_dev<false>(words, L, lut, pos, win, nullptr, d, used)) { // unusual on the true chain
-            atomicOr(&st->giveup, 16);
+        if (by_hand < cap) hand[(size_t)t * cap + by_hand] = (uint16_t)want; // first bit of the by-hand block (pos >= lo: the walk enters behind the range before)
+        if (!block_dev<false>(words, L, lut, pos, win, nullptr, d, used)) { // unusual on the true chain ...
+            // ... unless it stands at the stream's end: with margin_bits = 0 the chain of a whole stream arrives at the padding bits
+            // behind its last block (fewer than 8 zeros: no block) and ends there.  A cut stream's chain ends the same way, in front of
+            // its open block, and the host continues from it (whatever the ranges behind still add to the chain is caught where it
+            // is decoded: those blocks do not follow each other).
+            if (pos + 2048u <= fast_end) atomicOr(&st->giveup, 16);
             nblk[t] = by_hand;
             return;
         }
@@ -547,7 +552,7 @@ __device__ __forceinline__ void tr8x8_dwords(uint32_t *buf, int g, int i, uint32
 template <uint32_t kWinWords>
 __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                                     const uint32_t *__restrict__ bpos, const int32_t *__restrict__ dcsum, const uint8_t *__restrict__ dclen,
-                                                                    const long long *__restrict__ total_blocks, unsigned long long n_want,
+                                                                    const long long *__restrict__ total_blocks, unsigned long long n_want, uint32_t stream_bits,
                                                                     DecIdctArgs a, DecStatus *__restrict__ st) {
     // phase 1: tables + stream window; phase 2 (behind the barrier): the waves' transpose buffers
     constexpr uint32_t kBlkWin = kWinWords + kOver;
@@ -628,6 +633,9 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
         // the block is well-formed, and the next block of the chain starts where this one ends (the measure kernel vouches for
         // neither: its walk goes on through incidents)
         if (!ok || (b + 1 < m && next_pos != pos)) atomicOr(&st->giveup, 32);
+        // ... and it ends inside the stream: the words behind the stream's end read as zeros, and a codeword's last bits may have been
+        // such zeros (only with margin_bits = 0: a block that starts 2,048 bits in front of the end cannot reach it)
+        if (pos > stream_bits) atomicOr(&st->giveup, 256);
         if (b == m - 1) {
             st->pos_out = pos;
             st->m = m;
@@ -726,15 +734,20 @@ size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks) { // l
 
 hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
                                    size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, const DecIdctArgs &idct,
-                                   DecStatus *d_status, int range_bits, hipStream_t stream) {
+                                   DecStatus *d_status, int range_bits, int margin_bits, hipStream_t stream) {
     const size_t nbits = stream_bytes * 8;
     if (!entropy_decode_gpu_range_ok(range_bits)) return hipErrorInvalidValue;
     const uint32_t range = (uint32_t)range_bits;
     const uint32_t kCap = cap_of(range);
     const int kRange = range_bits;
-    if (nbits < 128 + 2048 + (size_t)kRangeMax || nbits >= (1ull << 32) || nblocks == 0) return hipErrorInvalidValue;
+    if (nbits < 128 + 2048 + (size_t)kRangeMax || nbits + 8192 >= (1ull << 32) || nblocks == 0) return hipErrorInvalidValue; // (a walk stands up to 1,827 bits behind the end)
+    if (margin_bits != 0 && margin_bits != 2048) return hipErrorInvalidValue;
     if (work_bytes < entropy_decode_gpu_work_bytes(stream_bytes, nblocks)) return hipErrorInvalidValue;
-    const uint32_t fast_end = (uint32_t)(nbits - 2048); // a block may START on the fast path up to here (as in the host decoder)
+    // a block may START up to here.  margin_bits = 2048 (the host decoder's rule, rounds 2-3): every block of the chain lies inside the
+    // stream whatever it holds, and the blocks that start behind are the caller's (bit-serial, on the host).  margin_bits = 0: the chain
+    // runs to the stream's end - nothing is left for the host when the stream is whole - and a block that reaches behind the end, where the
+    // words read as zeros, raises giveup bit 256 (a cut stream: the caller comes back with the margin).
+    const uint32_t fast_end = (uint32_t)(nbits - (size_t)margin_bits);
     const uint32_t nranges = (uint32_t)((fast_end - 128 + kRange - 1) / kRange);
     const size_t ntiles_r = ((size_t)nranges + kTile - 1) / kTile, ntiles_b = (nblocks + kTile - 1) / kTile;
     // The look-back words of the two scans live in an array of their own that holds nothing else, ever: a word there either is zero
@@ -748,19 +761,19 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     long long *totals = (long long *)take(16);
     uint16_t *starts = (uint16_t *)take((size_t)nranges * kCap * 2), *hand = (uint16_t *)take((size_t)nranges * kCap * 2);
     uint32_t *entry = (uint32_t *)take((size_t)nranges * 4), *bpos = (uint32_t *)take(nblocks * 4);
-    uint32_t *nrec = (uint32_t *)take((size_t)nranges * 4), *endpos = (uint32_t *)take((size_t)nranges * 4);
+    uint32_t *nrec = (uint32_t *)take((size_t)nranges * 4);
     uint32_t *nblk = (uint32_t *)take((size_t)nranges * 4);
     int32_t *dcsum = (int32_t *)take(nblocks * 4);
     uint8_t *dclen = (uint8_t *)take(nblocks);
     if ((size_t)(w - (char *)d_work) > work_bytes) return hipErrorInvalidValue;
     const uint32_t *words = (const uint32_t *)d_stream_words;
-    const dim3 gr((nranges + 63) / 64), bl(64);
+    const dim3 bl(64);
     const uint32_t nwords = (uint32_t)((stream_bytes + 3) / 4);
     const uint32_t last_mask = (stream_bytes & 3) ? 0xffffffffu << (8u * (4u - (uint32_t)(stream_bytes & 3))) : 0xffffffffu; // (big-endian: the stream's bytes are the word's high bytes)
     // (*d_status is zeroed by the caller: it is host-mapped memory)
     const unsigned win_lds = stage_lds_words(range) * 4u;
-    hipLaunchKernelGGL(dec_measure_kernel, gr, bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, d_status);
-    hipLaunchKernelGGL(dec_stitch_kernel, gr, bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, range, nranges, starts, nrec, endpos, nblk, hand, entry, d_status);
+    hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3((nranges + kOwned - 1u) / kOwned), bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, (uint32_t)nbits, range, nranges, starts, nrec,
+                       nblk, hand, entry, d_status);
     hipLaunchKernelGGL(scan_counts_bpos_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const uint32_t *)nblk, range, nranges, desc_r, 2u * epoch,
                        (const uint16_t *)starts, (const uint16_t *)hand, (const uint32_t *)nrec, (const uint32_t *)entry, (unsigned long long)nblocks, bpos, totals, d_status);
     hipLaunchKernelGGL(dec_dc_scan_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const long long *)totals,
@@ -768,10 +781,10 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
     if (nbits / nblocks <= 240) // sparse enough for the small window: one workgroup more per CU
         hipLaunchKernelGGL(dec_decode_idct_kernel<2048>, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos,
-                           (const int32_t *)dcsum, (const uint8_t *)dclen, (const long long *)totals, (unsigned long long)nblocks, idct, d_status);
+                           (const int32_t *)dcsum, (const uint8_t *)dclen, (const long long *)totals, (unsigned long long)nblocks, (uint32_t)nbits, idct, d_status);
     else
         hipLaunchKernelGGL(dec_decode_idct_kernel<4096>, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos,
-                           (const int32_t *)dcsum, (const uint8_t *)dclen, (const long long *)totals, (unsigned long long)nblocks, idct, d_status);
+                           (const int32_t *)dcsum, (const uint8_t *)dclen, (const long long *)totals, (unsigned long long)nblocks, (uint32_t)nbits, idct, d_status);
     return hipGetLastError();
 }
 
