@@ -1147,6 +1147,44 @@ def test_device_entropy_lane_kernel_and_its_fallback(oracle):
         c.close()
 
 
+def test_device_decoder_at_the_stream_end(ctx, oracle, monkeypatch):
+    """The device decoder's first run takes the chain to the stream's END (no host tail on a whole stream); a stream whose end is not what
+    a whole stream's is - cut inside its last blocks, cut at a block boundary, garbage or zeros behind its last block - must come out as
+    the reference decodes it (codec.py:167-189: missing bits end a block's symbols, the block stays as far as it got; bytes behind the last
+    block are ignored), through the second run with the 2,048-bit margin and the host's bit-serial tail.  Five frames: five different
+    paddings and positions of the last block in the last range."""
+    monkeypatch.setenv("TIC_TEST_HOOKS", "1")
+    L = N.load()
+    rbits, tries = C.c_int(), C.c_int()
+    for seed, (h, w), q in ((81, (1536, 1536), 50), (82, (1536, 1544), 50), (83, (1600, 1536), 35), (84, (1536, 1536), 80), (85, (2048, 1024), 50)):
+        img = rand_frame(seed, h, w)
+        s = T.compress(img, q, ctx=ctx)
+        assert len(s) * 8 >= 128 + (1 << 21)
+        want = oracle.decompress(s)
+        got = T.decompress(s, ctx=ctx)
+        assert np.array_equal(got, want) and np.array_equal(want.shape, img.shape), (seed, q)
+        assert L.tic_last_decode_path(ctx.handle) == 1 and L.tic_last_decode_giveup(ctx.handle) == 0
+        assert L.tic_last_decode_range(ctx.handle, C.byref(rbits), C.byref(tries)) == 0 and tries.value == 1, (seed, q, tries.value)  # nothing left to the host, no second run
+        monkeypatch.setenv("TIC_DECODE_MARGIN", "1")  # the same stream the way rounds 2-3 decoded it: margin + host tail
+        assert np.array_equal(T.decompress(s, ctx=ctx), want), (seed, q, "margin")
+        assert L.tic_last_decode_range(ctx.handle, C.byref(rbits), C.byref(tries)) == 0 and tries.value == 1
+        monkeypatch.delenv("TIC_DECODE_MARGIN")
+        rng = np.random.default_rng(seed)
+        variants = {}
+        for cut in (1, 2, 3, 5, 9, 17, 40, 100, 255, 256, 257, 300, 700):  # cut inside the last blocks (a block is ~27 bytes at q=50)
+            variants["cut %d" % cut] = s[:-cut]
+        variants["zeros behind"] = s + bytes(64)
+        variants["one zero byte behind"] = s + bytes(1)
+        variants["garbage behind"] = s + bytes(rng.integers(0, 256, 300, dtype=np.uint8))
+        variants["ones behind"] = s + bytes([255] * 40)
+        variants["last byte's padding set"] = s[:-1] + bytes([s[-1] | 0x01])
+        for name, v in variants.items():
+            want_v = oracle.decompress(v)
+            got_v = T.decompress(v, ctx=ctx)
+            assert np.array_equal(got_v, want_v), (seed, q, name)
+            assert L.tic_last_decode_path(ctx.handle) in (1, 2)
+
+
 def test_decompress_large_frame_device_against_host_decoder(ctx, monkeypatch):
     """A 4096 x 8192 noise frame (14 MB stream, 112,000 ranges, 524,288 blocks): the device decoder's pixels against the host decoder's
     (the oracle would take minutes here; both decoders are pinned on it at smaller sizes)."""
