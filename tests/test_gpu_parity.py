@@ -1286,15 +1286,15 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
                 assert tries.value == 1 and rbits.value % 64 == 32 and max(544, 3 * avg - 32) <= rbits.value <= max(544, 3 * avg + 64), \
                     (name, q, rbits.value, tries.value, avg)  # the first choice of range held: no second run
             assert np.array_equal(got, want), (name, q)
-            if name == "noise 2048x2048":  # range lengths of both layouts (powers of two: padded; odd word counts: not), and the
-                # second try with the longest range when 288 or 512 bits are shorter than the blocks (q=90: 404 bits)
-                for rb in ("288", "512", "928", "1024", "2016", "2048"):
+            if name == "noise 2048x2048":  # forced range lengths, and the second try with the longest range when 288 or 544 bits are
+                # shorter than the blocks (q=90: 404 bits)
+                for rb in ("288", "544", "928", "1056", "2016"):
                     monkeypatch.setenv("TIC_DECODE_RANGE", rb)
                     assert np.array_equal(T.decompress(s, ctx=ctx), want), (name, q, rb)
                     assert L.tic_last_decode_path(ctx.handle) == 1, (name, q, rb)
                     assert L.tic_last_decode_range(ctx.handle, C.byref(rbits), C.byref(tries)) == 0
                     assert (rbits.value, tries.value) in ((int(rb), 1), (2016, 2)), (name, q, rb, rbits.value, tries.value)
-                    if q == 90 and rb in ("288", "512"):  # blocks of 404 bits: these ranges cannot hold
+                    if q == 90 and rb == "288":  # blocks of 404 bits: this range cannot hold
                         assert tries.value == 2, (name, q, rb)
                 monkeypatch.delenv("TIC_DECODE_RANGE")
             monkeypatch.setenv("TIC_DECODE_HOST", "1")

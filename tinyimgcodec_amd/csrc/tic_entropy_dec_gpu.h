@@ -37,7 +37,7 @@ struct DecIdctArgs {
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks);
 // d_stream_words: the whole stream (header included) in device memory, 4-byte aligned; the 4-byte word that holds its last byte is
 // read whole (the bytes behind the stream's end are masked off), nothing behind that word is touched.  range_bits: stream bits per lane, a value entropy_decode_gpu_range_ok() accepts - an odd
-// number of 32-bit words from 288 to 2,016 bits, or 512 / 1024 / 2048 (shorter = shorter chains = faster, but every range must
+// number of 32-bit words from 288 to 2,016 bits (shorter = shorter chains = faster, but every range must
 // hold a block start of the true chain: giveup has bit 4 set when one did not - try a longer range).  d_work: zeroed when it was allocated;
 // `epoch`: a number never used before on this workspace (the single-launch scans recognise this call's words by it), != 0.
 // margin_bits: 2048 = blocks that start in the stream's last 2,048 bits are left to the caller (the host decoder's rule: whatever the

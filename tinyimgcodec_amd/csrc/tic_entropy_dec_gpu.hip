@@ -47,13 +47,14 @@
 namespace tic {
 namespace {
 
-// Stream bits per range: a multiple of 32 - an ODD number of words between 9 and 63 (288 ... 2,016 bits), or 512 / 1024 / 2048 -
+// Stream bits per range: an ODD number of 32-bit words between 9 and 63 (288 ... 2,016 bits; the lanes' words in the LDS window are
+// then an odd stride apart: no bank padding),
 // chosen by the caller from the stream's average block length (a block is at most 64 x 27 = 1,728 bits long).  The kernels are
 // latency-bound per lane (one dependent chain of table look-ups; the measure kernel takes the same time with a quarter of its grid,
 // profiles/r04_decoder.txt), so their time goes with the bits a lane walks - hence ranges as short as the stitch tolerates: it needs
 // every range to hold a block start of the true chain that the range's own walk recorded, and a range shorter than the stream's
 // long blocks makes it give up (the caller then tries the longest range).
-constexpr int kRangeMin = 288, kRangeMax = 2048;
+constexpr int kRangeMin = 288, kRangeMax = 2016;
 __host__ __device__ constexpr uint32_t cap_of(uint32_t range) { return range / 6u + 2u; } // block starts a range can hold (a block has at least 6 bits: 2-bit DC code + EOB)
 
 // The stream bits a workgroup walks, staged in LDS.  A workgroup is one wave, its lanes own 64 consecutive ranges: one contiguous
@@ -63,13 +64,7 @@ __host__ __device__ constexpr uint32_t cap_of(uint32_t range) { return range / 6
 // staged byte-swapped (the stream is big-endian) with coalesced loads, one padding word per range so that the lanes - a range apart -
 // fall on different banks.  A word outside the window (cannot happen by the bounds in the kernels) is read from memory.
 constexpr uint32_t kOver = 66;                                   // 1,728 bits of the longest block + the 64-bit window, in words
-// (An odd number of words per range needs no padding: the lanes' words are an odd stride apart.)
-__host__ __device__ constexpr uint32_t range_shift(uint32_t range) { // log2(words per range) for the padded layout; 31 = no padding
-    return range == 512u ? 4u : (range == 1024u ? 5u : (range == 2048u ? 6u : 31u));
-}
-__host__ __device__ constexpr uint32_t stage_lds_words(uint32_t range) { // LDS words of a workgroup's window
-    return 64u * (range >> 5) + kOver + ((64u * (range >> 5) + kOver) >> range_shift(range)) + 2u;
-}
+__host__ __device__ constexpr uint32_t stage_lds_words(uint32_t range) { return 64u * (range >> 5) + kOver + 2u; } // LDS words of a workgroup's window
 struct Bits {
     const uint32_t *lds, *glob;
     uint32_t wbase, wcount, sh, nwords; // first word of the window, its length, log2(words per range); words of the stream
@@ -128,7 +123,7 @@ __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__res
 // the window of 64 consecutive ranges from bit first_bit (128 + 64 k range: a multiple of 32)
 template <int T>
 __device__ __forceinline__ Bits stage_bits(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_bit, uint32_t range, uint32_t nwords, uint32_t last_mask) {
-    return stage_words<T>(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, range_shift(range), nwords, last_mask);
+    return stage_words<T>(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, 31u /* no padding */, nwords, last_mask);
 }
 // 32 stream bits (MSB first) from bit `pos`; the two words around it are cached in registers and refetched when the position
 // leaves them (a symbol is 5-8 bits on average: one refetch per ~5 symbols).
@@ -277,11 +272,11 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
     // One look-up per step, always: a lane whose AC prefix resolves in the long table (one symbol in a hundred at q = 50) spends a
     // second STEP on it instead of a second look-up inside the step.  With 64 lanes side by side every second step had such a lane,
     // and the whole wave went through a branch, a second LDS round trip and a second wait for it.
-    auto word_at = [&](uint32_t r) { return sbits[r + (r >> words.sh)]; };
-    uint32_t wi = (pos >> 5) - words.wbase; // window-relative index of the word `pos` lies in
-    uint32_t wa = word_at(wi), wb = word_at(wi + 1u), wc = word_at(wi + 2u);
+    const uint32_t *wp = sbits - words.wbase; // wp[w] = word w of the stream (inside the window)
+    uint32_t wi = pos >> 5;                   // the word `pos` lies in
+    uint32_t wa = wp[wi], wb = wp[wi + 1u], wc = wp[wi + 2u];
     while (live) {
-        const uint32_t wn = word_at(wi + 3u);
+        const uint32_t wn = wp[wi + 3u];
         asm volatile("" ::: "memory"); // (keeps the request in front of the table look-up: it has returned when the entry has)
         const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32); // 32 stream bits from `pos`
         const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
@@ -292,11 +287,12 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
         const bool eob = !at_dc && !none && (e & 0xffu) == 0u;
         pos += esc ? 0u : (none ? 1u : (e >> 8) + (e & 15u)); // (no codeword here: skip a bit)
         { // a step consumes at most 27 bits: at most one word boundary is crossed
-            const bool crossed = ((pos >> 5) - words.wbase) != wi;
+            const uint32_t now = pos >> 5;
+            const bool crossed = now != wi;
             wa = crossed ? wb : wa;
             wb = crossed ? wc : wb;
             wc = crossed ? wn : wc;
-            wi += crossed ? 1u : 0u;
+            wi = now;
         }
         if (eob && mine && cnt < cap) tr[cnt] = (uint16_t)(bstart - lo);
         cnt += eob ? 1u : 0u;
@@ -715,8 +711,7 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
 } // namespace
 
 bool entropy_decode_gpu_range_ok(int range_bits) {
-    if (range_bits == 512 || range_bits == 1024 || range_bits == 2048) return true;
-    return range_bits >= kRangeMin && range_bits <= kRangeMax && range_bits % 64 == 32; // an odd number of words
+    return range_bits >= kRangeMin && range_bits <= kRangeMax && range_bits % 64 == 32; // an odd number of 32-bit words
 }
 
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
@@ -740,7 +735,7 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const uint32_t range = (uint32_t)range_bits;
     const uint32_t kCap = cap_of(range);
     const int kRange = range_bits;
-    if (nbits < 128 + 2048 + (size_t)kRangeMax || nbits + 8192 >= (1ull << 32) || nblocks == 0) return hipErrorInvalidValue; // (a walk stands up to 1,827 bits behind the end)
+    if (nbits < 128 + 2048 + 2048 || nbits + 8192 >= (1ull << 32) || nblocks == 0) return hipErrorInvalidValue; // (a walk stands up to 1,827 bits behind the end)
     if (margin_bits != 0 && margin_bits != 2048) return hipErrorInvalidValue;
     if (work_bytes < entropy_decode_gpu_work_bytes(stream_bytes, nblocks)) return hipErrorInvalidValue;
     // a block may START up to here.  margin_bits = 2048 (the host decoder's rule, rounds 2-3): every block of the chain lies inside the

@@ -4,7 +4,10 @@
 // With TIC_TEST_HOOKS=1 in the environment WHEN THE LIBRARY IS FIRST USED, the test suite (and tools/) may set
 //   TIC_ENT_DIRECT_GROUPS   device entropy stage: group count above which stream offsets are summed in two levels
 //   TIC_DECODE_SERIAL       Huffman decoder: always the host's serial decoder
-//   TIC_DECODE_RANGE        device Huffman decoder: stream bits per lane (512, 1024, 2048) instead of the choice by block length
+//   TIC_DECODE_RANGE        device Huffman decoder: stream bits per lane (an odd number of 32-bit words, 288 ... 2016) instead of the choice by block length
+//   TIC_DECODE_RULE         device Huffman decoder: "<average blocks per range>,<least words per range>" instead of 3,17 (measurements of the rule)
+//   TIC_DECODE_MARGIN       device Huffman decoder: first run with the 2,048-bit margin and the host's tail (rounds 2-3's only mode; now the second run's)
+//   TIC_DECODE_TRACE        device Huffman decoder: one line per run on stderr (range, margin, give-up bits, blocks produced)
 //   TIC_DECODE_HOST         Huffman decoder: never the device decoder (host parallel / serial as the stream's length says)
 //   TIC_DECODE_THREADS      host Huffman decoder: threads of the parallel decoder
 //   TIC_COMM_FORCE_RCCL     a single rank goes through RCCL too (the only way to exercise tic_comm.hip on a one-GPU box)
