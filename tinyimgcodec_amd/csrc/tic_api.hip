@@ -1203,6 +1203,22 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
 // Batch compress with the entropy stage on the device: per chunk one H2D copy, one transform launch, the three
 // entropy steps, then only the finished streams (and 8 bytes of length per frame) come back.
 constexpr int kRetryEightLanes = -1000; // internal: compress_batch_gpu asks tic_compress_batch for another run with the 8-lane packing kernel
+
+// Read-back of a chunk's streams by the SHADER, not by a DMA engine: rows of `row16` 16-byte pieces from device memory into the slot's
+// pinned host buffer (device-accessible).  The runtime spreads the batch's uploads over both SDMA engines and queues every later copy
+// behind the uploads already submitted - with four chunks of uploads in the queue a chunk's read-back started 2 ms after its kernels
+// had finished, the read-backs came in bursts of four, and the uploads stalled 0.5-0.7 ms behind every burst for want of a free slot
+// (rocprofv3 --memory-copy-trace, profiles/r04_batch_timeline.txt).  Stores from a kernel cross the link in the other direction while
+// the engines upload.
+__global__ __launch_bounds__(256) void readback_rows_kernel(const uint4 *__restrict__ src, size_t src_pitch16, uint4 *__restrict__ dst, size_t dst_pitch16,
+                                                            size_t row16) {
+    const uint4 *s = src + (size_t)blockIdx.y * src_pitch16;
+    uint4 *d = dst + (size_t)blockIdx.y * dst_pitch16;
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < row16; i += (size_t)gridDim.x * 256u)
+        __builtin_nontemporal_store(reinterpret_cast<const u32x4v *>(s)[i], reinterpret_cast<u32x4v *>(d) + i);
+}
+
 static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
                               int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
     int rc = check_stream_geometry(ctx, h, w, row_stride, quality);
@@ -1254,7 +1270,11 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         const bool packed = row * (size_t)s.count <= pin_cap;
         BT_START();
         if (packed) {
-            hipError_t e = hipMemcpy2DAsync(s.pin_out, row, s.d_streams, bound, maxlen, (size_t)s.count, hipMemcpyDeviceToHost, st);
+            // (round 3: ONE strided hipMemcpy2DAsync per chunk - 16 separate copies of ~0.9 MB cost ~45 us each; now the kernel above)
+            const size_t row16 = (maxlen + 15) / 16; // (row and bound are multiples of 16; the bytes behind a stream are never handed out)
+            hipLaunchKernelGGL(readback_rows_kernel, dim3(64, (unsigned)s.count), dim3(256), 0, st, (const uint4 *)s.d_streams, bound / 16, (uint4 *)s.pin_out, row / 16,
+                               row16);
+            hipError_t e = hipGetLastError();
             if (e != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed: %s", hipGetErrorString(e));
         } else {
             for (int k = 0; k < s.count; k++) {
