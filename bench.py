@@ -475,14 +475,14 @@ def shard_measurements(args, ctx, L, N, T, q, variant, first, count, ms, steps, 
         "host_to_host_frames_per_s": round(count / t_h2h, 1),
         "host_to_host_phases_ms": ph,
         "host_to_host_note": "pageable caller frames (256 separate arrays), pinned in place for the call by ONE hipHostRegister over their address "
-        "range (%d of %d frames took that route), median of 5 calls; phases are per pipeline thread and overlap.  (An adaptive variant - stage, and "
-        "switch to pinning when the copy threads turn out slow - was built and dropped: on a noisy host the three chunks it stages before it can "
-        "tell cost more than the rest of the batch, 16.5 ms against 14.0)" % (n_auto.value, count),
+        "range (%d of %d frames took that route), median of 5 calls; phases are per pipeline thread and overlap.  The streams come back through "
+        "a kernel that stores them into pinned host memory while the DMA engines upload (as DMA copies they queued behind four chunks of "
+        "uploads: 13.8-14.2 ms, profiles/r04_batch_timeline.txt); the link's own bound for this batch is 9.5 ms" % (n_auto.value, count),
         "host_to_host_staged_s": round(t_h2h_staged, 5),
         "host_to_host_staged_frames_per_s": round(count / t_h2h_staged, 1),
         "host_to_host_staged_phases_ms": ph_staged,
         "host_to_host_staged_note": "the same frames copied into the pipeline's pinned slots by 8 host threads (tic_set_auto_register(0): "
-        "rounds 1-3's route for pageable input; 11.6 ms on a quiet host, 17-28 ms with other tenants on it)",
+        "rounds 1-3's route for pageable input: as fast as the pinned route on a quiet host, up to twice as slow with other tenants on it - see min_max_ms)",
         "frames_numa_nodes": frame_nodes(frames),
         "host_to_host_registered_mpix_s": round(pixels / t_h2h_reg / 1e6, 1),
         "host_to_host_registered_s": round(t_h2h_reg, 5),
