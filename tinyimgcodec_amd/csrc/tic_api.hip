@@ -1544,6 +1544,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     if (!ctx->d_dec_luts) {
         DecLutsDev *l = new DecLutsDev();
         dec_luts_fill(l->dc11, l->ac11, l->ac16);
+        dec_chain_luts_fill(l->mdc, l->mac, l->mlong);
         hipError_t e = hipMalloc((void **)&ctx->d_dec_luts, sizeof(DecLutsDev));
         if (e == hipSuccess) e = hipMemcpy(ctx->d_dec_luts, l, sizeof(DecLutsDev), hipMemcpyHostToDevice);
         delete l;

@@ -640,4 +640,44 @@ void dec_luts_fill(uint16_t *dc11, uint16_t *ac11, uint16_t *ac16) {
     memcpy(ac16, T.acd.lut, sizeof T.acd.lut);
 }
 
+// Chain tables of the device decoder's measure walk: what a walk that only needs the END of every block consumes in one look-up.
+// From a window of W stream bits: the first symbol (DC category or AC run/size; its codeword must be at most 11 bits, as in lut11 -
+// the walk resolves longer AC codewords in a second step), then as many further AC symbols as have their CODEWORD inside the window
+// (a symbol's length is its codeword's plus its size: the value bits themselves are not needed), stopping behind an EOB (the DC table
+// comes next) and in front of anything that is not a codeword.  Symbol by symbol this is exactly the sequence of steps the
+// one-symbol walk makes, so both walks stand on the same bits at every block end.
+static void build_chain(const uint16_t *first_lut16, bool first_is_dc, const uint16_t *ac_lut16, int W, uint8_t *out) {
+    for (unsigned w = 0; w < (1u << W); w++) {
+        int pos = 0, total = 0;
+        bool eob = false, first = true;
+        while (pos < W) {
+            const int vis = W - pos;
+            const unsigned next16 = ((w << pos) & ((1u << W) - 1u)) << (16 - W); // the bits from pos on, zeros behind the window
+            const uint16_t e = (first ? first_lut16 : ac_lut16)[next16];
+            const int L = e >> 8;
+            if (e == 0 || L > vis || (first && L > 11)) break; // no codeword, or not wholly inside the window
+            const bool is_dc = first && first_is_dc;
+            const int len = L + (e & 15);
+            total += len;
+            pos += len;
+            first = false;
+            if (!is_dc && (e & 0xff) == 0) {
+                eob = true;
+                break;
+            }
+        }
+        out[w] = (uint8_t)(total ? (total << 1) | (eob ? 1 : 0) : 0); // total <= 22
+    }
+}
+void dec_chain_luts_fill(uint8_t *mdc, uint8_t *mac, uint8_t *mlong) {
+    const EncTables &T = tables();
+    build_chain(T.dcd.lut, true, T.acd.lut, 11, mdc);
+    build_chain(T.acd.lut, false, T.acd.lut, 12, mac);
+    memset(mlong, 0, 256);
+    for (int i = 0; i < 0x10000 - 0xff40; i++) {
+        const uint16_t e = T.acd.lut[0xff40 + i];
+        mlong[i] = (uint8_t)(e ? ((e >> 8) + (e & 15)) << 1 : 0); // (never EOB: its codeword has 4 bits)
+    }
+}
+
 } // namespace tic

@@ -15,4 +15,6 @@ int entropy_decode(const uint8_t *data, size_t len, int h, int w, int16_t *zz);
 // running DC running_dc, into zz_tail (N - first_block blocks); and the decoder's look-up tables for the device.
 int entropy_decode_tail(const uint8_t *data, size_t len, int h, int w, size_t first_block, size_t pos_bits, int running_dc, int16_t *zz_tail);
 void dec_luts_fill(uint16_t *dc11, uint16_t *ac11, uint16_t *ac16);
+// the device decoder's chain tables (DecLutsDev::mdc / mac / mlong, tic_entropy_dec_gpu.h)
+void dec_chain_luts_fill(uint8_t *mdc /*[2048]*/, uint8_t *mac /*[4096]*/, uint8_t *mlong /*[256]*/);
 } // namespace tic

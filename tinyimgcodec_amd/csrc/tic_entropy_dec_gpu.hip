@@ -125,21 +125,6 @@ template <int T>
 __device__ __forceinline__ Bits stage_bits(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_bit, uint32_t range, uint32_t nwords, uint32_t last_mask) {
     return stage_words<T>(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, 31u /* no padding */, nwords, last_mask);
 }
-// 32 stream bits (MSB first) from bit `pos`; the two words around it are cached in registers and refetched when the position
-// leaves them (a symbol is 5-8 bits on average: one refetch per ~5 symbols).
-struct BitWin {
-    uint32_t idx, a, b;
-};
-__device__ __forceinline__ uint32_t peek32(const Bits &words, uint32_t pos, BitWin &c) {
-    const uint32_t wi = pos >> 5;
-    if (wi != c.idx) {
-        c.idx = wi;
-        c.a = word_be(words, wi);
-        c.b = word_be(words, wi + 1);
-    }
-    const uint32_t sh = pos & 31u;
-    return sh ? __builtin_amdgcn_alignbit(c.a, c.b, 32u - sh) : c.a; // ({a,b} >> (32 - sh)) low word = (a << sh) | (b >> (32 - sh))
-}
 // value bits behind a codeword of `len` bits (bitbuffer.py:55-65): x with its top bit clear stands for x - (2^size - 1)
 __device__ __forceinline__ int value_of(uint32_t pk, int len, int size) {
     if (size == 0) return 0;
@@ -148,44 +133,7 @@ __device__ __forceinline__ int value_of(uint32_t pk, int len, int size) {
 }
 
 constexpr int kLongFirst = 0xff40, kLongCodes = 0x10000 - kLongFirst; // ac16 entries of the 11-bit prefixes 0x7fa..0x7ff
-constexpr int kLutLds = 4096 + kLongCodes + 8; // (+ a zero entry behind the long codewords: the slot of an index out of their range)
-__device__ __forceinline__ uint32_t long_code(const uint16_t *lut, uint32_t pk) {
-    const uint32_t i = (pk >> 16) - (uint32_t)kLongFirst;
-    return i < (uint32_t)kLongCodes ? lut[4096u + i] : 0u;
-}
-
-// One block on the table-driven fast path: the device form of block_fast() in tic_entropy.cpp (same tables, same rules).  STORE: the
-// coefficients 1..63 go to c (zeroed by the caller).  Returns false on anything unusual with nothing consumed.
-template <bool STORE>
-__device__ __forceinline__ bool block_dev(const Bits &words, const DecLutsDev *__restrict__ L, const uint16_t *lut /* LDS: dc11, ac11 */,
-                                          uint32_t pos0, BitWin &win, int16_t *c, int &dc_diff, uint32_t &used) {
-    const uint16_t *ac11 = lut + 2048;
-    uint32_t pos = pos0;
-    uint32_t pk = peek32(words, pos, win);
-    uint32_t e = lut[pk >> 21];
-    if (!e) return false; // DC categories are at most 9 bits long
-    int len = (int)(e >> 8), size = (int)(e & 15u);
-    dc_diff = value_of(pk, len, size);
-    pos += (uint32_t)(len + size);
-    int k = 1;
-    for (;;) {
-        pk = peek32(words, pos, win);
-        e = ac11[pk >> 21];
-        if (!e) e = long_code(lut, pk);
-        if (!e) return false;
-        len = (int)(e >> 8);
-        size = (int)(e & 15u);
-        pos += (uint32_t)(len + size);
-        if ((e & 0xffu) == 0u) break; // EOB
-        k += (int)((e >> 4) & 15u);
-        if (k > 63) return false;
-        if (STORE) c[k] = (int16_t)value_of(pk, len, size);
-        k++;
-    }
-    used = pos - pos0;
-    return true;
-}
-
+constexpr int kChainLds = 2048 + 4096 + 256; // DecLutsDev::mdc, mac, mlong (mlong's entries behind the 192 long codewords are zero: the slot of an index out of range)
 // `n16` 16-byte pieces from memory to LDS with T threads: all of a lane's loads are in flight before its first LDS write
 template <int T, int n16>
 __device__ __forceinline__ void copy16_to_lds(void *lds, const void *__restrict__ src) {
@@ -205,24 +153,9 @@ __device__ __forceinline__ void copy16_to_lds(void *lds, const void *__restrict_
 static_assert(offsetof(DecLutsDev, dc11) % 16 == 0 && offsetof(DecLutsDev, ac11) % 16 == 0 && (offsetof(DecLutsDev, ac16) + 2 * kLongFirst) % 16 == 0 &&
                   (2 * kLongCodes) % 16 == 0,
               "the tables are copied in 16-byte pieces (the structure itself comes from hipMalloc)");
-// dc11 and ac11 (adjacent in DecLutsDev) into LDS: lut[0..2047] = DC, lut[2048..4095] = AC, lut[4096..4287] = long AC codewords
-// (`lds` 16-byte aligned)
-template <int T>
-__device__ __forceinline__ void load_lut(uint16_t *lds, const DecLutsDev *__restrict__ L) {
-    static_assert(offsetof(DecLutsDev, ac11) == offsetof(DecLutsDev, dc11) + 4096, "dc11 and ac11 are adjacent");
-    copy16_to_lds<T, 8192 / 16>(lds, L->dc11);
-    // ... and the AC codewords of 12 to 16 bits: their 11-bit prefixes are 0x7fa..0x7ff (the fixed AC table is a complete prefix code:
-    // every other prefix resolves in ac11), i.e. entries 0xff40..0xffff of ac16.  One symbol in a hundred at q = 50 - but with 64 lanes
-    // side by side every second step has one, and as a look-up in the 128 KB table in memory it stalled the whole wave for a microsecond.
-    copy16_to_lds<T, 2 * kLongCodes / 16>(lds + 4096, L->ac16 + kLongFirst);
-    if (threadIdx.x == 0) lds[4096 + kLongCodes] = 0;
-    __syncthreads();
-}
-
-// Measure and stitch, one kernel.  The walk goes one SYMBOL per step, the lanes of a wave side by side.  block_dev() above is a loop
-// per block: the lanes of a wave then wait for each other at every block end (a wave-step lasts as long as its longest block) - 630
-// symbol steps per wave where the longest lane has ~250 symbols.  Here the position inside the block (is the DC category next?) is
-// lane state and a block end is just another step.  Same tables, same rules as block_dev().
+// Measure and stitch, one kernel.  The lanes of a wave walk side by side, a look-up per step.  (Round 3's first version looped per
+// block: the lanes of a wave then wait for each other at every block end - 630 symbol steps per wave where the longest lane has ~250
+// symbols.)  Here the position inside the block (is the DC category next?) is lane state and a block end is just another step.
 //
 // A workgroup is one wave.  Lanes 1..63 own 63 consecutive ranges; lane 0 SHADOWS the range in front of them - it walks it exactly as
 // its owner (lane 63 of the workgroup before) does and writes nothing - so that every owner finds the exit of the range in front of
@@ -233,11 +166,14 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
                                                                 uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
                                                                 uint32_t *__restrict__ nrec, uint32_t *__restrict__ nblk, uint16_t *__restrict__ hand,
                                                                 uint32_t *__restrict__ entry, DecStatus *__restrict__ st) {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLds];
+    __shared__ __attribute__((aligned(16))) uint8_t lutm[kChainLds];   // the chain tables: the measure walk
     extern __shared__ uint32_t sbits[]; // stage_lds_words(range), the launch's dynamic LDS
     const uint32_t lane = threadIdx.x;
     const uint32_t t_first = blockIdx.x ? blockIdx.x * kOwned - 1u : 0u; // the window's first range
-    load_lut<64>(lut, L);
+    static_assert(offsetof(DecLutsDev, mac) == offsetof(DecLutsDev, mdc) + 2048 && offsetof(DecLutsDev, mlong) == offsetof(DecLutsDev, mac) + 4096 &&
+                      offsetof(DecLutsDev, mdc) % 16 == 0,
+                  "the chain tables are adjacent and copied in 16-byte pieces");
+    copy16_to_lds<64, kChainLds / 16>(lutm, L->mdc); // (stage_bits below ends with the barrier)
     const Bits words = stage_bits<64>(sbits, gwords, 128u + t_first * range, range, nwords, last_mask);
     const bool shadow = lane == 0u;
     const uint32_t t = blockIdx.x * kOwned + lane - 1u; // (lane 0 of workgroup 0: no such range)
@@ -269,6 +205,11 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
     // boundary is requested together with the table entry, at the top of the step, so that one wait covers both and the only LDS
     // access on the lane's dependent chain is the table look-up.
     //
+    // A step consumes a CHAIN of symbols: the walk needs the end of every block, not the values, and a symbol's length is known from its
+    // codeword alone - so one look-up of the next 12 bits (11 with the DC category next) gives the bits of every symbol whose codeword
+    // lies inside them, up to and including an EOB (DecLutsDev::mdc / mac, tic_entropy.cpp build_chain: symbol by symbol the very steps
+    // of a one-symbol walk).  2.3 symbols per step on noise at q = 50: the walk, one lane's dependent chain, is that much shorter.
+    //
     // One look-up per step, always: a lane whose AC prefix resolves in the long table (one symbol in a hundred at q = 50) spends a
     // second STEP on it instead of a second look-up inside the step.  With 64 lanes side by side every second step had such a lane,
     // and the whole wave went through a branch, a second LDS round trip and a second wait for it.
@@ -280,12 +221,12 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
         asm volatile("" ::: "memory"); // (keeps the request in front of the table look-up: it has returned when the entry has)
         const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32); // 32 stream bits from `pos`
         const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
-        const uint32_t idx = in_long ? 4096u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : (at_dc ? 0u : 2048u) + (pk >> 21);
-        const uint32_t e = lut[idx];
+        const uint32_t idx = in_long ? 6144u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : (at_dc ? pk >> 21 : 2048u + (pk >> 20));
+        const uint32_t e = lutm[idx]; // (bits of a chain of symbols << 1) | the chain ends with EOB; 0: no codeword of at most 11 bits here
         const bool none = e == 0u;
         const bool esc = none && !in_long && !at_dc; // an AC prefix of a long codeword: the next step resolves it
-        const bool eob = !at_dc && !none && (e & 0xffu) == 0u;
-        pos += esc ? 0u : (none ? 1u : (e >> 8) + (e & 15u)); // (no codeword here: skip a bit)
+        const bool eob = (e & 1u) != 0u;
+        pos += esc ? 0u : (none ? 1u : e >> 1); // (no codeword here: skip a bit)
         { // a step consumes at most 27 bits: at most one word boundary is crossed
             const uint32_t now = pos >> 5;
             const bool crossed = now != wi;
@@ -322,7 +263,6 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
     // the head of the trace, back from memory in one trip (this lane's own stores); entry 0 is the range's first bit
     const uint32_t tr1 = tr[1], tr2 = tr[2]; // (entries behind n are never looked at; cap >= 3)
     auto trace_at = [&](uint32_t k) { return k >= n ? 0xffffffffu : (k == 0u ? 0u : (k == 1u ? tr1 : (k == 2u ? tr2 : (uint32_t)tr[k]))); };
-    BitWin win = {0xffffffffu, 0u, 0u};
     uint32_t by_hand = 0;
     // the trace is sorted and the walk only moves forward: ONE pointer into the trace, advanced past the entries in front of the
     // walk (rounds 2-3 searched the trace from scratch at every block: eight dependent loads from memory where this takes one or two)
@@ -353,20 +293,46 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
             entry[t] = a;
             return;
         }
-        int d;
-        uint32_t used;
         if (by_hand < cap) hand[(size_t)t * cap + by_hand] = (uint16_t)want; // first bit of the by-hand block (pos >= lo: the walk enters behind the range before)
-        if (!block_dev<false>(words, L, lut, pos, win, nullptr, d, used)) { // unusual on the true chain ...
-            // ... unless it stands at the stream's end: with margin_bits = 0 the chain of a whole stream arrives at the padding bits
-            // behind its last block (fewer than 8 zeros: no block) and ends there.  A cut stream's chain ends the same way, in front of
-            // its open block, and the host continues from it (whatever the ranges behind still add to the chain is caught where it
-            // is decoded: those blocks do not follow each other).
-            if (pos + 2048u <= fast_end) atomicOr(&st->giveup, 16);
-            nblk[t] = by_hand;
-            return;
+        // one block by hand: the same chain walk, from `pos` with the DC category next, to its EOB.  (Rounds 2-3 decoded the block
+        // symbol by symbol with the one-symbol tables and checked it - a second set of tables in LDS, and three times the steps; whether
+        // a block of the true chain is well-formed is checked where it is decoded, in the fused kernel, as for the trace's blocks.)
+        {
+            uint32_t p = pos;
+            const uint32_t limit = p + 1800u < stream_bits ? p + 1800u : stream_bits; // (a block has at most 1,728 bits)
+            bool dcn = true, lng = false, open = true;
+            uint32_t bi = p >> 5;
+            uint32_t ba = wp[bi], bb = wp[bi + 1u], bc = wp[bi + 2u];
+            while (open && p < limit) {
+                const uint32_t bn = wp[bi + 3u];
+                asm volatile("" ::: "memory");
+                const uint32_t pk = (uint32_t)(((((unsigned long long)ba) << 32) | bb) << (p & 31u) >> 32);
+                const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
+                const uint32_t e = lutm[lng ? 6144u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : (dcn ? pk >> 21 : 2048u + (pk >> 20))];
+                const bool none = e == 0u;
+                const bool esc = none && !lng && !dcn;
+                p += esc ? 0u : (none ? 1u : e >> 1);
+                const uint32_t now = p >> 5;
+                const bool crossed = now != bi;
+                ba = crossed ? bb : ba;
+                bb = crossed ? bc : bb;
+                bc = crossed ? bn : bc;
+                bi = now;
+                open = (e & 1u) == 0u;
+                dcn = none ? dcn : false;
+                lng = esc;
+            }
+            if (open) { // no EOB within a block's length, or the stream ended first
+                // ... at the stream's end that is how the chain of a whole stream ends: in the padding bits behind its last block (fewer than
+                // 8 zeros, no block), and a cut stream's chain ends the same way in front of its open block - the host continues from it
+                // (whatever the ranges behind still add to the chain is caught where it is decoded: those blocks do not follow each other)
+                if (pos + 2048u <= fast_end) atomicOr(&st->giveup, 16);
+                nblk[t] = by_hand;
+                return;
+            }
+            pos = p;
         }
         by_hand++;
-        pos += used;
     }
 }
 
