@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
     const uint32_t w0 = bpos[b0] >> 5, w1 = bpos[last] >> 5;
     const uint32_t want = w1 >= w0 ? w1 - w0 + kOver : kOver;
     const Bits words = stage_words<kDecodeWG>(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords, last_mask); // (ends with a barrier: tables, window, zeros, zznat)
-    // ---- phase 1: a lane per block, one SYMBOL per step as in the measure kernel: the stream words under the read position sit
+    // ---- phase 1: a lane per block, one SYMBOL per step (the values are needed here; the measure walk takes chains): the stream words under the read position sit
     // in registers (wa, wb) and the word behind them (wc) is fetched a step ahead, so that the table look-up is the only LDS access
     // on the lane's dependent chain; the coefficient's store (its address comes through the zig-zag table) is off that chain.
     if (b < m) {
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
             c[0] = (int16_t)(dc < -32768 ? -32768 : (dc > 32767 ? 32767 : dc)); // the host decoder's sat16
             int k = 1;
             bool live = true, in_long = false;
-            // one table look-up per step, as in the measure kernel: a long codeword takes a second step, not a second look-up
+            // one table look-up per step, as in the measure walk: a long codeword takes a second step, not a second look-up
             while (live) {
                 const uint32_t wn = word_be(words, wi + 3u);
                 asm volatile("" ::: "memory"); // (the request stays in front of the table look-up)
