@@ -147,6 +147,83 @@ int main() {
             cases++;
         }
     }
+    // ---- the device decoder's chain tables (dec_chain_luts_fill): a walk that consumes a chain of symbols per look-up must stand on the
+    //      same bits at every EOB as the walk that takes one symbol per look-up (dec_luts_fill's tables: what the device decoder's
+    //      fused kernel and rounds 2-3's measure kernel use), from any bit of any stream, in step with the true symbols or not
+    {
+        std::vector<uint16_t> dc11(2048), ac11(2048), ac16(65536);
+        std::vector<uint8_t> mdc(2048), mac(4096), mlong(256);
+        tic::dec_luts_fill(dc11.data(), ac11.data(), ac16.data());
+        tic::dec_chain_luts_fill(mdc.data(), mac.data(), mlong.data());
+        for (int kind = 0; kind < 3; kind++) {
+            // kind 0: a real stream of dense blocks; 1: of short blocks; 2: random bits
+            const int h = 256, w = 512;
+            const size_t n = tic::num_blocks(h, w);
+            std::vector<uint8_t> bs(tic::compress_bound(h, w) + 64, 0);
+            size_t len = bs.size() - 64;
+            if (kind < 2) {
+                std::vector<int16_t> zz(n * 64);
+                for (size_t b = 0; b < n; b++)
+                    for (int k = 0; k < 64; k++) {
+                        const uint32_t r = rnd();
+                        int v = kind == 0 ? (r % 5 == 0 ? 0 : (int)(r % 2047) - 1023) : (k < 4 + (int)(b % 7) ? (int)(r % 31) - 15 : 0);
+                        if (kind == 0 && r % 97 == 0) v = 0;
+                        zz[b * 64 + k] = (int16_t)v;
+                    }
+                if (tic::entropy_encode(zz.data(), h, w, 50, bs.data(), bs.size() - 64, &len) != 0) return fail("chain tables: encode", h, w, kind);
+            } else {
+                for (size_t i = 16; i < len; i++) bs[i] = (uint8_t)rnd();
+            }
+            const size_t nbits = len * 8;
+            auto peek32 = [&](size_t pos) {
+                uint64_t v = 0;
+                for (int k = 0; k < 8; k++) v = (v << 8) | bs[(pos >> 3) + (size_t)k];
+                return (uint32_t)((v << (pos & 7)) >> 32);
+            };
+            for (int start = 0; start < 400; start++) {
+                const size_t from = 128 + (size_t)(rnd() % (uint32_t)(nbits - 128 - 4096));
+                // one symbol per step (the rules of the device walk: an invalid prefix skips a bit; EOB only inside the AC symbols)
+                std::vector<size_t> ends1, ends2;
+                {
+                    size_t pos = from;
+                    bool at_dc = true;
+                    while (pos < from + 3000) {
+                        const uint32_t pk = peek32(pos);
+                        uint32_t e = at_dc ? dc11[pk >> 21] : ac11[pk >> 21];
+                        if (!e && !at_dc) e = ac16[pk >> 16];
+                        if (!e) {
+                            pos += 1;
+                            continue;
+                        }
+                        pos += (e >> 8) + (e & 15);
+                        const bool eob = !at_dc && (e & 0xff) == 0;
+                        if (eob) ends1.push_back(pos);
+                        at_dc = eob;
+                    }
+                }
+                {
+                    size_t pos = from;
+                    bool at_dc = true, in_long = false;
+                    while (pos < from + 3000) {
+                        const uint32_t pk = peek32(pos);
+                        const uint32_t li = (pk >> 16) - 0xff40u;
+                        const uint32_t e = in_long ? mlong[li < 192u ? li : 192u] : (at_dc ? mdc[pk >> 21] : mac[pk >> 20]);
+                        const bool none = e == 0, esc = none && !in_long && !at_dc, eob = (e & 1u) != 0;
+                        pos += esc ? 0u : (none ? 1u : e >> 1);
+                        if (eob) ends2.push_back(pos);
+                        at_dc = none ? at_dc : eob;
+                        in_long = esc;
+                    }
+                }
+                // the chain walk may overshoot the 3,000-bit horizon by one chain: compare the common prefix, which must be nearly all
+                const size_t m = ends1.size() < ends2.size() ? ends1.size() : ends2.size();
+                if (m + 2 < ends1.size() || m + 2 < ends2.size()) return fail("chain tables: different number of block ends", (int)from, start, kind);
+                for (size_t k = 0; k < m; k++)
+                    if (ends1[k] != ends2[k]) return fail("chain tables: a block end differs", (int)from, (int)k, kind);
+                cases++;
+            }
+        }
+    }
     printf("host_selftest ok: %d cases\n", cases);
     return 0;
 }

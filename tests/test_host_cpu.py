@@ -143,7 +143,9 @@ def test_entropy_errors():
 def test_host_entropy_coder_under_sanitizers(tmp_path):
     """The product's host Huffman/RLE coder and decoder, built with AddressSanitizer + UBSan, against the oracle's coder
     on dense / sparse / maximal / long-run coefficient blocks: same streams, exact-size and undersized buffers, round
-    trips, truncated and corrupted streams (GPU sanitizers are not available on the pool; this is the CPU build)."""
+    trips, truncated and corrupted streams (GPU sanitizers are not available on the pool; this is the CPU build); and the device
+    decoder's chain tables (a chain of symbols per look-up) against the one-symbol walk: the same block ends from 1,200 random bits of
+    dense, short-block and random streams."""
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
