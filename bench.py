@@ -163,6 +163,8 @@ def main():
         if not args.no_config4:
             out["config4"] = shard_measurements(args, ctx, L, N, T, q, variant, 0, args.shard_frames, ms, steps=50)[0]
             out["config4"]["note"] = "the N = 1 baseline of every N > 1 line (scaling_baseline): same 256-frame shard, one GPU"
+        if not args.no_config4:
+            out["codec_resident"] = codec_resident(args, ctx, L, N, q)
         if not args.no_cpu_baseline:
             img = rand_frame(1234, args.height, args.width)
             out["cpu_baseline"] = cpu_baseline(img, q, args.cpu_seconds, 1)
@@ -539,6 +541,53 @@ def manifest_parity(q, first, sizes, streams):
     if first == 0 and len(sizes) == 256 and checked == 256:
         out["sizes_sha256_matches_manifest"] = hashlib.sha256(np.asarray(sizes, dtype="<i8").tobytes()).hexdigest() == m.get("sizes_sha256_first256")
     return out
+
+
+def codec_resident(args, ctx, L, N, q):
+    """The callers either side of the hot path on the same frame, everything resident in HBM: the whole encoder
+    (transform + device entropy stage, tic_compress_dev: the stream is byte-identical to the reference's, tests/) and the whole decoder
+    (device Huffman decode + inverse transform, tic_decompress_dev).  Informational: never `value`."""
+    import hashlib
+    h, w = args.height, args.width
+    img = rand_frame(1234, h, w)
+    cap = L.tic_compress_bound(h, w)
+    d_img, d_out, d_pix = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, cap + 64, C.byref(d_out)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_pix)))
+    try:
+        ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
+        n = C.c_size_t()
+        def timed(fn, reps=40):
+            for _ in range(5): fn()
+            t = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(reps): fn()
+                t.append((time.perf_counter() - t0) / reps)
+            return sorted(t)[len(t) // 2]
+        t_enc = timed(lambda: ctx.check(L.tic_compress_dev(ctx.handle, d_img, h, w, w, q, d_out, cap, C.byref(n))))
+        stream = np.empty(n.value, np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, stream.ctypes.data, d_out, n.value))
+        t_dec = timed(lambda: ctx.check(L.tic_decompress_dev(ctx.handle, d_out, n.value, d_pix, w, img.size, None, None)))
+        rb, tr = C.c_int(), C.c_int()
+        ctx.check(L.tic_last_decode_range(ctx.handle, C.byref(rb), C.byref(tr)))
+        back = np.empty((h, w), np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, back.ctypes.data, d_pix, back.size))
+        err = np.abs(back.astype(np.int16) - img.astype(np.int16))
+        return {
+            "workload": "the %dx%d frame of config 2 (seed 1234), quality=%d, image, stream and pixels resident in HBM" % (h, w, q),
+            "compress_dev_us": round(t_enc * 1e6, 1), "compress_dev_mpix_s": round(h * w / t_enc / 1e6, 1),
+            "stream_bytes": int(n.value), "stream_sha256": hashlib.sha256(stream.tobytes()).hexdigest(),
+            "decompress_dev_us": round(t_dec * 1e6, 1), "decompress_dev_mpix_s": round(h * w / t_dec / 1e6, 1),
+            "decoder_path": int(L.tic_last_decode_path(ctx.handle)), "decoder_range_bits": rb.value, "decoder_runs": tr.value,
+            "round_trip_max_abs_error": int(err.max()), "round_trip_mean_abs_error": round(float(err.mean()), 3),
+            "note": "host clock around the C-ABI call (launches + one wait included), median of 5 x 40 calls; parity of both directions is the test suite's business "
+                    "(streams against the reference's, pixels against the reference's decoder) - the round-trip error here is the quantiser's",
+        }
+    finally:
+        for p in (d_img, d_out, d_pix):
+            L.tic_dev_free(ctx.handle, p)
 
 
 def cpu_baseline(img, q, budget_s, threads):
