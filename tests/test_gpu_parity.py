@@ -1186,21 +1186,82 @@ def test_device_decoder_at_the_stream_end(ctx, oracle, monkeypatch):
 
 
 def test_decompress_large_frame_device_against_host_decoder(ctx, monkeypatch):
-    """A 4096 x 8192 noise frame (14 MB stream, 112,000 ranges, 524,288 blocks): the device decoder's pixels against the host decoder's
-    (the oracle would take minutes here; both decoders are pinned on it at smaller sizes)."""
+    """A 4096 x 8192 noise frame (14 MB stream, 112,000 ranges, 524,288 blocks): the streams and the pixels of the device decoder AND of
+    the host decoder against the pinned oracle's (tests/golden/big_frame_decode.json: the oracle ran once in the build container,
+    tests/golden/gen/make_goldens_r5.py) - the only size at which the device decoder's two-level scans run deep."""
+    import json
+
     L = N.load()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "big_frame_decode.json")) as f:
+        want = {e["quality"]: e for e in json.load(f)["entries"]}
     img = rand_frame(8192, 4096, 8192)
     for q in (50, 85):
+        assert (want[q]["seed"], want[q]["height"], want[q]["width"]) == (8192, 4096, 8192)
         s = T.compress(img, q, ctx=ctx)
+        assert len(s) == want[q]["bytes"] and sha(s) == want[q]["sha256"], q
         monkeypatch.delenv("TIC_DECODE_HOST", raising=False)
         dev = T.decompress(s, ctx=ctx)
         assert L.tic_last_decode_path(ctx.handle) == 1 and L.tic_last_decode_giveup(ctx.handle) == 0, q
+        assert sha(np.ascontiguousarray(dev).tobytes()) == want[q]["decoded_sha256"], q
         monkeypatch.setenv("TIC_DECODE_HOST", "1")
         host = T.decompress(s, ctx=ctx)
         assert L.tic_last_decode_path(ctx.handle) == 2
         monkeypatch.delenv("TIC_DECODE_HOST")
-        assert np.array_equal(dev, host), q
-        assert np.abs(dev.astype(np.int32) - img).mean() < (20 if q == 50 else 10), q  # (a decoded noise frame is close to its source: 14.6 at q = 50)
+        assert sha(np.ascontiguousarray(host).tobytes()) == want[q]["decoded_sha256"], q
+
+
+def test_the_references_own_benchmark_set(ctx, monkeypatch):
+    """Round 5: the reference's benchmark workload - data/1..49.gif x quality 90, 80, 50, 20, 10, 5 (/root/reference/tests/benchmark.py:12-23),
+    streams and decoded pixels taken from the unmodified reference (tests/golden/gen/make_goldens_r5.py; benchmark_set.json / .npz).
+    All 294 pairs through compress(), through compress_batch() with the device entropy stage and with the host coder, through the
+    resident tic_compress_dev, and back through decompress() (default path, serial host decoder) and the resident tic_decompress_dev."""
+    import json
+
+    L = N.load()
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    with open(os.path.join(gold, "benchmark_set.json")) as f:
+        m = json.load(f)
+    px = np.load(os.path.join(gold, "benchmark_set.npz"))["pixels"]
+    assert px.shape == (49, 512, 512) and sha(px.tobytes()) == m["pixels_sha256"] and len(m["entries"]) == 294
+    by_q = {}
+    for e in m["entries"]:
+        by_q.setdefault(e["quality"], {})[e["image"]] = e
+    d_img, d_str, d_pix = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    cap = L.tic_compress_bound(512, 512)
+    ctx.check(L.tic_dev_alloc(ctx.handle, 512 * 512, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, cap, C.byref(d_str)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, 512 * 512, C.byref(d_pix)))
+    try:
+        for q, ents in sorted(by_q.items()):
+            assert sorted(ents) == list(range(1, 50))
+            frames = [px[i - 1] for i in range(1, 50)]
+            for threads in (0, 4):  # device entropy stage / host coder
+                streams = T.compress_batch(frames, q, threads=threads, ctx=ctx)
+                for i, s in enumerate(streams, 1):
+                    assert len(s) == ents[i]["bytes"] and sha(s) == ents[i]["sha256"], (i, q, threads)
+            for i in range(1, 50):
+                e, img = ents[i], px[i - 1]
+                s = T.compress(img, q, ctx=ctx)
+                assert len(s) == e["bytes"] and sha(s) == e["sha256"], (i, q)
+                out = T.decompress(s, ctx=ctx)
+                assert out.dtype == np.uint8 and sha(np.ascontiguousarray(out).tobytes()) == e["decoded_sha256"], (i, q)
+                if i % 7 == 0:  # the serial host decoder and the resident pair on a spread of the images
+                    monkeypatch.setenv("TIC_DECODE_SERIAL", "1")
+                    assert sha(T.decompress(s, ctx=ctx).tobytes()) == e["decoded_sha256"], (i, q)
+                    monkeypatch.delenv("TIC_DECODE_SERIAL")
+                    n = C.c_size_t(0)
+                    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, np.ascontiguousarray(img).ctypes.data, img.size))
+                    ctx.check(L.tic_compress_dev(ctx.handle, d_img, 512, 512, 512, q, d_str, cap, C.byref(n)))
+                    back = np.empty(n.value, dtype=np.uint8)
+                    ctx.check(L.tic_memcpy_d2h(ctx.handle, back.ctypes.data, d_str, n.value))
+                    assert n.value == e["bytes"] and sha(back) == e["sha256"], (i, q)
+                    ctx.check(L.tic_decompress_dev(ctx.handle, d_str, n.value, d_pix, 512, 512 * 512, None, None))
+                    pix = np.empty((512, 512), dtype=np.uint8)
+                    ctx.check(L.tic_memcpy_d2h(ctx.handle, pix.ctypes.data, d_pix, pix.size))
+                    assert sha(pix.tobytes()) == e["decoded_sha256"], (i, q)
+    finally:
+        for d in (d_img, d_str, d_pix):
+            L.tic_dev_free(ctx.handle, d)
 
 
 def test_decompress_dev_resident_round_trip(ctx, oracle):

@@ -297,3 +297,24 @@ def test_oracle_non_integral_qualities(oracle, golden):
     img = d["img_rand_40x56"]
     a, b = oracle.encode(img, 37.0), oracle.encode(img, 37)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_oracle_on_the_references_own_benchmark_set(oracle):
+    """Round 5: the reference's benchmark workload (/root/reference/tests/benchmark.py:12-23: data/1..49.gif x quality 90, 80, 50, 20, 10,
+    5), generated by tests/golden/gen/make_goldens_r5.py from the unmodified reference.  The oracle's compress() gives the
+    reference's bytes for all 294 pairs and its decompress() the reference's pixels: natural content at q = 5 / 20 / 80 is where
+    the long zero runs, ZRL codes and tie-dense blocks live."""
+    import hashlib
+    import json
+
+    with open(os.path.join(GOLDEN, "benchmark_set.json")) as f:
+        m = json.load(f)
+    px = np.load(os.path.join(GOLDEN, "benchmark_set.npz"))["pixels"]
+    assert px.shape == (49, 512, 512) and hashlib.sha256(px.tobytes()).hexdigest() == m["pixels_sha256"]
+    assert len(m["entries"]) == 294 and all(e["source"] == "reference" for e in m["entries"])
+    assert sorted({e["quality"] for e in m["entries"]}) == [5, 10, 20, 50, 80, 90]
+    for e in m["entries"]:
+        bs = oracle.compress(px[e["image"] - 1], e["quality"])
+        assert len(bs) == e["bytes"] and hashlib.sha256(bs).hexdigest() == e["sha256"], (e["image"], e["quality"])
+        out = oracle.decompress(bs)
+        assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == e["decoded_sha256"], (e["image"], e["quality"])
