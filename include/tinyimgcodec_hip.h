@@ -143,6 +143,11 @@ int tic_set_stats(tic_ctx *ctx, int enable);
  * packed again with the 8-lane kernel (and the limit then drops below that quality).  Same bytes either way. */
 int tic_set_entropy_lane_kernel(tic_ctx *ctx, int max_quality);
 int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count);
+/* ... and the strip kernel's other rare paths over the same launches (reset by either call): stats[0] = blocks settled in float64 by
+ * the batch pass (= tic_last_fallback_blocks), [1] = strips whose rational coefficients were recomputed in the loop (a .5 tie of
+ * (0,0) (0,4) (4,0) (4,4) somewhere in the strip), [2] = strips redone as a whole in the exact operation order (batch full, or all
+ * eight blocks tripped), [3] = the largest batch any wave carried.  Diagnostics: no counterpart in the reference. */
+int tic_last_rare_path_stats(tic_ctx *ctx, unsigned long long stats[4]);
 
 /* ---- entropy stage (host): replaces the per-block loops of compress() codec.py:133-164:
  *      DC DPCM codec.py:34-35, encode_run_length huffman.py:12-33, encode_huffman huffman.py:41-63,

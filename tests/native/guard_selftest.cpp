@@ -1,13 +1,14 @@
 // guard_selftest.cpp - the guard band of the float32 fast path (kGuard in tic_math.h), checked on the CPU.
 //
-// tic_math.h is host-compilable: this program runs the kernel's own dct8_aan<float> (rows, then columns: the pass order of
-// the strip kernel) and the kernel's quantiser arithmetic against dct8_exact (columns, then rows: the reference's order,
-// float64) and asserts, for every coefficient of every block,
-//     |Z_fast * scale - X_exact| < kGuard[u][v]                      (coefficient units)
-//     |t_fast - X_exact / div|   < kGuard[u][v] / div                (quantised units, q = 1, 10, 50, 90, 99; t = the exact product
+// tic_math.h is host-compilable: this program runs the kernel's own dct8_aan<float> (columns, then rows: the pass order of
+// the strip kernel since round 5, which is the reference's) and the kernel's quantiser arithmetic against dct8_exact (columns, then
+// rows, float64) and asserts, for every coefficient of every block, with G[u][v] = guard_cf(u, v) = kGuard[v][u]
+// (the bound table is stated for the rows-first algorithm and is symmetric under transposition of block and algorithm),
+//     |Z_fast * scale - X_exact| < G[u][v]                           (coefficient units)
+//     |t_fast - X_exact / div|   < G[u][v] / div                     (quantised units, q = 1, 10, 50, 90, 99; t = the exact product
 //                                                                     z * mul that lives inside quant_fma's fused multiply-adds)
 // and, end to end, the kernel's own decision: wherever the accept test of the strip kernel (d = fmaf(z, mul, magic - s) against
-// the float thresholds thrT of build_consts) ACCEPTS a rounding, that rounding is rint(X_exact / div), the reference's.
+// the float thresholds thrR of build_consts) ACCEPTS a rounding, that rounding is rint(X_exact / div), the reference's.
 // on: blocks read from a file (the adversarial blocks of tools/fastpath_error_search.py, tests/golden/adversarial_blocks.npz
 // exported as raw bytes by the test), extreme patterns, and N random blocks (argv[2], default 2,000,000).
 // It also prints kGuard so that the test can compare it with the rigorous bound of tools/fastpath_error_bound.py.
@@ -40,21 +41,21 @@ static double worst_ratio_q[64]; // the same in quantised units (worst of the th
 static long n_blocks = 0, n_viol = 0;
 
 static void check_block(const uint8_t px[64]) {
-    // fast path: pass 1 along the pixel rows, level shift folded into output 0, pass 2 down the columns
-    float y[8][8];
-    for (int r = 0; r < 8; r++) {
+    // fast path: pass 1 down the pixel columns, level shift folded into output 0, pass 2 along the rows
+    float y[8][8]; // y[u][c]
+    for (int c = 0; c < 8; c++) {
         float d[8];
-        for (int c = 0; c < 8; c++) d[c] = (float)px[r * 8 + c];
+        for (int r = 0; r < 8; r++) d[r] = (float)px[r * 8 + c];
         dct8_aan(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
         d[0] -= 1024.0f;
-        for (int v = 0; v < 8; v++) y[r][v] = d[v];
+        for (int u = 0; u < 8; u++) y[u][c] = d[u];
     }
     float z[8][8]; // z[u][v]
-    for (int v = 0; v < 8; v++) {
+    for (int u = 0; u < 8; u++) {
         float e[8];
-        for (int r = 0; r < 8; r++) e[r] = y[r][v];
+        for (int c = 0; c < 8; c++) e[c] = y[u][c];
         dct8_aan(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
-        for (int u = 0; u < 8; u++) z[u][v] = e[u];
+        for (int v = 0; v < 8; v++) z[u][v] = e[v];
     }
     // reference order in float64: axis -2 (down the columns) first, then axis -1
     double x[8][8];
@@ -70,20 +71,20 @@ static void check_block(const uint8_t px[64]) {
         for (int v = 0; v < 8; v++) {
             const int i = u * 8 + v;
             const double fast = (double)z[u][v] / (aan[u] * aan[v] * 8.0);
-            const double r1 = fabs(fast - x[u][v]) / kGuard[i];
+            const double r1 = fabs(fast - x[u][v]) / guard_cf(u, v);
             if (r1 > worst_ratio[i]) worst_ratio[i] = r1;
             double rq = 0;
             for (const DctqConsts *C : {&C1, &C10, &C50, &C90, &C99}) {
-                const float mul = C->mulT[v * 8 + u];
+                const float mul = C->mulN[i];
                 const double t_fused = (double)z[u][v] * (double)mul;       // the exact product inside the fma
                 const double want = x[u][v] / C->div[i];
-                const double r = fabs(t_fused - want) / (kGuard[i] / C->div[i]);
+                const double r = fabs(t_fused - want) / (guard_cf(u, v) / C->div[i]);
                 if (r > rq) rq = r;
                 // the kernel's accept test, operation for operation (quant_fma + the max/compare of the strip kernel)
                 const float s = fmaf(z[u][v], mul, kMagic);
                 const float nr = kMagic - s;
                 const float d = fmaf(z[u][v], mul, nr);
-                const float thr = C->thrG[4 * v + ((u == 0 || u == 4) ? 2 : (u < 4 ? 0 : 1))]; // the strip kernel's three groups per column
+                const float thr = C->thrR[4 * u + ((v == 0 || v == 4) ? 2 : (v < 4 ? 0 : 1))]; // the strip kernel's three groups per frequency row
                 if (fabsf(d) > thr) {
                     n_trip++;
                     const int qi = C == &C1 ? 0 : C == &C10 ? 1 : C == &C50 ? 2 : C == &C90 ? 3 : 4;
@@ -111,9 +112,8 @@ int main(int argc, char **argv) {
             if (!build_consts(q, &a) || !build_consts((double)q, &b)) { printf("FAIL build_consts(%d)\n", q); return 1; }
             for (int i = 0; i < 64; i++) {
                 const double want = q < 50 ? ((double)kQTable[i] * (5000.0 / (double)q)) / 100.0 : (double)(kQTable[i] * (200 - 2 * q)) / 100.0;
-                if (a.div[i] != want || b.div[i] != want || a.mulT[i] != b.mulT[i] || a.thrG[i & 31] != b.thrG[i & 31]) { printf("FAIL divisors of quality %d\n", q); return 1; }
+                if (a.div[i] != want || b.div[i] != want || a.mulN[i] != b.mulN[i] || a.thrR[i & 31] != b.thrR[i & 31]) { printf("FAIL divisors of quality %d\n", q); return 1; }
             }
-            if (memcmp(a.dcflat, b.dcflat, sizeof a.dcflat) != 0) { printf("FAIL dcflat of quality %d\n", q); return 1; }
         }
         if (build_consts(0.999, &a) || build_consts(99.001, &a) || build_consts(nan(""), &a) || !build_consts(37.5, &a)) { printf("FAIL range of build_consts\n"); return 1; }
     }

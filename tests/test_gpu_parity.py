@@ -269,9 +269,10 @@ def _true_tie_block():
 
 
 def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden):
-    """Every rare path of the production kernel against the exact kernel and the oracle: the wave's batch (ties, second level,
-    exact order inside the batch), batch overflow with rational ties only (flat blocks from the DC table, anything else through
-    the exact sub-path inside the loop), batch overflow with irrational trips (whole strip redone in the exact order)."""
+    """Every rare path of the production kernel against the exact kernel and the oracle: rational ties settled inside the loop
+    (rational_quad: flat, banded, two-level and posterised content trips it in every strip, noise in one strip of six), the wave's
+    batch of irrational trips (second level, exact order inside the batch, strips with ties AND trips), batch overflow and strips in
+    which all eight blocks trip (whole strip redone in the exact order)."""
     tt = _true_tie_block()
     mix = rand_frame(5, 1024, 2048)
     for k in range(0, 128 * 256, 37):
@@ -294,12 +295,15 @@ def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden):
         "random + scattered irrational true ties": (mix, (50,)),
         "tie goldens tiled": (np.tile(golden("tie_blocks")["img"].astype(np.uint8), (8, 16)), (50, 37, 90)),
         "half random, half flat odd": (half, (50,)),
-        # flat-block table of the overflow path (DctqConsts::dcflat): every grey level, every kind of divisor
+        # flat blocks of every grey level, every kind of divisor: DC ties at the odd levels
         "flat blocks of every grey level": (np.repeat(np.repeat(levels, 8, 0), 8, 1), (50, 1, 10, 25, 49, 51, 75, 90, 99)),
         "flat blocks of every grey level among noise": (flat_mix, (50, 75)),
         "posterised ramp (banded content)": (banded, (50, 30, 80)),
-        # dense rational ties that are NOT flat (sum 32 (a + b) with a + b = 2 mod 4): the float64 sub-path inside the loop
+        # dense rational ties that are NOT flat (sum 32 (a + b) with a + b = 2 mod 4)
         "two-level checkerboards": (checker, (50, 90)),
+        # many irrational trips per wave (narrow divisors): full batches, overflowing batches, ties in the same strips
+        "noise at the top of the quality range": (rand_frame(12, 1024, 2048), (90, 97, 99)),
+        "posterised noise (ties and trips in the same strips)": ((rand_frame(13, 1024, 2048) // 8 * 8 + 1).astype(np.uint8), (50, 90, 99)),
     }
     for name, (img, quals) in frames.items():
         f = DevFrame(ctx, img)

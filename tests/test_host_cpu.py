@@ -170,7 +170,7 @@ def test_guard_band_of_the_fast_path_is_a_bound(tmp_path):
         coefficient, and not needlessly wider (the trip rate scales with it);
     (2) the systematic term is real: on the block that maximises it, the float-constant algorithm evaluated in float64
         differs from the true DCT by exactly that much;
-    (3) the kernel's own arithmetic (tic_math.h compiled for the host: dct8_aan<float> rows then columns, quant_fma) stays
+    (3) the kernel's own arithmetic (tic_math.h compiled for the host: dct8_aan<float> columns then rows - the strip kernel's order -, quant_fma) stays
         inside kGuard against the exact-order float64 DCT on the adversarial blocks of tools/fastpath_error_search.py
         (tests/golden/adversarial_blocks.npz), extreme patterns and 2,000,000 random blocks of four kinds, in coefficient
         units and in quantised units at q = 1, 10, 50, 90, 99; and wherever the kernel's accept test (float thresholds of
@@ -193,7 +193,10 @@ def test_guard_band_of_the_fast_path_is_a_bound(tmp_path):
         sys.path.pop(0)
     sysb, worst = feb.systematic_bound(want_blocks=True)
     raw = tmp_path / "adv.bin"
-    raw.write_bytes(adv.tobytes() + worst.tobytes())  # the maximisers of the systematic term join the adversarial set
+    # the maximisers of the systematic term join the adversarial set; both sets were searched for the rows-first algorithm, the strip
+    # kernel now runs columns first: the transposed blocks are ITS adversaries (both orientations are fed)
+    raw.write_bytes(adv.tobytes() + worst.tobytes() + np.ascontiguousarray(adv.transpose(0, 2, 1)).tobytes()
+                    + np.ascontiguousarray(worst.reshape(-1, 8, 8).transpose(0, 2, 1)).tobytes())
     r = subprocess.run([str(exe), str(raw), "2000000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "guard_selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 accepted roundings differ" in r.stdout

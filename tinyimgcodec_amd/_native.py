@@ -81,6 +81,7 @@ SIGNATURES = {
     "tic_set_stats": (C.c_int, [_ctxp, C.c_int]),
     "tic_set_entropy_lane_kernel": (C.c_int, [_ctxp, C.c_int]),
     "tic_last_fallback_blocks": (C.c_int, [_ctxp, C.POINTER(C.c_ulonglong)]),
+    "tic_last_rare_path_stats": (C.c_int, [_ctxp, C.POINTER(C.c_ulonglong)]),
     "tic_entropy_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "tic_entropy_encode_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "tic_compress_dev": (

@@ -322,8 +322,8 @@ static int create_impl(tic_ctx *ctx, int device) {
         CK(hipHostMalloc((void **)&ctx->h_stat, 64, hipHostMallocMapped));
         CK(hipHostGetDevicePointer((void **)&ctx->d_stat, ctx->h_stat, 0));
     }
-    CK(hipMalloc((void **)&ctx->d_fallback, sizeof(unsigned long long)));
-    CK(hipMemset(ctx->d_fallback, 0, sizeof(unsigned long long)));
+    CK(hipMalloc((void **)&ctx->d_fallback, 4 * sizeof(unsigned long long)));
+    CK(hipMemset(ctx->d_fallback, 0, 4 * sizeof(unsigned long long)));
 #undef CK
     return TIC_OK;
 }
@@ -666,14 +666,22 @@ int tic_set_stats(tic_ctx *ctx, int enable) {
     return TIC_OK;
 }
 
-int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count) {
+int tic_last_rare_path_stats(tic_ctx *ctx, unsigned long long stats[4]) {
     TIC_LOCK(ctx);
-    if (!ctx || !count) return TIC_E_ARG;
+    if (!ctx || !stats) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(count, ctx->d_fallback, sizeof *count, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_fallback, 0, sizeof *count, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(stats, ctx->d_fallback, 4 * sizeof *stats, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_fallback, 0, 4 * sizeof *stats, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return TIC_OK;
+}
+
+int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count) {
+    if (!ctx || !count) return TIC_E_ARG;
+    unsigned long long st[4];
+    const int rc = tic_last_rare_path_stats(ctx, st);
+    if (rc == TIC_OK) *count = st[0];
+    return rc;
 }
 
 static int ensure_scratch(tic_ctx *ctx, size_t img_bytes, size_t coef_bytes) {

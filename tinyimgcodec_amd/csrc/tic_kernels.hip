@@ -241,28 +241,37 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void dctq_exact_kernel(DctqArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Kernel 2: the production kernel (dctq_strip_kernel below): float32 fast path behind a guard band, wave-local batch pass.
+// Kernel 2: the production kernel (dctq_strip_kernel below): float32 fast path behind a guard band, rational ties settled inside the
+// loop from the fast path's own exact column sums, wave-local batch pass for the irrational trips.
 //
 // Persistent waves, each walking its strips (strip = 8 horizontally adjacent blocks) in the order the launcher chose:
 // team schedule when the grid fits the chip at once, chunked schedule for larger grids (launch_dctq).
 // Main loop, per strip (unrolled x3, the landing registers of the pixel loads rotate by name):
 //   load   : lane 8*r + b reads the 8 bytes of pixel row r of block b -> every 8 lanes read 64 contiguous bytes; inline
 //            assembly + hand-counted vmcnt keep two strips in flight.
-//   pass 1 : float32 AAN along the pixel row held by the lane (no cross-lane traffic); the level shift is folded
-//            into output 0 (row sum - 1024, an exact integer).
-//   xpose  : 8x8 dword transpose per block through wave-private LDS (conflict-free slot layout); lane 8*b + v then
-//            holds column v.
-//   pass 2 : float32 AAN down that column; quantise with the magic-number rounding trick; the guard test is the largest
-//            distance to the rounded value per lane against three per-column thresholds.
+//   xpose 0: the 8 bytes go to wave-private LDS straight out of the landing registers (one ds_write_b64 behind the counted wait);
+//            lane 8*b + c reads pixel column c of block b back with eight ds_read_u8 - a byte transpose without a vector instruction.
+//   pass 1 : float32 AAN DOWN the pixel column held by the lane - the reference's pass order (utils.py:33-37: axis -2 first).  Outputs
+//            0 and 4 are the column's sum and alternating sum: exact integers, the very numbers the reference's float64 row pass
+//            starts from for the four rational coefficients (0,0) (0,4) (4,0) (4,4).  The level shift is folded into output 0.
+//   xpose 1: 8x8 dword transpose per block through wave-private LDS (conflict-free slot layout); lane 8*b + u then holds frequency
+//            row u.
+//   pass 2 : float32 AAN along that row; quantise with the magic-number rounding trick; the guard test is the largest distance
+//            to the rounded value per lane against three per-row thresholds.
+//   ties   : if one of the four rational coefficients tripped anywhere in the strip (an exact .5 tie: 2.2 % of random blocks at q = 50,
+//            most blocks of posterised, two-level and flat content), ALL 32 rational coefficients of the strip are recomputed in the
+//            reference's float64 operation order by the 64 lanes at once (rational_quad: column sums re-read from xpose 1's buffer,
+//            two DPP exchanges, one division) and written over the fast path's values in the zig-zag staging.  ~40 instructions;
+//            rounds 2-4 took the pixels through a byte transpose, v_sad_u8 and three DPP butterflies per tie block after the loop.
 //   store  : int16 results scattered to zig-zag order in LDS, read back 16 B per lane, 1 KiB contiguous per wave.
-//   trips  : blocks of a strip in which a lane tripped its guard band are settled after the loop by the wave itself, from its
-//            batch.
-// The timing-only builds of this kernel (parts of the loop left out), its option / cache-policy / prefetch-depth variants, the
-// in-kernel stamps and the kernels that were explored and dropped (round-1 hybrid kernel with a workgroup-shared post-pass,
-// dynamic strip queue, one block per lane) live in tools/experiments/tic_kernels_experiments.hip, built by tools/Makefile only.
+//   trips  : blocks in which one of the 60 irrational coefficients tripped its guard band (0.2 % of random blocks at q = 50, 0.9 % at
+//            q = 90) join the wave's batch and are settled after the loop in float64.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B
-constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave
+constexpr int kTWaveBytes = kLdsWaveBytes;        // 2176 B: transpose buffer, two halves of 256 dwords 272 dwords apart
+constexpr int kTHalfDw = 272;                     // dword offset of the half that holds columns 4..7 (272 = 16 mod 32: the two halves of a
+                                                  // 32-lane write group fall into different banks)
+constexpr int kZzWaveBytes = 8 * kZzStrideB;      // 1152 B zig-zag staging per wave; its first 640 B double as the byte-transpose buffer
+constexpr int kPxBlkBytes = 80;                   // byte-transpose buffer: 64 pixel bytes per block + 16 (bank spread of the b64 writes)
 constexpr int kMaxStripsPerWave = 16;             // a grid is "larger than the chip" when its waves would walk more strips than this
 constexpr int kChunkStrips = 8;                   // chunked schedule: strips per wave (a workgroup streams 32 adjacent strips).  With the
                                                   // sc1 nt stores 8 beats round 2's 16: 256 x 1080p 270 against 288 us, 8192^2 37.3 against
@@ -289,31 +298,10 @@ __device__ __forceinline__ void store16_wt_nt(void *p, const uint4 &v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(d) : "memory");
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Kernel 2 (round 2): the strip kernel with a wave-local batch pass - no barrier, no store drain, no global patches.
-//
-// Same main loop as above.  What differs is the fate of a block whose guard band tripped:
-//   * the block joins the wave's batch (at most 8 entries in wave-private LDS): block id + kind, its 8x8 pixels (64 B,
-//     the lanes that loaded them still hold them) and its 128 output bytes as the fast path staged them;
-//   * after the loop the wave settles its batch in ONE pass, 8 lanes per block: float64 second level if an entry tripped
-//     on one of the 60 irrational coefficients, exact float64 sub-path for the four rational coefficients (exact .5 ties
-//     are common there: 2.2 % of random blocks at q=50; every flat block with an odd grey level), exact operation order
-//     for what the second level cannot decide; results patch the 128-byte images in LDS, which then leave with 16-byte
-//     stores.  Constants of the pass sit in wave-private LDS (filled behind the same counted wait as the loop's own).
-//   * a batch that would overflow (tie-dense content): if the strip's trips are rational ties only, the wave runs the
-//     exact sub-path for the whole strip right there, before its store (rational_slim: this branch sits in the loop and
-//     set the kernel's register count - 88 VGPRs - while it used special_block); otherwise the strip's bit is set in a
-//     per-wave mask and the strip is redone in the exact operation order after the loop.
-// Measured against the alternatives on a 4096^2 frame (profiles/r02_ablate.txt): workgroup-shared
-// post-pass behind a barrier (round 1) +2.0 us over the loop; settling every tripped strip inside the loop +2.9 us (a wave
-// with four tripped strips ends 2 us after its neighbours: static schedule, dependent float64 chains); this batch pass
-// +0.9 us.  Resources: 72 + 8 reserved VGPRs, 22 KiB of LDS per workgroup, six workgroups per CU.
-// ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxStripsPerWave2 = 64;                 // one bit per strip of a wave's walk in the exact-redo mask
 constexpr int kBatch = 8;                              // entries of the wave's batch
 constexpr int kBatchWaveBytes = kBatch * (128 + 64) + 64; // images, pixel rows, ids
 
-// ---- the batch pass of the strip kernel, round-2 form ("slim"): lower latency, it runs on the launch's tail -------------------
 // A double through DPP: lane i reads the value of the lane the control word names.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
@@ -321,44 +309,44 @@ __device__ __forceinline__ double dpp_f64(double x) {
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-// Exact float64 sub-path of the four rational coefficients, 8 lanes per block, no LDS: rowLo/rowHi = pixel row i of the lane's
-// block.  The row's bytes are first reordered (0,7,3,4,1,2,5,6) so that, after the byte transpose, neighbouring lanes hold the
-// columns pocketfft adds first: the 8-point sums of SURVEY Appendix A become three DPP butterflies (xor 1, xor 2, +4).
-// Column sums come from v_sad_u8.  Lanes 0..3 of the block return (0,0), (0,4), (4,0), (4,4) - one coefficient, one division at
-// most, per lane.  Same arithmetic, same order as special_block().
-__device__ __forceinline__ int rational_slim(uint32_t rowLo, uint32_t rowHi, int i, const double *cst_rat) {
+
+// The four rational coefficients (0,0) (0,4) (4,0) (4,4) of all eight blocks of a strip in the reference's float64 operation order
+// (same arithmetic as dct8_exact restricted to outputs 0 and 4 of both passes).  The column pass of the
+// reference turns the integer column sums S_c (level-shifted) and alternating sums A_c = (x0+x7+x3+x4) - (x1+x2+x5+x6) into
+// y0_c = fl(S_c * SQ2H/2), y4_c = fl(A_c * TW3/2) - one rounding each, everything before the constant is exact.  Those integers are
+// pass 1's outputs 0 and 4 of the fast path and sit in the transpose buffer as exact floats: row u = 0 and row u = 4 of every block.
+// The row pass adds the eight y in pocketfft's order: A = (y0+y7) + (y3+y4), B = (y1+y2) + (y5+y6), output 0 = fl((A+B) * SQ2H/2),
+// output 4 = fl((A-B) * TW3/2) (the power-of-two scalings are exact and commute with the roundings).
+// Lane 8*b + i works for block b: w = i >> 2 picks the frequency row u = 4w, k = i & 3 the pair (0,7) (3,4) (1,2) (5,6) whose two
+// values the lane converts, scales and adds; one quad_perm exchange gives A (lanes k = 0,1) and B (k = 2,3), a second brings the
+// other half over; lane k = 0 finishes v = 0, lane k = 1 finishes v = 4.  Returns the quantised coefficient (true IEEE division,
+// half-even) in the lanes i = 0, 1, 4, 5 - (0,0) (0,4) (4,0) (4,4) at scan positions 0, 14, 10, 39.
+__device__ __forceinline__ int rational_quad(const uint32_t *ldsT, int b, int i, const double *cst_rat) {
 #pragma clang fp contract(off)
-    uint32_t lo = perm_b32(rowHi, rowLo, 0x04030700u); // x0 x7 x3 x4
-    uint32_t hi = perm_b32(rowHi, rowLo, 0x06050201u); // x1 x2 x5 x6
-    transpose8x8_bytes(lo, hi, i);                     // lane i: column (0,7,3,4,1,2,5,6)[i], bytes = rows 0..7
-    const uint32_t tot = __builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
-    const uint32_t sa = __builtin_amdgcn_sad_u8(lo & 0xff0000ffu, 0u, __builtin_amdgcn_sad_u8(hi & 0xff0000ffu, 0u, 0u)); // rows 0,3,4,7
-    const int e0 = (int)tot - 1024, e4 = 2 * (int)sa - (int)tot;
-    double y0 = (double)e0 * (kSq2h * 0.5);
-    double y4 = (double)e4 * (kTW3 * 0.5);
-    y0 = y0 + dpp_f64<TIC_DPP_QP_XOR1>(y0); // a0+a7 | a3+a4 | a1+a2 | a5+a6
-    y4 = y4 + dpp_f64<TIC_DPP_QP_XOR1>(y4);
-    y0 = y0 + dpp_f64<TIC_DPP_QP_XOR2>(y0); // A = p07 + p34 (lanes 0..3) | B = p12 + p56 (lanes 4..7)
-    y4 = y4 + dpp_f64<TIC_DPP_QP_XOR2>(y4);
-    const double b0 = dpp_f64<TIC_DPP_ROW_SHL4>(y0), b4 = dpp_f64<TIC_DPP_ROW_SHL4>(y4); // lanes 0..3 read B
-    const double A = (i & 2) ? y4 : y0, B = (i & 2) ? b4 : b0;       // lanes 0,1: frequency row u = 0; lanes 2,3: u = 4
-    const double E = (i & 1) ? A - B : A + B;                         // v = 0 | v = 4
-    const double X = E * ((i & 1) ? (kTW3 * 0.5) : (kSq2h * 0.5));
-    const double div = cst_rat[i & 3], rdiv = cst_rat[4 + (i & 3)];
-    const double t = X * rdiv;
-    double r = rint(t);
-    // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
-    if (fabs(fabs(t - r) - 0.5) < 1e-9) r = rint(X / div);
-    return (int)r;
+    const int w = i >> 2, k = i & 3;
+    const uint32_t ca = (0x05010300u >> (8 * k)) & 0xffu, cb = (0x06020407u >> (8 * k)) & 0xffu;
+    const uint32_t *row = ldsT + w * 128 + 4 * b; // frequency row u = 4w of block b (rows 0 and 4 are not swizzled)
+    const float fa = __uint_as_float(row[(ca >> 2) * kTHalfDw + (ca & 3)]);
+    const float fb = __uint_as_float(row[(cb >> 2) * kTHalfDw + (cb & 3)]);
+    const double K = w ? (kTW3 * 0.5) : (kSq2h * 0.5);
+    const double ya = (double)fa * K, yb = (double)fb * K;
+    const double p = ya + yb;                                   // y0+y7 | y3+y4 | y1+y2 | y5+y6
+    const double s2 = p + dpp_f64<TIC_DPP_QP_XOR1>(p);          // A (k = 0, 1) | B (k = 2, 3)
+    const double o = dpp_f64<TIC_DPP_QP_XOR2>(s2);              // the other half
+    const double E = (k & 1) ? s2 - o : s2 + o;                 // k = 0: A + B, k = 1: A - B
+    const double X = E * ((k & 1) ? (kTW3 * 0.5) : (kSq2h * 0.5));
+    const double div = cst_rat[2 * w + (k & 1)];
+    return (int)rint(X / div); // np.round(X / div): IEEE divide, half-even
 }
+
 // A block redone by the whole wave in float64 straight from the definition (lane 8*u + c: t[u][c] = sum_r M[u][r] x[r][c], then
 // X[u][v = c] = sum_k M[v][k] t[u][k]; error ~1e-13, the reference's own is ~1e-12).  A rounding is decided when no .5 tie lies
-// within 1e-9 of X * (1/div); decided values go to their place in the block's 128-byte zig-zag image.  Returns through the
-// masks which lanes stayed undecided.  ~450 cycles for one block, against ~1,500 for the 8-blocks-at-once second level: the
-// batch of a wave seldom holds more than one such entry.
-__device__ __forceinline__ void wave_redo_block(const uint8_t *px /* 64 pixels, LDS */, double *tbuf /* 64 doubles, LDS */,
-                                                const double *cosm, const double *rdiv, const uint16_t *zzofs, int16_t *img16,
-                                                int lane, unsigned long long &und_rational, unsigned long long &und_other) {
+// within 1e-9 of X * (1/div); decided values go to their place in the block's 128-byte zig-zag image.  The four rational
+// coefficients are left alone: the image already holds their exact values (fast path outside the guard band, rational_quad inside).
+// Returns the lanes that stayed undecided.  ~450 cycles for one block.
+__device__ __forceinline__ unsigned long long wave_redo_block(const uint8_t *px /* 64 pixels, LDS */, double *tbuf /* 64 doubles, LDS */,
+                                                              const double *cosm, const double *rdiv, const uint16_t *zzofs, int16_t *img16,
+                                                              int lane) {
     const int u = lane >> 3, c = lane & 7;
     double t = 0.0;
 #pragma unroll
@@ -369,12 +357,12 @@ __device__ __forceinline__ void wave_redo_block(const uint8_t *px /* 64 pixels, 
 #pragma unroll
     for (int kk = 0; kk < 8; kk++) X = fma(cosm[c * 8 + kk], tbuf[u * 8 + kk], X);
     const double tq = X * rdiv[lane], rq = rint(tq);
-    const bool decided = fabs(tq - rq) < 0.5 - 1e-9;
-    if (decided) img16[zzofs[lane] >> 1] = (int16_t)(int)rq;
     const bool rational = (lane & 0x1b) == 0; // (u,v) in {0,4} x {0,4}
-    und_rational = __ballot(!decided && rational);
-    und_other = __ballot(!decided && !rational);
+    const bool decided = fabs(tq - rq) < 0.5 - 1e-9;
+    if (decided && !rational) img16[zzofs[lane] >> 1] = (int16_t)(int)rq;
+    const unsigned long long und = __ballot(!decided && !rational);
     wave_lds_fence();
+    return und;
 }
 
 __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr(72))) void dctq_strip_kernel(DctqArgs a) {
@@ -386,8 +374,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *ldsT = ldsT_all[wave];
     char *ldsZ = reinterpret_cast<char *>(ldsZ_all[wave]);
-    const uint16_t *cst_zz = reinterpret_cast<const uint16_t *>(cst_blk + 960);    // [64] index u*8+v
-    const double *cst_rat = reinterpret_cast<const double *>(cst_blk + 1088);      // div[4] then rdiv[4]: (0,0) (0,4) (4,0) (4,4)
+    const uint16_t *cst_zz = reinterpret_cast<const uint16_t *>(cst_blk + kBlkZz);  // [64] index u*8+v
+    const double *cst_rat = reinterpret_cast<const double *>(cst_blk + kBlkRat);    // div of (0,0) (0,4) (4,0) (4,4)
     uint4 *bat_img = reinterpret_cast<uint4 *>(bat_all[wave]);                      // [kBatch][8] 16-byte pieces: zig-zag images
     uint2 *bat_pix = reinterpret_cast<uint2 *>(bat_all[wave] + kBatch * 32);        // [kBatch][8] pixel rows
     uint32_t *bat_id = bat_all[wave] + kBatch * 48;                                 // [kBatch] block index
@@ -396,11 +384,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
     a.out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(a.out) + (long)blockIdx.z * a.frame_stride_out);
 
     const int lr = lane >> 3, lb = lane & 7; // load phase: pixel row lr of block lb
-    const int b = lane >> 3, i = lane & 7;   // compute phase: column / frequency v = i of block b
+    const int b = lane >> 3, i = lane & 7;   // compute phase: pixel column c = i of block b (pass 1), frequency row u = i (pass 2)
     unsigned long long mask_exact = 0;       // strips of this wave's walk to redo in the exact order (wave-uniform)
-    uint32_t n_second = 0;                   // blocks recomputed in float64 (statistics)
+    uint32_t n_second = 0, n_quad = 0;       // blocks recomputed in float64, strips through rational_quad (statistics)
     int nE = 0;                              // entries in the batch (wave-uniform)
-    uint32_t kind_mask = 0;                  // bit e: entry e tripped on an irrational coefficient (wave-uniform, scalar register)
     int t_first, n_my;
     const uint32_t st_off = (uint32_t)lane * 16u; // lane offset inside a strip's 1 KiB output
     {
@@ -409,23 +396,28 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         f32x4 m0, m1;
         f32x4 thr;
         u32x4 zzv;
-        // Constants: the workgroup copies the quality's 2816-byte block into LDS, 44 lanes of every wave one 16-byte piece
+        // Constants: the workgroup copies the quality's 1600-byte block into LDS, 25 lanes of every wave one 16-byte piece
         // each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
         // loads per wave in front of the first pixel load: four such loads more cost 0.67 us on a 4096^2 launch).
         // Every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_TAKE).
         u32x4 c_fill;
         {
-            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 44 pieces of 16 bytes per wave
+            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 25 pieces of 16 bytes per wave
             static_assert(kPpw * kWavesPerWG == kStripBlkPieces && kPpw <= 64, "constant block must split evenly over the waves");
             const uint32_t piece = lane < kPpw ? (uint32_t)(wave * kPpw + lane) : (uint32_t)kStripBlkPieces - 1u;
             const uint32_t fo = piece * 16u;
             asm volatile("global_load_dwordx4 v[76:79], %0, %1" : : "v"(fo), "s"(C->strip_blk) : "memory", "v76", "v77", "v78", "v79"); // (lands in reserved registers: see TIC_LOAD)
         }
-        // LDS layouts of the loop (conflict-free transpose and zig-zag staging)
-        uint32_t *twA = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * lb;       // v in {0,1,4,5}: + v*32 dwords
-        uint32_t *twB = ldsT + (lr >> 2) * 256 + (lr & 3) + 4 * (lb ^ 4); // v in {2,3,6,7}
+        // LDS layouts of the loop (conflict-free: tools/lds_bank_model.py)
+        //   byte transpose : block lb's pixel row lr at lb*80 + lr*8; lane (b, c) reads byte r*8 + c of block b, r = 0..7
+        //   dword transpose: value (u, c) of block b at dword (c>>2)*272 + u*32 + 4*(b ^ s(u)) + (c&3), s(u) = 4 for u in {2,3,6,7}
+        //   zig-zag staging: scan position p of block b at byte (p>>3)*128 + 16*(b ^ f(p>>3)) + 2*(p&7), f(c) = bit 1 of c | 4 * bit 2 of c
+        const uint32_t px_wr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(ldsZ + lb * kPxBlkBytes + lr * 8);
+        const uint8_t *px_rd = reinterpret_cast<const uint8_t *>(ldsZ + b * kPxBlkBytes + i);
+        uint32_t *twA = ldsT + (i >> 2) * kTHalfDw + (i & 3) + 4 * b;       // u in {0,1,4,5}: + u*32 dwords
+        uint32_t *twB = ldsT + (i >> 2) * kTHalfDw + (i & 3) + 4 * (b ^ 4); // u in {2,3,6,7}
         const uint4 *tr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // rows 0..3; rows 4..7 at +64 slots
+            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // columns 0..3; columns 4..7 at +272 dwords
         const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
 
         // Strip walk: one scalar cursor (that of the prefetch).  Its start state takes ~25 scalar instructions: no division
@@ -467,14 +459,15 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         const uint8_t *img_s = a.img;
         // Pixel loads land in RESERVED registers v72..v79: the kernel is compiled with amdgpu_num_vgpr(72), so the compiler
         // allocates v0..v71 only, and the asm statements below name v72.. explicitly (declared as clobbers, which makes the
-        // kernel descriptor cover them: 80 registers, six waves per SIMD).  The compiler never sees a loaded value before the
-        // counted wait that precedes its first use, inside the same asm statement.  (Rounds 1-2 gave the asm load a "=v" output: the
+        // kernel descriptor cover them: 80 registers, six waves per SIMD).  The compiler never sees a loaded value: it goes from the
+        // landing pair to LDS behind the counted wait, inside the same asm statement.  (Rounds 1-2 gave the asm load a "=v" output: the
         // compiler then believes the value exists from that statement on and is free to copy it - a phi move, a coalescing with a
         // register tuple - before it has landed, and to reuse a register that a load in flight will still write.  It happened not
         // to; tools/microbench7.hip faulted exactly that way.  Accumulator registers would do too, but the compiler then splits the
         // 80 registers 40:40 and spills.)  amdgpu_num_vgpr is a budget the allocator aims for, NOT a wall (a rare-path change once
-        // made it put float64 division temporaries into v72..v77): the guarantee is tests/test_host_cpu.py, which checks in the
-        // disassembly of the shipped binary that no instruction outside these statements touches v72..v79.  Keep it green.
+        // made it put float64 division temporaries into v72..v77): the guarantee is csrc/lint_strip_kernel.py (run by the Makefile
+        // behind the link and by tests/test_host_cpu.py), which checks in the disassembly of the shipped binary that no instruction
+        // outside these statements touches v72..v79.  Keep it green.
 #define TIC_RSV_CLOBBER "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
 #define TIC_LOAD(R, OB)                                                                                      \
     do {                                                                                                     \
@@ -484,14 +477,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
         if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
     } while (0)
-    // waits until all but the N youngest vector-memory operations are done, then converts the strip's eight pixels straight out
-    // of the landing registers v[R0], v[R1] (which keep the strip's bytes until the pair is loaded again, two strips later: the
-    // rare paths fetch the raw words from there, raw_words)
-#define TIC_TAKE(D, R0, R1, N)                                                                               \
-    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_cvt_f32_ubyte0 %0, v" #R0 "\n\tv_cvt_f32_ubyte1 %1, v" #R0 "\n\tv_cvt_f32_ubyte2 %2, v" #R0 \
-                 "\n\tv_cvt_f32_ubyte3 %3, v" #R0 "\n\tv_cvt_f32_ubyte0 %4, v" #R1 "\n\tv_cvt_f32_ubyte1 %5, v" #R1                       \
-                 "\n\tv_cvt_f32_ubyte2 %6, v" #R1 "\n\tv_cvt_f32_ubyte3 %7, v" #R1                                                       \
-                 : "=v"(D[0]), "=v"(D[1]), "=v"(D[2]), "=v"(D[3]), "=v"(D[4]), "=v"(D[5]), "=v"(D[6]), "=v"(D[7]) : : TIC_RSV_CLOBBER)
+    // waits until all but the N youngest vector-memory operations are done, then sends the strip's pixel rows from the landing pair
+    // v[R] (which keeps the strip's bytes until the pair is loaded again, two strips later: the batch fetches the raw words from
+    // there, raw_words) to the byte-transpose buffer
+#define TIC_TAKE(R, N) asm volatile("s_waitcnt vmcnt(" #N ")\n\tds_write_b64 %0, v[" R "]" : : "v"(px_wr) : TIC_RSV_CLOBBER)
         uint32_t ob0, ob1, ob2;
         uint32_t kstrip = 0; // ordinal of the strip in this wave's walk
         TIC_LOAD("72:73", ob0);
@@ -503,21 +492,22 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         if (lane < kStripBlkPieces / kWavesPerWG) *reinterpret_cast<u32x4 *>(cst_blk + (wave * (kStripBlkPieces / kWavesPerWG) + lane) * 16) = c_fill;
         // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
-        m0 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32);
-        m1 = *reinterpret_cast<const f32x4 *>(cst_blk + i * 32 + 16);
-        thr = *reinterpret_cast<const f32x4 *>(cst_blk + 2176 + i * 16); // accept thresholds of column v = i: u in {1,2,3} | {5,6,7} | {0,4}
-        zzv = *reinterpret_cast<const u32x4 *>(cst_blk + 320 + i * 16);
+        m0 = *reinterpret_cast<const f32x4 *>(cst_blk + kBlkMul + i * 32);      // multipliers of (u = i, v = 0..3)
+        m1 = *reinterpret_cast<const f32x4 *>(cst_blk + kBlkMul + i * 32 + 16); // ... v = 4..7
+        thr = *reinterpret_cast<const f32x4 *>(cst_blk + kBlkThr + i * 16);     // accept thresholds of row u = i: v in {1,2,3} | {5,6,7} | {0,4}
+        zzv = *reinterpret_cast<const u32x4 *>(cst_blk + kBlkZz + i * 16);      // byte offsets of (u = i, v = 0..7) in the block's zig-zag image
         auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
-            return reinterpret_cast<int16_t *>(ldsZ + (ofs >> 4) * 128 + (ofs & 15) + 16 * (b ^ (4 * ((ofs >> 5) & 1))));
+            const uint32_t c = ofs >> 4;
+            return reinterpret_cast<int16_t *>(ldsZ + c * 128 + (ofs & 15) + 16 * (b ^ (((c >> 1) & 1) | (c & 4))));
         };
         int16_t *zp0 = zz_ptr(zzv.x & 0xffff), *zp1 = zz_ptr(zzv.x >> 16), *zp2 = zz_ptr(zzv.y & 0xffff), *zp3 = zz_ptr(zzv.y >> 16);
         int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
         const uint4 *zr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (4 * ((i >> 1) & 1)))), 16));
+            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (((i >> 1) & 1) | (i & 4)))), 16));
         wave_lds_fence();
 
         int left = n_my;
-        // raw pixel words of the strip in work, out of its landing registers (rare paths only)
+        // raw pixel words of the strip in work, out of its landing registers (batch entries only)
         auto raw_words = [&](auto tag, uint32_t &lo, uint32_t &hi) {
             constexpr int R = decltype(tag)::value;
             static_assert(R == 72 || R == 74 || R == 76, "landing register pair");
@@ -525,107 +515,72 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
             else if constexpr (R == 74) asm volatile("v_mov_b32 %0, v74\n\tv_mov_b32 %1, v75" : "=v"(lo), "=v"(hi) : : "memory");
             else asm volatile("v_mov_b32 %0, v76\n\tv_mov_b32 %1, v77" : "=v"(lo), "=v"(hi) : : "memory");
         };
-        // are all tripped blocks of the strip (bits of fm) flat?  lane (lr, lb) of the load layout holds pixel row lr of block lb
-        auto flat_ties = [&](uint32_t lo0, uint32_t hi0, uint32_t fm) {
-            const uint32_t first = (uint32_t)__shfl((int)lo0, lane & 7, 64);                               // row 0 of this lane's block
-            const bool row_flat = lo0 == hi0 && lo0 == perm_b32(0u, lo0, 0x00000000u) && lo0 == first;  // 8 equal bytes, equal to row 0's
-            unsigned long long mf = __ballot(row_flat);
-            mf &= mf >> 32;
-            mf &= mf >> 16;
-            mf &= mf >> 8; // bit lb: all eight rows of block lb are flat and equal
-            return (fm & ~(uint32_t)mf & 0xffu) == 0u;
-        };
-        auto process = [&](auto tag, const float (&px)[8], const uint32_t ob) {
-            // ---- pass 1: along the pixel row (the pixels arrive converted: TIC_TAKE) -----------------------------
-            float d0 = px[0], d1 = px[1], d2 = px[2], d3 = px[3], d4 = px[4], d5 = px[5], d6 = px[6], d7 = px[7];
+        auto process = [&](auto tag, const uint32_t ob) {
+            // ---- byte transpose: pixel column c = i of block b, rows 0..7 (written by TIC_TAKE) ---------------------------
+            float d0 = (float)px_rd[0], d1 = (float)px_rd[8], d2 = (float)px_rd[16], d3 = (float)px_rd[24];
+            float d4 = (float)px_rd[32], d5 = (float)px_rd[40], d6 = (float)px_rd[48], d7 = (float)px_rd[56];
+            // ---- pass 1: down the pixel column --------------------------------------------------------------------------
             dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
             d0 -= 1024.0f;
             twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
             twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
             twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
             wave_lds_fence();
-            const uint4 ra = tr[0], rb = tr[64];
+            const uint4 ra = tr[0], rb = tr[kTHalfDw / 4];
             wave_lds_fence();
             float e0 = __uint_as_float(ra.x), e1 = __uint_as_float(ra.y), e2 = __uint_as_float(ra.z), e3 = __uint_as_float(ra.w);
             float e4 = __uint_as_float(rb.x), e5 = __uint_as_float(rb.y), e6 = __uint_as_float(rb.z), e7 = __uint_as_float(rb.w);
-            // ---- pass 2: down the column of horizontal frequency v = i ----------------------------------------
+            // ---- pass 2: along the frequency row u = i -------------------------------------------------------------------
             dct8_aan(e0, e1, e2, e3, e4, e5, e6, e7);
             uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
             float r0, r1, r2, r3, r4, r5, r6, r7;
             quant_fma(e0, m0.x, q0, r0); quant_fma(e1, m0.y, q1, r1); quant_fma(e2, m0.z, q2, r2); quant_fma(e3, m0.w, q3, r3);
             quant_fma(e4, m1.x, q4, r4); quant_fma(e5, m1.y, q5, r5); quant_fma(e6, m1.z, q6, r6); quant_fma(e7, m1.w, q7, r7);
-            // guard test: three groups per column, u in {1,2,3} | {5,6,7} | {0,4} (tic_math.h thrG)
+            // guard test: three groups per row, v in {1,2,3} | {5,6,7} | {0,4} (tic_math.h thrR)
             const float mA1 = fmaxf(fmaxf(fabsf(r1), fabsf(r2)), fabsf(r3)); // v_max3_f32 with |.| modifiers
             const float mA2 = fmaxf(fmaxf(fabsf(r5), fabsf(r6)), fabsf(r7));
             const float mB = fmaxf(fabsf(r0), fabsf(r4));
-            const unsigned long long cA = __ballot(mA1 > thr.x) | __ballot(mA2 > thr.y); // lanes whose guard band tripped: u in 1,2,3,5,6,7
-            const unsigned long long cB = __ballot(mB > thr.z);                           // ... u in 0,4
+            const unsigned long long cA = __ballot(mA1 > thr.x) | __ballot(mA2 > thr.y); // lanes whose guard band tripped: v in 1,2,3,5,6,7
+            const unsigned long long cB = __ballot(mB > thr.z);                           // ... v in 0,4
             *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
             *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
+            const unsigned long long kRat = 0x1111111111111111ull; // lanes u in {0,4}: their v in {0,4} are the rational coefficients
+            // ---- a rational coefficient sits on a tie somewhere in the strip (one strip in six at q = 50 on noise; every strip of
+            //      posterised, two-level or flat content): the exact values of all 32, over the fast path's ------------------------
+            if (__builtin_expect((cB & kRat) != 0ull, 0)) {
+                const int rq = rational_quad(ldsT, b, i, cst_rat);
+                n_quad++;
+                if ((i & 2) == 0) *zz_ptr(i == 0 ? 0u : (i == 1 ? 28u : (i == 4 ? 20u : 78u))) = (int16_t)rq; // scan positions 0, 14, 10, 39
+            }
             wave_lds_fence();
-            uint4 val = *zr;
+            const uint4 val = *zr;
             wave_lds_fence();
             char *dst = reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off;
-            // ---- a guard band tripped somewhere in the strip (one strip in five at q=50) ------------------------------
-            if (__builtin_expect((cA | cB) != 0ull, 0)) {
-                const unsigned long long kRat = 0x1111111111111111ull; // lanes v in {0,4}: rational coefficients at u in {0,4}
-                const unsigned long long mG = cA | (cB & ~kRat), mS = cB & kRat;
-                // per block: an irrational trip / any trip.  Lane l answers for block l & 7 (byte l & 7 of the lane masks); the
-                // low byte of the ballot is the 8-bit block mask (6 vector instructions; folding the bytes on the scalar unit
-                // took ~40 dependent scalar instructions per tripped strip)
-                const uint32_t sh = 8u * (uint32_t)i;
-                const uint32_t gm = (uint32_t)__ballot(((mG >> sh) & 0xffull) != 0ull) & 0xffu;
-                const uint32_t fm = (uint32_t)__ballot((((mG | mS) >> sh) & 0xffull) != 0ull) & 0xffu;
-                const int nnew = __builtin_popcount(fm);
-                uint32_t lo0, hi0;
-                raw_words(tag, lo0, hi0);
-                if (nE + nnew <= kBatch && fm != 0xffu) {
-                    // the blocks join the batch: id, kind, pixel rows (this lane holds row lr of block lb), staged image
+            // ---- an irrational coefficient inside its guard band (one strip in seventy at q = 50, one in fourteen at q = 90) ------
+            const unsigned long long mG = cA | (cB & ~kRat);
+            if (__builtin_expect(mG != 0ull, 0)) {
+                // per block: lane l answers for block l & 7 (byte l & 7 of the lane mask); the low byte of the ballot is the 8-bit
+                // block mask (folding the bytes on the scalar unit took ~40 dependent scalar instructions per tripped strip)
+                const uint32_t gm = (uint32_t)__ballot(((mG >> (8u * (uint32_t)i)) & 0xffull) != 0ull) & 0xffu;
+                const int nnew = __builtin_popcount(gm);
+                if (nE + nnew <= kBatch && gm != 0xffu) {
+                    // the blocks join the batch: id, pixel rows (in the load layout this lane holds row lr of block lb), staged image
+                    uint32_t lo0, hi0;
+                    raw_words(tag, lo0, hi0);
                     const uint32_t below = (1u << b) - 1u, lbelow = (1u << lb) - 1u;
-                    const bool mine = (fm >> b) & 1u;
-                    const int e = nE + __builtin_popcount(fm & below);
+                    const bool mine = (gm >> b) & 1u;
+                    const int e = nE + __builtin_popcount(gm & below);
                     if (mine) bat_img[e * 8 + i] = val;
                     if (mine && i == 0) bat_id[e] = ob + (uint32_t)b;
-                    for (uint32_t f = fm, kk = (uint32_t)nE; f != 0u; f &= f - 1u, kk++) // entry kinds, in entry order (scalar unit)
-                        kind_mask |= ((gm >> __builtin_ctz(f)) & 1u) << kk;
-                    if ((fm >> lb) & 1u) bat_pix[(nE + __builtin_popcount(fm & lbelow)) * 8 + lr] = make_uint2(lo0, hi0);
+                    if ((gm >> lb) & 1u) bat_pix[(nE + __builtin_popcount(gm & lbelow)) * 8 + lr] = make_uint2(lo0, hi0);
                     // the tripped blocks leave with the batch pass; the others now (at least one lane stores: the strip's one
                     // vector-memory instruction is issued on every path, which the counted waits rely on)
                     if (!mine) store16_wt_nt(dst, val);
                     nE += nnew;
-                    n_second += (uint32_t)__builtin_popcount(gm);
-                } else if (gm != 0u) {
-                    // no room and an irrational trip: the whole strip is redone in the exact order after the loop
-                    mask_exact |= 1ull << kstrip;
-                    store16_wt_nt(dst, val);
-                } else if (flat_ties(lo0, hi0, fm)) {
-                    // no room, rational ties only, and every tripped block is FLAT (64 equal pixels).  Such a block has exactly one
-                    // non-zero coefficient, and with an odd grey level its DC sits on a .5 tie at q = 50: flat areas, banded and
-                    // upscaled content trip in every strip.  The reference's DC of a flat block depends on the grey level alone
-                    // (DctqConsts::dcflat, computed on the host in the exact operation order): no float64 here.  (Round 2 sent those
-                    // strips through the sub-path below: flat 201 took 10.9 us, Lenna in 32 grey levels 12.5, noise 10.1.)
-                    const uint32_t grey = (uint32_t)__shfl((int)lo0, b, 64) & 0xffu; // (load layout: lane b holds row 0 of block b)
-                    const int16_t dcv = reinterpret_cast<const int16_t *>(cst_blk + 2304)[grey];
-                    if (i == 0 && ((fm >> b) & 1u)) *zz_ptr(0u) = dcv;
-                    wave_lds_fence();
-                    val = *zr;
-                    wave_lds_fence();
-                    store16_wt_nt(dst, val);
+                    n_second += (uint32_t)nnew;
                 } else {
-                    // no room, rational ties only (tie-dense content that is not flat, e.g. two-level patterns): exact sub-path
-                    // for the four rational coefficients of all eight blocks, here and now
-                    uint2 *pb = reinterpret_cast<uint2 *>(ldsT);
-                    pb[lb * 8 + lr] = make_uint2(lo0, hi0);
-                    wave_lds_fence();
-                    const uint2 rowv = pb[lane]; // row i of block b
-                    wave_lds_fence();
-                    // lanes 0..3 of a block: (0,0), (0,4), (4,0), (4,4) at scan positions 0, 14, 10, 39 (no LDS, few registers:
-                    // this branch sits in the loop and must not raise its register count)
-                    const int rq = rational_slim(rowv.x, rowv.y, i, cst_rat);
-                    if (i < 4) *zz_ptr(i == 0 ? 0u : (i == 1 ? 28u : (i == 2 ? 20u : 78u))) = (int16_t)rq;
-                    wave_lds_fence();
-                    val = *zr;
-                    wave_lds_fence();
+                    // no room (or all eight blocks tripped): the whole strip is redone in the exact order after the loop
+                    mask_exact |= 1ull << kstrip;
                     store16_wt_nt(dst, val);
                 }
             } else
@@ -636,19 +591,18 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         // Two strips ahead: strip j is consumed after L(j+2) is issued; in steady state the instructions younger than
         // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.  (A rare branch issues at most
         // the same single store per strip.  Three strips ahead: no faster, profiles/r02_ab_prefetch_depth.txt, r03_ablate_cold.txt.)
-        float pxf[8];
-#define TIC_STEP(RLOAD, OBL, R0, R1, OBP, N) TIC_LOAD(RLOAD, OBL); TIC_TAKE(pxf, R0, R1, N); process(std::integral_constant<int, R0>(), pxf, OBP)
+#define TIC_STEP(RLOAD, OBL, RTAKE, RTAG, OBP, N) TIC_LOAD(RLOAD, OBL); TIC_TAKE(RTAKE, N); process(std::integral_constant<int, RTAG>(), OBP)
         do {
             if (left == 0) break;
-            TIC_STEP("76:77", ob2, 72, 73, ob0, 2);
+            TIC_STEP("76:77", ob2, "72:73", 72, ob0, 2);
             if (left == 0) break;
-            TIC_STEP("72:73", ob0, 74, 75, ob1, 3);
+            TIC_STEP("72:73", ob0, "74:75", 74, ob1, 3);
             while (left != 0) {
-                TIC_STEP("74:75", ob1, 76, 77, ob2, 4);
+                TIC_STEP("74:75", ob1, "76:77", 76, ob2, 4);
                 if (left == 0) break;
-                TIC_STEP("76:77", ob2, 72, 73, ob0, 4);
+                TIC_STEP("76:77", ob2, "72:73", 72, ob0, 4);
                 if (left == 0) break;
-                TIC_STEP("72:73", ob0, 74, 75, ob1, 4);
+                TIC_STEP("72:73", ob0, "74:75", 74, ob1, 4);
             }
         } while (0);
 #undef TIC_STEP
@@ -661,31 +615,25 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
 #undef TIC_TAKE
 #undef TIC_RSV_CLOBBER
     }
-    // ---- the batch pass -------------------------------------------------------------------------------------------------
+    // ---- the batch pass: blocks with an irrational coefficient inside its guard band ----------------------------------------
     if (nE != 0) {
-        const double *cst_cos = reinterpret_cast<const double *>(cst_blk + 1152);  // orthonormal DCT-II matrix, index k*8+n
-        const double *cst_rdiv = reinterpret_cast<const double *>(cst_blk + 1664); // 1/div, index u*8+v
-        // (1) entries that tripped on an irrational coefficient: whole-wave float64 recompute, one block at a time.  (The kinds
-        // sit in a scalar register: round 2 read every entry's id back from LDS here, ~100 cycles per entry on the launch's
-        // tail, although most entries are tie entries that need nothing in this step.)
-        const uint32_t m_all = (1u << nE) - 1u;
-        uint32_t m_rat = m_all & ~kind_mask, m_exact = 0; // entries that need the rational sub-path / the exact operation order
-        for (uint32_t todo = kind_mask; todo != 0u; todo &= todo - 1u) {
-            const int e = __builtin_ctz(todo);
-            unsigned long long ur, uo;
-            wave_redo_block(reinterpret_cast<const uint8_t *>(bat_pix + e * 8), reinterpret_cast<double *>(ldsT), cst_cos, cst_rdiv, cst_zz,
-                            reinterpret_cast<int16_t *>(bat_img + e * 8), lane, ur, uo);
-            if (ur != 0ull) m_rat |= 1u << e;
-            if (uo != 0ull) m_exact |= 1u << e;
+        const double *cst_cos = reinterpret_cast<const double *>(cst_blk + kBlkCos);   // orthonormal DCT-II matrix, index k*8+n
+        const double *cst_rdiv = reinterpret_cast<const double *>(cst_blk + kBlkRdiv); // 1/div, index u*8+v
+        // (1) whole-wave float64 recompute, one block at a time
+        uint32_t m_exact = 0; // entries that need the exact operation order
+        for (int e = 0; e < nE; e++) {
+            const unsigned long long und = wave_redo_block(reinterpret_cast<const uint8_t *>(bat_pix + e * 8), reinterpret_cast<double *>(ldsT), cst_cos,
+                                                           cst_rdiv, cst_zz, reinterpret_cast<int16_t *>(bat_img + e * 8), lane);
+            if (und != 0ull) m_exact |= 1u << e;
         }
-        // (2) 8 lanes per entry: exact order where even float64 from the definition could not decide (a true tie of an
-        // irrational coefficient - practically never), then the rational sub-path
+        // (2) 8 lanes per entry: the exact order where even float64 from the definition could not decide (a true tie of an
+        // irrational coefficient - practically never)
         const bool have = b < nE;
         const int e = have ? b : 0;
         const uint32_t blk = bat_id[e];
-        const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
-        int16_t *img16 = reinterpret_cast<int16_t *>(bat_img + e * 8);
         if (m_exact != 0u) {
+            const uint2 rowv = bat_pix[e * 8 + i]; // pixel row i of the block
+            int16_t *img16 = reinterpret_cast<int16_t *>(bat_img + e * 8);
             uint32_t lo = rowv.x, hi = rowv.y;
             transpose8x8_bytes(lo, hi, i); // -> pixel column i
             const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8); // byte offsets in the image of (u = i, v = 0..7)
@@ -696,18 +644,17 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
 #pragma unroll
                 for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qx[v];
             }
-            m_rat &= ~m_exact;
-        }
-        if (m_rat != 0u) {
-            const int r = rational_slim(rowv.x, rowv.y, i, cst_rat);
-            // lanes 0..3: (0,0) (0,4) (4,0) (4,4) at scan positions 0, 14, 10, 39
-            if (have && i < 4 && ((m_rat >> e) & 1u)) img16[i == 0 ? 0 : (i == 1 ? 14 : (i == 2 ? 10 : 39))] = (int16_t)r;
         }
         wave_lds_fence();
         const uint4 val = bat_img[e * 8 + i];
         if (have) store16_wt_nt(reinterpret_cast<char *>(a.out) + ((unsigned long long)blk << 7) + (uint32_t)i * 16u, val);
     }
-    if (a.fallback_count != nullptr && lane == 0 && n_second != 0) atomicAdd(a.fallback_count, (unsigned long long)n_second);
+    if (a.fallback_count != nullptr && lane == 0) { // diagnostics (tic_set_stats): never in a timed launch
+        if (n_second != 0) atomicAdd(a.fallback_count, (unsigned long long)n_second);
+        if (n_quad != 0) atomicAdd(a.fallback_count + 1, (unsigned long long)n_quad);
+        if (mask_exact != 0ull) atomicAdd(a.fallback_count + 2, (unsigned long long)__builtin_popcountll(mask_exact));
+        if (nE != 0) atomicMax(a.fallback_count + 3, (unsigned long long)nE);
+    }
     // ---- strips the batch had no room for: the exact operation order, whole strip ---------------------------------------
     if (mask_exact == 0ull) return;
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); // the wave's fast-path stores to these strips must have landed

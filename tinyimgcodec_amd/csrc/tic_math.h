@@ -152,23 +152,10 @@ static constexpr double kGuard[64] = {
     1.1428e-04, 6.1485e-04, 5.1255e-04, 7.0510e-04, 1.1428e-04, 6.6162e-04, 3.4923e-04, 1.0793e-03,
     5.1054e-04, 1.5901e-03, 1.3262e-03, 1.8402e-03, 5.1054e-04, 1.7563e-03, 1.0117e-03, 2.7581e-03,
 };
-// Guard classes of the one-block-per-lane kernel: every lane quantises all 64 coefficients, so the accept test is a
-// max over the coefficients of a class against one threshold per class (0.5 - largest guard/div of the class).  That
-// kernel takes the passes columns first, so its guard at (u,v) is kGuard[v][u] (the bound is symmetric under
-// transposition of block and algorithm).
-// Class 0 = the four rational coefficients (tie-only entries of the post-pass); classes 1-3 = the other 60, cut where
-// the sum over classes of (members x largest guard) is smallest (the expected number of trips; 20 % below the
-// per-column grouping of the strip kernel).  The pattern kGuard/Q does not depend on the quality.
-static constexpr unsigned char kLaneClass[64] = {
-    0, 2, 2, 2, 0, 1, 1, 1,
-    3, 3, 3, 3, 2, 2, 2, 3,
-    2, 3, 2, 2, 1, 1, 1, 3,
-    3, 3, 2, 2, 1, 1, 1, 3,
-    0, 2, 1, 1, 0, 1, 1, 1,
-    2, 2, 1, 1, 1, 1, 1, 2,
-    1, 1, 1, 1, 1, 1, 1, 2,
-    1, 1, 1, 1, 1, 2, 2, 3,
-};
+// The strip kernel takes the passes COLUMNS first (as the reference does), then rows: the bound above is symmetric under transposition
+// of block and algorithm (the columns-first algorithm on x is the rows-first algorithm on the transposed block, read transposed), so
+// its guard band at (u,v) is kGuard[v][u].
+constexpr double guard_cf(int u, int v) { return kGuard[v * 8 + u]; }
 // Adding 1.5*2^23 to a float |t| < 2^22 rounds it to an integer (half-even) whose two's complement sits in the
 // low mantissa bits: the quantiser needs no v_rndne / v_cvt.
 static constexpr float kMagic = 12582912.0f;
@@ -177,32 +164,23 @@ static constexpr float kMagic = 12582912.0f;
 struct DctqConsts {
     double div[64];      // natural order u*8+v: (Q*factor)/100 as the reference computes it (utils.py:50-53)
     double rdiv[64];     // fl(1/div)
-    double mul64[64];    // second-level path, index u*8+v: 1 / (aan[u]*aan[v]*8*div[u][v]) in float64
-    float mulT[64];      // fast path, index v*8+u: 1 / (aan[u]*aan[v]*8*div[u][v])
-    float thrT[16];      // fast path, per column v: [2v] = accept threshold for u in {1,2,3,5,6,7}, [2v+1] = for u in {0,4}
-                         // (0.5 - largest guard band kGuard[u][v]/div[u][v] of the group; accept when |t - rint(t)| <= thr)
-    float thrG[32];      // strip kernel, per column v: [4v] = accept threshold for u in {1,2,3}, [4v+1] for u in {5,6,7}, [4v+2] for
-                         // u in {0,4}, [4v+3] unused.  Three groups instead of round 2's two ({1,2,3,5,6,7} | {0,4}): the largest
-                         // guard/div of a group stands for all its members, and with the triples the sum over the 60 irrational
-                         // coefficients of (group maximum) is 1.41x the sum of their own bands instead of 1.72x - 18 % fewer
-                         // tripped blocks for the same number of instructions (2 x v_max3 + v_max, 3 compares)
-    float thrC[4];       // one-block-per-lane kernel: accept threshold per guard class (kLaneClass)
+    float mulN[64];      // fast path, index u*8+v: 1 / (aan[u]*aan[v]*8*div[u][v]) (lane u of a block holds v = 0..7)
+    float thrR[32];      // strip kernel, per frequency row u: [4u] = accept threshold for v in {1,2,3}, [4u+1] for v in {5,6,7}, [4u+2] for
+                         // v in {0,4}, [4u+3] unused (0.5 - largest guard band guard_cf(u,v)/div[u][v] of the group; accept when
+                         // |t - rint(t)| <= thr).  Three groups: the largest guard/div of a group stands for all its members, and with the
+                         // triples the sum over the 60 irrational coefficients of (group maximum) is 1.4x the sum of their own bands
+                         // (2 x v_max3 + v_max, 3 compares per strip)
     double cosm[64];     // orthonormal DCT-II matrix, index k*8+n: c(k) cos((2n+1) k pi / 16) (direct float64 recompute)
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
-    uint16_t zzofsT[64]; // index v*8+u: same offsets, transposed (lane v holds u = 0..7)
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
-    int16_t dcflat[256]; // quantised DC of a block whose 64 pixels all have the value p, EXACTLY as the reference computes it (float64,
-                         // pocketfft order, IEEE divide, half-even): every such block with an odd grey level sits on a .5 tie of the DC at
-                         // q = 50 (X = 8 (p - 128), div = 16), so flat, banded and upscaled content is tie-dense; the strip kernel settles
-                         // those blocks from this table instead of the float64 sub-path
     // Everything the strip kernel needs, packed as the image its workgroups copy into LDS with one 16-byte load per lane
-    // (144 lanes): [0,256) mulT, [256,320) thrT (round-2 grouping, experiment kernels), [320,448) zzofsT, [448,960) mul64,
-    // [960,1088) zzofs, [1088,1152) div then rdiv of the rational coefficients (0,0) (0,4) (4,0) (4,4), [1152,1664) cosm,
-    // [1664,2176) rdiv, [2176,2304) thrG, [2304,2816) dcflat.
-    alignas(16) unsigned char strip_blk[2816];
+    // (100 lanes): [0,256) mulN, [256,384) thrR, [384,512) zzofs, [512,544) div of the rational coefficients (0,0) (0,4) (4,0) (4,4),
+    // [544,576) unused, [576,1088) cosm, [1088,1600) rdiv.
+    alignas(16) unsigned char strip_blk[1600];
 };
-constexpr int kStripBlkBytes = 2816;
+constexpr int kStripBlkBytes = 1600;
 constexpr int kStripBlkPieces = kStripBlkBytes / 16;
+constexpr int kBlkMul = 0, kBlkThr = 256, kBlkZz = 384, kBlkRat = 512, kBlkCos = 576, kBlkRdiv = 1088; // offsets inside strip_blk
 
 // Accept threshold of the fast path as a float: the kernel accepts a rounding when fl32(|t - rint(t)|) <= thr.  The distance
 // is a float32 result in [0, 0.5]: above 0.25 it is rounded by at most 2^-26, i.e. by less than the gap between thr and the next
@@ -231,72 +209,35 @@ inline bool build_consts(double quality, DctqConsts *c) {
     aan[0] = 1.0;
     for (int k = 1; k < 8; k++) aan[k] = sqrt(2.0) * cos(k * 3.14159265358979323846 / 16.0);
     for (int u = 0; u < 8; u++)
-        for (int v = 0; v < 8; v++) {
-            int i = u * 8 + v, t = v * 8 + u;
-            c->mulT[t] = (float)(1.0 / (aan[u] * aan[v] * 8.0 * c->div[i]));
-            c->mul64[i] = 1.0 / (aan[u] * aan[v] * 8.0 * c->div[i]);
-        }
-    for (int v = 0; v < 8; v++) {
-        double ga = 0.0, gb = 0.0;
-        for (int u = 0; u < 8; u++) {
-            double g = kGuard[u * 8 + v] / c->div[u * 8 + v];
-            if (u == 0 || u == 4)
-                gb = g > gb ? g : gb;
-            else
-                ga = g > ga ? g : ga;
-        }
-        c->thrT[2 * v] = thr_below(0.5 - ga);
-        c->thrT[2 * v + 1] = thr_below(0.5 - gb);
+        for (int v = 0; v < 8; v++) c->mulN[u * 8 + v] = (float)(1.0 / (aan[u] * aan[v] * 8.0 * c->div[u * 8 + v]));
+    for (int u = 0; u < 8; u++) {
         double g3[3] = {0.0, 0.0, 0.0};
-        for (int u = 0; u < 8; u++) {
-            const double g = kGuard[u * 8 + v] / c->div[u * 8 + v];
-            const int grp = (u == 0 || u == 4) ? 2 : (u < 4 ? 0 : 1);
+        for (int v = 0; v < 8; v++) {
+            const double g = guard_cf(u, v) / c->div[u * 8 + v];
+            const int grp = (v == 0 || v == 4) ? 2 : (v < 4 ? 0 : 1);
             if (g > g3[grp]) g3[grp] = g;
         }
-        for (int k = 0; k < 3; k++) c->thrG[4 * v + k] = thr_below(0.5 - g3[k]);
-        c->thrG[4 * v + 3] = 0.0f;
-    }
-    {
-        double gmax[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = 0; i < 64; i++) {
-            const double g = kGuard[(i & 7) * 8 + (i >> 3)] / c->div[i]; // columns-first: transposed bound
-            if (g > gmax[kLaneClass[i]]) gmax[kLaneClass[i]] = g;
-        }
-        for (int k = 0; k < 4; k++) c->thrC[k] = thr_below(0.5 - gmax[k]);
+        for (int k = 0; k < 3; k++) c->thrR[4 * u + k] = thr_below(0.5 - g3[k]);
+        c->thrR[4 * u + 3] = 0.0f;
     }
     for (int k = 0; k < 8; k++)
         for (int n = 0; n < 8; n++)
             c->cosm[k * 8 + n] = (k == 0 ? sqrt(0.125) : 0.5) * cos((2 * n + 1) * k * 3.14159265358979323846 / 16.0);
-    for (int pval = 0; pval < 256; pval++) { // a constant block: the column pass gives (y, 0, ..., 0) in every column, the row pass runs on eight y
-        double col[8], row[8];
-        for (int r = 0; r < 8; r++) col[r] = (double)(pval - 128);
-        dct8_exact(col[0], col[1], col[2], col[3], col[4], col[5], col[6], col[7]);
-        for (int k = 0; k < 8; k++) row[k] = col[0];
-        dct8_exact(row[0], row[1], row[2], row[3], row[4], row[5], row[6], row[7]);
-        c->dcflat[pval] = (int16_t)rint(row[0] / c->div[0]);
-    }
     for (int k = 0; k < 64; k++) {
-        int nat = kZigzag[k], u = nat >> 3, v = nat & 7;
+        int nat = kZigzag[k];
         c->zzofs[nat] = (uint16_t)(2 * k);
-        c->zzofsT[v * 8 + u] = (uint16_t)(2 * k);
         c->zznat[k] = (uint8_t)nat;
     }
     {
         unsigned char *p = c->strip_blk;
-        memcpy(p, c->mulT, 256);
-        memcpy(p + 256, c->thrT, 64);
-        memcpy(p + 320, c->zzofsT, 128);
-        memcpy(p + 448, c->mul64, 512);
-        memcpy(p + 960, c->zzofs, 128);
+        memset(p, 0, kStripBlkBytes);
+        memcpy(p + kBlkMul, c->mulN, 256);
+        memcpy(p + kBlkThr, c->thrR, 128);
+        memcpy(p + kBlkZz, c->zzofs, 128);
         const int rat[4] = {0, 4, 32, 36};
-        for (int k = 0; k < 4; k++) {
-            memcpy(p + 1088 + 8 * k, &c->div[rat[k]], 8);
-            memcpy(p + 1120 + 8 * k, &c->rdiv[rat[k]], 8);
-        }
-        memcpy(p + 1152, c->cosm, 512);
-        memcpy(p + 1664, c->rdiv, 512);
-        memcpy(p + 2176, c->thrG, 128);
-        memcpy(p + 2304, c->dcflat, 512);
+        for (int k = 0; k < 4; k++) memcpy(p + kBlkRat + 8 * k, &c->div[rat[k]], 8);
+        memcpy(p + kBlkCos, c->cosm, 512);
+        memcpy(p + kBlkRdiv, c->rdiv, 512);
     }
     return true;
 }

@@ -5,7 +5,16 @@ sys.path.insert(0, '.')
 import numpy as np
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N
+# python tools/natural_content.py [other.so ...]: further builds of the library are timed in the same process (boxes differ by +-5 %)
+libs = [("product", N.load())]
+for pth in sys.argv[1:]:
+    Lo = C.CDLL(pth)
+    for name in ("tic_create", "tic_dev_alloc", "tic_dev_free", "tic_memcpy_h2d", "tic_dctq_dev_timed"):
+        res, a = N.SIGNATURES[name]
+        fn = getattr(Lo, name); fn.restype = res; fn.argtypes = a
+    libs.append((pth.split("/")[-1], Lo))
 L = N.load(); ctx = T.Context(0)
+others = [(nm, Lo, Lo.tic_create(0)) for nm, Lo in libs[1:]]
 lenna = np.load('tests/golden/lenna.npz')['img']
 dim = 4096
 frames = {
@@ -31,9 +40,16 @@ for name, img in frames.items():
         t = ms.value * 1e3 / 2000
         L.tic_set_stats(ctx.handle, 1)  # (the statistics launch carries a diagnostic atomic: never timed)
         ctx.check(L.tic_dctq_dev(ctx.handle, d_img, dim, dim, dim, q, d_out, 2))
-        fb = C.c_ulonglong()
-        L.tic_last_fallback_blocks(ctx.handle, C.byref(fb))
+        st = (C.c_ulonglong * 4)()
+        L.tic_last_rare_path_stats(ctx.handle, st)
+        fb = C.c_ulonglong(st[0])
         L.tic_set_stats(ctx.handle, 0)
         n = C.c_size_t()
-        print("%-38s q=%d  kernel %6.2f us  (%.1f %% of 8 TB/s)  second-level blocks %d" % (name, q, t, 3.0 * dim * dim / t / 1e3 / 80, fb.value), flush=True)
+        extra = ""
+        for nm, Lo, co in others:
+            assert Lo.tic_dctq_dev_timed(co, d_img, dim, dim, dim, q, d_out, 2, 3000, C.byref(ms)) == 0
+            assert Lo.tic_dctq_dev_timed(co, d_img, dim, dim, dim, q, d_out, 2, 2000, C.byref(ms)) == 0
+            to = ms.value * 1e3 / 2000
+            extra += "  | %s %6.2f us (%.1f %%)" % (nm, to, 3.0 * dim * dim / to / 1e3 / 80)
+        print("%-38s q=%d  kernel %6.2f us  (%.1f %% of 8 TB/s)  second-level blocks %d, tie strips %d, exact strips %d, largest batch %d%s" % (name, q, t, 3.0 * dim * dim / t / 1e3 / 80, fb.value, st[1], st[2], st[3], extra), flush=True)
     L.tic_dev_free(ctx.handle, d_img); L.tic_dev_free(ctx.handle, d_out)
