@@ -268,7 +268,9 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
     host = np.zeros((h, pitch), dtype=np.uint8)
     host[:, :w] = img
     nblk = L.tic_num_blocks(h, w)
-    pairs = 1 if args.no_cold else COLD_PAIRS
+    # rotating pairs for the cold figure: 12 at 4096^2 (604 MB); frames whose pair alone exceeds the 256 MiB Infinity Cache need
+    # only a few - three 16384^2 pairs are 2.4 GB in rotation
+    pairs = 1 if args.no_cold else (COLD_PAIRS if 3 * h * w * COLD_PAIRS < (3 << 30) else 3)
     d_imgs, d_outs = (C.c_void_p * pairs)(), (C.c_void_p * pairs)()
     for k in range(pairs):
         a, b = C.c_void_p(), C.c_void_p()
@@ -301,12 +303,13 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
     wall_s = time.perf_counter() - t0
     ms_total_timed = ms.value
     kernel_ms = ms_total_timed / args.steps
+    parity = coefficient_parity(ctx, L, d_out, h, w, q, nblk)  # the buffer the timed launches just wrote
 
     cold = None
     if not args.no_cold:
         for _ in range(3):  # settle + warm-up of the rotating variant
-            ctx.check(L.tic_dctq_dev_timed_rotating(ctx.handle, d_imgs, d_outs, pairs, h, w, pitch, q, variant, 600, C.byref(ms)))
-        kcold = max(600, min(args.steps, 3000))
+            ctx.check(L.tic_dctq_dev_timed_rotating(ctx.handle, d_imgs, d_outs, pairs, h, w, pitch, q, variant, 600 if 3 * h * w < (200 << 20) else 20, C.byref(ms)))
+        kcold = max(600, min(args.steps, 3000)) if 3 * h * w < (200 << 20) else max(args.steps, 20)
         ctx.check(L.tic_dctq_dev_timed_rotating(ctx.handle, d_imgs, d_outs, pairs, h, w, pitch, q, variant, kcold, C.byref(ms)))
         cold_ms = ms.value / kcold
         cold_gbs = BYTES_PER_PIXEL * h * w / (cold_ms * 1e-3) / 1e9
@@ -347,6 +350,7 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             "untimed_launches": untimed + 1,
             "untimed_note": "back-to-back launches of the same kernel before the W warm-up steps (clock settling) + 1 statistics launch",
             "fallback_blocks_per_launch": fb.value,
+            "parity": parity,
             "device": ctx.arch,
             "timed_region": "the K launches between two HIP events recorded on the launch stream, inside the barrier + device-sync bracket: "
             "`value`, `ms_per_step` and `roofline.achieved` are all this one interval (value x 3 B = roofline.achieved).  The host "
@@ -378,6 +382,7 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
     }
     if cold is not None:
         out["roofline"]["cold"] = cold
+        out["roofline"]["frac_hbm_cold"] = cold["frac"]  # the HBM figure: the warm one above is (partly) an Infinity-Cache figure
     for k in range(pairs):
         ctx.check(L.tic_dev_free(ctx.handle, d_imgs[k]))
         ctx.check(L.tic_dev_free(ctx.handle, d_outs[k]))
@@ -514,6 +519,29 @@ def frame_nodes(frames):
         return sorted(set(int(v) for v in status))
     except Exception:  # noqa: BLE001
         return None
+
+
+def coefficient_parity(ctx, L, d_out, h, w, q, nblk):
+    """The bench line carries its own proof: the coefficient buffer the TIMED launches wrote is read back and its dc / ac digests are
+    compared with tests/golden/manifest.json (`rand1234_<h>x<w>_q<q>`: sha256 of the reference's own encode() output, dc differenced
+    as codec.py:34-35, tests/golden/gen/make_goldens.py).  Raises on a difference: a benchmark of wrong output is not a benchmark."""
+    path = os.path.join(ROOT, "tests", "golden", "manifest.json")
+    key = "rand1234_%dx%d_q%d" % (h, w, q)
+    if not os.path.exists(path):
+        return {"status": "unchecked", "why": "tests/golden/manifest.json missing"}
+    ent = json.load(open(path))["entries"].get(key)
+    if ent is None or "dc_i4_sha256" not in ent:
+        return {"status": "unchecked", "why": "no manifest entry %s" % key}
+    zz = np.empty((nblk, 64), dtype=np.int16)
+    ctx.check(L.tic_memcpy_d2h(ctx.handle, zz.ctypes.data, d_out, nblk * 128))
+    dc = zz[:, 0].astype(np.int32)
+    dc[1:] = np.diff(zz[:, 0].astype(np.int32))
+    got_dc = hashlib.sha256(dc.astype("<i4").tobytes()).hexdigest()
+    got_ac = hashlib.sha256(np.ascontiguousarray(zz[:, 1:]).astype("<i4").tobytes()).hexdigest()
+    if got_dc != ent["dc_i4_sha256"] or got_ac != ent["ac_i4_sha256"]:
+        raise AssertionError("coefficients of the timed launches differ from the reference's (%s): dc %s ac %s" % (key, got_dc[:16], got_ac[:16]))
+    return {"status": "ok", "against": "tests/golden/manifest.json %s (sha256 of the reference's encode() dc / ac)" % key,
+            "dc_i4_sha256": got_dc, "ac_i4_sha256": got_ac, "checked": "the coefficient buffer written by the timed launches"}
 
 
 def manifest_parity(q, first, sizes, streams):

@@ -297,6 +297,13 @@ __device__ __forceinline__ void store16_wt_nt(void *p, const uint4 &v) {
     const u32x4 d = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(d) : "memory");
 }
+// The same store with a scalar base and a 32-bit lane offset: the strip's address arithmetic stays on the scalar unit (the 64-bit
+// vector add per strip and its register pair are gone).
+__device__ __forceinline__ void store16_wt_nt(const void *sbase, uint32_t voff, const uint4 &v) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1 nt" : : "v"(voff), "v"(d), "s"(sbase) : "memory");
+}
 
 constexpr int kMaxStripsPerWave2 = 64;                 // one bit per strip of a wave's walk in the exact-redo mask
 constexpr int kBatch = 8;                              // entries of the wave's batch
@@ -362,6 +369,40 @@ __device__ __forceinline__ unsigned long long wave_redo_block(const uint8_t *px 
     if (decided && !rational) img16[zzofs[lane] >> 1] = (int16_t)(int)rq;
     const unsigned long long und = __ballot(!decided && !rational);
     wave_lds_fence();
+    return und;
+}
+
+// Second level, 8 lanes per block (up to eight blocks at once): the fast path's butterflies in float64 (error ~1e-13 against the
+// reference's ~1e-12).  colLo/colHi: the lane's pixel column.  q[v] = rounding of (u = i, v) where no .5 tie lies within 1e-9 of the
+// quotient; the return value has bit v set where it does (undecided: the caller goes to the exact operation order - or, for the four
+// rational coefficients, keeps what the image already holds).  ~1,000 cycles, against ~450 per block for wave_redo_block: the batch
+// pass takes this one from three entries on, and so do the strips the batch had no room for.
+__device__ __forceinline__ uint32_t second_level_8(uint32_t colLo, uint32_t colHi, uint32_t *lds, int b, int i, const double *mul64, int q[8]) {
+    double c[8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        c[r] = (double)(int)((colLo >> (8 * r)) & 0xffu);
+        c[r + 4] = (double)(int)((colHi >> (8 * r)) & 0xffu);
+    }
+    dct8_aan(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // down the column
+    c[0] -= 1024.0;
+    uint32_t w[8], wh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = (uint32_t)__double2loint(c[k]);
+    transpose8x8_dwords(lds, b, i, w);
+#pragma unroll
+    for (int k = 0; k < 8; k++) wh[k] = (uint32_t)__double2hiint(c[k]);
+    transpose8x8_dwords(lds, b, i, wh);
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = __hiloint2double((int)wh[k], (int)w[k]);
+    dct8_aan(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // along frequency row u = i
+    uint32_t und = 0;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        const double t = c[v] * mul64[i * 8 + v], r = rint(t);
+        q[v] = (int)r;
+        if (!(fabs(t - r) < 0.5 - 1e-9)) und |= 1u << v;
+    }
     return und;
 }
 
@@ -555,7 +596,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
             wave_lds_fence();
             const uint4 val = *zr;
             wave_lds_fence();
-            char *dst = reinterpret_cast<char *>(a.out) + ((unsigned long long)ob << 7) + st_off;
+            const char *dst = reinterpret_cast<const char *>(a.out) + ((unsigned long long)ob << 7); // (scalar: the strip's 1 KiB)
             // ---- an irrational coefficient inside its guard band (one strip in seventy at q = 50, one in fourteen at q = 90) ------
             const unsigned long long mG = cA | (cB & ~kRat);
             if (__builtin_expect(mG != 0ull, 0)) {
@@ -575,16 +616,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
                     if ((gm >> lb) & 1u) bat_pix[(nE + __builtin_popcount(gm & lbelow)) * 8 + lr] = make_uint2(lo0, hi0);
                     // the tripped blocks leave with the batch pass; the others now (at least one lane stores: the strip's one
                     // vector-memory instruction is issued on every path, which the counted waits rely on)
-                    if (!mine) store16_wt_nt(dst, val);
+                    if (!mine) store16_wt_nt(dst, st_off, val);
                     nE += nnew;
                     n_second += (uint32_t)nnew;
                 } else {
                     // no room (or all eight blocks tripped): the whole strip is redone in the exact order after the loop
                     mask_exact |= 1ull << kstrip;
-                    store16_wt_nt(dst, val);
+                    store16_wt_nt(dst, st_off, val);
                 }
             } else
-                store16_wt_nt(dst, val); // 16 B per lane, 1 KiB contiguous per wave
+                store16_wt_nt(dst, st_off, val); // 16 B per lane, 1 KiB contiguous per wave
             left--;
             kstrip++;
         };
@@ -619,12 +660,35 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
     if (nE != 0) {
         const double *cst_cos = reinterpret_cast<const double *>(cst_blk + kBlkCos);   // orthonormal DCT-II matrix, index k*8+n
         const double *cst_rdiv = reinterpret_cast<const double *>(cst_blk + kBlkRdiv); // 1/div, index u*8+v
-        // (1) whole-wave float64 recompute, one block at a time
+        // (1) float64 recompute: whole wave, one block at a time - or, when the wave met a cluster of trips (three entries and more),
+        // all entries at once, 8 lanes each
         uint32_t m_exact = 0; // entries that need the exact operation order
-        for (int e = 0; e < nE; e++) {
-            const unsigned long long und = wave_redo_block(reinterpret_cast<const uint8_t *>(bat_pix + e * 8), reinterpret_cast<double *>(ldsT), cst_cos,
-                                                           cst_rdiv, cst_zz, reinterpret_cast<int16_t *>(bat_img + e * 8), lane);
-            if (und != 0ull) m_exact |= 1u << e;
+        if (nE < 3) {
+            for (int ee = 0; ee < nE; ee++) {
+                const unsigned long long und = wave_redo_block(reinterpret_cast<const uint8_t *>(bat_pix + ee * 8), reinterpret_cast<double *>(ldsT), cst_cos,
+                                                               cst_rdiv, cst_zz, reinterpret_cast<int16_t *>(bat_img + ee * 8), lane);
+                if (und != 0ull) m_exact |= 1u << ee;
+            }
+        } else {
+            const bool have2 = b < nE;
+            const int e2 = have2 ? b : 0;
+            const uint2 rowv = bat_pix[e2 * 8 + i];
+            uint32_t lo = rowv.x, hi = rowv.y;
+            transpose8x8_bytes(lo, hi, i);
+            int qs[8];
+            uint32_t und = second_level_8(lo, hi, ldsT, b, i, reinterpret_cast<const double *>(cst_blk + kBlkMul64), qs);
+            if ((i & 3) == 0) und &= ~0x11u; // the rational coefficients (u, v in {0,4}): the image holds their exact values
+            const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8);
+            const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
+            int16_t *img2 = reinterpret_cast<int16_t *>(bat_img + e2 * 8);
+            if (have2) {
+#pragma unroll
+                for (int v = 0; v < 8; v++)
+                    if (!((und >> v) & 1u) && !((i & 3) == 0 && (v & 3) == 0)) img2[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qs[v];
+            }
+            const unsigned long long um = __ballot(have2 && und != 0u);
+            for (int ee = 0; ee < nE; ee++)
+                if ((um >> (8 * ee)) & 0xffull) m_exact |= 1u << ee;
         }
         // (2) 8 lanes per entry: the exact order where even float64 from the definition could not decide (a true tie of an
         // irrational coefficient - practically never)
@@ -674,7 +738,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         load_block_row(a.img, a.h, a.w, a.stride, true, s, i, lo, hi);
         transpose8x8_bytes(lo, hi, i);
         int q[8];
-        exact_block(lo, hi, ldsT, b, i, C, q);
+        // the second level for the whole strip; the exact order only if it leaves something undecided (a tie of a rational
+        // coefficient included: this path has no column sums at hand)
+        const uint32_t und = second_level_8(lo, hi, ldsT, b, i, reinterpret_cast<const double *>(cst_blk + kBlkMul64), q);
+        if (__ballot(und != 0u) != 0ull) exact_block(lo, hi, ldsT, b, i, C, q);
         store_zigzag(reinterpret_cast<uint32_t *>(ldsZ), b, i, zz, q, a.out, s);
     }
 }

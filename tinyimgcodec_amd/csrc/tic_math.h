@@ -165,6 +165,7 @@ struct DctqConsts {
     double div[64];      // natural order u*8+v: (Q*factor)/100 as the reference computes it (utils.py:50-53)
     double rdiv[64];     // fl(1/div)
     float mulN[64];      // fast path, index u*8+v: 1 / (aan[u]*aan[v]*8*div[u][v]) (lane u of a block holds v = 0..7)
+    double mul64[64];    // second level (the same butterflies in float64), index u*8+v: the same number in float64
     float thrR[32];      // strip kernel, per frequency row u: [4u] = accept threshold for v in {1,2,3}, [4u+1] for v in {5,6,7}, [4u+2] for
                          // v in {0,4}, [4u+3] unused (0.5 - largest guard band guard_cf(u,v)/div[u][v] of the group; accept when
                          // |t - rint(t)| <= thr).  Three groups: the largest guard/div of a group stands for all its members, and with the
@@ -174,13 +175,13 @@ struct DctqConsts {
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
     // Everything the strip kernel needs, packed as the image its workgroups copy into LDS with one 16-byte load per lane
-    // (100 lanes): [0,256) mulN, [256,384) thrR, [384,512) zzofs, [512,544) div of the rational coefficients (0,0) (0,4) (4,0) (4,4),
-    // [544,576) unused, [576,1088) cosm, [1088,1600) rdiv.
-    alignas(16) unsigned char strip_blk[1600];
+    // (132 lanes): [0,256) mulN, [256,384) thrR, [384,512) zzofs, [512,576) div, then 1/div, of the rational coefficients (0,0) (0,4) (4,0) (4,4),
+    // [576,1088) cosm, [1088,1600) rdiv, [1600,2112) mul64.
+    alignas(16) unsigned char strip_blk[2112];
 };
-constexpr int kStripBlkBytes = 1600;
+constexpr int kStripBlkBytes = 2112;
 constexpr int kStripBlkPieces = kStripBlkBytes / 16;
-constexpr int kBlkMul = 0, kBlkThr = 256, kBlkZz = 384, kBlkRat = 512, kBlkCos = 576, kBlkRdiv = 1088; // offsets inside strip_blk
+constexpr int kBlkMul = 0, kBlkThr = 256, kBlkZz = 384, kBlkRat = 512, kBlkCos = 576, kBlkRdiv = 1088, kBlkMul64 = 1600; // offsets inside strip_blk
 
 // Accept threshold of the fast path as a float: the kernel accepts a rounding when fl32(|t - rint(t)|) <= thr.  The distance
 // is a float32 result in [0, 0.5]: above 0.25 it is rounded by at most 2^-26, i.e. by less than the gap between thr and the next
@@ -209,7 +210,10 @@ inline bool build_consts(double quality, DctqConsts *c) {
     aan[0] = 1.0;
     for (int k = 1; k < 8; k++) aan[k] = sqrt(2.0) * cos(k * 3.14159265358979323846 / 16.0);
     for (int u = 0; u < 8; u++)
-        for (int v = 0; v < 8; v++) c->mulN[u * 8 + v] = (float)(1.0 / (aan[u] * aan[v] * 8.0 * c->div[u * 8 + v]));
+        for (int v = 0; v < 8; v++) {
+            c->mul64[u * 8 + v] = 1.0 / (aan[u] * aan[v] * 8.0 * c->div[u * 8 + v]);
+            c->mulN[u * 8 + v] = (float)c->mul64[u * 8 + v];
+        }
     for (int u = 0; u < 8; u++) {
         double g3[3] = {0.0, 0.0, 0.0};
         for (int v = 0; v < 8; v++) {
@@ -235,9 +239,13 @@ inline bool build_consts(double quality, DctqConsts *c) {
         memcpy(p + kBlkThr, c->thrR, 128);
         memcpy(p + kBlkZz, c->zzofs, 128);
         const int rat[4] = {0, 4, 32, 36};
-        for (int k = 0; k < 4; k++) memcpy(p + kBlkRat + 8 * k, &c->div[rat[k]], 8);
+        for (int k = 0; k < 4; k++) {
+            memcpy(p + kBlkRat + 8 * k, &c->div[rat[k]], 8);
+            memcpy(p + kBlkRat + 32 + 8 * k, &c->rdiv[rat[k]], 8);
+        }
         memcpy(p + kBlkCos, c->cosm, 512);
         memcpy(p + kBlkRdiv, c->rdiv, 512);
+        memcpy(p + kBlkMul64, c->mul64, 512);
     }
     return true;
 }
