@@ -114,6 +114,11 @@ def main():
     # one-GPU box: every rank on device 0 (RCCL needs one GPU per rank, so the rehearsal exchanges over the file communicator).
     share_gpu = os.environ.get("TIC_BENCH_SHARE_GPU", "0") == "1"
     ctx = T.Context(0 if share_gpu else local_rank)  # raises loudly if the HIP library / an MI355X is missing
+    # One process per GPU shares the node's cores: each rank's pipeline stages pageable frames on (cores / ranks of the node) / 2
+    # threads at most, instead of the single-process default of 8 (8 ranks would otherwise start 64 copy threads).
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1:
+        ctx.check(L.tic_set_stage_threads(ctx.handle, max(1, min(8, (os.cpu_count() or 8) // max(local_world, 1) // 2))))
     comm = None
     comm_note = "RCCL through the C-ABI (tic_comm_create_ex / tic_gather_sizes / tic_comm_allreduce_max)"
     if world > 1:
@@ -177,13 +182,23 @@ def main():
         lo, hi = shard_range(n_total, rank, world)
         info, t_wall, kernel_ms, sizes_mine = shard_measurements(args, ctx, L, N, T, q, variant, lo, hi - lo, ms, steps=args.steps,
                                                                  warmup=args.warmup, barrier=barrier, timed=True)
+        node_i, ncpu_i = C.c_int(), C.c_int()
+        ctx.check(L.tic_numa_info(ctx.handle, C.byref(node_i), C.byref(ncpu_i)))
+        pci = L.tic_pci_bus_id(ctx.handle).decode()
+        try:
+            bus = int(pci.split(":")[1], 16)
+        except Exception:  # noqa: BLE001
+            bus = 0xFF
+        me = [(L.tic_get_stage_threads(ctx.handle) << 32) | ((node_i.value & 0xFFFF) << 16) | ((ncpu_i.value & 0xFF) << 8) | bus]
         if comm is not None:
             red = comm.allreduce_max([t_wall, kernel_ms, info["host_to_host_s"], info["host_to_host_registered_s"]])  # max over ranks
             sizes, offsets = gather_sizes(sizes_mine, n_total, comm)          # RCCL all-gather of the actual stream sizes
+            rank_words, _ = gather_sizes(me, world, comm)                     # per-rank placement: threads, NUMA node, PCI bus
         else:  # --gpus 1 --workload config4
             red = [t_wall, kernel_ms, info["host_to_host_s"], info["host_to_host_registered_s"]]
             sizes = np.asarray(sizes_mine, dtype=np.int64)
             offsets = np.concatenate([[0], np.cumsum(sizes)])
+            rank_words = np.asarray(me, dtype=np.int64)
         if rank == 0:
             h, w = 1080, 1920
             pixels = float(h) * w * (hi - lo)
@@ -219,6 +234,11 @@ def main():
                     "per_rank": {"kernel_only_mpix_s": round(value / world, 1), "host_to_host_mpix_s": round(pixels / float(red[2]) / 1e6, 1),
                                  "host_to_host_registered_mpix_s": round(pixels / float(red[3]) / 1e6, 1)},
                     "numa": info.get("numa"),
+                    "ranks": [{"rank": r, "stage_threads": int(v) >> 32, "numa_node": (lambda x: x - 65536 if x >= 32768 else x)((int(v) >> 16) & 0xFFFF),
+                               "cpus_of_node": (int(v) >> 8) & 0xFF, "pci_bus": "%02x" % (int(v) & 0xFF)} for r, v in enumerate(rank_words)],
+                    "ranks_note": "host threads each rank's pipeline may stage pageable frames on (tic_set_stage_threads: cores / local ranks / 2, at most 8), "
+                    "the NUMA node of its GPU and the CPUs of that node in its affinity mask (0-255, saturating), the GPU's PCI bus",
+                    "rccl_version": (comm.version() if hasattr(comm, "version") else None),
                     "parity": dict(info["parity"], note="rank 0's shard; every rank checks its own shard and raises on a difference"),
                     "gathered_sizes": {"frames": int(len(sizes)), "total_bytes": int(offsets[-1]), "first": [int(v) for v in sizes[:8]],
                                             "sha256": hashlib.sha256(sizes.astype("<i8").tobytes()).hexdigest()},
@@ -597,6 +617,20 @@ def codec_resident(args, ctx, L, N, q):
         t_enc = timed(lambda: ctx.check(L.tic_compress_dev(ctx.handle, d_img, h, w, w, q, d_out, cap, C.byref(n))))
         stream = np.empty(n.value, np.uint8)
         ctx.check(L.tic_memcpy_d2h(ctx.handle, stream.ctypes.data, d_out, n.value))
+        # the same encoder, 64 resident frames back to back through the asynchronous form: one submission ramp and one wake-up per burst
+        burst = 64
+        tickets = (C.c_longlong * burst)()
+        def burst_fn():
+            for k in range(burst):
+                ctx.check(L.tic_compress_dev_async(ctx.handle, d_img, h, w, w, q, d_out, cap, C.byref(tickets[k])))
+            for k in range(burst):
+                nn = C.c_size_t()
+                ctx.check(L.tic_async_result(ctx.handle, tickets[k], 1, C.byref(nn)))
+                assert nn.value == n.value, (nn.value, n.value)
+        t_pipe = timed(burst_fn, reps=3) / burst
+        stream2 = np.empty(n.value, np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, stream2.ctypes.data, d_out, n.value))
+        assert np.array_equal(stream, stream2), "the asynchronous form wrote a different stream"
         t_dec = timed(lambda: ctx.check(L.tic_decompress_dev(ctx.handle, d_out, n.value, d_pix, w, img.size, None, None)))
         rb, tr = C.c_int(), C.c_int()
         ctx.check(L.tic_last_decode_range(ctx.handle, C.byref(rb), C.byref(tr)))
@@ -606,6 +640,8 @@ def codec_resident(args, ctx, L, N, q):
         return {
             "workload": "the %dx%d frame of config 2 (seed 1234), quality=%d, image, stream and pixels resident in HBM" % (h, w, q),
             "compress_dev_us": round(t_enc * 1e6, 1), "compress_dev_mpix_s": round(h * w / t_enc / 1e6, 1),
+            "pipelined_us": round(t_pipe * 1e6, 1), "pipelined_mpix_s": round(h * w / t_pipe / 1e6, 1),
+            "pipelined_note": "tic_compress_dev_async: %d frames queued back to back, results collected afterwards (same stream bytes); per frame" % burst,
             "stream_bytes": int(n.value), "stream_sha256": hashlib.sha256(stream.tobytes()).hexdigest(),
             "decompress_dev_us": round(t_dec * 1e6, 1), "decompress_dev_mpix_s": round(h * w / t_dec / 1e6, 1),
             "decoder_path": int(L.tic_last_decode_path(ctx.handle)), "decoder_range_bits": rb.value, "decoder_runs": tr.value,

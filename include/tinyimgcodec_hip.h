@@ -31,6 +31,7 @@ extern "C" {
 #define TIC_E_STREAM -5   /* malformed / unsupported stream */
 #define TIC_E_HIP -6      /* HIP runtime error (see tic_last_error) */
 #define TIC_E_NODEVICE -7 /* no gfx950 device / extension unusable */
+#define TIC_E_BUSY -8     /* an asynchronous call has not finished yet (tic_async_result with wait == 0) */
 
 /* kernel variants of the transform stage (all bit-identical in output) */
 #define TIC_QUALITY_CUSTOM 0 /* the quality installed with tic_set_custom_quality (any number in [1, 99]) */
@@ -164,6 +165,14 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
 /* compress() with image and stream both resident in HBM: transform kernels + device entropy stage. */
 int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out,
                      size_t cap, size_t *out_len);
+/* The same, asynchronously: the frame's launches are queued on the context's stream and the call returns with a ticket; up to 64
+ * tickets may be open per context.  For callers that compress resident frames back to back (compress() in a loop,
+ * /root/reference/tests/benchmark.py:12-23): submission and completion are paid once per burst, not once per frame.  Frames
+ * execute in call order.  tic_async_result delivers the frame's length or its error (same codes as tic_compress_dev) and closes
+ * the ticket; with wait == 0 it returns TIC_E_BUSY while the frame is still in flight (tic_sync waits for everything queued). */
+int tic_compress_dev_async(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out,
+                           size_t cap, long long *ticket);
+int tic_async_result(tic_ctx *ctx, long long ticket, int wait, size_t *out_len);
 /* compress() codec.py:133 with auto_generate_huffman_table=False, host buffers: upload, GPU transform stage, GPU
  * entropy stage, download of the finished stream. */
 int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, uint8_t *out,
@@ -176,6 +185,22 @@ int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row
  * out_lens[i] receives each size. */
 int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
                        int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads);
+
+/* The same batch spread over nctx contexts - one per GPU of the node - by ONE process: a host thread per context, contiguous
+ * shards of ceil(n / nctx) frames in frame order, no exchange between the shards; out_lens in frame order.  What a caller that
+ * loops over images (/root/reference/tests/benchmark.py:12-23) gets from a multi-GPU node without a launcher.  Returns the first
+ * failing shard's code; *failed_ctx (may be null) = that context's index (-1: none).  Contexts must be distinct; two may share a
+ * device. */
+int tic_compress_batch_multi(tic_ctx *const *ctxs, int nctx, const uint8_t *const *images, int n, int h, int w,
+                             ptrdiff_t row_stride, int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens,
+                             int threads, int *failed_ctx);
+
+/* Host threads the batch pipeline may use to stage pageable frames into its pinned slots (default 0: min(8, cores / 2)).  A node
+ * that runs one process per GPU sets cores_of_node / local_world_size / 2 here, so that 8 ranks do not start 64 copy threads. */
+int tic_set_stage_threads(tic_ctx *ctx, int threads);
+int tic_get_stage_threads(tic_ctx *ctx);
+/* PCI bus id of the context's device ("0000:c1:00.0"); never NULL. */
+const char *tic_pci_bus_id(const tic_ctx *ctx);
 
 /* Same batch, transform stage only (what the metric counts): per-frame coefficients land in coeffs[i]
  * (int16[N*64], host).  If coeffs == NULL the coefficients stay on the device and are discarded. */
@@ -236,6 +261,9 @@ int tic_comm_create_ex(tic_ctx *ctx, int rank, int world, const char *rendezvous
                        tic_comm **out);
 int tic_comm_destroy(tic_comm *comm);
 int tic_comm_rank(const tic_comm *comm);
+/* NCCL_VERSION_CODE of the RCCL library the communicator runs on (0: single rank, no library loaded).  tic_comm_create refuses a
+ * library whose major version is not 2: the RCCL entry points are bound through hand-written RCCL 2.x prototypes. */
+int tic_comm_rccl_version(const tic_comm *comm);
 int tic_comm_world(const tic_comm *comm);
 const char *tic_comm_last_error(const tic_comm *comm);
 /* all[r * n_mine + k] = size k of rank r (every rank passes the same n_mine; pad short shards). */

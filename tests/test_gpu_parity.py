@@ -568,6 +568,117 @@ def test_compress_dev_resident(ctx, manifest):
     assert n.value == m["bytes"] and sha(out.tobytes()) == m["sha256"]
 
 
+def test_compress_dev_async_matches_the_synchronous_call(ctx, manifest):
+    """tic_compress_dev_async / tic_async_result (round 5): frames queued back to back on the context's stream give the streams of
+    tic_compress_dev (= the reference's, tests above), in call order, with per-frame status: a frame whose stream does not fit
+    reports TIC_E_SPACE and the frames around it are unaffected; at most 64 tickets are open; an empty image is a header."""
+    L = N.load()
+    frames = [rand_frame(900 + k, 256 + 8 * (k % 3), 320) for k in range(6)]
+    want = [T.compress(f, 40 + 10 * k, ctx=ctx) for k, f in enumerate(frames)]
+    cap = L.tic_compress_bound(272, 320)
+    d_imgs, d_outs = [], []
+    try:
+        for f in frames:
+            a, b = C.c_void_p(), C.c_void_p()
+            ctx.check(L.tic_dev_alloc(ctx.handle, f.size, C.byref(a)))
+            ctx.check(L.tic_dev_alloc(ctx.handle, cap, C.byref(b)))
+            ctx.check(L.tic_memcpy_h2d(ctx.handle, a, np.ascontiguousarray(f).ctypes.data, f.size))
+            d_imgs.append(a)
+            d_outs.append(b)
+        tickets = []
+        for k, f in enumerate(frames):
+            t = C.c_longlong(-1)
+            small = 64 if k == 3 else cap  # frame 3: a buffer that cannot hold its stream
+            ctx.check(L.tic_compress_dev_async(ctx.handle, d_imgs[k], f.shape[0], f.shape[1], f.shape[1], 40 + 10 * k, d_outs[k], small, C.byref(t)))
+            tickets.append(t.value)
+        assert tickets == list(range(tickets[0], tickets[0] + 6))
+        n = C.c_size_t()
+        rc = L.tic_async_result(ctx.handle, tickets[-1], 0, C.byref(n))  # (poll: either still busy or done)
+        assert rc in (N.TIC_E_BUSY, N.TIC_OK)
+        if rc == N.TIC_OK:
+            assert n.value == len(want[-1])
+            tickets_left = tickets[:-1]
+        else:
+            tickets_left = tickets
+        for k, t in enumerate(tickets_left):
+            rc = L.tic_async_result(ctx.handle, t, 1, C.byref(n))
+            if k == 3:
+                assert rc == N.TIC_E_SPACE
+                continue
+            assert rc == N.TIC_OK and n.value == len(want[k]), (k, rc)
+            got = np.empty(n.value, np.uint8)
+            ctx.check(L.tic_memcpy_d2h(ctx.handle, got.ctypes.data, d_outs[k], n.value))
+            assert got.tobytes() == want[k], k
+        assert L.tic_async_result(ctx.handle, tickets[0], 1, C.byref(n)) == N.TIC_E_ARG  # closed
+        # 64 open tickets at most; results may be collected in any order
+        ts = []
+        for k in range(64):
+            t = C.c_longlong()
+            ctx.check(L.tic_compress_dev_async(ctx.handle, d_imgs[0], frames[0].shape[0], 320, 320, 40, d_outs[0], cap, C.byref(t)))
+            ts.append(t.value)
+        t = C.c_longlong()
+        assert L.tic_compress_dev_async(ctx.handle, d_imgs[0], frames[0].shape[0], 320, 320, 40, d_outs[0], cap, C.byref(t)) == N.TIC_E_ARG
+        for t in reversed(ts):
+            assert L.tic_async_result(ctx.handle, t, 1, C.byref(n)) == N.TIC_OK and n.value == len(want[0])
+        # an empty image, a bad quality, a misaligned buffer
+        t = C.c_longlong()
+        ctx.check(L.tic_compress_dev_async(ctx.handle, None, 0, 8, 8, 50, d_outs[1], cap, C.byref(t)))
+        assert L.tic_async_result(ctx.handle, t.value, 1, C.byref(n)) == N.TIC_OK and n.value == 16
+        hdr = np.empty(16, np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, hdr.ctypes.data, d_outs[1], 16))
+        assert hdr.tobytes() == T.compress(np.zeros((0, 8), np.uint8), 50, ctx=ctx)
+        assert L.tic_compress_dev_async(ctx.handle, d_imgs[0], 256, 320, 320, 100, d_outs[0], cap, C.byref(t)) == N.TIC_E_QUALITY
+        assert L.tic_compress_dev_async(ctx.handle, d_imgs[0], 256, 320, 320, 50, C.c_void_p(d_outs[0].value + 4), cap - 4, C.byref(t)) == N.TIC_E_ARG
+        ctx.check(L.tic_sync(ctx.handle))
+    finally:
+        for d in d_imgs + d_outs:
+            L.tic_dev_free(ctx.handle, d)
+
+
+def test_compress_batch_over_several_contexts(ctx, manifest):
+    """tic_compress_batch_multi / compress_batch(devices=[...]) (round 5): one process, a context and a host thread per listed device,
+    contiguous shards, sizes in frame order - on a one-GPU box two contexts on device 0.  Streams equal the single-context batch
+    (= the reference's: manifest_r4.json for the 1080p seeds)."""
+    import json
+
+    L = N.load()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "manifest_r4.json")) as f:
+        by_seed = {e["seed"]: e for e in json.load(f)["frames"]}
+    frames = [rand_frame(1234 + k, 1080, 1920) for k in range(21)]  # 21 frames over 2 contexts: shards of 11 and 10
+    for devices, threads in (([0, 0], 0), ([0, 0, 0], 0), ([0, 0], 4), ([0], 0)):
+        streams = T.compress_batch(frames, 50, threads=threads, devices=devices)
+        assert len(streams) == 21
+        for k, s in enumerate(streams):
+            e = by_seed[1234 + k]
+            assert len(s) == e["bytes"] and sha(s) == e["sha256"], (devices, threads, k)
+    assert T.compress_batch(frames[:2], 50, devices=[0, 0, 0]) == [T.compress(f, 50, ctx=ctx) for f in frames[:2]]  # more contexts than frames
+    assert T.compress_batch([], 50, devices=[0, 0]) == []
+    with pytest.raises(ValueError):
+        T.compress_batch(frames[:2], 50, devices=[])
+    with pytest.raises(KeyError):  # a shard's error is the call's error
+        T.compress_batch([np.full((64, 64), 255, np.uint8) * (k % 2) for k in range(4)] + [(np.indices((64, 64)).sum(0) % 2 * 255).astype(np.uint8)], 99, devices=[0, 0])
+    # C-ABI argument checks: the same context twice, null arrays
+    c2 = T.Context(0)
+    try:
+        hs = (C.c_void_p * 2)(ctx.handle, ctx.handle)
+        failed = C.c_int(7)
+        assert L.tic_compress_batch_multi(hs, 2, None, 1, 8, 8, 8, 50, None, None, None, 0, C.byref(failed)) == N.TIC_E_ARG
+        hs = (C.c_void_p * 2)(ctx.handle, c2.handle)
+        assert L.tic_compress_batch_multi(hs, 2, None, 1, 8, 8, 8, 50, None, None, None, 0, C.byref(failed)) == N.TIC_E_ARG
+        assert L.tic_compress_batch_multi(hs, 2, None, 0, 8, 8, 8, 50, None, None, None, 0, C.byref(failed)) == N.TIC_OK and failed.value == -1
+        assert L.tic_compress_batch_multi(hs, 0, None, 0, 8, 8, 8, 50, None, None, None, 0, None) == N.TIC_E_ARG
+        # placement helpers of the multi-rank bench line
+        assert L.tic_get_stage_threads(ctx.handle) in range(1, 9)
+        ctx.check(L.tic_set_stage_threads(ctx.handle, 3))
+        assert L.tic_get_stage_threads(ctx.handle) == 3
+        ctx.check(L.tic_set_stage_threads(ctx.handle, 0))
+        assert L.tic_set_stage_threads(ctx.handle, -1) == N.TIC_E_ARG
+        pci = L.tic_pci_bus_id(ctx.handle).decode()
+        assert len(pci.split(":")) == 3, pci
+    finally:
+        c2.close()
+
+
 def test_device_entropy_content_sweep(ctx):
     """Device entropy stage against the host coder on content that stresses the placing kernel: flat frames (48-bit partitions:
     a stream word holds the ends of two partitions), gradients, sparse spikes (long zero runs: ZRL decided per wave), noise at
@@ -824,7 +935,7 @@ def test_non_integral_qualities_round4(ctx, golden, oracle):
     assert L.tic_set_custom_quality(ctx.handle, 100.0) == N.TIC_E_QUALITY
 
 
-def test_rccl_single_rank_smoke(ctx, monkeypatch, tmp_path):
+def test_rccl_single_rank_smoke(ctx, monkeypatch, tmp_path):  # (+ round 5: the library's version is read and checked before any call)
     """The RCCL leg of the C-ABI (tic_comm.hip) with ONE rank forced through the library: dlopen of librccl, unique id through
     the rendezvous file, ncclCommInitRank on the context's device, all-gather and all-reduce on its stream.  (Two ranks need
     two GPUs: that run is the driver's; the two-process flow is rehearsed with gloo in test_config4_rehearsal_two_ranks_on_one_gpu.)"""
@@ -836,6 +947,7 @@ def test_rccl_single_rank_smoke(ctx, monkeypatch, tmp_path):
         mine = np.arange(1, 257, dtype=np.uint64) * np.uint64(1000003)
         got = comm.all_gather_u64(mine)
         assert got.shape == (1, 256) and np.array_equal(got[0], mine)
+        assert 20000 <= comm.version() < 30000, comm.version()  # NCCL_VERSION_CODE of an RCCL 2.x (any other major is refused at creation)
         v = comm.allreduce_max([3.5, -2.0, 1e300])
         assert list(v) == [3.5, -2.0, 1e300]
         sizes, offsets = gather_sizes(list(range(10, 20)), 10, comm)

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtinyimgcodec_hip.so")
 
 TIC_OK = 0
-TIC_E_ARG, TIC_E_QUALITY, TIC_E_RANGE, TIC_E_SPACE, TIC_E_STREAM, TIC_E_HIP, TIC_E_NODEVICE = -1, -2, -3, -4, -5, -6, -7
+TIC_E_ARG, TIC_E_QUALITY, TIC_E_RANGE, TIC_E_SPACE, TIC_E_STREAM, TIC_E_HIP, TIC_E_NODEVICE, TIC_E_BUSY = -1, -2, -3, -4, -5, -6, -7, -8
 KERNEL_AUTO, KERNEL_EXACT, KERNEL_HYBRID = 0, 1, 2
 QUALITY_CUSTOM = 0  # TIC_QUALITY_CUSTOM: the quality installed with tic_set_custom_quality
 
@@ -51,6 +51,9 @@ SIGNATURES = {
     "tic_host_unregister": (C.c_int, [_ctxp, C.c_void_p]),
     "tic_numa_info": (C.c_int, [_ctxp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tic_set_numa_binding": (C.c_int, [_ctxp, C.c_int]),
+    "tic_set_stage_threads": (C.c_int, [_ctxp, C.c_int]),
+    "tic_get_stage_threads": (C.c_int, [_ctxp]),
+    "tic_pci_bus_id": (C.c_char_p, [_ctxp]),
     "tic_last_batch_input_path": (C.c_int, [_ctxp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tic_set_auto_register": (C.c_int, [_ctxp, C.c_int]),
     "tic_last_batch_auto_registered": (C.c_int, [_ctxp, C.POINTER(C.c_int)]),
@@ -81,6 +84,8 @@ SIGNATURES = {
     "tic_set_stats": (C.c_int, [_ctxp, C.c_int]),
     "tic_set_entropy_lane_kernel": (C.c_int, [_ctxp, C.c_int]),
     "tic_last_fallback_blocks": (C.c_int, [_ctxp, C.POINTER(C.c_ulonglong)]),
+    "tic_compress_dev_async": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_longlong)]),
+    "tic_async_result": (C.c_int, [_ctxp, C.c_longlong, C.c_int, C.POINTER(C.c_size_t)]),
     "tic_last_rare_path_stats": (C.c_int, [_ctxp, C.POINTER(C.c_ulonglong)]),
     "tic_entropy_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "tic_entropy_encode_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -96,6 +101,11 @@ SIGNATURES = {
         C.c_int,
         [_ctxp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.POINTER(C.c_void_p),
          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int],
+    ),
+    "tic_compress_batch_multi": (
+        C.c_int,
+        [C.POINTER(_ctxp), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.POINTER(C.c_void_p),
+         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)],
     ),
     "tic_dctq_batch": (
         C.c_int,
@@ -117,6 +127,7 @@ SIGNATURES = {
     "tic_comm_create_ex": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "tic_comm_destroy": (C.c_int, [C.c_void_p]),
     "tic_comm_rank": (C.c_int, [C.c_void_p]),
+    "tic_comm_rccl_version": (C.c_int, [C.c_void_p]),
     "tic_comm_world": (C.c_int, [C.c_void_p]),
     "tic_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "tic_gather_sizes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -195,6 +206,23 @@ class Context:
 
 
 _tls = threading.local()
+_device_ctxs = {}  # (device, replica) -> Context shared by compress_batch(devices=[...]) calls of this process
+
+
+def device_contexts(devices):
+    """One long-lived Context per entry of `devices` (a device listed twice gets two contexts: separate streams and slots on the
+    same GPU).  Created on first use under the module lock, kept for the life of the process (pinned batch slots are expensive)."""
+    out, seen = [], {}
+    with _lock:
+        for d in devices:
+            d = int(d)
+            k = seen.get(d, 0)
+            seen[d] = k + 1
+            c = _device_ctxs.get((d, k))
+            if c is None or not c.handle:
+                c = _device_ctxs[(d, k)] = Context(d)
+            out.append(c)
+    return out
 
 
 def default_context():

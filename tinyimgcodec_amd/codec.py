@@ -177,14 +177,20 @@ def compress(image, quality=50, auto_generate_huffman_table=False, ctx=None):
         return out[: n.value].tobytes()
 
 
-def compress_batch(images, quality=50, threads=0, ctx=None):
-    """Batch of equally sized frames through the stream-overlapped pipeline -> list of bytes.
+def compress_batch(images, quality=50, threads=0, ctx=None, devices=None):
+    """Batch of equally sized frames through the stream-overlapped pipeline -> list of bytes (frame order).
 
-    threads=0: entropy stage on the GPU; threads>0: host entropy coder on that many worker threads."""
+    threads=0: entropy stage on the GPU; threads>0: host entropy coder on that many worker threads.
+    devices=[0, 1, ...]: the batch is cut into contiguous shards, one per listed device, and every shard runs its own pipeline on its
+    own context and host thread inside this process (tic_compress_batch_multi; the GIL is released for the whole call) - the
+    multi-GPU form of a loop over images (/root/reference/tests/benchmark.py:12-23) without a launcher.  A device may be listed
+    twice (two pipelines on one GPU)."""
     q = _check_quality(quality, packs_header=True)
     frames = [_as_u8_image(im) for im in images]
     if not frames:
         return []
+    if devices is not None:
+        return _compress_batch_multi(frames, q, int(threads), list(devices))
     ctx = _ctx(ctx)
     h, w = frames[0][1], frames[0][2]
     if any((f[1], f[2]) != (h, w) for f in frames):
@@ -208,6 +214,37 @@ def compress_batch(images, quality=50, threads=0, ctx=None):
             raise KeyError("coefficient magnitude has no Huffman code")
         ctx.check(rc)
         return [outs[i][: lens[i]].tobytes() for i in range(n)]
+
+
+def _compress_batch_multi(frames, q, threads, devices):
+    if not devices:
+        raise ValueError("devices must name at least one device")
+    ctxs = N.device_contexts(devices)
+    h, w = frames[0][1], frames[0][2]
+    if any((f[1], f[2]) != (h, w) for f in frames):
+        raise ValueError("all frames of a batch must have the same shape")
+    L = N.load()
+    n = len(frames)
+    cap = L.tic_compress_bound(h, w)
+    pool = np.empty((n, cap), dtype=np.uint8)
+    handles = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+    inp = (C.c_void_p * n)(*[f[0].ctypes.data for f in frames])
+    outp = (C.c_void_p * n)(*[pool[i].ctypes.data for i in range(n)])
+    caps = (C.c_size_t * n)(*([cap] * n))
+    lens = (C.c_size_t * n)()
+    failed = C.c_int(-1)
+    for c in ctxs:
+        c.lock.acquire()
+    try:
+        rc = L.tic_compress_batch_multi(handles, len(ctxs), inp, n, h, w, max(w, 1), q, outp, caps, lens, threads, C.byref(failed))
+        if rc == N.TIC_E_RANGE:
+            raise KeyError("coefficient magnitude has no Huffman code")
+        if rc != N.TIC_OK:
+            ctxs[max(failed.value, 0)].check(rc)
+    finally:
+        for c in ctxs:
+            c.lock.release()
+    return [pool[i, : lens[i]].tobytes() for i in range(n)]
 
 
 def entropy_encode(coeffs_zz, height, width, quality):

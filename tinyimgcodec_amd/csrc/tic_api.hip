@@ -29,6 +29,7 @@
 using namespace tic;
 
 namespace {
+constexpr int kAsyncSlots = 64; // tickets of the asynchronous calls that may be open at once per context
 // Phase times of the batch pipeline (tic_last_batch_phases): a handful of steady_clock reads per chunk, summed per context.
 // 0 staging copies into pinned memory (pageable input) or registration of the caller's frames, 1 enqueueing (H2D, kernels, lengths),
 // 2 waiting for a chunk, 3 stream read-back, 4 hand-out into the caller's buffers, 5 waiting for a free slot.
@@ -93,7 +94,12 @@ struct tic_ctx {
     HuffDev *d_huff = nullptr;
     int *d_err = nullptr;
     unsigned long long *d_total_bits = nullptr; // status block of the device entropy stage: payload bits [2], error flags [2] (used in turn)
-    unsigned long long *h_stat = nullptr, *d_stat = nullptr; // host-mapped status block of the device entropy stage (bits, error)
+    unsigned long long *h_stat = nullptr, *d_stat = nullptr; // host-mapped status block of the device entropy stage (bits, error); behind
+                                                            // its first 64 bytes: the {bits, error} pairs of the asynchronous calls' tickets
+    // asynchronous device-resident calls (tic_compress_dev_async): ticket t lives in slot t % kAsyncSlots
+    struct AsyncSlot { long long ticket = -1; size_t cap = 0; int early_rc = TIC_OK; hipEvent_t done = nullptr; bool empty_image = false; };
+    AsyncSlot async_slots[64];
+    long long async_next = 0;
     void *d_ent_work = nullptr;                 // workspace of the device entropy stage (tile sums, bit counts, staging slots)
     size_t ent_work_bytes = 0;
     int ent_parity = 0;
@@ -136,6 +142,8 @@ struct tic_ctx {
     bool auto_register = true;
     std::vector<void *> autoregs;      // ranges this call registered (unregistered before it returns)
     int last_batch_autoreg_frames = 0;
+    int stage_threads = 0; // host threads that stage pageable frames (0: min(8, cores / 2)); tic_set_stage_threads
+    char pci[32] = {0};
     std::string err;
     char arch[128] = {0};
 };
@@ -267,6 +275,8 @@ void tic_destroy(tic_ctx *ctx) {
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
     if (ctx->d_total_bits) (void)hipFree(ctx->d_total_bits); // d_err lives in the same block
     if (ctx->d_ent_work) (void)hipFree(ctx->d_ent_work);
+    for (auto &sl : ctx->async_slots)
+        if (sl.done) (void)hipEventDestroy(sl.done);
     if (ctx->h_stat) (void)hipHostFree(ctx->h_stat);
     if (ctx->h_zz) (void)hipHostFree(ctx->h_zz);
     if (ctx->d_stream_buf) (void)hipFree(ctx->d_stream_buf);
@@ -291,6 +301,10 @@ static int create_impl(tic_ctx *ctx, int device) {
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
         return set_err(nullptr, TIC_E_HIP, "cannot open device %d: %s", device, hipGetErrorString(e));
     snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
+    if (hipDeviceGetPCIBusId(ctx->pci, sizeof ctx->pci, device) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->pci[0] = 0;
+    }
     find_numa(ctx);
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_err(nullptr, TIC_E_NODEVICE, "device %d is %s; this library contains gfx950 (MI355X) code only", device,
@@ -319,7 +333,8 @@ static int create_impl(tic_ctx *ctx, int device) {
         CK(hipMemset(ctx->d_total_bits, 0, 32));
         ctx->d_err = reinterpret_cast<int *>(ctx->d_total_bits + 2);
         // the stage's last kernel writes {payload bits, error} straight into pinned host memory: no copy behind it
-        CK(hipHostMalloc((void **)&ctx->h_stat, 64, hipHostMallocMapped));
+        CK(hipHostMalloc((void **)&ctx->h_stat, 64 + kAsyncSlots * 16, hipHostMallocMapped));
+        memset(ctx->h_stat, 0, 64 + kAsyncSlots * 16);
         CK(hipHostGetDevicePointer((void **)&ctx->d_stat, ctx->h_stat, 0));
     }
     CK(hipMalloc((void **)&ctx->d_fallback, 4 * sizeof(unsigned long long)));
@@ -392,6 +407,22 @@ int tic_numa_info(tic_ctx *ctx, int *node, int *ncpus) {
     if (ncpus) *ncpus = ctx->numa_ncpus;
     return TIC_OK;
 }
+int tic_set_stage_threads(tic_ctx *ctx, int threads) {
+    TIC_LOCK(ctx);
+    if (!ctx || threads < 0) return TIC_E_ARG;
+    ctx->stage_threads = threads > 8 ? 8 : threads;
+    return TIC_OK;
+}
+int tic_get_stage_threads(tic_ctx *ctx) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    if (ctx->stage_threads > 0) return ctx->stage_threads;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int T = (int)(hw ? hw / 2 : 4);
+    return T < 1 ? 1 : (T > 8 ? 8 : T);
+}
+const char *tic_pci_bus_id(const tic_ctx *ctx) { return ctx ? ctx->pci : ""; }
+
 int tic_set_numa_binding(tic_ctx *ctx, int enable) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
@@ -860,6 +891,96 @@ int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t 
     return tic_entropy_encode_dev(ctx, ctx->d_coef, h, w, quality, d_out, cap, out_len);
 }
 
+// Asynchronous form of tic_compress_dev: the frame's launches (transform, pack, tile sums, place) are queued on the context's stream
+// and the call returns; a caller that compresses resident frames back to back pays the submission ramp and the completion wake-up
+// once per burst instead of once per frame.  The context's coefficient scratch and entropy workspace are reused from frame to
+// frame: the stream executes the frames in order.  The placing kernel leaves {payload bits, error} in the ticket's pair of the
+// host-mapped status block; tic_async_result reads it once the ticket's event has fired.
+int tic_compress_dev_async(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out, size_t cap,
+                           long long *ticket) {
+    TIC_LOCK(ctx);
+    if (!ctx || !ticket) return TIC_E_ARG;
+    int rc = check_stream_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (!d_out || cap < 16) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+    if (((uintptr_t)d_out & 15u) != 0) return set_err(ctx, TIC_E_ARG, "device output buffer must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long long t = ctx->async_next;
+    tic_ctx::AsyncSlot &sl = ctx->async_slots[t % kAsyncSlots];
+    if (sl.ticket >= 0) return set_err(ctx, TIC_E_ARG, "%d asynchronous calls are open: collect results (tic_async_result) first", kAsyncSlots);
+    if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    volatile unsigned long long *hs = ctx->h_stat + 8 + 2 * (t % kAsyncSlots);
+    unsigned long long *ds = ctx->d_stat + 8 + 2 * (t % kAsyncSlots);
+    const size_t n = num_blocks(h, w);
+    sl.cap = cap;
+    sl.empty_image = n == 0;
+    if (n == 0) { // header only (codec.py:151: an empty image is a 16-byte stream)
+        uint8_t hdr[16];
+        write_header(hdr, h, w, quality);
+        HIPCHK(ctx, hipMemcpyAsync(d_out, hdr, 16, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        if (!d_image) return set_err(ctx, TIC_E_ARG, "null image pointer");
+        rc = ensure_scratch(ctx, 0, n * 128 + 16); // (grows only between bursts of one geometry: a reallocation waits for the stream)
+        if (rc) return rc;
+        const size_t wb = entropy_fused_work_bytes(n);
+        if (wb > ctx->ent_work_bytes) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // frames in flight still use the old workspace
+            if (ctx->d_ent_work) HIPCHK(ctx, hipFree(ctx->d_ent_work));
+            ctx->d_ent_work = nullptr;
+            ctx->ent_work_bytes = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->d_ent_work, wb));
+            ctx->ent_work_bytes = wb;
+        }
+        hs[0] = 0;
+        hs[1] = 0;
+        DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, ctx->d_coef);
+        HIPCHK(ctx, launch_dctq(a, dctq_kernel_id(TIC_KERNEL_HYBRID), ctx->stream));
+        const size_t cap_words = ((cap - 16) / 16) * 4;
+        const int par = ctx->ent_parity;
+        ctx->ent_parity ^= 1;
+        // (the 8-lane packing kernel: it takes any block the format allows, so no second run can be needed)
+        HIPCHK(ctx, entropy_gpu_fused((const int16_t *)ctx->d_coef, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, d_out, 0, cap_words, h, w,
+                                      quality, nullptr, ds, ctx->d_err + par, ctx->d_err + (par ^ 1), kEntropyEightLanes, ctx->stream));
+    }
+    HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
+    sl.ticket = t;
+    ctx->async_next = t + 1;
+    *ticket = t;
+    return TIC_OK;
+}
+
+// Result of an asynchronous call: TIC_OK and the stream's length, or that frame's error (TIC_E_RANGE: a coefficient without a Huffman
+// code, TIC_E_SPACE: the stream did not fit).  wait == 0: returns TIC_E_BUSY while the frame is still in flight.  A ticket is closed
+// by the call that returns anything but TIC_E_BUSY.
+int tic_async_result(tic_ctx *ctx, long long ticket, int wait, size_t *out_len) {
+    TIC_LOCK(ctx);
+    if (!ctx || !out_len || ticket < 0) return TIC_E_ARG;
+    tic_ctx::AsyncSlot &sl = ctx->async_slots[ticket % kAsyncSlots];
+    if (sl.ticket != ticket) return set_err(ctx, TIC_E_ARG, "ticket %lld is not open", ticket);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!wait) {
+        const hipError_t q = hipEventQuery(sl.done);
+        if (q == hipErrorNotReady) return TIC_E_BUSY;
+        HIPCHK(ctx, q);
+    } else {
+        HIPCHK(ctx, hipEventSynchronize(sl.done));
+    }
+    sl.ticket = -1;
+    if (sl.empty_image) {
+        *out_len = 16;
+        return TIC_OK;
+    }
+    volatile unsigned long long *hs = ctx->h_stat + 8 + 2 * (ticket % kAsyncSlots);
+    const unsigned long long total_bits = hs[0];
+    const int err = (int)(hs[1] & 0xffffffffull);
+    if (err == 1) return set_err(ctx, TIC_E_RANGE, "coefficient without a Huffman code (reference raises KeyError)");
+    const size_t payload = (size_t)((total_bits + 7) / 8);
+    if (err == 2 || 16 + payload > sl.cap)
+        return set_err(ctx, TIC_E_SPACE, "output buffer too small (%zu bytes needed)", 16 + (size_t)((total_bits + 31) / 32) * 4);
+    *out_len = 16 + payload;
+    return TIC_OK;
+}
+
 int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row_stride, int quality, uint8_t *out,
                  size_t cap, size_t *out_len) {
     TIC_LOCK(ctx);
@@ -916,7 +1037,7 @@ static void stage_frame(uint8_t *dst, size_t pitch, const uint8_t *src, ptrdiff_
 static void stage_chunk(const tic_ctx *ctx, uint8_t *pin, size_t img_bytes, size_t pitch, const uint8_t *const *images, int first, int cnt,
                         ptrdiff_t row_stride, int h, int w) {
     unsigned hw = std::thread::hardware_concurrency();
-    int T = (int)(hw ? hw / 2 : 4);
+    int T = ctx->stage_threads > 0 ? ctx->stage_threads : (int)(hw ? hw / 2 : 4);
     T = T < 1 ? 1 : (T > 8 ? 8 : T);
     if (T > cnt) T = cnt;
     if (T <= 1 || img_bytes * (size_t)cnt < (4u << 20)) {
@@ -1478,6 +1599,40 @@ int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h,
         return rc;
     }
     return batch_impl(ctx, images, n, h, w, row_stride, quality, nullptr, outs, caps, out_lens, threads, true);
+}
+
+// One batch over several contexts - normally one per GPU of the node - from ONE process: a host thread per context, contiguous shards
+// (frame i of n goes to context i / ceil(n / nctx): the partition of DESIGN.md 7 and of tinyimgcodec_amd/distributed.py
+// shard_range), every thread runs the stream-overlapped pipeline of tic_compress_batch on its shard.  Sizes come back in frame
+// order in out_lens; there is no data-path exchange between the shards.  The first failing shard's code is returned (its message:
+// tic_last_error of that context); *failed_ctx (may be null) receives its index, -1 when all succeeded.  Two contexts may sit on the
+// same device (each has its own streams, slots and scratch): that is how a one-GPU box tests this path.
+int tic_compress_batch_multi(tic_ctx *const *ctxs, int nctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
+                             int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads, int *failed_ctx) {
+    if (failed_ctx) *failed_ctx = -1;
+    if (!ctxs || nctx < 1 || n < 0) return TIC_E_ARG;
+    for (int k = 0; k < nctx; k++) {
+        if (!ctxs[k]) return TIC_E_ARG;
+        for (int j = 0; j < k; j++)
+            if (ctxs[j] == ctxs[k]) return set_err(ctxs[k], TIC_E_ARG, "context %d and %d of a multi-context batch are the same", j, k);
+    }
+    if (n == 0) return TIC_OK;
+    if (!images || !outs || !caps || !out_lens) return set_err(ctxs[0], TIC_E_ARG, "null pointer argument");
+    const int per = (n + nctx - 1) / nctx;
+    std::vector<int> rcs((size_t)nctx, TIC_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < nctx; k++) {
+        const int lo = std::min(k * per, n), hi = std::min(lo + per, n);
+        if (hi <= lo) continue;
+        th.emplace_back([=, &rcs] { rcs[(size_t)k] = tic_compress_batch(ctxs[k], images + lo, hi - lo, h, w, row_stride, quality, outs + lo, caps + lo, out_lens + lo, threads); });
+    }
+    for (auto &t : th) t.join();
+    for (int k = 0; k < nctx; k++)
+        if (rcs[(size_t)k] != TIC_OK) {
+            if (failed_ctx) *failed_ctx = k;
+            return rcs[(size_t)k];
+        }
+    return TIC_OK;
 }
 
 int tic_dctq_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride, int quality,

@@ -54,6 +54,7 @@ struct tic_comm {
     void *d_send = nullptr, *d_recv = nullptr;
     size_t send_cap = 0, recv_cap = 0;
     std::string err;
+    int version = 0; // NCCL_VERSION_CODE of the loaded library (0: no library loaded - single rank)
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -240,6 +241,22 @@ int tic_comm_create_ex(tic_ctx *ctx, int rank, int world, const char *rendezvous
 #define SYM(field, name)                                                                                  \
     c->field = reinterpret_cast<decltype(c->field)>(dlsym(c->lib, name));                                  \
     if (!c->field) { delete c; return comm_fail(nullptr, TIC_E_NODEVICE, "librccl lacks a symbol", name); }
+        // The prototypes above are written out by hand (ncclUniqueId = 128 bytes by value, ncclUint64 = 5, ncclFloat64 = 8, ncclMax = 2:
+        // rccl.h of RCCL 2.x, checked against /opt/rocm/include/rccl/rccl.h 2.27): a library of another MAJOR version may have changed
+        // any of them, so it is refused here instead of being called through them.
+        {
+            ncclResult_t (*GetVersion)(int *) = reinterpret_cast<ncclResult_t (*)(int *)>(dlsym(c->lib, "ncclGetVersion"));
+            int ver = 0;
+            if (!GetVersion || GetVersion(&ver) != ncclSuccess) { delete c; return comm_fail(nullptr, TIC_E_NODEVICE, "librccl does not report its version", "ncclGetVersion"); }
+            const int major = ver >= 10000 ? ver / 10000 : ver / 1000; // NCCL_VERSION_CODE: X*10000 + Y*100 + Z (X*1000 + ... up to 2.8)
+            c->version = ver;
+            if (major != 2) {
+                char buf[96];
+                snprintf(buf, sizeof buf, "version code %d (major %d); this build binds the RCCL 2.x C API", ver, major);
+                delete c;
+                return comm_fail(nullptr, TIC_E_NODEVICE, "unsupported librccl", buf);
+            }
+        }
         SYM(GetUniqueId, "ncclGetUniqueId")
         SYM(CommInitRank, "ncclCommInitRank")
         SYM(CommDestroy, "ncclCommDestroy")
@@ -284,6 +301,7 @@ int tic_comm_create_ex(tic_ctx *ctx, int rank, int world, const char *rendezvous
 }
 
 int tic_comm_rank(const tic_comm *c) { return c ? c->rank : -1; }
+int tic_comm_rccl_version(const tic_comm *c) { return c ? c->version : -1; }
 int tic_comm_world(const tic_comm *c) { return c ? c->world : 0; }
 
 int tic_gather_sizes(tic_comm *c, const uint64_t *mine, int n_mine, uint64_t *all) {

@@ -222,6 +222,10 @@ class RcclComm:
     def barrier(self):
         self.allreduce_max([0.0])
 
+    def version(self):
+        """NCCL_VERSION_CODE of the RCCL library in use (0 for a single rank: no library is loaded)."""
+        return int(self._L.tic_comm_rccl_version(self._h))
+
     def close(self):
         if self._h:
             self._L.tic_comm_destroy(self._h)
