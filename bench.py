@@ -619,13 +619,13 @@ def codec_resident(args, ctx, L, N, q):
         ctx.check(L.tic_memcpy_d2h(ctx.handle, stream.ctypes.data, d_out, n.value))
         # the same encoder, 64 resident frames back to back through the asynchronous form: one submission ramp and one wake-up per burst
         burst = 64
-        tickets = (C.c_longlong * burst)()
+        tickets = [C.c_longlong() for _ in range(burst)]
         def burst_fn():
             for k in range(burst):
                 ctx.check(L.tic_compress_dev_async(ctx.handle, d_img, h, w, w, q, d_out, cap, C.byref(tickets[k])))
             for k in range(burst):
                 nn = C.c_size_t()
-                ctx.check(L.tic_async_result(ctx.handle, tickets[k], 1, C.byref(nn)))
+                ctx.check(L.tic_async_result(ctx.handle, tickets[k].value, 1, C.byref(nn)))
                 assert nn.value == n.value, (nn.value, n.value)
         t_pipe = timed(burst_fn, reps=3) / burst
         stream2 = np.empty(n.value, np.uint8)

@@ -912,8 +912,10 @@ static Tunables read_tunables() {
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
     t.chunk = geti("TIC_CHUNK", kChunkStrips);      // strips per wave of schedules 1 and 2
     // per-round row weights of the team schedule ("0" disables it): the six workgroups of a CU reach their first pixel
-    // 1,400 ... 6,200 cycles after their own entry (profiles/r03_stamps_tail.txt), later rounds get fewer strip rows
-    const char *sp = test_hook("TIC_SPLIT") ? test_hook("TIC_SPLIT") : "16,13,10,7,4,2";
+    // 1,400 ... 6,200 cycles after their own entry (profiles/r03_stamps_tail.txt), later rounds get fewer strip rows.  Round 5: the
+    // first round gives a row to the last (4096^2: 9,8,6,4,3,2 rows instead of round 3's 10,8,6,4,3,1 - a wave's rare work grows with
+    // its strips, and the launch ends with the unluckiest wave: 9.9-10.0 against 10.2-10.3 us, profiles/r05_split_weights.txt)
+    const char *sp = test_hook("TIC_SPLIT") ? test_hook("TIC_SPLIT") : "15,13,10,7,5,3";
     for (int k = 0; k < 8; k++) t.split[k] = 0;
     for (int k = 0; k < 8 && sp && *sp; k++) {
         t.split[k] = atoi(sp);

@@ -16,6 +16,9 @@ if "--lib" in sys.argv:  # a second build of the library, timed on the same buff
     for name in ("tic_create", "tic_dctq_dev_timed"):
         res, a = N.SIGNATURES[name]; fn = getattr(Lo, name); fn.restype = res; fn.argtypes = a
     other = (Lo, Lo.tic_create(0))
+ITERS = 30
+if "--iters" in sys.argv:
+    k = sys.argv.index("--iters"); ITERS = int(sys.argv[k + 1]); del sys.argv[k:k + 2]
 if "--shapes" in sys.argv:
     k = sys.argv.index("--shapes"); SH = [tuple(int(v) for v in a.split("x")) for a in sys.argv[k + 1].split(",")]; del sys.argv[k:k + 2]
 else:
@@ -25,7 +28,7 @@ shapes = [(1024, 1024), (1088, 1088), (1152, 1152), (1280, 1280), (1920, 1920), 
 settings = [{}, {"TIC_CHUNK": "4"}, {"TIC_CHUNK": "16"}, {"TIC_CHUNK": "2"}, {"TIC_SCHED": "0"}, {"TIC_SCHED": "2"}, {"TIC_SCHED": "2", "TIC_CHUNK": "4"}]
 if SH: shapes = SH
 if len(sys.argv) > 2:
-    settings = [dict(kv.split("=") for kv in a.split(",") if kv) for a in sys.argv[2:]]
+    settings = [dict(kv.split("=") for kv in a.split(";") if kv) for a in sys.argv[2:]]
 buf = np.random.default_rng(1).integers(0, 256, px + (1 << 24), dtype=np.uint8)
 d_in, d_out = C.c_void_p(), C.c_void_p()
 ctx.check(L.tic_dev_alloc(ctx.handle, buf.size, C.byref(d_in)))
@@ -46,12 +49,12 @@ for w, p in shapes:
     h = px // p // 8 * 8
     for s in settings: run(h, w, p, 10, s)
     res = [[] for _ in settings]
-    for r in range(3):
-        for k, s in enumerate(settings): res[k].append(run(h, w, p, 30, s))
+    for r in range(5 if ITERS > 100 else 3):
+        for k, s in enumerate(settings): res[k].append(run(h, w, p, ITERS, s))
     print("w %5d pitch %5d h %7d: " % (w, p, h) + "  ".join("%7.2f us %.3f" % (statistics.median(v), 3.0 * h * w / (statistics.median(v) * 1e-6) / 8e12) for v in res), flush=True)
     if other:
         for s in settings: run(h, w, p, 10, s, other)
         res = [[] for _ in settings]
         for r in range(3):
-            for k, s in enumerate(settings): res[k].append(run(h, w, p, 30, s, other))
+            for k, s in enumerate(settings): res[k].append(run(h, w, p, ITERS, s, other))
         print("   (other library)            : " + "  ".join("%7.2f us %.3f" % (statistics.median(v), 3.0 * h * w / (statistics.median(v) * 1e-6) / 8e12) for v in res), flush=True)
