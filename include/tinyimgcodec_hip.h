@@ -43,6 +43,9 @@ typedef struct tic_ctx tic_ctx;
 
 /* ---- lifecycle -------------------------------------------------------------------------------------- */
 const char *tic_version(void);
+/* 0 for the shipped library (it reads no environment variable); 1 for the test-hooks build of the same sources
+ * (libtinyimgcodec_hip_hooks.so, -DTIC_TEST_HOOKS: csrc/tic_hooks.h lists the variables that build honours). */
+int tic_build_has_test_hooks(void);
 int tic_device_count(void);
 /* Create a context on HIP device `device`.  NULL on failure (tic_last_error(NULL) explains). */
 tic_ctx *tic_create(int device);

@@ -67,6 +67,54 @@ def zz_to_dc_ac(zz):
     return dc, zz[:, 1:].astype(np.int32)
 
 
+def test_shipped_library_in_a_fresh_process(tmp_path):
+    """This test process runs the test-hooks build (tests/conftest.py sets TIC_TEST_HOOKS=1: the same sources with -DTIC_TEST_HOOKS,
+    whose schedules and decoder paths the tests steer).  The SHIPPED library - no hooks, no environment - gets the parity core in
+    a fresh process here: config-2 coefficient digests at three qualities, Lenna's streams, a spread of the reference's benchmark set
+    through compress() / compress_batch() / decompress(), all against the reference-generated goldens."""
+    import subprocess
+    import sys
+
+    code = r'''
+import hashlib, json, os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import tinyimgcodec_amd as T
+from tinyimgcodec_amd import _native as N
+L = N.load()
+assert L.tic_build_has_test_hooks() == 0 and N._lib_path() == N.LIB_PATH
+sha = lambda b: hashlib.sha256(bytes(b)).hexdigest()
+G = os.path.join("tests", "golden")
+man = json.load(open(os.path.join(G, "manifest.json")))["entries"]
+ctx = T.Context(0)
+img = np.random.default_rng(1234).integers(0, 256, (4096, 4096), dtype=np.uint8)
+for q in (10, 50, 90):
+    e = T.encode(img, q, ctx=ctx)
+    m = man["rand1234_4096x4096_q%d" % q]
+    assert sha(e["dc"].astype("<i4").tobytes()) == m["dc_i4_sha256"] and sha(e["ac"].astype("<i4").tobytes()) == m["ac_i4_sha256"], q
+lenna = np.load(os.path.join(G, "lenna.npz"))
+for q in (10, 50, 90):
+    assert T.compress(lenna["img"], q, ctx=ctx) == lenna["q%d_bs" % q].tobytes(), q
+bm = json.load(open(os.path.join(G, "benchmark_set.json")))["entries"]
+px = np.load(os.path.join(G, "benchmark_set.npz"))["pixels"]
+n = 0
+for e in bm[::7]:
+    s = T.compress(px[e["image"] - 1], e["quality"], ctx=ctx)
+    assert len(s) == e["bytes"] and sha(s) == e["sha256"], e
+    assert sha(np.ascontiguousarray(T.decompress(s, ctx=ctx)).tobytes()) == e["decoded_sha256"], e
+    n += 1
+by = {(e["image"], e["quality"]): e for e in bm}
+for q in (5, 80):
+    for i, s in enumerate(T.compress_batch([px[i] for i in range(49)], q, ctx=ctx), 1):
+        assert sha(s) == by[(i, q)]["sha256"], (i, q)
+print("shipped library ok:", n, "benchmark pairs")
+'''
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TIC_")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "shipped library ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_dpp_byte_transpose_selftest(ctx):
     """The in-register DPP/v_perm 8x8 byte transpose equals the shuffle formulation and a numpy transpose."""
     n = 4096

@@ -24,10 +24,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(tic_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 25
-    lib = ctypes.CDLL(N.LIB_PATH)
-    for name in declared:
-        assert hasattr(lib, name), "library does not export %s" % name
+    for path, hooks in ((N.LIB_PATH, 0), (N.HOOKS_LIB_PATH, 1)):
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), "%s does not export %s" % (os.path.basename(path), name)
+        # the shipped library reads no environment: the hook gate is compiled out of it (csrc/tic_hooks.h), and with it every
+        # variable name; the test-hooks build of the same sources says what it is
+        assert lib.tic_build_has_test_hooks() == hooks
+        blob = open(path, "rb").read()
+        for var in (b"TIC_SCHED", b"TIC_SPLIT", b"TIC_DECODE_HOST", b"TIC_DECODE_SERIAL", b"TIC_COMM_FORCE_RCCL", b"TIC_BAND_BYTES", b"TIC_TEST_HOOKS"):
+            assert (var in blob) == bool(hooks) or var == b"TIC_TEST_HOOKS", (os.path.basename(path), var)
+        assert b"TIC_TEST_HOOKS" not in blob  # (neither build reads that one: _native.py picks the build by it)
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    assert N.load().tic_build_has_test_hooks() == 1  # tests/conftest.py sets TIC_TEST_HOOKS=1: this process runs the test-hooks build
     L = N.load()
     assert b"gfx950" in L.tic_version()
     assert L.tic_num_blocks(1080, 1920) == 32400 and L.tic_num_blocks(9, 9) == 4 and L.tic_num_blocks(0, 8) == 0
@@ -245,6 +254,7 @@ def test_strip_kernel_binary_keeps_its_landing_registers_private():
     spec.loader.exec_module(lint)
     try:
         summary = lint.check(N.LIB_PATH)
+        assert "80 VGPRs" in lint.check(N.HOOKS_LIB_PATH)
     except lint.ToolsMissing as e:
         pytest.skip(str(e))
     assert "80 VGPRs" in summary

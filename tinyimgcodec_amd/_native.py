@@ -8,7 +8,14 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinyimgcodec_hip.so")
+LIB_PATH = os.path.join(_HERE, "libtinyimgcodec_hip.so")              # the product: reads no environment variable
+HOOKS_LIB_PATH = os.path.join(_HERE, "libtinyimgcodec_hip_hooks.so")  # the same sources with -DTIC_TEST_HOOKS (csrc/tic_hooks.h)
+
+
+def _lib_path():
+    """The product library - unless TIC_TEST_HOOKS=1 is set when the library is first loaded (tests/conftest.py, tools/): then the
+    test-hooks build, whose code paths can be steered through TIC_* variables from inside one process."""
+    return HOOKS_LIB_PATH if os.environ.get("TIC_TEST_HOOKS") == "1" else LIB_PATH
 
 TIC_OK = 0
 TIC_E_ARG, TIC_E_QUALITY, TIC_E_RANGE, TIC_E_SPACE, TIC_E_STREAM, TIC_E_HIP, TIC_E_NODEVICE, TIC_E_BUSY = -1, -2, -3, -4, -5, -6, -7, -8
@@ -32,6 +39,7 @@ _ctxp = C.c_void_p
 # name -> (restype, argtypes): exactly the symbols include/tinyimgcodec_hip.h declares
 SIGNATURES = {
     "tic_version": (C.c_char_p, []),
+    "tic_build_has_test_hooks": (C.c_int, []),
     "tic_device_count": (C.c_int, []),
     "tic_create": (_ctxp, [C.c_int]),
     "tic_destroy": (None, [_ctxp]),
@@ -145,15 +153,16 @@ def load():
     global _lib
     with _lock:
         if _lib is None:
-            if not os.path.exists(LIB_PATH):
+            path = _lib_path()
+            if not os.path.exists(path):
                 raise NativeUnavailable(
                     "%s not found: build it with `make -C tinyimgcodec_amd/csrc` (or __graft_entry__.build()); "
-                    "tinyimgcodec_amd has no CPU fallback" % LIB_PATH
+                    "tinyimgcodec_amd has no CPU fallback" % path
                 )
             try:
-                L = C.CDLL(LIB_PATH)
+                L = C.CDLL(path)
             except OSError as e:  # missing ROCm runtime etc.
-                raise NativeUnavailable("cannot load %s: %s" % (LIB_PATH, e)) from e
+                raise NativeUnavailable("cannot load %s: %s" % (path, e)) from e
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)
                 fn.restype = res

@@ -227,6 +227,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 extern "C" {
 
 const char *tic_version(void) { return "tinyimgcodec_amd 0.1.0 (gfx950)"; }
+int tic_build_has_test_hooks(void) { return tic::test_hooks_enabled() ? 1 : 0; }
 
 int tic_device_count(void) {
     int n = 0;

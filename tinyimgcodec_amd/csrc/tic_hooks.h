@@ -1,7 +1,9 @@
 // tic_hooks.h - the one gate in front of every environment variable that changes which code path the library takes.
 //
-// Production never consults the environment for that: a stray variable cannot silently change a kernel path or a decoder.
-// With TIC_TEST_HOOKS=1 in the environment WHEN THE LIBRARY IS FIRST USED, the test suite (and tools/) may set
+// The SHIPPED library (libtinyimgcodec_hip.so) never consults the environment: test_hook() is a constant nullptr there and every
+// branch behind it folds away.  The same sources compiled with -DTIC_TEST_HOOKS (libtinyimgcodec_hip_hooks.so, built beside the
+// product by csrc/Makefile; tinyimgcodec_amd/_native.py loads it when TIC_TEST_HOOKS=1 is set, which tests/conftest.py and the
+// measurement scripts under tools/ do) read
 //   TIC_ENT_DIRECT_GROUPS   device entropy stage: group count above which stream offsets are summed in two levels
 //   TIC_DECODE_SERIAL       Huffman decoder: always the host's serial decoder
 //   TIC_DECODE_RANGE        device Huffman decoder: stream bits per lane (an odd number of 32-bit words, 288 ... 2016) instead of the choice by block length
@@ -13,18 +15,17 @@
 //   TIC_COMM_FORCE_RCCL     a single rank goes through RCCL too (the only way to exercise tic_comm.hip on a one-GPU box)
 //   TIC_TUNE, TIC_SPLIT, TIC_SCHED, TIC_CHUNK, TIC_MAX_WGS   schedule knobs of the strip kernel's launcher
 //   TIC_BAND_BYTES          size from which a frame is transformed in bands of block rows (4 GiB in production)
-// and these are then read at every call (tests flip them inside one process).
+// at every call (tests flip them inside one process).  tic_build_has_test_hooks() tells which build a process has loaded;
+// tests/test_gpu_parity.py::test_shipped_library_in_a_fresh_process runs the parity core on the product build.
 #pragma once
 #include <stdlib.h>
 
 namespace tic {
-inline bool test_hooks_enabled() {
-    static const bool on = [] {
-        const char *v = getenv("TIC_TEST_HOOKS");
-        return v != nullptr && v[0] == '1' && v[1] == 0;
-    }();
-    return on;
-}
-// Value of test hook `name`, or nullptr when hooks are off (the usual case: one load of a static flag) or the variable is unset.
-inline const char *test_hook(const char *name) { return test_hooks_enabled() ? getenv(name) : nullptr; }
+#ifdef TIC_TEST_HOOKS
+inline bool test_hooks_enabled() { return true; }
+inline const char *test_hook(const char *name) { return getenv(name); }
+#else
+inline constexpr bool test_hooks_enabled() { return false; }
+inline constexpr const char *test_hook(const char *) { return nullptr; }
+#endif
 } // namespace tic

@@ -5,7 +5,7 @@ import argparse, ctypes as C, os, statistics, sys
 os.environ["TIC_TUNE"] = "1"
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tools')
-import _ablate  # noqa: F401  (experiment build of the library)
+os.environ["TIC_TEST_HOOKS"] = "1"  # the test-hooks build of the product sources honours the schedule knobs
 import numpy as np
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N

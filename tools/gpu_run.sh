@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs a list of GPU steps on the gpurun box, each under its own timeout; stops at the first step that is killed
 # by its timeout (never starts another GPU step after a hang).  Usage: tools/gpu_run.sh step1 step2 ...
-# Steps: microbench[2|3] | tests | tests_fast | tests_all | smoke | bench | bench_exact | bench16k | sweep | ablate | ab |
-#        stamps | prof | pmc_rd | pmc_wr | pmc_sq | pmc_sq2 | pmc_cal | pmc_cal_wr | config5   (binaries: make -C tools)
+# Steps: microbench[2..7] | tests | tests_fast | tests_all | smoke | bench | bench_cold | bench_exact | bench16k | sweep | content |
+#        width_sweep | shape_ab | prof | prof_cold | pmc_rd | pmc_wr | pmc_sq | pmc_sq2 | pmc_cal | pmc_cal_wr | config5 | ...   (binaries: make -C tools)
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
@@ -25,14 +25,8 @@ for step in "$@"; do
     microbench5) run microbench5 300 ./tools/bin/microbench5 ;;
     microbench6) run microbench6 300 ./tools/bin/microbench6 ;;
     microbench7) run microbench7 300 ./tools/bin/microbench7 ;;
-    parity)     run parity 600 python tools/parity_variant.py ${TIC_PARITY_VARIANTS:-50} ;;
-    ab_pol)     run ab_pol 600 python tools/ab.py --dims 4096 --rounds ${TIC_AB_ROUNDS:-5} --iters 400 --variants ${TIC_AB_VARIANTS:-2,50} "" ;;
-    ab_pol16k)  run ab_pol16k 600 python tools/ab.py --dims 16384 --rounds 4 --iters 20 --variants ${TIC_AB_VARIANTS16:-2,50} "" ;;
     compress_dev) run compress_dev 200 python tools/prof_compress_dev.py 4096 200 ;;
     prof_cdev)  rm -rf gpurun_out/prof_cdev; run prof_cdev 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cdev -- python tools/prof_compress_dev.py 4096 200 ;;
-    ent_abl)    for a in ${TIC_ENT_ABLS:-0 1 2 3 4 7}; do rm -rf gpurun_out/ent_abl$a; export TIC_USE_ABLATE=1 TIC_ENT_ABL=$a; run ent_abl$a 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ent_abl$a -- python tools/prof_compress_dev.py 4096 100; unset TIC_USE_ABLATE TIC_ENT_ABL; done ;;
-    pmc_ent_abl) for a in ${TIC_ENT_ABLS:-0 2 4 7 32}; do rm -rf gpurun_out/pmc_ent_abl$a; export TIC_USE_ABLATE=1 TIC_ENT_ABL=$a; run pmc_ent_abl$a 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_ent_abl$a -- python tools/prof_compress_dev.py 4096 10; unset TIC_USE_ABLATE TIC_ENT_ABL; done ;;
-    place_abl)  for a in ${TIC_PLACE_ABLS:-0 1 2 3 4 7}; do rm -rf gpurun_out/place_abl$a; export TIC_USE_ABLATE=1 TIC_PLACE_ABL=$a; run place_abl$a 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/place_abl$a -- python tools/prof_compress_dev.py 4096 100; unset TIC_USE_ABLATE TIC_PLACE_ABL; done ;;
     stress)     run stress 900 python tools/stress_parity.py ${TIC_STRESS_ITERS:-300} ;;
     decomp)     run decomp 200 python tools/prof_decompress.py 4096 30 50; run decomp90 200 python tools/prof_decompress.py 4096 30 90; export TIC_CONTENT=lenna; run decomp_lenna 200 python tools/prof_decompress.py 4096 30 50; unset TIC_CONTENT ;;
     prof_decomp) rm -rf gpurun_out/prof_decomp; run prof_decomp 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_decomp -- python tools/prof_decompress.py 4096 50 50 ;;
@@ -41,13 +35,10 @@ for step in "$@"; do
     stress_ent) run stress_ent 600 python tools/stress_entropy.py ${TIC_STRESS_ENT:-300} ;;
     decomp16k)  run decomp16k 300 python tools/prof_decompress.py 16384 5 50 ;;
     stress_dec) run stress_dec 600 python tools/stress_decoder.py ${TIC_STRESS_DEC:-150} ;;
-    content)    run content 300 python tools/natural_content.py ;;
+    content)    run content 300 python tools/natural_content.py ${TIC_CONTENT_LIBS:-} ;;
+    width_sweep) run width_sweep 400 python tools/width_sweep.py 134 1024 4096 64 ;;
+    shape_ab)   run shape_ab 400 python tools/shape_ab.py ;;
     ab_cold)    run ab_cold 400 python tools/ab_cold.py ;;
-    stamps2)    run stamps2 200 python tools/stamps2.py ;;
-    stamps3)    run stamps3 200 python tools/stamps3.py ;;
-    ablate)     run ablate 300 python tools/ablate.py ;;
-    stamps)     run stamps 200 python tools/stamps.py ;;
-    ab)         run ab 600 python tools/ab.py --variants 2,12,15,18,20 "" ;;
     tests)      run pytest_gpu 900 python -m pytest tests -m gpu -x -q ;;
     tests_fast) run pytest_gpu_fast 600 python -m pytest tests -m gpu -x -q -k "not 16384" ;;
     tests_all)  run pytest_gpu_all 900 python -m pytest tests -m gpu -q ;;
@@ -59,6 +50,7 @@ for step in "$@"; do
     config5)    for q in 10 50 90; do
                   rm -rf gpurun_out/c5_prof_q$q gpurun_out/c5_rd_q$q gpurun_out/c5_wr_q$q
                   C5="bench.py --height 16384 --width 16384 --quality $q --steps 20 --warmup 3 --no-cpu-baseline --no-config4 --no-cold"
+                  run c5_cold_q$q 300 python bench.py --height 16384 --width 16384 --quality $q --steps 20 --warmup 3 --no-cpu-baseline --no-config4
                   run c5_prof_q$q 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/c5_prof_q$q -- python $C5
                   run c5_rd_q$q 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/c5_rd_q$q -- python bench.py --height 16384 --width 16384 --quality $q --steps 3 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-config4 --no-cold
                   run c5_wr_q$q 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/c5_wr_q$q -- python bench.py --height 16384 --width 16384 --quality $q --steps 3 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-config4 --no-cold

@@ -8,7 +8,7 @@ import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N
 import os
 if os.environ.get('TIC_LIB'):  # another build of the library (tools/Makefile bin/libvar_%.so)
-    N.LIB_PATH = os.environ['TIC_LIB']
+    N.LIB_PATH = N.HOOKS_LIB_PATH = os.environ['TIC_LIB']
 L = N.load(); ctx = T.Context(0)
 n, h, w = 256, 1080, 1920
 frames = [np.random.default_rng(1234 + i).integers(0, 256, (h, w), dtype=np.uint8) for i in range(n)]

@@ -4,9 +4,6 @@ import ctypes as C, sys, time
 sys.path.insert(0, '.')
 import numpy as np
 import os
-if os.environ.get('TIC_USE_ABLATE'):
-    sys.path.insert(0, 'tools')
-    import _ablate  # noqa: F401  (the experiment build: honours TIC_ENT_ABL)
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N
 L = N.load(); ctx = T.Context(0)

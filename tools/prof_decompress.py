@@ -6,7 +6,7 @@ import numpy as np
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N
 if os.environ.get('TIC_LIB'):  # another build of the library (tools/Makefile bin/libvar_%.so)
-    N.LIB_PATH = os.environ['TIC_LIB']
+    N.LIB_PATH = N.HOOKS_LIB_PATH = os.environ['TIC_LIB']
 L = N.load(); ctx = T.Context(0)
 dim = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20

@@ -42,6 +42,29 @@ if ks:
         if KERNEL in r["Name"]:
             out["kernel_stats"] = {"kernel": r["Name"], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
                                    "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+# The K timed launches are the LAST K strip-kernel launches of the trace (bench.py --no-cold --no-config4: a statistics launch, the
+# settling bursts, W warm-up launches, then the K steps between the two HIP events): their average is the figure to hold against the
+# same run's bench line (roofline.kernel_us = ms_per_step), on the same box; rocprofv3's own AverageNs includes the settling launches.
+kt = sorted(glob.glob(os.path.join(G, "prof", "*", "*kernel_trace.csv")), key=os.path.getmtime, reverse=True)
+bench_line = None
+for cand in ("prof.txt",):
+    pth = os.path.join(G, cand)
+    if os.path.exists(pth):
+        for ln in open(pth).read().splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                bench_line = json.loads(ln)
+if kt and bench_line:
+    K = int(bench_line["steps"])
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if KERNEL in r["Kernel_Name"]]
+    if len(d) >= K:
+        t = statistics.mean(d[-K:])
+        out["timed_steps"] = {"steps": K, "average_ns": round(t, 1), "frac_of_8TBps": round(3.0 * 4096 * 4096 / t / 8000.0, 4),
+                              "bench_line_kernel_us_hip_events": bench_line["roofline"]["kernel_us"], "bench_line_ms_per_step": bench_line["ms_per_step"],
+                              "kernel_time_le_ms_per_step": bool(t / 1e6 <= bench_line["ms_per_step"] * 1.0005),
+                              "note": "the last K launches of the same rocprofv3 trace the bench line was printed under: kernel time (trace) <= ms_per_step (HIP events "
+                                      "around the K launches, which add the gaps between launches)"}
+        with open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w") as f:
+            json.dump(bench_line, f)
 kc = sorted(glob.glob(os.path.join(G, "prof_cold", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if kc:
     shutil.copy(kc[0], os.path.join(P, f"{tag}_rocprofv3_kernel_stats_cold.csv"))
