@@ -1,11 +1,13 @@
-"""Same-box, same-clock comparison of frame shapes at ~265 Mpixel (dense rows): rounds interleaved, long runs."""
+"""Same-box, same-clock comparison of frame shapes of EQUAL input footprint (h x pitch ~ 265 MB, at the edge of the 256 MiB Infinity Cache;
+the config-4 shard at 531 MB): rounds interleaved, long runs.  (Round 4 listed the padded shape with the dense shape's height: 283 MB against
+265 MB - the 0.65 it read for pitch 2048 was the cache footprint, profiles/r05_geometry.txt.)"""
 import ctypes as C, statistics, sys
 sys.path.insert(0, '.')
 import numpy as np
 import tinyimgcodec_amd as T
 from tinyimgcodec_amd import _native as N
 L = N.load(); ctx = T.Context(0)
-shapes = [(138240, 1920, 1920), (138240, 1920, 2048), (129600, 2048, 2048), (16384, 16384, 16384), (276480, 1920, 1920), (64800, 4096, 4096)]
+shapes = [(138240, 1920, 1920), (129600, 1920, 2048), (129600, 2048, 2048), (16384, 16384, 16384), (276480, 1920, 1920), (64800, 4096, 4096)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 big = max(h * p for h, w, p in shapes)
