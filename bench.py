@@ -397,10 +397,6 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             "path) runs a 4096^2 launch in 7.7-7.8 us = 0.81 on every content; what the shipped kernel adds is the rare work on the launch's tail - the batch of "
             "blocks with an irrational coefficient inside its guard band (528 of 262,144 here: ~1.0 us, the launch ends with the unluckiest of 6,144 waves) and "
             "the strips whose rational ties are settled in the loop (one strip in six: ~0.3-1.0 us by box) - profiles/r05_content_ablation.txt, DESIGN.md 5.5",
-            "HBM on frames beyond the caches (0.72 of 8 TB/s: the 531-Mpixel config-4 shard, twelve 16384^2 pairs in rotation - DESIGN.md 5.5, "
-            "profiles/r04_shape_ab.txt); what a 4096^2 launch adds to that stream is its fill (first pixels ~0.8 us after the first wave) and its tail: the "
-            "batch pass that settles the tripped blocks costs 1.0-1.3 us warm and cold, and the launch ends with the slowest of 6,144 waves "
-            "(profiles/r04_tail_experiments.txt: a per-workgroup pooled pass was built and does not shorten it)",
         },
     }
     if cold is not None:
