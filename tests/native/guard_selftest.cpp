@@ -40,22 +40,44 @@ static double worst_ratio[64];  // max over blocks of error / kGuard, coefficien
 static double worst_ratio_q[64]; // the same in quantised units (worst of the three qualities)
 static long n_blocks = 0, n_viol = 0;
 
-static void check_block(const uint8_t px[64]) {
-    // fast path: pass 1 down the pixel columns, level shift folded into output 0, pass 2 along the rows
-    float y[8][8]; // y[u][c]
-    for (int c = 0; c < 8; c++) {
-        float d[8];
-        for (int r = 0; r < 8; r++) d[r] = (float)px[r * 8 + c];
-        dct8_aan(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
-        d[0] -= 1024.0f;
-        for (int u = 0; u < 8; u++) y[u][c] = d[u];
-    }
+static void check_block_order(const uint8_t px[64], bool cols_first);
+static void check_block(const uint8_t px[64]) { // both instantiations of the strip kernel
+    check_block_order(px, true);
+    check_block_order(px, false);
+}
+static void check_block_order(const uint8_t px[64], bool cols_first) {
+    // fast path: pass 1 down the pixel columns (columns first) or along the pixel rows (rows first), level shift folded into output 0
     float z[8][8]; // z[u][v]
-    for (int u = 0; u < 8; u++) {
-        float e[8];
-        for (int c = 0; c < 8; c++) e[c] = y[u][c];
-        dct8_aan(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
-        for (int v = 0; v < 8; v++) z[u][v] = e[v];
+    if (cols_first) {
+        float y[8][8]; // y[u][c]
+        for (int c = 0; c < 8; c++) {
+            float d[8];
+            for (int r = 0; r < 8; r++) d[r] = (float)px[r * 8 + c];
+            dct8_aan(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+            d[0] -= 1024.0f;
+            for (int u = 0; u < 8; u++) y[u][c] = d[u];
+        }
+        for (int u = 0; u < 8; u++) {
+            float e[8];
+            for (int c = 0; c < 8; c++) e[c] = y[u][c];
+            dct8_aan(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+            for (int v = 0; v < 8; v++) z[u][v] = e[v];
+        }
+    } else {
+        float y[8][8]; // y[r][v]
+        for (int r = 0; r < 8; r++) {
+            float d[8];
+            for (int c = 0; c < 8; c++) d[c] = (float)px[r * 8 + c];
+            dct8_aan(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+            d[0] -= 1024.0f;
+            for (int v = 0; v < 8; v++) y[r][v] = d[v];
+        }
+        for (int v = 0; v < 8; v++) {
+            float e[8];
+            for (int r = 0; r < 8; r++) e[r] = y[r][v];
+            dct8_aan(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+            for (int u = 0; u < 8; u++) z[u][v] = e[u];
+        }
     }
     // reference order in float64: axis -2 (down the columns) first, then axis -1
     double x[8][8];
@@ -66,25 +88,27 @@ static void check_block(const uint8_t px[64]) {
         for (int u = 0; u < 8; u++) x[u][c] = d[u];
     }
     for (int u = 0; u < 8; u++) dct8_exact(x[u][0], x[u][1], x[u][2], x[u][3], x[u][4], x[u][5], x[u][6], x[u][7]);
-    n_blocks++;
+    if (cols_first) n_blocks++;
     for (int u = 0; u < 8; u++)
         for (int v = 0; v < 8; v++) {
             const int i = u * 8 + v;
             const double fast = (double)z[u][v] / (aan[u] * aan[v] * 8.0);
-            const double r1 = fabs(fast - x[u][v]) / guard_cf(u, v);
+            const double G = cols_first ? guard_cf(u, v) : kGuard[i];
+            const double r1 = fabs(fast - x[u][v]) / G;
             if (r1 > worst_ratio[i]) worst_ratio[i] = r1;
             double rq = 0;
             for (const DctqConsts *C : {&C1, &C10, &C50, &C90, &C99}) {
-                const float mul = C->mulN[i];
+                const float mul = cols_first ? C->mulN[i] : C->mulT[v * 8 + u];
                 const double t_fused = (double)z[u][v] * (double)mul;       // the exact product inside the fma
                 const double want = x[u][v] / C->div[i];
-                const double r = fabs(t_fused - want) / (guard_cf(u, v) / C->div[i]);
+                const double r = fabs(t_fused - want) / (G / C->div[i]);
                 if (r > rq) rq = r;
                 // the kernel's accept test, operation for operation (quant_fma + the max/compare of the strip kernel)
                 const float s = fmaf(z[u][v], mul, kMagic);
                 const float nr = kMagic - s;
                 const float d = fmaf(z[u][v], mul, nr);
-                const float thr = C->thrR[4 * u + ((v == 0 || v == 4) ? 2 : (v < 4 ? 0 : 1))]; // the strip kernel's three groups per frequency row
+                const float thr = cols_first ? C->thrR[4 * u + ((v == 0 || v == 4) ? 2 : (v < 4 ? 0 : 1))]   // three groups per frequency row
+                                             : C->thrG[4 * v + ((u == 0 || u == 4) ? 2 : (u < 4 ? 0 : 1))];  // ... per frequency column
                 if (fabsf(d) > thr) {
                     n_trip++;
                     const int qi = C == &C1 ? 0 : C == &C10 ? 1 : C == &C50 ? 2 : C == &C90 ? 3 : 4;
@@ -112,7 +136,7 @@ int main(int argc, char **argv) {
             if (!build_consts(q, &a) || !build_consts((double)q, &b)) { printf("FAIL build_consts(%d)\n", q); return 1; }
             for (int i = 0; i < 64; i++) {
                 const double want = q < 50 ? ((double)kQTable[i] * (5000.0 / (double)q)) / 100.0 : (double)(kQTable[i] * (200 - 2 * q)) / 100.0;
-                if (a.div[i] != want || b.div[i] != want || a.mulN[i] != b.mulN[i] || a.thrR[i & 31] != b.thrR[i & 31]) { printf("FAIL divisors of quality %d\n", q); return 1; }
+                if (a.div[i] != want || b.div[i] != want || a.mulN[i] != b.mulN[i] || a.thrR[i & 31] != b.thrR[i & 31] || a.mulT[i] != b.mulT[i] || a.thrG[i & 31] != b.thrG[i & 31]) { printf("FAIL divisors of quality %d\n", q); return 1; }
             }
         }
         if (build_consts(0.999, &a) || build_consts(99.001, &a) || build_consts(nan(""), &a) || !build_consts(37.5, &a)) { printf("FAIL range of build_consts\n"); return 1; }

@@ -316,7 +316,7 @@ def _true_tie_block():
     return blk.astype(np.uint8)
 
 
-def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden):
+def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden, monkeypatch):
     """Every rare path of the production kernel against the exact kernel and the oracle: rational ties settled inside the loop
     (rational_quad: flat, banded, two-level and posterised content trips it in every strip, noise in one strip of six), the wave's
     batch of irrational trips (second level, exact order inside the batch, strips with ties AND trips), batch overflow and strips in
@@ -353,12 +353,17 @@ def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden):
         "noise at the top of the quality range": (rand_frame(12, 1024, 2048), (90, 97, 99)),
         "posterised noise (ties and trips in the same strips)": ((rand_frame(13, 1024, 2048) // 8 * 8 + 1).astype(np.uint8), (50, 90, 99)),
     }
+    monkeypatch.setenv("TIC_TUNE", "1")  # re-read the knobs at every launch
     for name, (img, quals) in frames.items():
         f = DevFrame(ctx, img)
         for q in quals:
             want = oracle.encode_zz16(img, q)
             assert np.array_equal(f.run(q, N.KERNEL_EXACT), want), (name, q, "exact kernel")
-            assert np.array_equal(f.run(q, N.KERNEL_HYBRID), want), (name, q, "production kernel")
+            for order in ("1", "0"):  # both instantiations of the strip kernel: columns first, rows first (TIC_ORDER: csrc/tic_hooks.h)
+                monkeypatch.setenv("TIC_ORDER", order)
+                assert np.array_equal(f.run(q, N.KERNEL_HYBRID), want), (name, q, "production kernel", "columns first" if order == "1" else "rows first")
+            monkeypatch.delenv("TIC_ORDER")
+            assert np.array_equal(f.run(q, N.KERNEL_HYBRID), want), (name, q, "production kernel, order by grid")
         f.free()
 
 
@@ -373,8 +378,9 @@ def test_strip_schedules_are_equivalent(ctx, monkeypatch):
         f = DevFrame(ctx, img)
         ref = f.run(50, N.KERNEL_EXACT)
         for knobs in ({}, {"TIC_SPLIT": "0"}, {"TIC_SPLIT": "1,1,1,1,1"}, {"TIC_SCHED": "0"}, {"TIC_SCHED": "1", "TIC_CHUNK": "5"},
-                      {"TIC_SCHED": "2"}, {"TIC_MAX_WGS": "512"}):
-            for k in ("TIC_SPLIT", "TIC_SCHED", "TIC_CHUNK", "TIC_MAX_WGS"):
+                      {"TIC_SCHED": "2"}, {"TIC_MAX_WGS": "512"}, {"TIC_ORDER": "0"}, {"TIC_ORDER": "1"}, {"TIC_ORDER": "0", "TIC_SCHED": "0"},
+                      {"TIC_ORDER": "1", "TIC_SCHED": "1", "TIC_CHUNK": "3"}):
+            for k in ("TIC_SPLIT", "TIC_SCHED", "TIC_CHUNK", "TIC_MAX_WGS", "TIC_ORDER"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in knobs.items():
                 monkeypatch.setenv(k, v)

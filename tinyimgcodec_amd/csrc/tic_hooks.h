@@ -14,6 +14,7 @@
 //   TIC_DECODE_THREADS      host Huffman decoder: threads of the parallel decoder
 //   TIC_COMM_FORCE_RCCL     a single rank goes through RCCL too (the only way to exercise tic_comm.hip on a one-GPU box)
 //   TIC_TUNE, TIC_SPLIT, TIC_SCHED, TIC_CHUNK, TIC_MAX_WGS   schedule knobs of the strip kernel's launcher
+//   TIC_ORDER               pass order of the strip kernel (0 rows first, 1 columns first) instead of the choice by grid
 //   TIC_BAND_BYTES          size from which a frame is transformed in bands of block rows (4 GiB in production)
 // at every call (tests flip them inside one process).  tic_build_has_test_hooks() tells which build a process has loaded;
 // tests/test_gpu_parity.py::test_shipped_library_in_a_fresh_process runs the parity core on the product build.

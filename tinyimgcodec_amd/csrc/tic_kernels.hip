@@ -346,6 +346,36 @@ __device__ __forceinline__ int rational_quad(const uint32_t *ldsT, int b, int i,
     return (int)rint(X / div); // np.round(X / div): IEEE divide, half-even
 }
 
+// Exact float64 sub-path of the four rational coefficients, 8 lanes per block, no LDS: rowLo/rowHi = pixel row i of the lane's
+// block.  The row's bytes are first reordered (0,7,3,4,1,2,5,6) so that, after the byte transpose, neighbouring lanes hold the
+// columns pocketfft adds first: the 8-point sums of SURVEY Appendix A become three DPP butterflies (xor 1, xor 2, +4).
+// Column sums come from v_sad_u8.  Lanes 0..3 of the block return (0,0), (0,4), (4,0), (4,4) - one coefficient, one division at
+// most, per lane.  Used by the rows-first instantiation, whose fast path has no column sums.
+__device__ __forceinline__ int rational_slim(uint32_t rowLo, uint32_t rowHi, int i, const double *cst_rat) {
+#pragma clang fp contract(off)
+    uint32_t lo = perm_b32(rowHi, rowLo, 0x04030700u); // x0 x7 x3 x4
+    uint32_t hi = perm_b32(rowHi, rowLo, 0x06050201u); // x1 x2 x5 x6
+    transpose8x8_bytes(lo, hi, i);                     // lane i: column (0,7,3,4,1,2,5,6)[i], bytes = rows 0..7
+    const uint32_t tot = __builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+    const uint32_t sa = __builtin_amdgcn_sad_u8(lo & 0xff0000ffu, 0u, __builtin_amdgcn_sad_u8(hi & 0xff0000ffu, 0u, 0u)); // rows 0,3,4,7
+    const int e0 = (int)tot - 1024, e4 = 2 * (int)sa - (int)tot;
+    double y0 = (double)e0 * (kSq2h * 0.5);
+    double y4 = (double)e4 * (kTW3 * 0.5);
+    y0 = y0 + dpp_f64<TIC_DPP_QP_XOR1>(y0); // a0+a7 | a3+a4 | a1+a2 | a5+a6
+    y4 = y4 + dpp_f64<TIC_DPP_QP_XOR1>(y4);
+    y0 = y0 + dpp_f64<TIC_DPP_QP_XOR2>(y0); // A = p07 + p34 (lanes 0..3) | B = p12 + p56 (lanes 4..7)
+    y4 = y4 + dpp_f64<TIC_DPP_QP_XOR2>(y4);
+    const double b0 = dpp_f64<TIC_DPP_ROW_SHL4>(y0), b4 = dpp_f64<TIC_DPP_ROW_SHL4>(y4); // lanes 0..3 read B
+    const double A = (i & 2) ? y4 : y0, B = (i & 2) ? b4 : b0;       // lanes 0,1: frequency row u = 0; lanes 2,3: u = 4
+    const double E = (i & 1) ? A - B : A + B;                         // v = 0 | v = 4
+    const double X = E * ((i & 1) ? (kTW3 * 0.5) : (kSq2h * 0.5));
+    const double div = cst_rat[i & 3], rdiv = cst_rat[4 + (i & 3)];
+    const double t = X * rdiv;
+    double r = rint(t);
+    // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
+    if (fabs(fabs(t - r) - 0.5) < 1e-9) r = rint(X / div);
+    return (int)r;
+}
 // A block redone by the whole wave in float64 straight from the definition (lane 8*u + c: t[u][c] = sum_r M[u][r] x[r][c], then
 // X[u][v = c] = sum_k M[v][k] t[u][k]; error ~1e-13, the reference's own is ~1e-12).  A rounding is decided when no .5 tie lies
 // within 1e-9 of X * (1/div); decided values go to their place in the block's 128-byte zig-zag image.  The four rational
@@ -406,6 +436,14 @@ __device__ __forceinline__ uint32_t second_level_8(uint32_t colLo, uint32_t colH
     return und;
 }
 
+// kCols: the pass order of the fast path.  true  - columns first, byte transpose through LDS, ties from the exact column sums (rational_quad):
+//                 grids that fit the chip at once, where every wave owns its strips in advance and the launch ends with the unluckiest one;
+//        false - rows first, the pixels converted straight out of the landing registers (no byte transpose: 22 LDS cycles and a dependent
+//                 LDS round trip less per strip), ties from the pixels (rational_slim, ~75 instructions per tie strip): grids of several
+//                 rounds (16384^2, batches), where workgroups are dispatched as others finish and what counts is the average cost per
+//                 strip - 16384^2 at q = 10 / 50 / 90: 107 / 119 / 127 us rows first against 123 / 130 / 137 us columns first
+//                 (profiles/r05_config5.json, r04_config5.json).  Same results, bit for bit (tests run both orders on every rare-path frame).
+template <bool kCols>
 __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr(72))) void dctq_strip_kernel(DctqArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t ldsT_all[kWavesPerWG][kTWaveBytes / 4];
     __shared__ __attribute__((aligned(16))) uint32_t ldsZ_all[kWavesPerWG][kZzWaveBytes / 4];
@@ -455,10 +493,14 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         //   zig-zag staging: scan position p of block b at byte (p>>3)*128 + 16*(b ^ f(p>>3)) + 2*(p&7), f(c) = bit 1 of c | 4 * bit 2 of c
         const uint32_t px_wr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(ldsZ + lb * kPxBlkBytes + lr * 8);
         const uint8_t *px_rd = reinterpret_cast<const uint8_t *>(ldsZ + b * kPxBlkBytes + i);
-        uint32_t *twA = ldsT + (i >> 2) * kTHalfDw + (i & 3) + 4 * b;       // u in {0,1,4,5}: + u*32 dwords
-        uint32_t *twB = ldsT + (i >> 2) * kTHalfDw + (i & 3) + 4 * (b ^ 4); // u in {2,3,6,7}
+        // (pass 1 runs in the compute layout - lane 8*b + c - columns first, in the load layout - lane 8*r + b - rows first; the half
+        //  offset of 272 dwords keeps the compute layout's 32-lane write groups conflict-free, the load layout needs none: 256)
+        constexpr int kHalf = kCols ? kTHalfDw : 256;
+        const int p1a = kCols ? i : lr, p1b = kCols ? b : lb;
+        uint32_t *twA = ldsT + (p1a >> 2) * kHalf + (p1a & 3) + 4 * p1b;       // outputs {0,1,4,5}: + k*32 dwords
+        uint32_t *twB = ldsT + (p1a >> 2) * kHalf + (p1a & 3) + 4 * (p1b ^ 4); // outputs {2,3,6,7}
         const uint4 *tr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // columns 0..3; columns 4..7 at +272 dwords
+            __builtin_assume_aligned(ldsT + i * 32 + 4 * (b ^ (4 * ((i >> 1) & 1))), 16)); // first half; the second kHalf dwords on
         const uint32_t ld_off = (uint32_t)(lr * (int)a.stride + lb * 8); // lane offset from the strip's first pixel
 
         // Strip walk: one scalar cursor (that of the prefetch).  Its start state takes ~25 scalar instructions: no division
@@ -521,7 +563,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
     // waits until all but the N youngest vector-memory operations are done, then sends the strip's pixel rows from the landing pair
     // v[R] (which keeps the strip's bytes until the pair is loaded again, two strips later: the batch fetches the raw words from
     // there, raw_words) to the byte-transpose buffer
-#define TIC_TAKE(R, N) asm volatile("s_waitcnt vmcnt(" #N ")\n\tds_write_b64 %0, v[" R "]" : : "v"(px_wr) : TIC_RSV_CLOBBER)
+#define TIC_TAKE_COLS(R, N) asm volatile("s_waitcnt vmcnt(" #N ")\n\tds_write_b64 %0, v[" R "]" : : "v"(px_wr) : TIC_RSV_CLOBBER)
+    // rows first: waits, then converts the strip's eight pixels straight out of the landing registers v[R0], v[R1]
+#define TIC_TAKE_ROWS(D, R0, R1, N)                                                                          \
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_cvt_f32_ubyte0 %0, v" #R0 "\n\tv_cvt_f32_ubyte1 %1, v" #R0 "\n\tv_cvt_f32_ubyte2 %2, v" #R0 \
+                 "\n\tv_cvt_f32_ubyte3 %3, v" #R0 "\n\tv_cvt_f32_ubyte0 %4, v" #R1 "\n\tv_cvt_f32_ubyte1 %5, v" #R1                       \
+                 "\n\tv_cvt_f32_ubyte2 %6, v" #R1 "\n\tv_cvt_f32_ubyte3 %7, v" #R1                                                       \
+                 : "=v"(D[0]), "=v"(D[1]), "=v"(D[2]), "=v"(D[3]), "=v"(D[4]), "=v"(D[5]), "=v"(D[6]), "=v"(D[7]) : : TIC_RSV_CLOBBER)
         uint32_t ob0, ob1, ob2;
         uint32_t kstrip = 0; // ordinal of the strip in this wave's walk
         TIC_LOAD("72:73", ob0);
@@ -533,18 +581,20 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         if (lane < kStripBlkPieces / kWavesPerWG) *reinterpret_cast<u32x4 *>(cst_blk + (wave * (kStripBlkPieces / kWavesPerWG) + lane) * 16) = c_fill;
         // workgroup barrier by hand (the compiler's would also wait for the pixel loads it does not know about)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
-        m0 = *reinterpret_cast<const f32x4 *>(cst_blk + kBlkMul + i * 32);      // multipliers of (u = i, v = 0..3)
-        m1 = *reinterpret_cast<const f32x4 *>(cst_blk + kBlkMul + i * 32 + 16); // ... v = 4..7
-        thr = *reinterpret_cast<const f32x4 *>(cst_blk + kBlkThr + i * 16);     // accept thresholds of row u = i: v in {1,2,3} | {5,6,7} | {0,4}
-        zzv = *reinterpret_cast<const u32x4 *>(cst_blk + kBlkZz + i * 16);      // byte offsets of (u = i, v = 0..7) in the block's zig-zag image
+        // pass 2's lane holds frequency row u = i (columns first) or frequency column v = i (rows first): its eight multipliers, its
+        // three accept thresholds (groups {1,2,3} | {5,6,7} | {0,4} of the other index), its eight offsets in the zig-zag image
+        m0 = *reinterpret_cast<const f32x4 *>(cst_blk + (kCols ? kBlkMul : kBlkMulT) + i * 32);
+        m1 = *reinterpret_cast<const f32x4 *>(cst_blk + (kCols ? kBlkMul : kBlkMulT) + i * 32 + 16);
+        thr = *reinterpret_cast<const f32x4 *>(cst_blk + (kCols ? kBlkThr : kBlkThrT) + i * 16);
+        zzv = *reinterpret_cast<const u32x4 *>(cst_blk + (kCols ? kBlkZz : kBlkZzT) + i * 16);
         auto zz_ptr = [&](uint32_t ofs) { // ofs = 2 * scan position of the coefficient
-            const uint32_t c = ofs >> 4;
-            return reinterpret_cast<int16_t *>(ldsZ + c * 128 + (ofs & 15) + 16 * (b ^ (((c >> 1) & 1) | (c & 4))));
+            const uint32_t c = ofs >> 4; // (the chunk's swizzle: found by search for either lane mapping, tools/lds_bank_model.py)
+            return reinterpret_cast<int16_t *>(ldsZ + c * 128 + (ofs & 15) + 16 * (b ^ (kCols ? (((c >> 1) & 1) | (c & 4)) : (4 * ((c >> 1) & 1)))));
         };
         int16_t *zp0 = zz_ptr(zzv.x & 0xffff), *zp1 = zz_ptr(zzv.x >> 16), *zp2 = zz_ptr(zzv.y & 0xffff), *zp3 = zz_ptr(zzv.y >> 16);
         int16_t *zp4 = zz_ptr(zzv.z & 0xffff), *zp5 = zz_ptr(zzv.z >> 16), *zp6 = zz_ptr(zzv.w & 0xffff), *zp7 = zz_ptr(zzv.w >> 16);
         const uint4 *zr = reinterpret_cast<const uint4 *>(
-            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (((i >> 1) & 1) | (i & 4)))), 16));
+            __builtin_assume_aligned(ldsZ + 16 * (i * 8 + (b ^ (kCols ? (((i >> 1) & 1) | (i & 4)) : (4 * ((i >> 1) & 1))))), 16));
         wave_lds_fence();
 
         int left = n_my;
@@ -556,18 +606,22 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
             else if constexpr (R == 74) asm volatile("v_mov_b32 %0, v74\n\tv_mov_b32 %1, v75" : "=v"(lo), "=v"(hi) : : "memory");
             else asm volatile("v_mov_b32 %0, v76\n\tv_mov_b32 %1, v77" : "=v"(lo), "=v"(hi) : : "memory");
         };
-        auto process = [&](auto tag, const uint32_t ob) {
-            // ---- byte transpose: pixel column c = i of block b, rows 0..7 (written by TIC_TAKE) ---------------------------
-            float d0 = (float)px_rd[0], d1 = (float)px_rd[8], d2 = (float)px_rd[16], d3 = (float)px_rd[24];
-            float d4 = (float)px_rd[32], d5 = (float)px_rd[40], d6 = (float)px_rd[48], d7 = (float)px_rd[56];
-            // ---- pass 1: down the pixel column --------------------------------------------------------------------------
+        auto process = [&](auto tag, const float (&pxr)[8], const uint32_t ob) {
+            float d0, d1, d2, d3, d4, d5, d6, d7;
+            if constexpr (kCols) { // byte transpose: pixel column c = i of block b, rows 0..7 (written by TIC_TAKE_COLS)
+                d0 = (float)px_rd[0]; d1 = (float)px_rd[8]; d2 = (float)px_rd[16]; d3 = (float)px_rd[24];
+                d4 = (float)px_rd[32]; d5 = (float)px_rd[40]; d6 = (float)px_rd[48]; d7 = (float)px_rd[56];
+            } else {               // pixel row lr of block lb, converted by TIC_TAKE_ROWS
+                d0 = pxr[0]; d1 = pxr[1]; d2 = pxr[2]; d3 = pxr[3]; d4 = pxr[4]; d5 = pxr[5]; d6 = pxr[6]; d7 = pxr[7];
+            }
+            // ---- pass 1: down the pixel column | along the pixel row -----------------------------------------------------
             dct8_aan(d0, d1, d2, d3, d4, d5, d6, d7);
             d0 -= 1024.0f;
             twA[0 * 32] = __float_as_uint(d0); twA[1 * 32] = __float_as_uint(d1); twB[2 * 32] = __float_as_uint(d2);
             twB[3 * 32] = __float_as_uint(d3); twA[4 * 32] = __float_as_uint(d4); twA[5 * 32] = __float_as_uint(d5);
             twB[6 * 32] = __float_as_uint(d6); twB[7 * 32] = __float_as_uint(d7);
             wave_lds_fence();
-            const uint4 ra = tr[0], rb = tr[kTHalfDw / 4];
+            const uint4 ra = tr[0], rb = tr[kHalf / 4];
             wave_lds_fence();
             float e0 = __uint_as_float(ra.x), e1 = __uint_as_float(ra.y), e2 = __uint_as_float(ra.z), e3 = __uint_as_float(ra.w);
             float e4 = __uint_as_float(rb.x), e5 = __uint_as_float(rb.y), e6 = __uint_as_float(rb.z), e7 = __uint_as_float(rb.w);
@@ -585,13 +639,25 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
             const unsigned long long cB = __ballot(mB > thr.z);                           // ... v in 0,4
             *zp0 = (int16_t)q0; *zp1 = (int16_t)q1; *zp2 = (int16_t)q2; *zp3 = (int16_t)q3;
             *zp4 = (int16_t)q4; *zp5 = (int16_t)q5; *zp6 = (int16_t)q6; *zp7 = (int16_t)q7;
-            const unsigned long long kRat = 0x1111111111111111ull; // lanes u in {0,4}: their v in {0,4} are the rational coefficients
+            const unsigned long long kRat = 0x1111111111111111ull; // lanes i in {0,4}: their coefficients 0 and 4 are the rational ones (either order)
             // ---- a rational coefficient sits on a tie somewhere in the strip (one strip in six at q = 50 on noise; every strip of
             //      posterised, two-level or flat content): the exact values of all 32, over the fast path's ------------------------
             if (__builtin_expect((cB & kRat) != 0ull, 0)) {
-                const int rq = rational_quad(ldsT, b, i, cst_rat);
                 n_quad++;
-                if ((i & 2) == 0) *zz_ptr(i == 0 ? 0u : (i == 1 ? 28u : (i == 4 ? 20u : 78u))) = (int16_t)rq; // scan positions 0, 14, 10, 39
+                if constexpr (kCols) {
+                    const int rq = rational_quad(ldsT, b, i, cst_rat);
+                    if ((i & 2) == 0) *zz_ptr(i == 0 ? 0u : (i == 1 ? 28u : (i == 4 ? 20u : 78u))) = (int16_t)rq; // scan positions 0, 14, 10, 39
+                } else { // rows first: no column sums at hand - from the pixels (load layout -> a row per lane of the block, through LDS)
+                    uint32_t lo0, hi0;
+                    raw_words(tag, lo0, hi0);
+                    uint2 *pb = reinterpret_cast<uint2 *>(ldsT);
+                    pb[lb * 8 + lr] = make_uint2(lo0, hi0);
+                    wave_lds_fence();
+                    const uint2 rowv = pb[lane]; // row i of block b
+                    wave_lds_fence();
+                    const int rq = rational_slim(rowv.x, rowv.y, i, cst_rat); // lanes 0..3 of a block: (0,0), (0,4), (4,0), (4,4)
+                    if (i < 4) *zz_ptr(i == 0 ? 0u : (i == 1 ? 28u : (i == 2 ? 20u : 78u))) = (int16_t)rq;
+                }
             }
             wave_lds_fence();
             const uint4 val = *zr;
@@ -632,18 +698,22 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         // Two strips ahead: strip j is consumed after L(j+2) is issued; in steady state the instructions younger than
         // L(j) are S(j-2) L(j+1) S(j-1) L(j+2) -> vmcnt(4); the first two strips see 2 and 3.  (A rare branch issues at most
         // the same single store per strip.  Three strips ahead: no faster, profiles/r02_ab_prefetch_depth.txt, r03_ablate_cold.txt.)
-#define TIC_STEP(RLOAD, OBL, RTAKE, RTAG, OBP, N) TIC_LOAD(RLOAD, OBL); TIC_TAKE(RTAKE, N); process(std::integral_constant<int, RTAG>(), OBP)
+        float pxf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define TIC_STEP(RLOAD, OBL, RTAKE, R0, R1, OBP, N)                                                          \
+        TIC_LOAD(RLOAD, OBL);                                                                                \
+        if constexpr (kCols) { TIC_TAKE_COLS(RTAKE, N); } else { TIC_TAKE_ROWS(pxf, R0, R1, N); }            \
+        process(std::integral_constant<int, R0>(), pxf, OBP)
         do {
             if (left == 0) break;
-            TIC_STEP("76:77", ob2, "72:73", 72, ob0, 2);
+            TIC_STEP("76:77", ob2, "72:73", 72, 73, ob0, 2);
             if (left == 0) break;
-            TIC_STEP("72:73", ob0, "74:75", 74, ob1, 3);
+            TIC_STEP("72:73", ob0, "74:75", 74, 75, ob1, 3);
             while (left != 0) {
-                TIC_STEP("74:75", ob1, "76:77", 76, ob2, 4);
+                TIC_STEP("74:75", ob1, "76:77", 76, 77, ob2, 4);
                 if (left == 0) break;
-                TIC_STEP("76:77", ob2, "72:73", 72, ob0, 4);
+                TIC_STEP("76:77", ob2, "72:73", 72, 73, ob0, 4);
                 if (left == 0) break;
-                TIC_STEP("72:73", ob0, "74:75", 74, ob1, 4);
+                TIC_STEP("72:73", ob0, "74:75", 74, 75, ob1, 4);
             }
         } while (0);
 #undef TIC_STEP
@@ -653,7 +723,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         // batch pass; profiles/r04_tail_experiments.txt).  The statement stays as a scheduling fence with the same clobbers.
         asm volatile("; end of the strip walk" : : : TIC_RSV_CLOBBER);
 #undef TIC_LOAD
-#undef TIC_TAKE
+#undef TIC_TAKE_COLS
+#undef TIC_TAKE_ROWS
 #undef TIC_RSV_CLOBBER
     }
     // ---- the batch pass: blocks with an irrational coefficient inside its guard band ----------------------------------------
@@ -902,7 +973,7 @@ static inline int grid_for(int ntiles) { return (ntiles + kWavesPerWG - 1) / kWa
 // the test-hook gate (tic_hooks.h, TIC_TEST_HOOKS=1: tests/test_gpu_parity.py::test_strip_schedules_are_equivalent drives every
 // schedule against the exact kernel) - read once, or at every launch when TIC_TUNE is set too.
 struct Tunables {
-    int max_wgs, sched, chunk;
+    int max_wgs, sched, chunk, order;
     int split[8];
 };
 static Tunables read_tunables() {
@@ -911,6 +982,7 @@ static Tunables read_tunables() {
     t.max_wgs = geti("TIC_MAX_WGS", 0);             // persistent grid size (0: resident workgroups of the chip)
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
     t.chunk = geti("TIC_CHUNK", kChunkStrips);      // strips per wave of schedules 1 and 2
+    t.order = geti("TIC_ORDER", -1);                // pass order of the strip kernel: -1 by grid (default), 0 rows first, 1 columns first
     // per-round row weights of the team schedule ("0" disables it): the six workgroups of a CU reach their first pixel
     // 1,400 ... 6,200 cycles after their own entry (profiles/r03_stamps_tail.txt), later rounds get fewer strip rows.  Round 5: the
     // first round gives a row to the last (4096^2: 9,8,6,4,3,2 rows instead of round 3's 10,8,6,4,3,1 - a wave's rare work grows with
@@ -987,7 +1059,7 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             int dev = 0, per_cu = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel, kWavesPerWG * 64, 0) != hipSuccess || per_cu < 1)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dctq_strip_kernel<true>, kWavesPerWG * 64, 0) != hipSuccess || per_cu < 1)
                 per_cu = 4;
             // 80 VGPRs and 22 KiB of LDS allow 6 workgroups per CU (7 measured no better when the kernel still fitted them:
             // a seventh lengthens the start ramp by as much as it hides, profiles/r02_ab_occupancy.txt)
@@ -1069,7 +1141,13 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
                 }
                 grid = dim3(a.team_count, R, nf);
             }
-            hipLaunchKernelGGL(dctq_strip_kernel, grid, block, 0, stream, a);
+            // pass order: columns first where the whole grid is resident at once (static shares: the tail decides), rows first for grids
+            // of several rounds (dynamic dispatch: the average cost per strip decides); TIC_ORDER (test hook) forces one
+            const bool cols = tune.order < 0 ? !multi_round : tune.order == 1;
+            if (cols)
+                hipLaunchKernelGGL(dctq_strip_kernel<true>, grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL(dctq_strip_kernel<false>, grid, block, 0, stream, a);
         }
     } else {
         a.fast_tx = a.fast_ty = 0;

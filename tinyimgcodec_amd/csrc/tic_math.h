@@ -166,6 +166,10 @@ struct DctqConsts {
     double rdiv[64];     // fl(1/div)
     float mulN[64];      // fast path, index u*8+v: 1 / (aan[u]*aan[v]*8*div[u][v]) (lane u of a block holds v = 0..7)
     double mul64[64];    // second level (the same butterflies in float64), index u*8+v: the same number in float64
+    // the rows-first instantiation of the strip kernel (multi-round grids: DESIGN.md 5.1) holds a frequency COLUMN per lane:
+    float mulT[64];      // index v*8+u: the multiplier of (u,v)
+    float thrG[32];      // per column v: [4v] = accept threshold for u in {1,2,3}, [4v+1] for u in {5,6,7}, [4v+2] for u in {0,4} (band kGuard[u][v]/div)
+    uint16_t zzofsT[64]; // index v*8+u: byte offset of (u,v) in the zig-zag image
     float thrR[32];      // strip kernel, per frequency row u: [4u] = accept threshold for v in {1,2,3}, [4u+1] for v in {5,6,7}, [4u+2] for
                          // v in {0,4}, [4u+3] unused (0.5 - largest guard band guard_cf(u,v)/div[u][v] of the group; accept when
                          // |t - rint(t)| <= thr).  Three groups: the largest guard/div of a group stands for all its members, and with the
@@ -175,13 +179,14 @@ struct DctqConsts {
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
     // Everything the strip kernel needs, packed as the image its workgroups copy into LDS with one 16-byte load per lane
-    // (132 lanes): [0,256) mulN, [256,384) thrR, [384,512) zzofs, [512,576) div, then 1/div, of the rational coefficients (0,0) (0,4) (4,0) (4,4),
-    // [576,1088) cosm, [1088,1600) rdiv, [1600,2112) mul64.
-    alignas(16) unsigned char strip_blk[2112];
+    // (164 lanes): [0,256) mulN, [256,384) thrR, [384,512) zzofs, [512,576) div, then 1/div, of the rational coefficients (0,0) (0,4) (4,0) (4,4),
+    // [576,1088) cosm, [1088,1600) rdiv, [1600,2112) mul64, [2112,2368) mulT, [2368,2496) thrG, [2496,2624) zzofsT.
+    alignas(16) unsigned char strip_blk[2624];
 };
-constexpr int kStripBlkBytes = 2112;
+constexpr int kStripBlkBytes = 2624;
 constexpr int kStripBlkPieces = kStripBlkBytes / 16;
 constexpr int kBlkMul = 0, kBlkThr = 256, kBlkZz = 384, kBlkRat = 512, kBlkCos = 576, kBlkRdiv = 1088, kBlkMul64 = 1600; // offsets inside strip_blk
+constexpr int kBlkMulT = 2112, kBlkThrT = 2368, kBlkZzT = 2496;
 
 // Accept threshold of the fast path as a float: the kernel accepts a rounding when fl32(|t - rint(t)|) <= thr.  The distance
 // is a float32 result in [0, 0.5]: above 0.25 it is rounded by at most 2^-26, i.e. by less than the gap between thr and the next
@@ -214,6 +219,18 @@ inline bool build_consts(double quality, DctqConsts *c) {
             c->mul64[u * 8 + v] = 1.0 / (aan[u] * aan[v] * 8.0 * c->div[u * 8 + v]);
             c->mulN[u * 8 + v] = (float)c->mul64[u * 8 + v];
         }
+    for (int u = 0; u < 8; u++)
+        for (int v = 0; v < 8; v++) c->mulT[v * 8 + u] = c->mulN[u * 8 + v];
+    for (int v = 0; v < 8; v++) { // rows-first instantiation: the bound as tabulated, groups of u per column v
+        double g3[3] = {0.0, 0.0, 0.0};
+        for (int u = 0; u < 8; u++) {
+            const double g = kGuard[u * 8 + v] / c->div[u * 8 + v];
+            const int grp = (u == 0 || u == 4) ? 2 : (u < 4 ? 0 : 1);
+            if (g > g3[grp]) g3[grp] = g;
+        }
+        for (int k = 0; k < 3; k++) c->thrG[4 * v + k] = thr_below(0.5 - g3[k]);
+        c->thrG[4 * v + 3] = 0.0f;
+    }
     for (int u = 0; u < 8; u++) {
         double g3[3] = {0.0, 0.0, 0.0};
         for (int v = 0; v < 8; v++) {
@@ -230,6 +247,7 @@ inline bool build_consts(double quality, DctqConsts *c) {
     for (int k = 0; k < 64; k++) {
         int nat = kZigzag[k];
         c->zzofs[nat] = (uint16_t)(2 * k);
+        c->zzofsT[(nat & 7) * 8 + (nat >> 3)] = (uint16_t)(2 * k);
         c->zznat[k] = (uint8_t)nat;
     }
     {
@@ -246,6 +264,9 @@ inline bool build_consts(double quality, DctqConsts *c) {
         memcpy(p + kBlkCos, c->cosm, 512);
         memcpy(p + kBlkRdiv, c->rdiv, 512);
         memcpy(p + kBlkMul64, c->mul64, 512);
+        memcpy(p + kBlkMulT, c->mulT, 256);
+        memcpy(p + kBlkThrT, c->thrG, 128);
+        memcpy(p + kBlkZzT, c->zzofsT, 128);
     }
     return true;
 }

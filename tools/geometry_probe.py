@@ -35,7 +35,7 @@ ctx.check(L.tic_dev_alloc(ctx.handle, buf.size, C.byref(d_in)))
 ctx.check(L.tic_dev_alloc(ctx.handle, 2 * buf.size, C.byref(d_out)))
 ctx.check(L.tic_memcpy_h2d(ctx.handle, d_in, buf.ctypes.data, buf.size))
 ms = C.c_float()
-KNOBS = ("TIC_SPLIT", "TIC_SCHED", "TIC_CHUNK", "TIC_MAX_WGS", "TIC_STAGGER")
+KNOBS = ("TIC_SPLIT", "TIC_SCHED", "TIC_CHUNK", "TIC_MAX_WGS", "TIC_ORDER")
 def run(h, w, p, it, st, lib=None):
     for k in KNOBS: os.environ.pop(k, None)
     os.environ.update(st)
