@@ -98,7 +98,7 @@ struct tic_ctx {
                                                             // its first 64 bytes: the {bits, error} pairs of the asynchronous calls' tickets
     // asynchronous device-resident calls (tic_compress_dev_async): ticket t lives in slot t % kAsyncSlots
     struct AsyncSlot { long long ticket = -1; size_t cap = 0; int early_rc = TIC_OK; hipEvent_t done = nullptr; bool empty_image = false; };
-    AsyncSlot async_slots[64];
+    AsyncSlot async_slots[kAsyncSlots];
     long long async_next = 0;
     void *d_ent_work = nullptr;                 // workspace of the device entropy stage (tile sums, bit counts, staging slots)
     size_t ent_work_bytes = 0;

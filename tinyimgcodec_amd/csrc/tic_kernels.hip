@@ -385,14 +385,28 @@ __device__ __forceinline__ unsigned long long wave_redo_block(const uint8_t *px 
                                                               const double *cosm, const double *rdiv, const uint16_t *zzofs, int16_t *img16,
                                                               int lane) {
     const int u = lane >> 3, c = lane & 7;
-    double t = 0.0;
+    // (two accumulators per sum and 16-byte table reads: the pass runs on the launch's tail, one wave alone on its SIMD - what counts is
+    //  the length of the dependent chain, not the instruction count; the 1e-9 test below does not care about the order of the additions)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 *mu = reinterpret_cast<const d2 *>(cosm + u * 8), *mc = reinterpret_cast<const d2 *>(cosm + c * 8);
+    const d2 m0 = mu[0], m1 = mu[1], m2 = mu[2], m3 = mu[3];
+    double x[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) t = fma(cosm[u * 8 + r], (double)((int)px[r * 8 + c] - 128), t);
-    tbuf[u * 8 + c] = t;
+    for (int r = 0; r < 8; r++) x[r] = (double)((int)px[r * 8 + c] - 128);
+    double ta = m0.x * x[0], tb = m0.y * x[1];
+    ta = fma(m1.x, x[2], ta); tb = fma(m1.y, x[3], tb);
+    ta = fma(m2.x, x[4], ta); tb = fma(m2.y, x[5], tb);
+    ta = fma(m3.x, x[6], ta); tb = fma(m3.y, x[7], tb);
+    tbuf[u * 8 + c] = ta + tb;
+    const d2 n0 = mc[0], n1 = mc[1], n2 = mc[2], n3 = mc[3]; // (requested in front of the fence: they do not depend on it)
     wave_lds_fence();
-    double X = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < 8; kk++) X = fma(cosm[c * 8 + kk], tbuf[u * 8 + kk], X);
+    const d2 *tu = reinterpret_cast<const d2 *>(tbuf + u * 8);
+    const d2 y0 = tu[0], y1 = tu[1], y2 = tu[2], y3 = tu[3];
+    double xa = n0.x * y0.x, xb = n0.y * y0.y;
+    xa = fma(n1.x, y1.x, xa); xb = fma(n1.y, y1.y, xb);
+    xa = fma(n2.x, y2.x, xa); xb = fma(n2.y, y2.y, xb);
+    xa = fma(n3.x, y3.x, xa); xb = fma(n3.y, y3.y, xb);
+    const double X = xa + xb;
     const double tq = X * rdiv[lane], rq = rint(tq);
     const bool rational = (lane & 0x1b) == 0; // (u,v) in {0,4} x {0,4}
     const bool decided = fabs(tq - rq) < 0.5 - 1e-9;
