@@ -502,7 +502,7 @@ struct PackL {
     static constexpr int kStageWords = kImageWords;                        // staging slot of a partition
 };
 
-template <int W, int ABL = 0> // ABL != 0: timing-only builds of the experiment library (1: no walk, 2: no coefficient loads, 4: no slot store, 8: no merge)
+template <int W, int ABL = 0> // ABL != 0: timing-only instantiations (1: no walk, 2: no coefficient loads, 4: no slot store, 8: no merge); the library instantiates <W, 0> only
 __global__ __launch_bounds__(kGroupL * 64) void entropy_pack_lane_kernel(const int16_t *__restrict__ zz, const HuffDev *__restrict__ tab,
                                                                      unsigned long long blocks_per_frame, unsigned long long parts_per_frame,
                                                                      unsigned long long groups_per_frame, uint32_t *__restrict__ stage,

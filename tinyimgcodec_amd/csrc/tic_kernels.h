@@ -51,9 +51,6 @@ struct DctqArgs {
     // rows of round r from byte r of split_lo (byte 8: split_hi).
     uint32_t magic_fast_tx, magic_tstep;
     unsigned long long split_lo, split_hi;
-    // queue kernel: teams (= gridDim.x) of q_waves waves share a ticket counter; a ticket is one strip, runs of
-    // 2^q_run_shift adjacent strips belong to one team
-    int q_teams, q_waves, q_run_shift, q_ppw;
 };
 
 struct WideArgs {          // dctq_exact_wide_kernel: integer images outside 0..255
@@ -83,8 +80,6 @@ struct IdctArgs {
 };
 
 // C-ABI kernel selector (TIC_KERNEL_AUTO / _EXACT / _HYBRID) -> launch_dctq's variant (1 exact, 2 strip kernel), -1 for anything else.
-// Defined beside the kernels: the experiment build of tools/ compiles its own kernel file, whose definition also lets its
-// timing-only variants (>= 10) through - which is why tic_api.hip holds no switch for them.
 int dctq_kernel_id(int abi_variant);
 hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream);
 hipError_t launch_dctq_wide(const WideArgs &a, hipStream_t stream);
