@@ -242,9 +242,10 @@ def test_strip_kernel_binary_keeps_its_landing_registers_private():
     """The production kernel's pixel loads land in v72..v79, registers the compiler may not allocate (amdgpu_num_vgpr(72)):
     a load in flight must never share a register with anything the compiler placed.  Checked on the SHIPPED binary by
     tinyimgcodec_amd/csrc/lint_strip_kernel.py - the same script csrc/Makefile runs behind the link, where a violation fails the
-    build: in dctq_strip_kernel the only instructions that name v72..v79 are the hand-written loads into them, the byte-to-float
-    conversions out of them (every group of eight directly behind an s_waitcnt vmcnt) and plain moves out of them; no scratch,
-    no accumulator registers, exactly 80 vector registers (six waves per SIMD)."""
+    build, for BOTH instantiations of dctq_strip_kernel (columns first / rows first): the only instructions that name v72..v79 are the
+    hand-written loads into them, the hand-off out of them directly behind an s_waitcnt vmcnt (columns first: the ds_write_b64 to the
+    byte-transpose buffer; rows first: the group of eight byte-to-float conversions) and plain moves out of them; no scratch, no
+    accumulator registers, exactly 80 vector registers (six waves per SIMD)."""
     import importlib.util
     from tinyimgcodec_amd import _native as N
     if not os.path.exists(N.LIB_PATH):

@@ -4,19 +4,18 @@
 // level shift (codec.py:29), 8x8 tiling (utils.py:13-20), 2-D DCT (utils.py:32-37), quantisation (utils.py:48-53)
 // and the zig-zag gather (codec.py:32-33); and of decode() (codec.py:46-70): dequantise, inverse DCT, clip, cast.
 //
-// Work decomposition (wave64): one wavefront owns a strip of 8 horizontally adjacent 8x8 blocks (64x8 pixels).
-// Lane l = 8*b + i serves block b of the strip; i is, in turn, the pixel row it loads, the pixel column it
-// transforms (after an in-register 8x8 byte transpose across the 8 lanes of the block, DPP + v_perm), and the
-// frequency row u it quantises (after a dword transpose through LDS).  Every wave-level store of coefficients is
-// 1 KiB contiguous (8 blocks x 128 B, zig-zag order established in LDS).  No MFMA: the stage is a byte-in /
-// int16-out streaming stencil, bounded by HBM (3 B per pixel).
+// Work decomposition (wave64): one wavefront owns a strip of 8 horizontally adjacent 8x8 blocks (64x8 pixels); 8 lanes serve a block.
+// Every wave-level store of coefficients is 1 KiB contiguous (8 blocks x 128 B, zig-zag order established in LDS).  No MFMA: the
+// stage is a byte-in / int16-out streaming stencil, bounded by HBM (3 B per pixel).
 //
-// Two arithmetic paths, bit-identical results (see DESIGN.md):
-//   exact  : float64, scipy/pocketfft operation order for all 64 coefficients (tic_math.h dct8_exact).
-//   hybrid : float32 AAN butterflies, every rounding accepted only outside a rigorous guard band around the .5 ties;
-//            blocks with a coefficient inside its band are settled after the loop in float64 (exact ties of the four
-//            rational coefficients by an exact sub-path, anything else by a second level and, if need be, the exact
-//            order).
+// Two arithmetic paths, bit-identical results (DESIGN.md 3):
+//   exact : float64, scipy/pocketfft operation order for all 64 coefficients (tic_math.h dct8_exact): dctq_exact_kernel - padding
+//           strips, the reference kernel of the tests, the last resort of the production kernel.
+//   strip : the production kernel (dctq_strip_kernel<kCols>): float32 AAN butterflies, every rounding accepted only outside a rigorous
+//           guard band around the .5 ties.  Ties of the four rational coefficients are settled inside the loop in the reference's
+//           float64 operation order (columns first: from the fast path's own exact column sums, rational_quad; rows first: from the
+//           pixels, rational_slim); blocks with an irrational coefficient inside its band join a wave-local batch that is settled
+//           behind the loop in float64 (wave_redo_block / second_level_8), and only what that cannot decide takes the exact order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
