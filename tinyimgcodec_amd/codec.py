@@ -233,7 +233,8 @@ def _compress_batch_multi(frames, q, threads, devices):
     caps = (C.c_size_t * n)(*([cap] * n))
     lens = (C.c_size_t * n)()
     failed = C.c_int(-1)
-    for c in ctxs:
+    locked = sorted(ctxs, key=id)  # (one global order: two threads that list the same devices in different orders cannot deadlock)
+    for c in locked:
         c.lock.acquire()
     try:
         rc = L.tic_compress_batch_multi(handles, len(ctxs), inp, n, h, w, max(w, 1), q, outp, caps, lens, threads, C.byref(failed))
@@ -242,7 +243,7 @@ def _compress_batch_multi(frames, q, threads, devices):
         if rc != N.TIC_OK:
             ctxs[max(failed.value, 0)].check(rc)
     finally:
-        for c in ctxs:
+        for c in reversed(locked):
             c.lock.release()
     return [pool[i, : lens[i]].tobytes() for i in range(n)]
 
