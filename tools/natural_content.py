@@ -1,6 +1,10 @@
 """Kernel time on natural content: the 512x512 Lenna pixels tiled to 4096^2 (and a smoothed, a flat and a gradient frame) against
 the random frame of the benchmark.  Natural images have flat and smooth blocks, i.e. many exact ties of the rational coefficients."""
-import ctypes as C, sys
+import ctypes as C, os, sys
+SETTINGS = None
+if "--settings" in sys.argv:  # python tools/natural_content.py --settings "TIC_ROT=0" "TIC_ROT=1;TIC_SPLIT=..." : the hooks build, one column per setting
+    k = sys.argv.index("--settings"); SETTINGS = [dict(kv.split("=") for kv in a.split(";") if kv) for a in sys.argv[k + 1:]]; del sys.argv[k:]
+    os.environ["TIC_TEST_HOOKS"] = "1"; os.environ["TIC_TUNE"] = "1"
 sys.path.insert(0, '.')
 import numpy as np
 import tinyimgcodec_amd as T
@@ -46,6 +50,13 @@ for name, img in frames.items():
         L.tic_set_stats(ctx.handle, 0)
         n = C.c_size_t()
         extra = ""
+        for st_ in SETTINGS or ():
+            for k_, v_ in st_.items(): os.environ[k_] = v_
+            ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, dim, dim, dim, q, d_out, 2, 3000, C.byref(ms)))
+            ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, dim, dim, dim, q, d_out, 2, 2000, C.byref(ms)))
+            for k_ in st_: os.environ.pop(k_)
+            to = ms.value * 1e3 / 2000
+            extra += "  | %s %6.2f us (%.1f %%)" % (";".join("%s=%s" % kv for kv in st_.items()), to, 3.0 * dim * dim / to / 1e3 / 80)
         for nm, Lo, co in others:
             assert Lo.tic_dctq_dev_timed(co, d_img, dim, dim, dim, q, d_out, 2, 3000, C.byref(ms)) == 0
             assert Lo.tic_dctq_dev_timed(co, d_img, dim, dim, dim, q, d_out, 2, 2000, C.byref(ms)) == 0
