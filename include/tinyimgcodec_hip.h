@@ -245,6 +245,12 @@ int tic_last_decode_giveup(tic_ctx *ctx);
  * last long stream took: 2 = the first choice met a range without a synchronisation point and the longest range was tried.
  * Either pointer may be null.  (No counterpart in the reference: huffman.py:77-98 decodes bit by bit.) */
 int tic_last_decode_range(tic_ctx *ctx, int *range_bits, int *tries);
+/* tic_decompress_dev launches a long stream on a GUESS of its 16-byte header (the header of the stream this context decoded last: the
+ * frames of a sequence, the images of a batch) instead of reading it from device memory first; the kernels echo the real header and a
+ * wrong guess costs a second decode.  Returns 1 when the last tic_decompress_dev's guess held, -1 when it did not (the stream was
+ * decoded again with its own header), 0 when no guess was made.  (No counterpart in the reference: decompress() codec.py:133-164 reads
+ * the header from host memory.) */
+int tic_last_decode_guess(tic_ctx *ctx);
 
 /* ---- multi-GPU (the reference has no counterpart: it is single-process, codec.py:133-164 runs one image
  *      at a time).  One process per GPU; a batch shards by independent frames (frame i -> rank i / ceil(B/G)) with no

@@ -1471,6 +1471,55 @@ def test_decompress_dev_resident_round_trip(ctx, oracle):
             L.tic_dev_free(ctx.handle, p)
 
 
+def test_decompress_dev_launches_on_a_guess_of_the_header(ctx, oracle, monkeypatch):
+    """tic_decompress_dev decodes a long stream on a guess of its header (the header of the stream the context decoded last) and reads the
+    header only when the kernels' echo of it differs: same geometry and quality -> the guess holds; another quality, another geometry, a
+    destination the guessed geometry does not fit, a short stream -> the stream is decoded with its own header; pixels equal the oracle's
+    every time, the errors are the ones of a call that read the header first."""
+    L = N.load()
+    specs = [((2048, 2048), 50, 1), ((2048, 2048), 50, 2), ((2048, 2048), 80, 3), ((1504, 2000), 50, 4), ((2048, 2048), 50, 5), ((512, 512), 50, 6), ((2048, 2048), 50, 7)]
+    streams = {}
+    bufs = []
+    for (h, w), q, seed in specs:
+        s = np.frombuffer(T.compress(rand_frame(900 + seed, h, w), q, ctx=ctx), np.uint8)
+        d_s, d_p = C.c_void_p(), C.c_void_p()
+        ctx.check(L.tic_dev_alloc(ctx.handle, s.size + 64, C.byref(d_s)))
+        ctx.check(L.tic_dev_alloc(ctx.handle, h * w, C.byref(d_p)))
+        ctx.check(L.tic_memcpy_h2d(ctx.handle, d_s, s.ctypes.data, s.size))
+        bufs.append((d_s, d_p, s, h, w))
+    ctx2 = T.Context(0)  # a fresh context: no stream decoded yet, no guess
+    want_guess = [0, 1, -1, -1, -1, 0, 1]  # first call: none; same header: held; quality / geometry changed: not held; 512^2: short stream, no guess (and the guess survives it)
+    for k, (d_s, d_p, s, h, w) in enumerate(bufs):
+        ctx2.check(L.tic_memset_dev(ctx2.handle, d_p, 0xEE, h * w))
+        hh, ww = C.c_int(), C.c_int()
+        ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w, C.byref(hh), C.byref(ww)))
+        assert (hh.value, ww.value) == (h, w)
+        assert L.tic_last_decode_guess(ctx2.handle) == want_guess[k], (k, L.tic_last_decode_guess(ctx2.handle))
+        pix = np.empty((h, w), np.uint8)
+        ctx2.check(L.tic_memcpy_d2h(ctx2.handle, pix.ctypes.data, d_p, pix.size))
+        assert np.array_equal(pix, oracle.decompress(s.tobytes())), k
+    # a destination too small for the guessed geometry (which is this stream's): the error of a call that read the header
+    d_s, d_p, s, h, w = bufs[0]
+    assert L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w - 1, None, None) == N.TIC_E_SPACE
+    assert L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w - 1, h * w, None, None) == N.TIC_E_ARG
+    # ... and a larger stream after a smaller guess: the guessed geometry fits the destination, the echo differs
+    d_s4, d_p4, s4, h4, w4 = bufs[3]
+    ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s4, s4.size, d_p4, w4, h4 * w4, None, None))
+    ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w, None, None))
+    assert L.tic_last_decode_guess(ctx2.handle) == -1
+    pix = np.empty((h, w), np.uint8)
+    ctx2.check(L.tic_memcpy_d2h(ctx2.handle, pix.ctypes.data, d_p, pix.size))
+    assert np.array_equal(pix, oracle.decompress(s.tobytes()))
+    if L.tic_build_has_test_hooks():
+        monkeypatch.setenv("TIC_DECODE_NO_GUESS", "1")
+        ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w, None, None))
+        assert L.tic_last_decode_guess(ctx2.handle) == 0
+        monkeypatch.delenv("TIC_DECODE_NO_GUESS")
+    for d_s, d_p, *_ in bufs:
+        L.tic_dev_free(ctx.handle, d_s); L.tic_dev_free(ctx.handle, d_p)
+    ctx2.close()
+
+
 def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch):
     """The strip walk uses 32-bit pixel offsets; a frame of 4 GiB or more is cut into bands of whole block rows, one launch each
     (round 2 ran such frames on the exact kernel only).  TIC_BAND_BYTES lowers the limit so that a 3000 x 2112 frame is cut into

@@ -122,6 +122,9 @@ struct tic_ctx {
     uint32_t dec_epoch = 0;                                     // calls of the device decoder on this workspace (its single-launch scans tell their words by it)
     DecStatus *h_dec_status = nullptr, *d_dec_status = nullptr; // host-mapped
     int last_decode_path = 0;                                  // 0 none, 1 device decoder, 2 host decoder (tic_last_decode_path)
+    uint8_t dec_head[16] = {0};                                  // header of the last stream tic_decompress_dev decoded on the device: the next call's guess
+    bool dec_head_valid = false;
+    int last_decode_guess = 0;                                  // tic_decompress_dev: 1 the last call's guess of the header held, -1 it did not (decoded again), 0 no guess
     int last_decode_range = 0, last_decode_tries = 0;          // stream bits per lane of the device decoder's last run, and how many runs the last long stream took
     int last_decode_giveup = 0;                                // why the device decoder handed the last long stream to the host (DecStatus::giveup bits)
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
@@ -1699,8 +1702,10 @@ static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int 
 // or does not apply - the caller then decodes on the host, which reproduces the reference's behaviour on malformed streams (what
 // the device wrote to `out` until then is overwritten).
 static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h, int w, int quality, int scaled_exp, uint8_t *out,
-                            bool out_on_device, size_t out_stride, bool *done, bool src_on_device = false) {
+                            bool out_on_device, size_t out_stride, bool *done, bool src_on_device = false, const uint8_t *guessed_head = nullptr,
+                            bool *guess_held = nullptr) {
     *done = false;
+    if (guess_held) *guess_held = false;
     const size_t n = num_blocks(h, w);
     // the host parallel decoder's own threshold: shorter streams are decoded serially in well under a millisecond
     if (n < 16384 || len * 8 < 128 + (1u << 21) || len * 8 >= (1ull << 32) || test_hook("TIC_DECODE_SERIAL") || test_hook("TIC_DECODE_HOST")) return TIC_OK;
@@ -1816,6 +1821,10 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
                                             ctx->dec_desc_words, ctx->dec_epoch, ia, ctx->d_dec_status, range_bits, margin_bits, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(&st, ctx->h_dec_status, sizeof st); // (host-mapped: the stream has drained)
+        if (guessed_head) { // geometry and quality were a guess (tic_decompress_dev): what this run produced counts only if the stream's header is the guessed one
+            if (memcmp(st.head, guessed_head, 16) != 0) return TIC_OK;
+            *guess_held = true;
+        }
         if (test_hook("TIC_DECODE_TRACE"))
             fprintf(stderr, "device decoder run %d: range %d margin %d -> giveup %d, m %llu of %zu, pos_out %llu of %zu bits\n", ctx->last_decode_tries, range_bits,
                     margin_bits, st.giveup, st.m, n, st.pos_out, len * 8);
@@ -1913,6 +1922,11 @@ int tic_last_decode_range(tic_ctx *ctx, int *range_bits, int *tries) {
     return TIC_OK;
 }
 
+int tic_last_decode_guess(tic_ctx *ctx) {
+    TIC_LOCK(ctx);
+    return ctx ? ctx->last_decode_guess : TIC_E_ARG;
+}
+
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
@@ -1963,33 +1977,60 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
     if (!ctx) return TIC_E_ARG;
     ctx->last_decode_giveup = 0;
     ctx->last_decode_tries = 0;
+    ctx->last_decode_guess = 0;
     if (!d_stream && len) return set_err(ctx, TIC_E_ARG, "null stream pointer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    uint8_t head[16] = {0};
     if (len < 16) return set_err(ctx, TIC_E_STREAM, "stream shorter than the 16-byte header");
-    HIPCHK(ctx, hipMemcpy(head, d_stream, 16, hipMemcpyDeviceToHost));
-    int h, w, quality;
-    uint32_t flag;
-    if (parse_header(head, 16, &h, &w, &quality, &flag) != TIC_OK) return set_err(ctx, TIC_E_STREAM, "stream shorter than the 16-byte header");
-    if (flag & (1u << 31)) return set_err(ctx, TIC_E_STREAM, "streams with an embedded Huffman table are not supported");
-    const bool scaled = (flag & (1u << 30)) != 0;
-    if (h < 0 || w < 0) return set_err(ctx, TIC_E_STREAM, "bad geometry in header");
-    if (scaled && (quality < 0 || quality > 62)) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d in header outside 0..62", quality);
-    if (!scaled && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "quality %d in header outside 1..99", quality);
-    if (h_out) *h_out = h;
-    if (w_out) *w_out = w;
-    const size_t n = num_blocks(h, w);
-    if (n == 0) return TIC_OK;
-    if (out_stride < (ptrdiff_t)w) return set_err(ctx, TIC_E_ARG, "row stride %td smaller than the width %d", out_stride, w);
-    if (!d_out || (size_t)(h - 1) * (size_t)out_stride + (size_t)w > out_cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
-    bool done = false;
-    int rc = decode_on_device(ctx, (const uint8_t *)d_stream, len, h, w, scaled ? 50 : quality, scaled ? quality : -1, (uint8_t *)d_out, true,
-                              (size_t)out_stride, &done, true);
-    if (rc) return rc;
-    if (done) {
-        ctx->last_decode_path = 1;
-        return TIC_OK;
-    } else {
+    // Geometry and quality are in the stream's header - in device memory; a synchronous 16-byte read in front of the first launch is a
+    // sixth of the call for a 4096^2 stream.  A long stream is therefore decoded on a GUESS - the header of the stream this context decoded
+    // last (frames of a sequence, the images of a batch) - and the first kernel echoes the real header into the status words: when it is
+    // the guessed one, everything the run produced stands, without the read; when it is not (or the guess does not fit this call's
+    // buffers), the header is read and the stream decoded again - what the first run wrote to d_out lies inside the bounds checked for
+    // the guess and is overwritten.  (On an error return the contents of d_out are unspecified.)
+    const bool may_guess = ctx->dec_head_valid && len * 8 >= 128 + (1u << 21) && len * 8 < (1ull << 32) && !test_hook("TIC_DECODE_NO_GUESS");
+    for (int attempt = may_guess ? 0 : 1; attempt < 2; attempt++) {
+        const bool guess = attempt == 0;
+        uint8_t head[16] = {0};
+        if (guess)
+            memcpy(head, ctx->dec_head, 16);
+        else
+            HIPCHK(ctx, hipMemcpy(head, d_stream, 16, hipMemcpyDeviceToHost));
+        int h, w, quality;
+        uint32_t flag;
+        if (parse_header(head, 16, &h, &w, &quality, &flag) != TIC_OK) return set_err(ctx, TIC_E_STREAM, "stream shorter than the 16-byte header");
+        if (flag & (1u << 31)) return set_err(ctx, TIC_E_STREAM, "streams with an embedded Huffman table are not supported"); // (a cached header passed these checks when it was cached)
+        const bool scaled = (flag & (1u << 30)) != 0;
+        if (h < 0 || w < 0) return set_err(ctx, TIC_E_STREAM, "bad geometry in header");
+        if (scaled && (quality < 0 || quality > 62)) return set_err(ctx, TIC_E_QUALITY, "scaled_dct exponent %d in header outside 0..62", quality);
+        if (!scaled && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "quality %d in header outside 1..99", quality);
+        const size_t n = num_blocks(h, w);
+        if (guess && (n == 0 || out_stride < (ptrdiff_t)w || !d_out || (size_t)(h - 1) * (size_t)out_stride + (size_t)w > out_cap)) { // the guess does not fit this call
+            ctx->last_decode_guess = -1;
+            continue;
+        }
+        if (!guess) {
+            if (h_out) *h_out = h;
+            if (w_out) *w_out = w;
+            if (n == 0) return TIC_OK;
+            if (out_stride < (ptrdiff_t)w) return set_err(ctx, TIC_E_ARG, "row stride %td smaller than the width %d", out_stride, w);
+            if (!d_out || (size_t)(h - 1) * (size_t)out_stride + (size_t)w > out_cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
+        }
+        bool done = false, held = false;
+        int rc = decode_on_device(ctx, (const uint8_t *)d_stream, len, h, w, scaled ? 50 : quality, scaled ? quality : -1, (uint8_t *)d_out, true,
+                                  (size_t)out_stride, &done, true, guess ? head : nullptr, guess ? &held : nullptr);
+        if (rc) return rc;
+        if (guess) {
+            ctx->last_decode_guess = held ? 1 : -1;
+            if (!held) continue; // another header (or the device decoder does not take this stream): read it
+            if (h_out) *h_out = h;
+            if (w_out) *w_out = w;
+        }
+        if (done) {
+            ctx->last_decode_path = 1;
+            memcpy(ctx->dec_head, head, 16);
+            ctx->dec_head_valid = true;
+            return TIC_OK;
+        }
         std::vector<uint8_t> host(len);
         HIPCHK(ctx, hipMemcpy(host.data(), d_stream, len, hipMemcpyDeviceToHost));
         if (n * 128 > ctx->h_zz_bytes) {
@@ -2004,8 +2045,9 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
         rc = ensure_scratch(ctx, align_up((size_t)w, 256) * (size_t)h, n * 128);
         if (rc) return rc;
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_coef, ctx->h_zz, n * 128, hipMemcpyHostToDevice, ctx->stream));
+        return idct_from_device(ctx, h, w, scaled ? 50 : quality, scaled ? quality : -1, (uint8_t *)d_out, true, (size_t)out_stride);
     }
-    return idct_from_device(ctx, h, w, scaled ? 50 : quality, scaled ? quality : -1, (uint8_t *)d_out, true, (size_t)out_stride);
+    return set_err(ctx, TIC_E_ARG, "tic_decompress_dev: unreachable");
 }
 
 // ---- self test hook (used by tests/ only; not part of the drop-in surface) --------------------------------

@@ -25,6 +25,7 @@ struct DecStatus {
     int dc_out;                 // running DC behind the last block produced here
     unsigned long long m;       // blocks produced: the pixels of blocks [0, m) have been written
     unsigned long long pos_out; // first stream bit behind block m - 1
+    uint32_t head[4];           // the stream's first 16 bytes as the kernels saw them (a caller that launched on a GUESS of the header compares)
 };
 
 // Where the pixels go and how the coefficients become pixels (the inverse stage of decode(), codec.py:46-70): the arguments of

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
     __shared__ __attribute__((aligned(16))) uint8_t lutm[kChainLds];   // the chain tables: the measure walk
     extern __shared__ uint32_t sbits[]; // stage_lds_words(range), the launch's dynamic LDS
     const uint32_t lane = threadIdx.x;
+    if (blockIdx.x == 0u && lane < 4u) st->head[lane] = gwords[lane]; // (a stream has its 16-byte header: nwords >= 4)
     const uint32_t t_first = blockIdx.x ? blockIdx.x * kOwned - 1u : 0u; // the window's first range
     static_assert(offsetof(DecLutsDev, mac) == offsetof(DecLutsDev, mdc) + 2048 && offsetof(DecLutsDev, mlong) == offsetof(DecLutsDev, mac) + 4096 &&
                       offsetof(DecLutsDev, mdc) % 16 == 0,
@@ -484,54 +485,39 @@ __device__ __forceinline__ void load_ac_lut(uint16_t *lds, const DecLutsDev *__r
     copy16_to_lds<T, 2 * kLongCodes / 16>(lds + 2048, L->ac16 + kLongFirst);
     if (threadIdx.x == 0) lds[2048 + kLongCodes] = 0; // the slot of an index outside the long codewords
 }
-constexpr int kImgStrideB = 144;  // bytes between the images of two blocks
-constexpr int kTrStrideDw = 68;   // dwords per block in a wave's transpose buffer (64 + 4 pad)
+constexpr int kImgStrideB = 132;  // bytes between the images of two blocks: 33 dwords (a lane per image: a dword of every image in one access, no bank conflict)
 __constant__ int kAnnScalesDec[64] = { // ANNSCALES of the reference's scaled_dct branch (constants.py; utils.py:59-62), as integers x 2048
     16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
     21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906,  19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
     16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  12873, 17855, 16819, 15137, 12873, 10114, 6967,  3552,
     8867,  12299, 11585, 10426, 8867,  6967,  4799,  2446,  4520,  6270,  5906,  5315,  4520,  3552,  2446,  1247};
-__device__ __forceinline__ void wave_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// 8 dwords per lane transposed across the 8 lanes of each block through the wave's buffer: in lane (g,c) v[u] = M[u][c]; out lane (g,u) v[c]
-__device__ __forceinline__ void tr8x8_dwords(uint32_t *buf, int g, int i, uint32_t v[8]) {
-    uint32_t *blk = buf + g * kTrStrideDw;
-#pragma unroll
-    for (int u = 0; u < 8; u++) blk[u * 8 + i] = v[u];
-    wave_fence();
-    const uint4 *rp = reinterpret_cast<const uint4 *>(blk + i * 8);
-    const uint4 a = rp[0], c = rp[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-    wave_fence();
-}
 
 // kWinWords: stream words of the workgroup's window: 2048 (+ kOver) hold 256 blocks of up to 256 bits on average - three workgroups
 // per CU - 4096 of up to 512 - two; what lies behind the window is read from memory
-template <uint32_t kWinWords>
-__global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+template <uint32_t kWinWords, bool kScaled>
+__global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                                     const uint32_t *__restrict__ bpos, const int32_t *__restrict__ dcsum, const uint8_t *__restrict__ dclen,
                                                                     const long long *__restrict__ total_blocks, unsigned long long n_want, uint32_t stream_bits,
                                                                     DecIdctArgs a, DecStatus *__restrict__ st) {
-    // phase 1: tables + stream window; phase 2 (behind the barrier): the waves' transpose buffers
+    // tables + stream window
     constexpr uint32_t kBlkWin = kWinWords + kOver;
     constexpr uint32_t kBlkLds = kBlkWin + kBlkWin / 32 + 2;
     constexpr int kLutDw = (kAcLutLds * 2 + 15) / 16 * 4;
-    constexpr int kTrDw = (kDecodeWG / 64) * 8 * kTrStrideDw;
-    constexpr int kScratchDw = kLutDw + (int)kBlkLds > kTrDw ? kLutDw + (int)kBlkLds : kTrDw;
+    constexpr int kScratchDw = kLutDw + (int)kBlkLds;
     __shared__ __attribute__((aligned(16))) uint32_t scratch[kScratchDw];
     __shared__ __attribute__((aligned(16))) unsigned char img[kDecodeWG * kImgStrideB];
     __shared__ uint8_t zznat[64];
+    __shared__ __attribute__((aligned(16))) double dq[64]; // the dequantisation constants, natural order (every lane reads the same entry: a broadcast)
     uint16_t *lut = reinterpret_cast<uint16_t *>(scratch);
     uint32_t *sbits = scratch + kLutDw;
     const unsigned long long total = (unsigned long long)*total_blocks;
     const unsigned long long m = total < n_want ? total : n_want; // blocks produced here
     const unsigned long long b0 = (unsigned long long)blockIdx.x * kDecodeWG, b = b0 + threadIdx.x;
     if (b0 >= m) return; // (the whole workgroup)
-    if (threadIdx.x < 64) zznat[threadIdx.x] = a.consts->zznat[threadIdx.x];
+    if (threadIdx.x < 64) {
+        zznat[threadIdx.x] = a.consts->zznat[threadIdx.x];
+        dq[threadIdx.x] = a.consts->div[threadIdx.x];
+    }
     { // the images start as zeros: the decoder writes the non-zero coefficients only
         uint4 *z = reinterpret_cast<uint4 *>(img);
         for (int k = threadIdx.x; k < kDecodeWG * kImgStrideB / 16; k += kDecodeWG) z[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -571,6 +557,9 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
             int k = 1;
             bool live = true, in_long = false;
             // one table look-up per step, as in the measure walk: a long codeword takes a second step, not a second look-up
+#if TIC_EXP == 2
+            live = false;
+#endif
             while (live) {
                 const uint32_t wn = word_be(words, wi + 3u);
                 asm volatile("" ::: "memory"); // (the request stays in front of the table look-up)
@@ -603,74 +592,76 @@ __global__ __launch_bounds__(kDecodeWG) void dec_decode_idct_kernel(const uint32
             st->m = m;
         }
     }
-    __syncthreads();
-    // ---- phase 2: 8 lanes per block, a wave takes 8 consecutive blocks per round.  (Two blocks per lane group and round - two
-    // independent float64 chains per lane - measured no faster and cost a second transpose buffer per wave, i.e. the third workgroup
-    // per CU.)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 3, i = lane & 7;
-    const DctqConsts *__restrict__ C = a.consts;
-    uint32_t *tb = scratch + wave * (8 * kTrStrideDw); // (tables and window are dead: behind the barrier)
-    double dq[8]; // the lane's eight dequantisation constants (column v = i): read once, not once per round
+    // ---- phase 2: the lane that decoded a block transforms it - all 64 coefficients in registers, no transposition, no barrier between
+    // the phases (a wave whose blocks were short goes on while the others still decode), nothing but the lane's own image read back.
+    // (Rounds 2-4: 8 lanes per block, 8 blocks per wave and round, the 8x8 float64 matrix transposed through LDS between the passes:
+    // the same arithmetic, plus two LDS round trips and a workgroup barrier per round; profiles/r05_decoder.txt.)
+#if TIC_EXP == 1
+    return;
+#endif
+    if (b >= m) return;
+    asm volatile("" ::: "memory"); // (the image's two-byte stores above are read back as 16-byte pieces)
+    double x[64]; // x[u * 8 + v]: natural order
+    // axis -2, two columns at a time: their sixteen coefficients come back as eight dwords (the lanes' images are an odd number of dwords
+    // apart: no bank conflict), the constants as eight 16-byte broadcasts; nothing of the columns behind is in registers yet (the whole
+    // block at once, packed, plus its constants would be 160 registers on top of the 128 of x: the third wave per SIMD)
+    const uint32_t *im32 = reinterpret_cast<const uint32_t *>(img + (size_t)threadIdx.x * kImgStrideB);
+    const double2 *dq2 = reinterpret_cast<const double2 *>(dq);
 #pragma unroll
-    for (int u = 0; u < 8; u++) dq[u] = C->div[u * 8 + i];
-    auto load_col = [&](int lb, double (&c)[8]) { // lane i takes column v = i of the natural 8x8 coefficient matrix of block lb
-        const int16_t *c16 = reinterpret_cast<const int16_t *>(img + (size_t)lb * kImgStrideB);
-        int cv[8];
+    for (int vp = 0; vp < 4; vp++) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) cv[u] = (int)c16[u * 8 + i]; // (eight reads in flight: with the branch below inside this loop the
-                                                                  // compiler waited for every one of them before issuing the next)
-        if (a.scaled) { // codec.py:60-62: (coeffs / ANNSCALES) * 2**quality, then the inverse quantiser of quality 50: three roundings
-#pragma unroll
-            for (int u = 0; u < 8; u++) c[u] = (((double)cv[u] / ((double)kAnnScalesDec[u * 8 + i] / 2048.0)) * a.pow2) * dq[u];
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; u++) c[u] = (double)cv[u] * dq[u]; // coeffs * (Q*factor/100)
+        for (int u = 0; u < 8; u++) {
+            const uint32_t w2 = im32[u * 4 + vp];
+            const double2 d2 = dq2[u * 4 + vp];
+            const int lo = (int)(int16_t)(w2 & 0xffffu), hi = (int)w2 >> 16;
+            if (kScaled) { // codec.py:60-62: (coeffs / ANNSCALES) * 2**quality, then the inverse quantiser of quality 50: three roundings
+                x[u * 8 + 2 * vp] = (((double)lo / ((double)kAnnScalesDec[u * 8 + 2 * vp] / 2048.0)) * a.pow2) * d2.x;
+                x[u * 8 + 2 * vp + 1] = (((double)hi / ((double)kAnnScalesDec[u * 8 + 2 * vp + 1] / 2048.0)) * a.pow2) * d2.y;
+            } else { // coeffs * (Q*factor/100)
+                x[u * 8 + 2 * vp] = (double)lo * d2.x;
+                x[u * 8 + 2 * vp + 1] = (double)hi * d2.y;
+            }
         }
-    };
-    auto store_rows = [&](int lb, const double (&c)[8]) { // lane i holds pixel row i of block lb
+#pragma unroll
+        for (int v = 2 * vp; v < 2 * vp + 2; v++) {
+            idct8_exact(x[v], x[8 + v], x[16 + v], x[24 + v], x[32 + v], x[40 + v], x[48 + v], x[56 + v]);
+            // the column's results exist HERE: element (u, v) feeds pixel row u only, whose store sits behind a condition, and the compiler
+            // otherwise sinks the tail of every column's arithmetic into those conditions - twice as many values in flight, 250 registers
+            asm volatile("" : "+v"(x[v]), "+v"(x[8 + v]), "+v"(x[16 + v]), "+v"(x[24 + v]), "+v"(x[32 + v]), "+v"(x[40 + v]), "+v"(x[48 + v]), "+v"(x[56 + v]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const uint32_t blk = (uint32_t)b; // (bit positions are 32-bit: fewer than 2^32 / 6 blocks)
+    const uint32_t by = blk / (uint32_t)a.bw, bx = blk - by * (uint32_t)a.bw;
+    const int x0 = (int)bx * 8;
+    const bool whole = a.aligned8 && x0 + 8 <= a.w;
+    uint8_t *p = a.out + (long)by * 8 * a.stride + x0;
+    const int rows_here = a.h - (int)by * 8; // (>= 1: the block exists)
+#pragma unroll
+    for (int u = 0; u < 8; u++) { // axis -1, a pixel row at a time
+        idct8_exact(x[u * 8], x[u * 8 + 1], x[u * 8 + 2], x[u * 8 + 3], x[u * 8 + 4], x[u * 8 + 5], x[u * 8 + 6], x[u * 8 + 7]);
         uint32_t px[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            double v = c[k] + 128.0;
-            v = v < 0.0 ? 0.0 : v;
-            v = v > 255.0 ? 255.0 : v;
-            px[k] = (uint32_t)(int)v; // truncation toward zero, as astype(np.uint8) on a clipped value
+            // + 128, clip, truncation toward zero as astype(np.uint8) on a clipped value (the sum is a finite number: v_max / v_min instead of two
+            // compares and four selects)
+            px[k] = (uint32_t)(int)__builtin_fmin(__builtin_fmax(x[u * 8 + k] + 128.0, 0.0), 255.0);
         }
-        const unsigned long long blk = b0 + (unsigned long long)lb;
-        if (blk >= m) return;
-        const unsigned long long by = blk / (unsigned long long)a.bw, bx = blk - by * (unsigned long long)a.bw;
-        const long y = (long)by * 8 + i;
-        const int x0 = (int)bx * 8;
-        if (y >= a.h) return;
-        uint8_t *p = a.out + y * a.stride + x0;
-        if (a.aligned8 && x0 + 8 <= a.w) {
-            uint2 o;
-            o.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-            o.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
-            *reinterpret_cast<uint2 *>(p) = o;
-        } else {
+        uint2 o;
+        o.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        o.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+        asm volatile("" : "+v"(o.x), "+v"(o.y)); // (as above: the row's arithmetic stays in front of the condition)
+        if (u < rows_here) {
+            if (whole) {
+                *reinterpret_cast<uint2 *>(p) = o;
+            } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (x0 + k < a.w) p[k] = (uint8_t)px[k];
+                for (int k = 0; k < 8; k++)
+                    if (x0 + k < a.w) p[k] = (uint8_t)((k < 4 ? o.x : o.y) >> (8 * (k & 3)));
+            }
         }
-    };
-    for (int round = 0; round < kDecodeWG / 32; round++) {
-        const int lb = round * 32 + wave * 8 + g; // block of this lane group inside the workgroup
-        double c[8];
-        load_col(lb, c);
-        idct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -2
-        uint32_t w[8], wh[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = (uint32_t)__double2loint(c[k]);
-        tr8x8_dwords(tb, g, i, w);
-#pragma unroll
-        for (int k = 0; k < 8; k++) wh[k] = (uint32_t)__double2hiint(c[k]);
-        tr8x8_dwords(tb, g, i, wh);
-#pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = __hiloint2double((int)wh[k], (int)w[k]);
-        idct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -1: lane i holds pixel row i
-        store_rows(lb, c);
+        p += a.stride;
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -740,12 +731,13 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     hipLaunchKernelGGL(dec_dc_scan_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const long long *)totals,
                        (unsigned long long)nblocks, desc_b, 2u * epoch + 1u, dcsum, dclen, d_status);
     const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
-    if (nbits / nblocks <= 240) // sparse enough for the small window: one workgroup more per CU
-        hipLaunchKernelGGL(dec_decode_idct_kernel<2048>, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos,
-                           (const int32_t *)dcsum, (const uint8_t *)dclen, (const long long *)totals, (unsigned long long)nblocks, (uint32_t)nbits, idct, d_status);
-    else
-        hipLaunchKernelGGL(dec_decode_idct_kernel<4096>, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos,
-                           (const int32_t *)dcsum, (const uint8_t *)dclen, (const long long *)totals, (unsigned long long)nblocks, (uint32_t)nbits, idct, d_status);
+    auto fused = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const int32_t *)dcsum, (const uint8_t *)dclen,
+                           (const long long *)totals, (unsigned long long)nblocks, (uint32_t)nbits, idct, d_status);
+    };
+    const bool small_win = nbits / nblocks <= 240; // sparse enough for the small window: one workgroup more per CU
+    if (idct.scaled) small_win ? fused(dec_decode_idct_kernel<2048, true>) : fused(dec_decode_idct_kernel<4096, true>);
+    else small_win ? fused(dec_decode_idct_kernel<2048, false>) : fused(dec_decode_idct_kernel<4096, false>);
     return hipGetLastError();
 }
 

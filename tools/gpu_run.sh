@@ -25,6 +25,7 @@ for step in "$@"; do
     microbench5) run microbench5 300 ./tools/bin/microbench5 ;;
     microbench6) run microbench6 300 ./tools/bin/microbench6 ;;
     microbench7) run microbench7 300 ./tools/bin/microbench7 ;;
+    microbench8) run microbench8 300 ./tools/bin/microbench8 ;;
     compress_dev) run compress_dev 200 python tools/prof_compress_dev.py 4096 200 ;;
     prof_cdev)  rm -rf gpurun_out/prof_cdev; run prof_cdev 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cdev -- python tools/prof_compress_dev.py 4096 200 ;;
     stress)     run stress 900 python tools/stress_parity.py ${TIC_STRESS_ITERS:-300} ;;
