@@ -153,6 +153,42 @@ __device__ __forceinline__ void copy16_to_lds(void *lds, const void *__restrict_
 static_assert(offsetof(DecLutsDev, dc11) % 16 == 0 && offsetof(DecLutsDev, ac11) % 16 == 0 && (offsetof(DecLutsDev, ac16) + 2 * kLongFirst) % 16 == 0 &&
                   (2 * kLongCodes) % 16 == 0,
               "the tables are copied in 16-byte pieces (the structure itself comes from hipMalloc)");
+// ---- prefix sums inside the kernels that need them ---------------------------------------------------------------------------------
+// The decoder has two: the ranges' block counts (-> index of each range's first block) and the blocks' DC differences (np.cumsum,
+// codec.py:53).  Every workgroup sums its own elements, PUBLISHES the sum - one 8-byte agent-scope atomic store that carries the sum
+// and the launch's epoch, so that nothing has to be zeroed between launches and no fence is needed: the word is the whole message -
+// and then adds up the words of all workgroups in front of it, lane j reading workgroup j's, j + 64's ...  No workgroup waits for a
+// RESULT of another, only for its publication, which every workgroup makes before it looks back; workgroups are dispatched in index
+// order, so the ones a workgroup waits for are running or done.  (Rounds 2-3: three launches per scan - tile sums, a one-workgroup scan
+// of the sums, apply; round 4: one launch per scan; now none - the sums are taken where their inputs are produced and their results used.)
+__device__ __forceinline__ long long wg_inclusive_scan(long long v, long long *lds /* [16] */, long long &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    long long off = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; k++) {
+        if (k < wave) off += lds[k];
+        tot += lds[k];
+    }
+    __syncthreads();
+    total = tot;
+    return v + off;
+}
+// 24 bits of epoch, 40 bits of sum (two's complement): |sum| < 2^39 covers 2^32 blocks of +-2047 each... by a wide margin for every
+// frame the 32-bit bit positions of this file admit
+__device__ __forceinline__ unsigned long long scan_pack(uint32_t epoch, long long sum) {
+    return ((unsigned long long)(epoch & 0xffffffu) << 40) | ((unsigned long long)sum & 0xffffffffffull);
+}
+__device__ __forceinline__ long long scan_sum_of(unsigned long long d) { return ((long long)(d << 24)) >> 24; }
+__device__ __forceinline__ void scan_publish(unsigned long long *desc, uint32_t epoch, long long tot) {
+    if (threadIdx.x == 0) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // Measure and stitch, one kernel.  The lanes of a wave walk side by side, a look-up per step.  (Round 3's first version looped per
 // block: the lanes of a wave then wait for each other at every block end - 630 symbol steps per wave where the longest lane has ~250
 // symbols.)  Here the position inside the block (is the DC category next?) is lane state and a block end is just another step.
@@ -164,8 +200,9 @@ static_assert(offsetof(DecLutsDev, dc11) % 16 == 0 && offsetof(DecLutsDev, ac11)
 constexpr uint32_t kOwned = 63; // ranges a workgroup owns
 __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                                 uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
-                                                                uint32_t *__restrict__ nrec, uint32_t *__restrict__ nblk, uint16_t *__restrict__ hand,
-                                                                uint32_t *__restrict__ entry, DecStatus *__restrict__ st) {
+                                                                uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t epoch,
+                                                                unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
+                                                                DecStatus *__restrict__ st) {
     __shared__ __attribute__((aligned(16))) uint8_t lutm[kChainLds];   // the chain tables: the measure walk
     extern __shared__ uint32_t sbits[]; // stage_lds_words(range), the launch's dynamic LDS
     const uint32_t lane = threadIdx.x;
@@ -246,222 +283,142 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
     if (mine && cnt > cap) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
     // ---- stitch: does the true chain, entering where the walk of the range in front ended, meet this range's trace?
     const uint32_t pos_in = (uint32_t)__shfl_up((int)pos, 1, 64); // (all 64 lanes are here: nobody has returned)
-    if (!mine) return;
     const uint32_t n_rec = cnt;
-    nrec[t] = n_rec;
-    entry[t] = n_rec; // (until the walk below meets the trace: no trace block belongs to the true chain)
-    if (t == 0u) {
-        nblk[0] = n_rec;
-        entry[0] = 0u;
-        return;
-    }
-    pos = pos_in; // hypothesis: where the true chain enters this range
-    if (pos >= fast_end) { // the chain left the fast part of the stream in front of this range
-        nblk[t] = 0u;
-        return;
-    }
     const uint32_t n = n_rec < cap ? n_rec : cap;
-    // the head of the trace, back from memory in one trip (this lane's own stores); entry 0 is the range's first bit
-    const uint32_t tr1 = tr[1], tr2 = tr[2]; // (entries behind n are never looked at; cap >= 3)
-    auto trace_at = [&](uint32_t k) { return k >= n ? 0xffffffffu : (k == 0u ? 0u : (k == 1u ? tr1 : (k == 2u ? tr2 : (uint32_t)tr[k]))); };
-    uint32_t by_hand = 0;
-    // the trace is sorted and the walk only moves forward: ONE pointer into the trace, advanced past the entries in front of the
-    // walk (rounds 2-3 searched the trace from scratch at every block: eight dependent loads from memory where this takes one or two)
-    uint32_t a = 0;
-    uint32_t ta = trace_at(0u);
-    for (;;) {
-        if (pos >= hi) { // walked through the whole range without meeting its trace: the hypothesis for the next range fails
-            // (... unless there is no next range: the last one may be a few bits long, its own walk then has no time to fall in step,
-            // and nothing depends on where that walk ended - its blocks are the ones walked by hand here.  Rounds 2-3 gave up on
-            // such a stream and decoded it a second time with the longest range.)
-            if (t + 1u != nranges) atomicOr(&st->giveup, 4);
-            nblk[t] = by_hand;
+    // what the stitch finds out about this range: its blocks on the true chain (nb): `by_hand` of them measured below, from where the
+    // chain entered, the others the range's own trace from entry `a` on
+    uint32_t nb = 0, by_hand = 0, a = n;
+    auto stitch = [&]() {
+        if (t == 0u) { // the first range starts on a true block start: its trace is the chain
+            nb = n_rec;
+            a = 0u;
             return;
         }
-        if (pos + 6u > stream_bits) { // fewer bits than a block has: the chain has arrived at the stream's end (its padding)
-            nblk[t] = by_hand;
-            return;
-        }
-        // is `pos` a block start this range's trace recorded?
-        const uint32_t want = pos - lo;
-        while (ta < want) {
-            a++;
-            ta = trace_at(a);
-        }
-        if (ta == want) {
-            // from here on the trace walked the true chain (whether its blocks are well-formed is checked where they are decoded)
-            nblk[t] = by_hand + (n_rec - a);
-            entry[t] = a;
-            return;
-        }
-        if (by_hand < cap) hand[(size_t)t * cap + by_hand] = (uint16_t)want; // first bit of the by-hand block (pos >= lo: the walk enters behind the range before)
-        // one block by hand: the same chain walk, from `pos` with the DC category next, to its EOB.  (Rounds 2-3 decoded the block
-        // symbol by symbol with the one-symbol tables and checked it - a second set of tables in LDS, and three times the steps; whether
-        // a block of the true chain is well-formed is checked where it is decoded, in the fused kernel, as for the trace's blocks.)
-        {
-            uint32_t p = pos;
-            const uint32_t limit = p + 1800u < stream_bits ? p + 1800u : stream_bits; // (a block has at most 1,728 bits)
-            bool dcn = true, lng = false, open = true;
-            uint32_t bi = p >> 5;
-            uint32_t ba = wp[bi], bb = wp[bi + 1u], bc = wp[bi + 2u];
-            while (open && p < limit) {
-                const uint32_t bn = wp[bi + 3u];
-                asm volatile("" ::: "memory");
-                const uint32_t pk = (uint32_t)(((((unsigned long long)ba) << 32) | bb) << (p & 31u) >> 32);
-                const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
-                const uint32_t e = lutm[lng ? 6144u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : (dcn ? pk >> 21 : 2048u + (pk >> 20))];
-                const bool none = e == 0u;
-                const bool esc = none && !lng && !dcn;
-                p += esc ? 0u : (none ? 1u : e >> 1);
-                const uint32_t now = p >> 5;
-                const bool crossed = now != bi;
-                ba = crossed ? bb : ba;
-                bb = crossed ? bc : bb;
-                bc = crossed ? bn : bc;
-                bi = now;
-                open = (e & 1u) == 0u;
-                dcn = none ? dcn : false;
-                lng = esc;
-            }
-            if (open) { // no EOB within a block's length, or the stream ended first
-                // ... at the stream's end that is how the chain of a whole stream ends: in the padding bits behind its last block (fewer than
-                // 8 zeros, no block), and a cut stream's chain ends the same way in front of its open block - the host continues from it
-                // (whatever the ranges behind still add to the chain is caught where it is decoded: those blocks do not follow each other)
-                if (pos + 2048u <= fast_end) atomicOr(&st->giveup, 16);
-                nblk[t] = by_hand;
+        pos = pos_in; // hypothesis: where the true chain enters this range
+        if (pos >= fast_end) return; // the chain left the fast part of the stream in front of this range
+        // the head of the trace, back from memory in one trip (this lane's own stores); entry 0 is the range's first bit
+        const uint32_t tr1 = tr[1], tr2 = tr[2]; // (entries behind n are never looked at; cap >= 3)
+        auto trace_at = [&](uint32_t k) { return k >= n ? 0xffffffffu : (k == 0u ? 0u : (k == 1u ? tr1 : (k == 2u ? tr2 : (uint32_t)tr[k]))); };
+        // the trace is sorted and the walk only moves forward: ONE pointer into the trace, advanced past the entries in front of the
+        // walk (rounds 2-3 searched the trace from scratch at every block: eight dependent loads from memory where this takes one or two)
+        uint32_t ap = 0;
+        uint32_t ta = trace_at(0u);
+        for (;;) {
+            if (pos >= hi) { // walked through the whole range without meeting its trace: the hypothesis for the next range fails
+                // (... unless there is no next range: the last one may be a few bits long, its own walk then has no time to fall in step,
+                // and nothing depends on where that walk ended - its blocks are the ones walked by hand here.  Rounds 2-3 gave up on
+                // such a stream and decoded it a second time with the longest range.)
+                if (t + 1u != nranges) atomicOr(&st->giveup, 4);
+                nb = by_hand;
                 return;
             }
-            pos = p;
-        }
-        by_hand++;
-    }
-}
-
-// ---- prefix sums in ONE launch ----------------------------------------------------------------------------------------------------
-// Every tile of kTile elements scans itself, PUBLISHES its own sum - one 8-byte agent-scope atomic store that carries the sum
-// and the launch's epoch, so that nothing has to be zeroed between launches and no fence is needed: the word is the whole message -
-// and then adds up the words of all tiles in front of it, thread j reading tile j's.  No tile waits for a RESULT of another tile,
-// only for its publication, which every tile makes before it looks back; workgroups are dispatched in index order, so the tiles
-// a tile waits for are running or done.  (Rounds 2-3: three launches per scan - tile sums, a one-workgroup scan of the sums, apply.)
-constexpr int kTile = 1024;
-__device__ __forceinline__ long long wg_inclusive_scan(long long v, long long *lds /* [16] */, long long &total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const long long o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    if (lane == 63) lds[wave] = v;
-    __syncthreads();
-    long long off = 0, tot = 0;
-    const int nw = blockDim.x >> 6;
-    for (int k = 0; k < nw; k++) {
-        if (k < wave) off += lds[k];
-        tot += lds[k];
-    }
-    __syncthreads();
-    total = tot;
-    return v + off;
-}
-// 24 bits of epoch, 40 bits of sum (two's complement): |sum| < 2^39 covers 2^32 blocks of +-2047 each... by a wide margin for every
-// frame the 32-bit bit positions of this file admit
-__device__ __forceinline__ unsigned long long scan_pack(uint32_t epoch, long long sum) {
-    return ((unsigned long long)(epoch & 0xffffffu) << 40) | ((unsigned long long)sum & 0xffffffffffull);
-}
-__device__ __forceinline__ long long scan_sum_of(unsigned long long d) { return ((long long)(d << 24)) >> 24; }
-// sum of the tiles in front of this one (the caller has published its own `tot` through scan_publish)
-__device__ __forceinline__ void scan_publish(unsigned long long *desc, uint32_t epoch, long long tot) {
-    if (threadIdx.x == 0) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ long long scan_lookback(const unsigned long long *desc, uint32_t epoch, long long *lds /* [16] */, DecStatus *st) {
-    long long part = 0;
-    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += blockDim.x) {
-        unsigned long long d;
-        uint32_t spins = 0;
-        do {
-            d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (an exit every wave reaches: a tile in front that never publishes - which the dispatch order rules out - ends the wait after
-            // about a second, and the flag sends the whole stream to the host decoder)
-            if (++spins == (1u << 20)) {
-                atomicOr(&st->giveup, 128);
-                d = scan_pack(epoch, 0);
+            if (pos + 6u > stream_bits) { // fewer bits than a block has: the chain has arrived at the stream's end (its padding)
+                nb = by_hand;
+                return;
             }
-        } while ((uint32_t)(d >> 40) != (epoch & 0xffffffu));
-        part += scan_sum_of(d);
-    }
-    long long total;
-    (void)wg_inclusive_scan(part, lds, total);
-    return total;
-}
-// Index of every range's first true block (exclusive scan of the ranges' block counts; *grand_total = all of them) and, with it, the
-// first bit of every block of the true chain: range t's blocks are the ones its stitch walked by hand, then its trace from the entry
-// on.  (Rounds 2-3: three scan launches and a bpos launch.)
-__global__ __launch_bounds__(kTile) void scan_counts_bpos_kernel(const uint32_t *__restrict__ nblk, uint32_t range, uint32_t nranges, unsigned long long *__restrict__ desc,
-                                                                 uint32_t epoch, const uint16_t *__restrict__ starts, const uint16_t *__restrict__ hand,
-                                                                 const uint32_t *__restrict__ nrec, const uint32_t *__restrict__ entry, unsigned long long nblocks,
-                                                                 uint32_t *__restrict__ bpos, long long *__restrict__ grand_total, DecStatus *__restrict__ st) {
-    __shared__ long long lds[16];
-    const size_t t = (size_t)blockIdx.x * kTile + threadIdx.x;
-    const bool mine = t < nranges;
-    long long tot;
-    const long long v = mine ? (long long)nblk[t] : 0ll;
-    const uint32_t nrec_t = mine ? nrec[t] : 0u, entry_t = mine ? entry[t] : 0u; // (requested in front of the scan's barriers)
-    const long long inc = wg_inclusive_scan(v, lds, tot);
-    scan_publish(desc, epoch, tot);
-    const long long off = scan_lookback(desc, epoch, lds, st);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grand_total = off + tot;
-    if (!mine) return;
-    const unsigned long long first = (unsigned long long)(off + inc - v);
-    const uint32_t lo = 128u + (uint32_t)t * range, cap = cap_of(range);
-    const uint32_t nr = nrec_t < cap ? nrec_t : cap, a = entry_t < nr ? entry_t : nr;
-    const uint32_t nb = (uint32_t)v, from_trace = nr - a < nb ? nr - a : nb, by_hand = nb - from_trace;
-    // a range has five blocks or so: four offsets are requested before the first position is written
-    auto emit = [&](const uint16_t *__restrict__ src, uint32_t cnt, unsigned long long dst0) {
-        for (uint32_t j0 = 0; j0 < cnt; j0 += 4u) {
-            uint32_t x[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) x[k] = (uint32_t)src[j0 + k < cnt ? j0 + k : cnt - 1u];
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; k++)
-                if (j0 + k < cnt && dst0 + j0 + k < nblocks) bpos[dst0 + j0 + k] = lo + x[k];
+            // is `pos` a block start this range's trace recorded?
+            const uint32_t want = pos - lo;
+            while (ta < want) {
+                ap++;
+                ta = trace_at(ap);
+            }
+            if (ta == want) {
+                // from here on the trace walked the true chain (whether its blocks are well-formed is checked where they are decoded)
+                nb = by_hand + (n_rec - ap);
+                a = ap;
+                return;
+            }
+            if (by_hand < cap) hand[(size_t)t * cap + by_hand] = (uint16_t)want; // first bit of the by-hand block (pos >= lo: the walk enters behind the range before)
+            // one block by hand: the same chain walk, from `pos` with the DC category next, to its EOB.  (Rounds 2-3 decoded the block
+            // symbol by symbol with the one-symbol tables and checked it - a second set of tables in LDS, and three times the steps; whether
+            // a block of the true chain is well-formed is checked where it is decoded, in the fused kernel, as for the trace's blocks.)
+            {
+                uint32_t p = pos;
+                const uint32_t limit = p + 1800u < stream_bits ? p + 1800u : stream_bits; // (a block has at most 1,728 bits)
+                bool dcn = true, lng = false, open = true;
+                uint32_t bi = p >> 5;
+                uint32_t ba = wp[bi], bb = wp[bi + 1u], bc = wp[bi + 2u];
+                while (open && p < limit) {
+                    const uint32_t bn = wp[bi + 3u];
+                    asm volatile("" ::: "memory");
+                    const uint32_t pk = (uint32_t)(((((unsigned long long)ba) << 32) | bb) << (p & 31u) >> 32);
+                    const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
+                    const uint32_t e = lutm[lng ? 6144u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : (dcn ? pk >> 21 : 2048u + (pk >> 20))];
+                    const bool none = e == 0u;
+                    const bool esc = none && !lng && !dcn;
+                    p += esc ? 0u : (none ? 1u : e >> 1);
+                    const uint32_t now = p >> 5;
+                    const bool crossed = now != bi;
+                    ba = crossed ? bb : ba;
+                    bb = crossed ? bc : bb;
+                    bc = crossed ? bn : bc;
+                    bi = now;
+                    open = (e & 1u) == 0u;
+                    dcn = none ? dcn : false;
+                    lng = esc;
+                }
+                if (open) { // no EOB within a block's length, or the stream ended first
+                    // ... at the stream's end that is how the chain of a whole stream ends: in the padding bits behind its last block (fewer than
+                    // 8 zeros, no block), and a cut stream's chain ends the same way in front of its open block - the host continues from it
+                    // (whatever the ranges behind still add to the chain is caught where it is decoded: those blocks do not follow each other)
+                    if (pos + 2048u <= fast_end) atomicOr(&st->giveup, 16);
+                    nb = by_hand;
+                    return;
+                }
+                pos = p;
+            }
+            by_hand++;
         }
     };
-    emit(hand + t * cap, by_hand < cap ? by_hand : cap, first);
-    emit(starts + t * cap + a, from_trace, first + by_hand);
-}
-
-// np.cumsum of the DC differences (codec.py:53), one launch: lane b decodes the DC symbol of block b (the first symbol at bpos[b]:
-// one table look-up) and the differences are summed inclusively over the blocks, tile by tile with the look-back above.
-// dcsum[b] = sum of the differences of blocks 0..b (int32: at most 2^32 blocks of +-2047... the host decoder's long long, narrowed
-// where it is used: sat16).  Blocks past the m produced here contribute nothing.
-__global__ __launch_bounds__(kTile) void dec_dc_scan_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
-                                                            const uint32_t *__restrict__ bpos, const long long *__restrict__ total_blocks,
-                                                            unsigned long long n_want, unsigned long long *__restrict__ desc, uint32_t epoch,
-                                                            int32_t *__restrict__ dcsum, uint8_t *__restrict__ dclen, DecStatus *__restrict__ st) {
-    __shared__ long long lds[16];
-    __shared__ __attribute__((aligned(16))) uint16_t dc11[2048];
-    copy16_to_lds<kTile, 4096 / 16>(dc11, L->dc11);
-    __syncthreads();
-    const unsigned long long total = (unsigned long long)*total_blocks;
-    const unsigned long long m = total < n_want ? total : n_want;
-    const unsigned long long b = (unsigned long long)blockIdx.x * kTile + threadIdx.x;
-    long long v = 0;
-    if (b < m) {
-        const uint32_t pos = bpos[b], wi = pos >> 5, sh = pos & 31u;
-        const uint32_t wa = stream_word(gwords, wi, nwords, last_mask), wb = stream_word(gwords, wi + 1u, nwords, last_mask);
-        const uint32_t pk = sh ? __builtin_amdgcn_alignbit(wa, wb, 32u - sh) : wa;
-        const uint32_t e = dc11[pk >> 21]; // (measure or stitch walked this block: a DC codeword is there)
-        if (!e) atomicOr(&st->giveup, 32);
-        v = (long long)value_of(pk, (int)(e >> 8), (int)(e & 15u));
-        dclen[b] = (uint8_t)((e >> 8) + (e & 15u)); // bits of the DC symbol: the fused kernel starts behind it and needs no DC table
-    }
-    long long tot;
-    const long long inc = wg_inclusive_scan(v, lds, tot);
-    scan_publish(desc, epoch, tot);
-    const long long off = scan_lookback(desc, epoch, lds, st);
-    if (b < m) {
-        dcsum[b] = (int32_t)(off + inc);
-        if (b == m - 1) st->dc_out = (int)(off + inc); // running DC behind the last block produced here (the host's tail continues from it)
+    if (mine) stitch();
+    // ---- index of every range's first true block, and with it the first bit of every block of the true chain - HERE, in the same launch
+    // (rounds 2-4: a launch of its own, scan_counts_bpos_kernel, over arrays this kernel wrote): the wave sums its 63 counts, PUBLISHES the
+    // sum (one 8-byte word that carries the launch's epoch, scan_pack below) and adds up the words of the workgroups in front of it - they were
+    // dispatched earlier and publish without waiting for anybody.  Then every lane writes its blocks' positions: the ones it walked by
+    // hand, then its trace from the entry on.
+    {
+        long long inc = (long long)nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long o = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc += o;
+        }
+        const long long tot = __shfl(inc, 63, 64);
+        if (lane == 63u) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long part = 0;
+        for (uint32_t j = lane; j < blockIdx.x; j += 64u) {
+            unsigned long long d;
+            uint32_t spins = 0;
+            do {
+                d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (an exit every wave reaches: a workgroup in front that never publishes - which the dispatch order rules out - ends the
+                // wait after about a second, and the flag sends the whole stream to the host decoder)
+                if (++spins == (1u << 20)) {
+                    atomicOr(&st->giveup, 128);
+                    d = scan_pack(epoch, 0);
+                }
+            } while ((uint32_t)(d >> 40) != (epoch & 0xffffffu));
+            part += scan_sum_of(d);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (blockIdx.x == gridDim.x - 1u && lane == 63u) *grand_total = part + tot;
+        if (!mine) return;
+        const unsigned long long first = (unsigned long long)(part + inc - (long long)nb);
+        const uint32_t from_trace = n - a < nb ? n - a : nb, hand_n = nb - from_trace < cap ? nb - from_trace : cap; // (a <= n)
+        // a range has five blocks or so: four offsets are requested before the first position is written
+        auto emit = [&](const uint16_t *__restrict__ src, uint32_t cnt_, unsigned long long dst0) {
+            for (uint32_t j0 = 0; j0 < cnt_; j0 += 4u) {
+                uint32_t x[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++) x[k] = (uint32_t)src[j0 + k < cnt_ ? j0 + k : cnt_ - 1u];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++)
+                    if (j0 + k < cnt_ && dst0 + j0 + k < nblocks) bpos[dst0 + j0 + k] = lo + x[k];
+            }
+        };
+        emit(hand + (size_t)t * cap, hand_n, first);
+        emit(tr + a, from_trace, first + (nb - from_trace));
     }
 }
 
@@ -496,7 +453,7 @@ __constant__ int kAnnScalesDec[64] = { // ANNSCALES of the reference's scaled_dc
 // per CU - 4096 of up to 512 - two; what lies behind the window is read from memory
 template <uint32_t kWinWords, bool kScaled>
 __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
-                                                                    const uint32_t *__restrict__ bpos, const int32_t *__restrict__ dcsum, const uint8_t *__restrict__ dclen,
+                                                                    const uint32_t *__restrict__ bpos, unsigned long long *__restrict__ desc, uint32_t epoch,
                                                                     const long long *__restrict__ total_blocks, unsigned long long n_want, uint32_t stream_bits,
                                                                     DecIdctArgs a, DecStatus *__restrict__ st) {
     // tables + stream window
@@ -508,6 +465,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     __shared__ __attribute__((aligned(16))) unsigned char img[kDecodeWG * kImgStrideB];
     __shared__ uint8_t zznat[64];
     __shared__ __attribute__((aligned(16))) double dq[64]; // the dequantisation constants, natural order (every lane reads the same entry: a broadcast)
+    __shared__ long long scan_lds[16];
     uint16_t *lut = reinterpret_cast<uint16_t *>(scratch);
     uint32_t *sbits = scratch + kLutDw;
     const unsigned long long total = (unsigned long long)*total_blocks;
@@ -522,11 +480,9 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
         uint4 *z = reinterpret_cast<uint4 *>(img);
         for (int k = threadIdx.x; k < kDecodeWG * kImgStrideB / 16; k += kDecodeWG) z[k] = make_uint4(0u, 0u, 0u, 0u);
     }
-    // this lane's block: position, the position of the block behind it, and what the DC scan left - requested here, in front of the
-    // staging, so that they arrive while the tables and the window do (behind the barrier each would be a trip to memory of its own)
+    // this lane's block: position and the position of the block behind it - requested here, in front of the staging, so that they
+    // arrive while the tables and the window do (behind the barrier each would be a trip to memory of its own)
     const uint32_t my_pos = b < m ? bpos[b] : 0u, next_pos = b + 1 < m ? bpos[b + 1] : 0u;
-    const uint32_t my_dclen = b < m ? (uint32_t)dclen[b] : 0u;
-    const int32_t my_dc = b < m ? dcsum[b] : 0;
     load_ac_lut<kDecodeWG>(lut, L);
     const unsigned long long last = b0 + kDecodeWG - 1 < m - 1 ? b0 + kDecodeWG - 1 : m - 1;
     const uint32_t w0 = bpos[b0] >> 5, w1 = bpos[last] >> 5;
@@ -535,31 +491,43 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     // ---- phase 1: a lane per block, one SYMBOL per step (the values are needed here; the measure walk takes chains): the stream words under the read position sit
     // in registers (wa, wb) and the word behind them (wc) is fetched a step ahead, so that the table look-up is the only LDS access
     // on the lane's dependent chain; the coefficient's store (its address comes through the zig-zag table) is off that chain.
+    //
+    // np.cumsum of the DC differences (codec.py:53) happens HERE (rounds 2-4: a launch of its own in front of this one, a lane per block
+    // as well): the lane decodes its block's DC symbol first, the workgroup sums its 256 differences and PUBLISHES the sum (scan_publish),
+    // then the lanes decode their AC symbols - and only behind them every wave adds up the sums of the workgroups in front (published
+    // long since: nobody spins), because the integrated DC is needed for one store at the block's end and nothing else.
+    int16_t *c = reinterpret_cast<int16_t *>(img + (size_t)threadIdx.x * kImgStrideB);
+    const uint16_t *ac11 = lut;
+    uint32_t pos = my_pos;
+    uint32_t wi = pos >> 5;
+    uint32_t wa = 0, wb = 0, wc = 0;
+    auto advance = [&](uint32_t bits, uint32_t wn) { // a symbol consumes at most 27 bits: at most one word boundary is crossed
+        pos += bits;
+        const bool crossed = (pos >> 5) != wi;
+        wa = crossed ? wb : wa;
+        wb = crossed ? wc : wb;
+        wc = crossed ? wn : wc;
+        wi += crossed ? 1u : 0u;
+    };
+    long long dc_diff = 0;
     if (b < m) {
-        int16_t *c = reinterpret_cast<int16_t *>(img + (size_t)threadIdx.x * kImgStrideB);
-        const uint16_t *ac11 = lut;
-        uint32_t pos = my_pos;
-        uint32_t wi = pos >> 5;
-        uint32_t wa = word_be(words, wi), wb = word_be(words, wi + 1u), wc = word_be(words, wi + 2u);
-        auto advance = [&](uint32_t bits, uint32_t wn) { // a symbol consumes at most 27 bits: at most one word boundary is crossed
-            pos += bits;
-            const bool crossed = (pos >> 5) != wi;
-            wa = crossed ? wb : wa;
-            wb = crossed ? wc : wb;
-            wc = crossed ? wn : wc;
-            wi += crossed ? 1u : 0u;
-        };
+        wa = word_be(words, wi), wb = word_be(words, wi + 1u), wc = word_be(words, wi + 2u);
+        const uint32_t wn = word_be(words, wi + 3u);
+        const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32);
+        const uint32_t e = L->dc11[pk >> 21]; // (one look-up per lane: from memory, no room in LDS for this table)
+        if (!e) atomicOr(&st->giveup, 32);    // (measure or stitch walked this block: a DC codeword is there)
+        dc_diff = (long long)value_of(pk, (int)(e >> 8), (int)(e & 15u));
+        advance((e >> 8) + (e & 15u), wn);
+    }
+    long long dc_tile;
+    const long long dc_inc = wg_inclusive_scan(dc_diff, scan_lds, dc_tile);
+    scan_publish(desc, epoch, dc_tile);
+    if (b < m) {
         bool ok = true;
         {
-            advance(my_dclen, word_be(words, wi + 3u)); // the DC symbol went through the scan, which left its length and the integrated DC
-            const int32_t dc = my_dc;
-            c[0] = (int16_t)(dc < -32768 ? -32768 : (dc > 32767 ? 32767 : dc)); // the host decoder's sat16
             int k = 1;
             bool live = true, in_long = false;
             // one table look-up per step, as in the measure walk: a long codeword takes a second step, not a second look-up
-#if TIC_EXP == 2
-            live = false;
-#endif
             while (live) {
                 const uint32_t wn = word_be(words, wi + 3u);
                 asm volatile("" ::: "memory"); // (the request stays in front of the table look-up)
@@ -592,13 +560,33 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
             st->m = m;
         }
     }
+    { // the sums of the workgroups in front, wave by wave (no barrier: a wave whose blocks were short goes on)
+        long long part = 0;
+        for (uint32_t j = threadIdx.x & 63u; j < blockIdx.x; j += 64u) {
+            unsigned long long d;
+            uint32_t spins = 0;
+            do {
+                d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins == (1u << 20)) { // (an exit every wave reaches, as in scan_lookback)
+                    atomicOr(&st->giveup, 128);
+                    d = scan_pack(epoch, 0);
+                }
+            } while ((uint32_t)(d >> 40) != (epoch & 0xffffffu));
+            part += scan_sum_of(d);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (b < m) {
+            const long long dc = part + dc_inc; // sum of the differences of blocks 0..b
+            const int32_t dc32 = (int32_t)dc;   // (the host decoder's long long, narrowed where it is used)
+            c[0] = (int16_t)(dc32 < -32768 ? -32768 : (dc32 > 32767 ? 32767 : dc32)); // the host decoder's sat16
+            if (b == m - 1) st->dc_out = (int)dc32; // running DC behind the last block produced here (the host's tail continues from it)
+        }
+    }
     // ---- phase 2: the lane that decoded a block transforms it - all 64 coefficients in registers, no transposition, no barrier between
     // the phases (a wave whose blocks were short goes on while the others still decode), nothing but the lane's own image read back.
     // (Rounds 2-4: 8 lanes per block, 8 blocks per wave and round, the 8x8 float64 matrix transposed through LDS between the passes:
     // the same arithmetic, plus two LDS round trips and a workgroup barrier per round; profiles/r05_decoder.txt.)
-#if TIC_EXP == 1
-    return;
-#endif
     if (b >= m) return;
     asm volatile("" ::: "memory"); // (the image's two-byte stores above are read back as 16-byte pieces)
     double x[64]; // x[u * 8 + v]: natural order
@@ -674,14 +662,13 @@ bool entropy_decode_gpu_range_ok(int range_bits) {
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
     const size_t nbits = stream_bytes * 8;
     const size_t nranges = nbits / kRangeMin + 2; // (the smallest range: most ranges, and the most room per stream bit)
-    const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
-    return nranges * ((size_t)cap_of(kRangeMin) * 2 * 2 + 9 * 4) + nblocks * 9 + ntiles * 8 * 2 + 16384; // (two traces and seven 4-byte arrays per range, two 4-byte arrays and a byte per block; every piece is rounded up to 256 B)
+    return nranges * ((size_t)cap_of(kRangeMin) * 2 * 2) + nblocks * 4 + 16384; // (two traces per range, a 4-byte position per block; every piece is rounded up to 256 B)
 }
 
 size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks) { // look-back words of the two scans (half of the array each)
     const size_t nranges = stream_bytes * 8 / kRangeMin + 2;
-    const size_t ntiles = (nranges > nblocks ? nranges : nblocks) / kTile + 2;
-    return 2 * ntiles;
+    const size_t tr = nranges / kOwned + 2, tb = nblocks / kDecodeWG + 2; // (workgroups of the measure kernel and of the fused kernel)
+    return 2 * (tr > tb ? tr : tb);
 }
 
 hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
@@ -701,8 +688,9 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     // words read as zeros, raises giveup bit 256 (a cut stream: the caller comes back with the margin).
     const uint32_t fast_end = (uint32_t)(nbits - (size_t)margin_bits);
     const uint32_t nranges = (uint32_t)((fast_end - 128 + kRange - 1) / kRange);
-    const size_t ntiles_r = ((size_t)nranges + kTile - 1) / kTile, ntiles_b = (nblocks + kTile - 1) / kTile;
-    // The look-back words of the two scans live in an array of their own that holds nothing else, ever: a word there either is zero
+    const unsigned measure_wgs = (nranges + kOwned - 1u) / kOwned;
+    const size_t ntiles_r = measure_wgs, ntiles_b = (nblocks + kDecodeWG - 1) / kDecodeWG; // (the workgroups of the two kernels are the tiles of the two sums)
+    // The look-back words of the two sums live in an array of their own that holds nothing else, ever: a word there either is zero
     // (since allocation) or carries the epoch of the launch that wrote it, and the caller never reuses an epoch on it.  (Inside the
     // workspace the pieces move with the sizes of the call: a stale trace entry could pass for a published sum.)
     if (!d_desc || desc_words < 2 * (ntiles_r > ntiles_b ? ntiles_r : ntiles_b) || epoch == 0 || epoch >= (1u << 22)) return hipErrorInvalidValue;
@@ -712,11 +700,7 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) / 256 * 256; return (void *)p; };
     long long *totals = (long long *)take(16);
     uint16_t *starts = (uint16_t *)take((size_t)nranges * kCap * 2), *hand = (uint16_t *)take((size_t)nranges * kCap * 2);
-    uint32_t *entry = (uint32_t *)take((size_t)nranges * 4), *bpos = (uint32_t *)take(nblocks * 4);
-    uint32_t *nrec = (uint32_t *)take((size_t)nranges * 4);
-    uint32_t *nblk = (uint32_t *)take((size_t)nranges * 4);
-    int32_t *dcsum = (int32_t *)take(nblocks * 4);
-    uint8_t *dclen = (uint8_t *)take(nblocks);
+    uint32_t *bpos = (uint32_t *)take(nblocks * 4);
     if ((size_t)(w - (char *)d_work) > work_bytes) return hipErrorInvalidValue;
     const uint32_t *words = (const uint32_t *)d_stream_words;
     const dim3 bl(64);
@@ -724,15 +708,11 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const uint32_t last_mask = (stream_bytes & 3) ? 0xffffffffu << (8u * (4u - (uint32_t)(stream_bytes & 3))) : 0xffffffffu; // (big-endian: the stream's bytes are the word's high bytes)
     // (*d_status is zeroed by the caller: it is host-mapped memory)
     const unsigned win_lds = stage_lds_words(range) * 4u;
-    hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3((nranges + kOwned - 1u) / kOwned), bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, (uint32_t)nbits, range, nranges, starts, nrec,
-                       nblk, hand, entry, d_status);
-    hipLaunchKernelGGL(scan_counts_bpos_kernel, dim3((unsigned)ntiles_r), dim3(kTile), 0, stream, (const uint32_t *)nblk, range, nranges, desc_r, 2u * epoch,
-                       (const uint16_t *)starts, (const uint16_t *)hand, (const uint32_t *)nrec, (const uint32_t *)entry, (unsigned long long)nblocks, bpos, totals, d_status);
-    hipLaunchKernelGGL(dec_dc_scan_kernel, dim3((unsigned)ntiles_b), dim3(kTile), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const long long *)totals,
-                       (unsigned long long)nblocks, desc_b, 2u * epoch + 1u, dcsum, dclen, d_status);
+    hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3(measure_wgs), bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, (uint32_t)nbits, range, nranges, starts,
+                       hand, desc_r, 2u * epoch, (unsigned long long)nblocks, bpos, totals, d_status);
     const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
     auto fused = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, (const int32_t *)dcsum, (const uint8_t *)dclen,
+        hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, desc_b, 2u * epoch + 1u,
                            (const long long *)totals, (unsigned long long)nblocks, (uint32_t)nbits, idct, d_status);
     };
     const bool small_win = nbits / nblocks <= 240; // sparse enough for the small window: one workgroup more per CU
