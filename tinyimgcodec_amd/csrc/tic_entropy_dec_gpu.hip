@@ -189,6 +189,40 @@ __device__ __forceinline__ long long scan_sum_of(unsigned long long d) { return 
 __device__ __forceinline__ void scan_publish(unsigned long long *desc, uint32_t epoch, long long tot) {
     if (threadIdx.x == 0) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// sum of the words of the workgroups in front of this one, taken by ONE WAVE (all 64 lanes call): lane j reads workgroup j's, j + 64's ...
+// eight words requested before the first is looked at (one after the other they were 16 - 21 dependent trips to memory: 6 - 8 us at the
+// end of a kernel); a word that does not carry this launch's epoch yet is read again until it does
+__device__ __forceinline__ long long wave_lookback(const unsigned long long *desc, uint32_t epoch, DecStatus *st) {
+    const uint32_t lane = threadIdx.x & 63u, nfront = blockIdx.x;
+    long long part = 0;
+    for (uint32_t j0 = lane; j0 < nfront; j0 += 64u * 8u) {
+        unsigned long long d[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t j = j0 + 64u * k;
+            d[k] = __hip_atomic_load(&desc[j < nfront ? j : nfront - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t j = j0 + 64u * k;
+            if (j >= nfront) continue;
+            uint32_t spins = 0;
+            while ((uint32_t)(d[k] >> 40) != (epoch & 0xffffffu)) {
+                d[k] = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (an exit every wave reaches: a workgroup in front that never publishes - which the dispatch order rules out - ends the
+                // wait after about a second, and the flag sends the whole stream to the host decoder)
+                if (++spins == (1u << 20)) {
+                    atomicOr(&st->giveup, 128);
+                    d[k] = scan_pack(epoch, 0);
+                }
+            }
+            part += scan_sum_of(d[k]);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    return part;
+}
 // Measure and stitch, one kernel.  The lanes of a wave walk side by side, a look-up per step.  (Round 3's first version looped per
 // block: the lanes of a wave then wait for each other at every block end - 630 symbol steps per wave where the longest lane has ~250
 // symbols.)  Here the position inside the block (is the DC category next?) is lane state and a block end is just another step.
@@ -385,23 +419,7 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
         }
         const long long tot = __shfl(inc, 63, 64);
         if (lane == 63u) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long long part = 0;
-        for (uint32_t j = lane; j < blockIdx.x; j += 64u) {
-            unsigned long long d;
-            uint32_t spins = 0;
-            do {
-                d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // (an exit every wave reaches: a workgroup in front that never publishes - which the dispatch order rules out - ends the
-                // wait after about a second, and the flag sends the whole stream to the host decoder)
-                if (++spins == (1u << 20)) {
-                    atomicOr(&st->giveup, 128);
-                    d = scan_pack(epoch, 0);
-                }
-            } while ((uint32_t)(d >> 40) != (epoch & 0xffffffu));
-            part += scan_sum_of(d);
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        const long long part = wave_lookback(desc, epoch, st);
         if (blockIdx.x == gridDim.x - 1u && lane == 63u) *grand_total = part + tot;
         if (!mine) return;
         const unsigned long long first = (unsigned long long)(part + inc - (long long)nb);
@@ -561,21 +579,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
         }
     }
     { // the sums of the workgroups in front, wave by wave (no barrier: a wave whose blocks were short goes on)
-        long long part = 0;
-        for (uint32_t j = threadIdx.x & 63u; j < blockIdx.x; j += 64u) {
-            unsigned long long d;
-            uint32_t spins = 0;
-            do {
-                d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (++spins == (1u << 20)) { // (an exit every wave reaches, as in scan_lookback)
-                    atomicOr(&st->giveup, 128);
-                    d = scan_pack(epoch, 0);
-                }
-            } while ((uint32_t)(d >> 40) != (epoch & 0xffffffu));
-            part += scan_sum_of(d);
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        const long long part = wave_lookback(desc, epoch, st);
         if (b < m) {
             const long long dc = part + dc_inc; // sum of the differences of blocks 0..b
             const int32_t dc32 = (int32_t)dc;   // (the host decoder's long long, narrowed where it is used)
