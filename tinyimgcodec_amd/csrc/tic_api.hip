@@ -1714,6 +1714,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
         DecLutsDev *l = new DecLutsDev();
         dec_luts_fill(l->dc11, l->ac11, l->ac16);
         dec_chain_luts_fill(l->mdc, l->mac, l->mlong);
+        dec_pair_luts_fill(l->ac2, l->long32); // (new DecLutsDev() zeroed the entries behind the long codewords)
         hipError_t e = hipMalloc((void **)&ctx->d_dec_luts, sizeof(DecLutsDev));
         if (e == hipSuccess) e = hipMemcpy(ctx->d_dec_luts, l, sizeof(DecLutsDev), hipMemcpyHostToDevice);
         delete l;

@@ -680,4 +680,35 @@ void dec_chain_luts_fill(uint8_t *mdc, uint8_t *mac, uint8_t *mlong) {
     }
 }
 
+// Pair table of the device decoder's fused kernel (a lane per block, values needed): what one look-up of the next 11 stream bits
+// settles inside the AC symbols - the first symbol (codeword of at most 11 bits, as in lut11) and, when the first is not EOB and the
+// CODEWORD of the symbol behind it lies inside the same 11 bits, that second symbol too (its value bits may lie behind the window).
+// Entry: bits 0-12 the first symbol as in lut11 (size | run << 4 | codeword length << 8), bit 13 a second symbol follows, bits 14-26
+// the second symbol in the same form, bits 27-31 the stream bits both consume together.  0: no codeword of at most 11 bits here.
+// long32: the AC codewords of 12..16 bits (index: the next 16 bits - 0xff40), one symbol each, same form.
+void dec_pair_luts_fill(uint32_t *ac2 /*[2048]*/, uint32_t *long32 /*[192]*/) {
+    const EncTables &T = tables();
+    for (unsigned w = 0; w < 2048u; w++) {
+        const uint32_t e1 = T.acd.lut11[w];
+        uint32_t e = 0;
+        if (e1) {
+            const unsigned used = (e1 >> 8) + (e1 & 15u);
+            e = e1 | (uint32_t)used << 27;
+            if ((e1 & 0xffu) != 0 && used < 11u) {
+                const unsigned left = 11u - used;
+                const uint32_t e2 = T.acd.lut11[(w << used) & 0x7ffu]; // (zeros behind the window: a codeword no longer than `left` does not see them)
+                if (e2 && (e2 >> 8) <= left) {
+                    const unsigned both = used + (e2 >> 8) + (e2 & 15u);
+                    e = e1 | 1u << 13 | (uint32_t)e2 << 14 | (uint32_t)both << 27;
+                }
+            }
+        }
+        ac2[w] = e;
+    }
+    for (int i = 0; i < 0x10000 - 0xff40; i++) {
+        const uint32_t e = T.acd.lut[0xff40 + i];
+        long32[i] = e ? e | ((e >> 8) + (e & 15u)) << 27 : 0u;
+    }
+}
+
 } // namespace tic

@@ -17,4 +17,5 @@ int entropy_decode_tail(const uint8_t *data, size_t len, int h, int w, size_t fi
 void dec_luts_fill(uint16_t *dc11, uint16_t *ac11, uint16_t *ac16);
 // the device decoder's chain tables (DecLutsDev::mdc / mac / mlong, tic_entropy_dec_gpu.h)
 void dec_chain_luts_fill(uint8_t *mdc /*[2048]*/, uint8_t *mac /*[4096]*/, uint8_t *mlong /*[256]*/);
+void dec_pair_luts_fill(uint32_t *ac2 /*[2048]*/, uint32_t *long32 /*[192]*/);
 } // namespace tic

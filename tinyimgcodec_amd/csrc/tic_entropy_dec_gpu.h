@@ -18,6 +18,10 @@ struct DecLutsDev {
     uint8_t mdc[2048];
     uint8_t mac[4096];
     uint8_t mlong[256];
+    // the fused kernel's table: one look-up of the next 11 stream bits gives up to TWO AC symbols with their values' places
+    // (tic_entropy.cpp dec_pair_luts_fill), then the long codewords one by one, then a zero entry (the slot of an index out of range)
+    uint32_t ac2[2048];
+    uint32_t long32[192 + 4];
 };
 
 struct DecStatus {

@@ -452,14 +452,10 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
 // (~100 cycles per symbol), which two waves per SIMD already overlap; what made the separate decode kernel slow were its 45
 // two-byte global stores per lane.
 constexpr int kDecodeWG = 256;
-constexpr int kAcLutLds = 2048 + kLongCodes + 8; // (+ a zero entry) ac11 + the long codewords (the DC symbol's length comes from the DC scan: no dc11 here)
-// ac11 and the long AC codewords into LDS: lut[0..2047] = ac11, lut[2048..] = long codewords, then a zero entry
-template <int T>
-__device__ __forceinline__ void load_ac_lut(uint16_t *lds, const DecLutsDev *__restrict__ L) {
-    copy16_to_lds<T, 4096 / 16>(lds, L->ac11);
-    copy16_to_lds<T, 2 * kLongCodes / 16>(lds + 2048, L->ac16 + kLongFirst);
-    if (threadIdx.x == 0) lds[2048 + kLongCodes] = 0; // the slot of an index outside the long codewords
-}
+constexpr int kPairLutDw = 2048 + kLongCodes + 4; // DecLutsDev::ac2 + long32 (the DC symbol is looked up in memory, once per lane: no dc11 here)
+static_assert(offsetof(DecLutsDev, long32) == offsetof(DecLutsDev, ac2) + 8192 && offsetof(DecLutsDev, ac2) % 16 == 0 && (kPairLutDw * 4) % 16 == 0 &&
+                  sizeof(DecLutsDev) >= offsetof(DecLutsDev, ac2) + kPairLutDw * 4,
+              "the pair table and the long codewords are adjacent and copied in 16-byte pieces");
 constexpr int kImgStrideB = 132;  // bytes between the images of two blocks: 33 dwords (a lane per image: a dword of every image in one access, no bank conflict)
 __constant__ int kAnnScalesDec[64] = { // ANNSCALES of the reference's scaled_dct branch (constants.py; utils.py:59-62), as integers x 2048
     16384, 22725, 21407, 19266, 16384, 12873, 8867,  4520,  22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
@@ -477,14 +473,14 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     // tables + stream window
     constexpr uint32_t kBlkWin = kWinWords + kOver;
     constexpr uint32_t kBlkLds = kBlkWin + kBlkWin / 32 + 2;
-    constexpr int kLutDw = (kAcLutLds * 2 + 15) / 16 * 4;
+    constexpr int kLutDw = kPairLutDw;
     constexpr int kScratchDw = kLutDw + (int)kBlkLds;
     __shared__ __attribute__((aligned(16))) uint32_t scratch[kScratchDw];
     __shared__ __attribute__((aligned(16))) unsigned char img[kDecodeWG * kImgStrideB];
     __shared__ uint8_t zznat[64];
     __shared__ __attribute__((aligned(16))) double dq[64]; // the dequantisation constants, natural order (every lane reads the same entry: a broadcast)
     __shared__ long long scan_lds[16];
-    uint16_t *lut = reinterpret_cast<uint16_t *>(scratch);
+    uint32_t *lut = scratch;
     uint32_t *sbits = scratch + kLutDw;
     const unsigned long long total = (unsigned long long)*total_blocks;
     const unsigned long long m = total < n_want ? total : n_want; // blocks produced here
@@ -501,7 +497,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     // this lane's block: position and the position of the block behind it - requested here, in front of the staging, so that they
     // arrive while the tables and the window do (behind the barrier each would be a trip to memory of its own)
     const uint32_t my_pos = b < m ? bpos[b] : 0u, next_pos = b + 1 < m ? bpos[b + 1] : 0u;
-    load_ac_lut<kDecodeWG>(lut, L);
+    copy16_to_lds<kDecodeWG, kPairLutDw / 4>(lut, L->ac2);
     const unsigned long long last = b0 + kDecodeWG - 1 < m - 1 ? b0 + kDecodeWG - 1 : m - 1;
     const uint32_t w0 = bpos[b0] >> 5, w1 = bpos[last] >> 5;
     const uint32_t want = w1 >= w0 ? w1 - w0 + kOver : kOver;
@@ -515,7 +511,6 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     // then the lanes decode their AC symbols - and only behind them every wave adds up the sums of the workgroups in front (published
     // long since: nobody spins), because the integrated DC is needed for one store at the block's end and nothing else.
     int16_t *c = reinterpret_cast<int16_t *>(img + (size_t)threadIdx.x * kImgStrideB);
-    const uint16_t *ac11 = lut;
     uint32_t pos = my_pos;
     uint32_t wi = pos >> 5;
     uint32_t wa = 0, wb = 0, wc = 0;
@@ -545,26 +540,36 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
         {
             int k = 1;
             bool live = true, in_long = false;
-            // one table look-up per step, as in the measure walk: a long codeword takes a second step, not a second look-up
+            // One table look-up per step, as in the measure walk (a long codeword takes a second step, not a second look-up) - and the look-up
+            // settles TWO symbols when the second one's codeword lies inside the same 11 bits (dec_pair_luts_fill): 25 steps per block
+            // instead of 46 on noise at q = 50, and the step is no longer - the lane's dependent chain is look-up -> bits consumed -> next
+            // window; the two values and their stores hang off it.
             while (live) {
                 const uint32_t wn = word_be(words, wi + 3u);
                 asm volatile("" ::: "memory"); // (the request stays in front of the table look-up)
                 const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32);
                 const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
-                const uint32_t e = ac11[in_long ? 2048u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : pk >> 21];
+                const uint32_t e = lut[in_long ? 2048u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : pk >> 21];
                 const bool none = e == 0u;
                 const bool esc = none && !in_long;  // the prefix of a long codeword: the next step resolves it
                 const bool nocode = none && in_long; // no codeword at all
-                const bool eob = !none && (e & 0xffu) == 0u;
-                const int len = (int)(e >> 8), size = (int)(e & 15u);
-                const int k_at = k + (int)((e >> 4) & 15u);
-                const bool bad = nocode || (!none && !eob && k_at > 63);
-                if (!none && !eob && !bad) c[zznat[k_at]] = (int16_t)value_of(pk, len, size);
-                advance(none ? 0u : (uint32_t)(len + size), wn);
-                k = none ? k : k_at + 1;
+                const bool eob1 = !none && (e & 0xffu) == 0u;
+                const int len1 = (int)((e >> 8) & 31u), size1 = (int)(e & 15u);
+                const int k1 = k + (int)((e >> 4) & 15u);
+                const bool bad1 = nocode || (!none && !eob1 && k1 > 63);
+                if (!none && !eob1 && !bad1) c[zznat[k1]] = (int16_t)value_of(pk, len1, size1);
+                const bool has2 = ((e >> 13) & 1u) != 0u; // (never behind an EOB, never in a long codeword's step)
+                const uint32_t e2 = e >> 14;
+                const bool eob2 = has2 && (e2 & 0xffu) == 0u;
+                const int len2 = (int)((e2 >> 8) & 31u), size2 = (int)(e2 & 15u);
+                const int k2 = k1 + 1 + (int)((e2 >> 4) & 15u);
+                const bool bad2 = has2 && !bad1 && !eob2 && k2 > 63;
+                if (has2 && !eob2 && !bad1 && !bad2) c[zznat[k2]] = (int16_t)value_of(pk << (len1 + size1), len2, size2); // (at most 11 + 10 bits in front of and in it)
+                advance(none ? 0u : e >> 27, wn); // (at most 26 bits)
+                k = none ? k : (has2 ? k2 + 1 : k1 + 1);
                 in_long = esc;
-                ok = ok && !bad;
-                live = !eob && !bad;
+                ok = ok && !bad1 && !bad2;
+                live = !eob1 && !eob2 && !bad1 && !bad2;
             }
         }
         // the block is well-formed, and the next block of the chain starts where this one ends (the measure kernel vouches for
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
         }
 #pragma unroll
         for (int v = 2 * vp; v < 2 * vp + 2; v++) {
-            idct8_exact(x[v], x[8 + v], x[16 + v], x[24 + v], x[32 + v], x[40 + v], x[48 + v], x[56 + v]);
+            idct8_exact_impl<false>(x[v], x[8 + v], x[16 + v], x[24 + v], x[32 + v], x[40 + v], x[48 + v], x[56 + v]); // (four times the column's values)
             // the column's results exist HERE: element (u, v) feeds pixel row u only, whose store sits behind a condition, and the compiler
             // otherwise sinks the tail of every column's arithmetic into those conditions - twice as many values in flight, 250 registers
             asm volatile("" : "+v"(x[v]), "+v"(x[8 + v]), "+v"(x[16 + v]), "+v"(x[24 + v]), "+v"(x[32 + v]), "+v"(x[40 + v]), "+v"(x[48 + v]), "+v"(x[56 + v]));
@@ -631,13 +636,14 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     const int rows_here = a.h - (int)by * 8; // (>= 1: the block exists)
 #pragma unroll
     for (int u = 0; u < 8; u++) { // axis -1, a pixel row at a time
-        idct8_exact(x[u * 8], x[u * 8 + 1], x[u * 8 + 2], x[u * 8 + 3], x[u * 8 + 4], x[u * 8 + 5], x[u * 8 + 6], x[u * 8 + 7]);
+        idct8_exact_impl<false>(x[u * 8], x[u * 8 + 1], x[u * 8 + 2], x[u * 8 + 3], x[u * 8 + 4], x[u * 8 + 5], x[u * 8 + 6], x[u * 8 + 7]); // (sixteen times the row's)
         uint32_t px[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            // + 128, clip, truncation toward zero as astype(np.uint8) on a clipped value (the sum is a finite number: v_max / v_min instead of two
-            // compares and four selects)
-            px[k] = (uint32_t)(int)__builtin_fmin(__builtin_fmax(x[u * 8 + k] + 128.0, 0.0), 255.0);
+            // + 128, clip, truncation toward zero as astype(np.uint8) on a clipped value - on sixteen times the value (idct8_exact_impl: the
+            // passes above leave out their 1/4): fl(16 r + 2048) = 16 fl(r + 128), the clip bounds scale along, and floor(y / 16) of a
+            // non-negative y is floor(y) >> 4.  (The sum is a finite number: v_max / v_min instead of two compares and four selects.)
+            px[k] = (uint32_t)(int)__builtin_fmin(__builtin_fmax(x[u * 8 + k] + 2048.0, 0.0), 4080.0) >> 4;
         }
         uint2 o;
         o.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);

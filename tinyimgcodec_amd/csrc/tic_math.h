@@ -66,8 +66,13 @@ TIC_HD void dct8_exact(double &c0, double &c1, double &c2, double &c3, double &c
 
 // scipy.fftpack.idct(x, norm="ortho") (DCT-III), pocketfft order: T_dcst23 type 3 -> radf4(ido=1) -> radf2(ido=4).
 // Replaces the arithmetic of block_idct, utils.py:40-45.
-TIC_HD void idct8_exact(double &c0, double &c1, double &c2, double &c3, double &c4, double &c5, double &c6,
-                        double &c7) {
+// kQuarter = false leaves out the normalisation by 1/4 (eight multiplications per call): the results are then EXACTLY four times the
+// normalised ones, bit for bit - every operation here is an addition, a subtraction or a multiplication by a constant, and scaling all
+// inputs of such an operation by a power of two scales its rounded result by the same power (no overflow or underflow in reach: the
+// values are sums of |coefficient x quantiser| <= 2^23 times constants near one, and a non-zero difference of two such doubles is no
+// smaller than 2^-40).  The device decoder's fused kernel runs both passes that way and folds the 1/16 into the pixel conversion.
+template <bool kQuarter>
+TIC_HD void idct8_exact_impl(double &c0, double &c1, double &c2, double &c3, double &c4, double &c5, double &c6, double &c7) {
 #pragma clang fp contract(off)
     c0 = c0 * kSqrt2;
     double t1, t2, p1, p2, p3, p4;
@@ -88,12 +93,20 @@ TIC_HD void idct8_exact(double &c0, double &c1, double &c2, double &c3, double &
     double m1 = kWR * a5, m2 = kWI * a6, q2 = m1 + m2;
     double m3 = kWR * a6, m4 = kWI * a5, qi = m3 - m4;
     double r1 = a1 + q2, r5 = a1 - q2, r2 = qi + a2, r6 = qi - a2;
-    c0 = r0 * 0.25; c1 = r1 * 0.25; c2 = r2 * 0.25; c3 = r3 * 0.25;
-    c4 = r4 * 0.25; c5 = r5 * 0.25; c6 = r6 * 0.25; c7 = r7 * 0.25;
+    if (kQuarter) {
+        c0 = r0 * 0.25; c1 = r1 * 0.25; c2 = r2 * 0.25; c3 = r3 * 0.25;
+        c4 = r4 * 0.25; c5 = r5 * 0.25; c6 = r6 * 0.25; c7 = r7 * 0.25;
+    } else {
+        c0 = r0; c1 = r1; c2 = r2; c3 = r3;
+        c4 = r4; c5 = r5; c6 = r6; c7 = r7;
+    }
     double t;
     t = c1; c1 = t - c2; c2 = t + c2;
     t = c3; c3 = t - c4; c4 = t + c4;
     t = c5; c5 = t - c6; c6 = t + c6;
+}
+TIC_HD void idct8_exact(double &c0, double &c1, double &c2, double &c3, double &c4, double &c5, double &c6, double &c7) {
+    idct8_exact_impl<true>(c0, c1, c2, c3, c4, c5, c6, c7);
 }
 
 // ---------------------------------------------------------------------------------------------------------
