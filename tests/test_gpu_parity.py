@@ -1566,6 +1566,13 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
                 assert tries.value == 1 and rbits.value % 64 == 32 and max(544, 3 * avg - 32) <= rbits.value <= max(544, 3 * avg + 64), \
                     (name, q, rbits.value, tries.value, avg)  # the first choice of range held: no second run
             assert np.array_equal(got, want), (name, q)
+            # the sums inside the two kernels (block counts, DC differences): launches above TIC_DECODE_FLAT_GRID workgroups look back through
+            # inclusive sums (a 16384^2 stream in production; here forced on every launch, and on the larger part of them)
+            for fg in ("0", "100"):
+                monkeypatch.setenv("TIC_DECODE_FLAT_GRID", fg)
+                assert np.array_equal(T.decompress(s, ctx=ctx), want), (name, q, "flat grid", fg)
+                assert L.tic_last_decode_path(ctx.handle) == (1 if long_enough else 2) and L.tic_last_decode_giveup(ctx.handle) == 0
+            monkeypatch.delenv("TIC_DECODE_FLAT_GRID")
             if name == "noise 2048x2048":  # forced range lengths, and the second try with the longest range when 288 or 544 bits are
                 # shorter than the blocks (q=90: 404 bits)
                 for rb in ("288", "544", "928", "1056", "2016"):

@@ -1805,6 +1805,8 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     // one is (cut, damaged, too few blocks for its header) and it is decoded once more the way rounds 2-3 did: blocks that start in the last
     // 2,048 bits go to the host's bit-serial decoder, which reproduces the reference's behaviour at a stream's end.
     int margin_bits = test_hook("TIC_DECODE_MARGIN") ? 2048 : 0;
+    int flat_grid = 4096; // (tic_entropy_dec_gpu.hip wave_lookback)
+    if (const char *e = test_hook("TIC_DECODE_FLAT_GRID")) flat_grid = atoi(e) < 0 ? 0 : atoi(e);
     DecStatus st;
     for (;;) {
         if (margin_bits && src_on_device && !tail_prefetched) {
@@ -1819,7 +1821,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
         ctx->last_decode_tries++;
         ctx->last_decode_range = range_bits;
         HIPCHK(ctx, entropy_decode_idct_gpu(d_stream, len, n, ctx->d_dec_luts, ctx->d_dec_work, ctx->dec_work_bytes, ctx->d_dec_desc,
-                                            ctx->dec_desc_words, ctx->dec_epoch, ia, ctx->d_dec_status, range_bits, margin_bits, ctx->stream));
+                                            ctx->dec_desc_words, ctx->dec_epoch, ia, ctx->d_dec_status, range_bits, margin_bits, ctx->stream, flat_grid));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(&st, ctx->h_dec_status, sizeof st); // (host-mapped: the stream has drained)
         if (guessed_head) { // geometry and quality were a guess (tic_decompress_dev): what this run produced counts only if the stream's header is the guessed one

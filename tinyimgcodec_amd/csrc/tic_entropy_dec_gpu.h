@@ -54,12 +54,13 @@ size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks);
 // margin_bits: 2048 = blocks that start in the stream's last 2,048 bits are left to the caller (the host decoder's rule: whatever the
 // stream holds, no block of the chain reaches its end); 0 = the chain runs to the end, m = all blocks of a whole stream, and giveup bit 256
 // says that a block reached behind the end (a cut stream: call again with 2048).
+// flat_grid: launches of up to this many workgroups add up all sums in front of a workgroup; larger ones use inclusive sums (wave_lookback).
 // Writes the PIXELS of blocks [0, m) through `idct`; *d_status (zeroed by the caller) says how many that is and where the stream
 // and the running DC stand behind them.  Asynchronous on `stream`; *d_status is complete when the stream has drained.
 size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks);
 bool entropy_decode_gpu_range_ok(int range_bits);
 hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
                                    size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, const DecIdctArgs &idct,
-                                   DecStatus *d_status, int range_bits, int margin_bits, hipStream_t stream);
+                                   DecStatus *d_status, int range_bits, int margin_bits, hipStream_t stream, int flat_grid = 4096);
 
 } // namespace tic

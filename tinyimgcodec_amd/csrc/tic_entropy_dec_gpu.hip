@@ -17,20 +17,23 @@
 //             trace recorded; from that entry on the trace IS the true chain (a block start carries no state), so the trace's end is
 //             where the true chain enters range t+1 - which is the hypothesis for t+1.  Range 0 starts on a true block start, so if
 //             EVERY lane finds its synchronisation point inside its range, induction makes every hypothesis true.  Otherwise: give up.
-//   scan + bpos   exclusive prefix sum of the ranges' true block counts -> index of each range's first block (ONE launch: every tile
-//             publishes its own sum and adds up the sums of the tiles in front of it, scan_lookback below); the lane of a range then
-//             writes the first bit of each of its true blocks (by-hand ones, then the trace from the entry on).
-//   dc scan   a lane per BLOCK decodes the block's DC symbol and the differences are summed inclusively over the blocks
-//             (np.cumsum, codec.py:53): one launch, the same look-back.
-//   decode + inverse transform   a workgroup per 256 consecutive blocks: a lane per block decodes it from its first bit into an LDS
-//             image of the block (natural order), then the workgroup dequantises and inverse-transforms its 256 images, 8 lanes per
-//             block, in the reference's float64 operation order, and stores PIXELS.  The coefficients never exist in memory.
+//   block positions   still the same kernel: exclusive prefix sum of the ranges' true block counts -> index of each range's first block
+//             (every workgroup publishes its own sum and adds up the sums of the workgroups in front of it, wave_lookback below); the
+//             lane of a range then writes the first bit of each of its true blocks (by-hand ones, then the trace from the entry on).
+//   decode + inverse transform   the second and last kernel, a workgroup per 256 consecutive blocks, a LANE PER BLOCK from start to end:
+//             the lane decodes its block's DC symbol, the workgroup sums the DC differences and publishes the sum (np.cumsum, codec.py:53:
+//             the same look-back, taken when the lane needs the value - at the block's end), the lane decodes the AC symbols, two per
+//             table look-up where two codewords lie inside the window, into an LDS image of the block (natural order), reads the image
+//             back into 64 registers, dequantises and inverse-transforms it in the reference's float64 operation order, and stores PIXELS.
+//             The coefficients never exist in memory.
 //             (Rounds 2-3: a decode kernel that scattered the non-zero coefficients into a zeroed int16 [N][64] array - 45 two-byte
-//             stores per lane to 64 different lines each - then idct_kernel read the array back: 68 + 24 us and a 33.5 MB fill.)
+//             stores per lane to 64 different lines each - then idct_kernel read the array back: 68 + 24 us and a 33.5 MB fill.  Round 4:
+//             four launches - measure + stitch, counts scan + positions, DC scan, decode + inverse with 8 lanes per block and the 8x8
+//             float64 matrix transposed through LDS: 111 us of kernels for a 4096^2 stream; now 85, profiles/r05_decoder.txt.)
 // The walks are one dependent chain of look-ups per lane: stream words and tables are staged in LDS (the codewords of 12-16 bits
 // included: as look-ups in memory they stalled a whole wave in every second step), and the chain is kept short - a range for the
 // measure walk, a block for the decode phase.  7 MB stream (4096^2 noise, q=50), rocprofv3: measure 282 -> 125 us, decode
-// 102 -> 67 us against the first version of this file (profiles/r03_decoder.txt); round 4: profiles/r04_decoder.txt.
+// 102 -> 67 us against the first version of this file (profiles/r03_decoder.txt); rounds 4 and 5: profiles/r04_decoder.txt, r05_decoder.txt.
 // Anything unusual ON THE TRUE CHAIN - an invalid prefix, more than 63 coefficients in a block, a range without a synchronisation
 // point, a measurement that failed behind the synchronisation point - raises a flag and the caller decodes the whole stream on the
 // host, whose bit-serial path reproduces the reference's behaviour on malformed streams (exactly the host parallel decoder's rule).
@@ -189,39 +192,71 @@ __device__ __forceinline__ long long scan_sum_of(unsigned long long d) { return 
 __device__ __forceinline__ void scan_publish(unsigned long long *desc, uint32_t epoch, long long tot) {
     if (threadIdx.x == 0) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// sum of the words of the workgroups in front of this one, taken by ONE WAVE (all 64 lanes call): lane j reads workgroup j's, j + 64's ...
+// Sum of the workgroups in front of this one, taken by ONE WAVE (all 64 lanes call; `desc` = this sum's two word arrays, `half` words
+// each: own sums, then inclusive sums).
+// Launches of up to `flat_grid` workgroups (the caller's choice, 4,096; a 4096^2 stream: 1,024 and 1,350): lane l adds up the own sums of workgroups l, l + 64 ...,
 // eight words requested before the first is looked at (one after the other they were 16 - 21 dependent trips to memory: 6 - 8 us at the
-// end of a kernel); a word that does not carry this launch's epoch yet is read again until it does
-__device__ __forceinline__ long long wave_lookback(const unsigned long long *desc, uint32_t epoch, DecStatus *st) {
-    const uint32_t lane = threadIdx.x & 63u, nfront = blockIdx.x;
-    long long part = 0;
-    for (uint32_t j0 = lane; j0 < nfront; j0 += 64u * 8u) {
-        unsigned long long d[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) {
-            const uint32_t j = j0 + 64u * k;
-            d[k] = __hip_atomic_load(&desc[j < nfront ? j : nfront - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) {
-            const uint32_t j = j0 + 64u * k;
-            if (j >= nfront) continue;
-            uint32_t spins = 0;
-            while ((uint32_t)(d[k] >> 40) != (epoch & 0xffffffu)) {
-                d[k] = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // (an exit every wave reaches: a workgroup in front that never publishes - which the dispatch order rules out - ends the
-                // wait after about a second, and the flag sends the whole stream to the host decoder)
-                if (++spins == (1u << 20)) {
-                    atomicOr(&st->giveup, 128);
-                    d[k] = scan_pack(epoch, 0);
-                }
+// end of a kernel); a word that does not carry this launch's epoch yet is read again until it does.
+// Larger launches (16384^2: 16,384 and 21,600 workgroups - adding up all own sums would read 8.6 GB of them, quadratic in the
+// workgroups): lane l looks at workgroup i - 1 - l, at its INCLUSIVE sum (everything up to and including it) if it has published one -
+// the nearest such workgroup ends the look-back: the own sums of the workgroups between it and this one, waited for, plus its inclusive
+// sum - and 64 workgroups further back when none of the 64 has one yet; then this workgroup's inclusive sum is published for the ones
+// behind.  (Measured, profiles/r05_decoder.txt: the inclusive sums everywhere cost a 4096^2 stream 11 us - the workgroups of a launch's
+// first round arrive here together, nobody has an inclusive sum yet, and every window is a trip to memory of its own; eight windows
+// per trip: 19 us; without them a 16384^2 stream takes 1.15 ms instead of 0.95.)
+__device__ __forceinline__ long long wave_lookback(unsigned long long *desc, uint32_t half, uint32_t flat_grid, uint32_t epoch, long long own_total, DecStatus *st) {
+    const uint32_t lane = threadIdx.x & 63u, ep = epoch & 0xffffffu, nfront = blockIdx.x;
+    const unsigned long long *own = desc;
+    // (an exit every wave reaches: a workgroup in front that never publishes - which the dispatch order rules out - ends the wait
+    // after about a second, and the flag sends the whole stream to the host decoder)
+    auto wait_for = [&](unsigned long long d, uint32_t j) {
+        uint32_t spins = 0;
+        while ((uint32_t)(d >> 40) != ep) {
+            d = __hip_atomic_load(&own[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins == (1u << 20)) {
+                atomicOr(&st->giveup, 128);
+                d = scan_pack(epoch, 0);
             }
-            part += scan_sum_of(d[k]);
         }
-    }
+        return scan_sum_of(d);
+    };
+    long long sum = 0;
+    if (gridDim.x <= flat_grid) {
+        for (uint32_t j0 = lane; j0 < nfront; j0 += 64u * 8u) {
+            unsigned long long d[8];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-    return part;
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint32_t j = j0 + 64u * k;
+                d[k] = __hip_atomic_load(&own[j < nfront ? j : nfront - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint32_t j = j0 + 64u * k;
+                if (j < nfront) sum += wait_for(d[k], j);
+            }
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) sum += __shfl_xor(sum, sh, 64);
+        return sum;
+    }
+    unsigned long long *incl = desc + half;
+    uint32_t j_hi = nfront; // workgroups [0, j_hi) are still to be accounted for
+    while (j_hi > 0u) {
+        const bool in = lane < j_hi;
+        const uint32_t j = in ? j_hi - 1u - lane : 0u;
+        const unsigned long long a = __hip_atomic_load(&own[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long c = __hip_atomic_load(&incl[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long found = __ballot(in && (uint32_t)(c >> 40) == ep);
+        const uint32_t f = found ? (uint32_t)__builtin_ctzll(found) : 64u; // the nearest workgroup with an inclusive sum
+        long long v = in && lane < f ? wait_for(a, j) : (lane == f ? scan_sum_of(c) : 0ll);
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh, 64);
+        sum += v;
+        if (f < 64u) break;
+        j_hi = j_hi > 64u ? j_hi - 64u : 0u;
+    }
+    if (lane == 0u) __hip_atomic_store(&incl[blockIdx.x], scan_pack(epoch, sum + own_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return sum;
 }
 // Measure and stitch, one kernel.  The lanes of a wave walk side by side, a look-up per step.  (Round 3's first version looped per
 // block: the lanes of a wave then wait for each other at every block end - 630 symbol steps per wave where the longest lane has ~250
@@ -234,7 +269,7 @@ __device__ __forceinline__ long long wave_lookback(const unsigned long long *des
 constexpr uint32_t kOwned = 63; // ranges a workgroup owns
 __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                                 uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
-                                                                uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t epoch,
+                                                                uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
                                                                 unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
                                                                 DecStatus *__restrict__ st) {
     __shared__ __attribute__((aligned(16))) uint8_t lutm[kChainLds];   // the chain tables: the measure walk
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
         }
         const long long tot = __shfl(inc, 63, 64);
         if (lane == 63u) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long part = wave_lookback(desc, epoch, st);
+        const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, tot, st);
         if (blockIdx.x == gridDim.x - 1u && lane == 63u) *grand_total = part + tot;
         if (!mine) return;
         const unsigned long long first = (unsigned long long)(part + inc - (long long)nb);
@@ -467,7 +502,7 @@ __constant__ int kAnnScalesDec[64] = { // ANNSCALES of the reference's scaled_dc
 // per CU - 4096 of up to 512 - two; what lies behind the window is read from memory
 template <uint32_t kWinWords, bool kScaled>
 __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
-                                                                    const uint32_t *__restrict__ bpos, unsigned long long *__restrict__ desc, uint32_t epoch,
+                                                                    const uint32_t *__restrict__ bpos, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
                                                                     const long long *__restrict__ total_blocks, unsigned long long n_want, uint32_t stream_bits,
                                                                     DecIdctArgs a, DecStatus *__restrict__ st) {
     // tables + stream window
@@ -584,7 +619,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
         }
     }
     { // the sums of the workgroups in front, wave by wave (no barrier: a wave whose blocks were short goes on)
-        const long long part = wave_lookback(desc, epoch, st);
+        const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, dc_tile, st); // (every wave of the workgroup publishes the same inclusive sum: whichever is first)
         if (b < m) {
             const long long dc = part + dc_inc; // sum of the differences of blocks 0..b
             const int32_t dc32 = (int32_t)dc;   // (the host decoder's long long, narrowed where it is used)
@@ -641,9 +676,11 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             // + 128, clip, truncation toward zero as astype(np.uint8) on a clipped value - on sixteen times the value (idct8_exact_impl: the
-            // passes above leave out their 1/4): fl(16 r + 2048) = 16 fl(r + 128), the clip bounds scale along, and floor(y / 16) of a
-            // non-negative y is floor(y) >> 4.  (The sum is a finite number: v_max / v_min instead of two compares and four selects.)
-            px[k] = (uint32_t)(int)__builtin_fmin(__builtin_fmax(x[u * 8 + k] + 2048.0, 0.0), 4080.0) >> 4;
+            // passes above leave out their 1/4): fl(16 r + 2048) = 16 fl(r + 128); truncation first and the clip on the integer (the
+            // bounds are integers, truncation is monotonic, the sum is far inside the int range: one v_med3_i32 instead of a float64
+            // maximum and minimum), and floor(y / 16) of a non-negative integer y is y >> 4.
+            const int y = (int)(x[u * 8 + k] + 2048.0);
+            px[k] = (uint32_t)(y < 0 ? 0 : (y > 4080 ? 4080 : y)) >> 4;
         }
         uint2 o;
         o.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
@@ -675,15 +712,15 @@ size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
     return nranges * ((size_t)cap_of(kRangeMin) * 2 * 2) + nblocks * 4 + 16384; // (two traces per range, a 4-byte position per block; every piece is rounded up to 256 B)
 }
 
-size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks) { // look-back words of the two scans (half of the array each)
+size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks) { // look-back words of the two sums (own and inclusive sums: a quarter of the array each)
     const size_t nranges = stream_bytes * 8 / kRangeMin + 2;
     const size_t tr = nranges / kOwned + 2, tb = nblocks / kDecodeWG + 2; // (workgroups of the measure kernel and of the fused kernel)
-    return 2 * (tr > tb ? tr : tb);
+    return 4 * (tr > tb ? tr : tb);
 }
 
 hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
                                    size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, const DecIdctArgs &idct,
-                                   DecStatus *d_status, int range_bits, int margin_bits, hipStream_t stream) {
+                                   DecStatus *d_status, int range_bits, int margin_bits, hipStream_t stream, int flat_grid) {
     const size_t nbits = stream_bytes * 8;
     if (!entropy_decode_gpu_range_ok(range_bits)) return hipErrorInvalidValue;
     const uint32_t range = (uint32_t)range_bits;
@@ -691,6 +728,7 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const int kRange = range_bits;
     if (nbits < 128 + 2048 + 2048 || nbits + 8192 >= (1ull << 32) || nblocks == 0) return hipErrorInvalidValue; // (a walk stands up to 1,827 bits behind the end)
     if (margin_bits != 0 && margin_bits != 2048) return hipErrorInvalidValue;
+    if (flat_grid < 0) return hipErrorInvalidValue;
     if (work_bytes < entropy_decode_gpu_work_bytes(stream_bytes, nblocks)) return hipErrorInvalidValue;
     // a block may START up to here.  margin_bits = 2048 (the host decoder's rule, rounds 2-3): every block of the chain lies inside the
     // stream whatever it holds, and the blocks that start behind are the caller's (bit-serial, on the host).  margin_bits = 0: the chain
@@ -703,8 +741,9 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     // The look-back words of the two sums live in an array of their own that holds nothing else, ever: a word there either is zero
     // (since allocation) or carries the epoch of the launch that wrote it, and the caller never reuses an epoch on it.  (Inside the
     // workspace the pieces move with the sizes of the call: a stale trace entry could pass for a published sum.)
-    if (!d_desc || desc_words < 2 * (ntiles_r > ntiles_b ? ntiles_r : ntiles_b) || epoch == 0 || epoch >= (1u << 22)) return hipErrorInvalidValue;
-    unsigned long long *desc_r = d_desc, *desc_b = d_desc + desc_words / 2;
+    if (!d_desc || desc_words < 4 * (ntiles_r > ntiles_b ? ntiles_r : ntiles_b) || epoch == 0 || epoch >= (1u << 22)) return hipErrorInvalidValue;
+    const uint32_t desc_half = (uint32_t)(desc_words / 4); // per sum: own sums, then inclusive sums
+    unsigned long long *desc_r = d_desc, *desc_b = d_desc + 2 * (size_t)desc_half;
     // workspace carve-up
     char *w = (char *)d_work;
     auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) / 256 * 256; return (void *)p; };
@@ -719,10 +758,10 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     // (*d_status is zeroed by the caller: it is host-mapped memory)
     const unsigned win_lds = stage_lds_words(range) * 4u;
     hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3(measure_wgs), bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, (uint32_t)nbits, range, nranges, starts,
-                       hand, desc_r, 2u * epoch, (unsigned long long)nblocks, bpos, totals, d_status);
+                       hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, (unsigned long long)nblocks, bpos, totals, d_status);
     const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
     auto fused = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, desc_b, 2u * epoch + 1u,
+        hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, desc_b, desc_half, (uint32_t)flat_grid, 2u * epoch + 1u,
                            (const long long *)totals, (unsigned long long)nblocks, (uint32_t)nbits, idct, d_status);
     };
     const bool small_win = nbits / nblocks <= 240; // sparse enough for the small window: one workgroup more per CU
