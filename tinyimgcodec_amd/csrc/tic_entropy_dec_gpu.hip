@@ -258,6 +258,25 @@ __device__ __forceinline__ long long wave_lookback(unsigned long long *desc, uin
     if (lane == 0u) __hip_atomic_store(&incl[blockIdx.x], scan_pack(epoch, sum + own_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return sum;
 }
+// One step of a chain walk: the look-up for the 32 stream bits `pk` in the chain tables (mdc | mac | mlong, adjacent in LDS) - the next
+// 11 bits with the DC category next (mode 0), the next 12 inside the AC symbols (mode 1), the next 16 - 0xff40 when the step before met
+// the prefix of a long codeword (mode 2) - and what follows from the entry: the bits to advance, whether a block ended, the next mode.
+// Integer state and arithmetic: with the state in two booleans and the index in nested conditions the compiler kept the booleans as lane
+// masks in scalar registers, merged under the loop's exec mask at every step, and built three exec-mask regions out of the index - 75
+// instructions per step where this takes 50.  (The kernel's time did not move, 38.8 us: a walk is ~80 steps of ~200 ns, one wave per
+// SIMD, most of a step spent waiting for the table entry; profiles/r05_decoder.txt.)
+// An entry of 0 (no codeword of at most 11 bits here): inside the AC symbols it is the prefix of a long codeword - no advance, mode 2;
+// with the DC category next or in the long table it is no codeword at all - skip a bit (a walk that is out of step, or a damaged stream).
+__device__ __forceinline__ void chain_step(const uint8_t *lutm, uint32_t pk, uint32_t &mode, uint32_t &adv, uint32_t &eob) {
+    const uint32_t shift = mode == 2u ? 16u : 21u - mode;
+    const uint32_t base = mode == 2u ? 6144u - (uint32_t)kLongFirst : mode << 11; // (wraps: a long codeword's 16 bits are >= 0xff40)
+    const uint32_t idx = base + (pk >> shift);
+    const uint32_t e = lutm[idx < 6144u + (uint32_t)kLongCodes ? idx : 6144u + (uint32_t)kLongCodes]; // (never out of range by the walk's own rules; the slot behind the tables holds a zero)
+    const bool none = e == 0u;
+    eob = e & 1u; // (bits of a chain of symbols << 1) | the chain ends with EOB
+    adv = none ? (mode != 1u ? 1u : 0u) : e >> 1;
+    mode = none ? ((0x18u >> (2u * mode)) & 3u) /* 0 -> 0, 1 -> 2, 2 -> 1 */ : (eob ^ 1u);
+}
 // Measure and stitch, one kernel.  The lanes of a wave walk side by side, a look-up per step.  (Round 3's first version looped per
 // block: the lanes of a wave then wait for each other at every block end - 630 symbol steps per wave where the longest lane has ~250
 // symbols.)  Here the position inside the block (is the DC category next?) is lane state and a block end is just another step.
@@ -305,8 +324,7 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
     const uint32_t cap = cap_of(range);
     uint16_t *tr = starts + (size_t)(mine ? t : 0u) * cap;
     uint32_t pos = lo, bstart = lo, cnt = 0; // a block that STARTS in front of `hi` is measured to its end
-    bool at_dc = true;     // the DC category comes next (a block starts here)
-    bool in_long = false;  // the step before met an AC prefix of a 12..16-bit codeword: this step looks it up in the long table
+    uint32_t mode = 0; // chain_step: the DC category comes next (a block starts here)
     bool live = walks && pos < hi;
     // The stream words under the read position sit in registers (wa, wb, wc); the word that becomes wc when a step crosses a word
     // boundary is requested together with the table entry, at the top of the step, so that one wait covers both and the only LDS
@@ -327,13 +345,9 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
         const uint32_t wn = wp[wi + 3u];
         asm volatile("" ::: "memory"); // (keeps the request in front of the table look-up: it has returned when the entry has)
         const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32); // 32 stream bits from `pos`
-        const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
-        const uint32_t idx = in_long ? 6144u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : (at_dc ? pk >> 21 : 2048u + (pk >> 20));
-        const uint32_t e = lutm[idx]; // (bits of a chain of symbols << 1) | the chain ends with EOB; 0: no codeword of at most 11 bits here
-        const bool none = e == 0u;
-        const bool esc = none && !in_long && !at_dc; // an AC prefix of a long codeword: the next step resolves it
-        const bool eob = (e & 1u) != 0u;
-        pos += esc ? 0u : (none ? 1u : e >> 1); // (no codeword here: skip a bit)
+        uint32_t adv, eob;
+        chain_step(lutm, pk, mode, adv, eob);
+        pos += adv;
         { // a step consumes at most 27 bits: at most one word boundary is crossed
             const uint32_t now = pos >> 5;
             const bool crossed = now != wi;
@@ -343,10 +357,8 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
             wi = now;
         }
         if (eob && mine && cnt < cap) tr[cnt] = (uint16_t)(bstart - lo);
-        cnt += eob ? 1u : 0u;
+        cnt += eob;
         bstart = eob ? pos : bstart;
-        at_dc = none ? at_dc : eob;
-        in_long = esc;
         live = (eob ? pos < hi : true) && pos < stop;
     }
     if (mine && cnt > cap) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
@@ -404,27 +416,24 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
             {
                 uint32_t p = pos;
                 const uint32_t limit = p + 1800u < stream_bits ? p + 1800u : stream_bits; // (a block has at most 1,728 bits)
-                bool dcn = true, lng = false, open = true;
+                uint32_t md = 0; // (the DC category next)
+                bool open = true;
                 uint32_t bi = p >> 5;
                 uint32_t ba = wp[bi], bb = wp[bi + 1u], bc = wp[bi + 2u];
                 while (open && p < limit) {
                     const uint32_t bn = wp[bi + 3u];
                     asm volatile("" ::: "memory");
                     const uint32_t pk = (uint32_t)(((((unsigned long long)ba) << 32) | bb) << (p & 31u) >> 32);
-                    const uint32_t li = (pk >> 16) - (uint32_t)kLongFirst;
-                    const uint32_t e = lutm[lng ? 6144u + (li < (uint32_t)kLongCodes ? li : (uint32_t)kLongCodes) : (dcn ? pk >> 21 : 2048u + (pk >> 20))];
-                    const bool none = e == 0u;
-                    const bool esc = none && !lng && !dcn;
-                    p += esc ? 0u : (none ? 1u : e >> 1);
+                    uint32_t adv, eob;
+                    chain_step(lutm, pk, md, adv, eob);
+                    p += adv;
                     const uint32_t now = p >> 5;
                     const bool crossed = now != bi;
                     ba = crossed ? bb : ba;
                     bb = crossed ? bc : bb;
                     bc = crossed ? bn : bc;
                     bi = now;
-                    open = (e & 1u) == 0u;
-                    dcn = none ? dcn : false;
-                    lng = esc;
+                    open = eob == 0u;
                 }
                 if (open) { // no EOB within a block's length, or the stream ended first
                     // ... at the stream's end that is how the chain of a whole stream ends: in the padding bits behind its last block (fewer than
