@@ -636,14 +636,33 @@ def codec_resident(args, ctx, L, N, q):
         back = np.empty((h, w), np.uint8)
         ctx.check(L.tic_memcpy_d2h(ctx.handle, back.ctypes.data, d_pix, back.size))
         err = np.abs(back.astype(np.int16) - img.astype(np.int16))
+        # the leg proves itself where a fixture exists: stream and decoded pixels against the digests the pinned oracle left for this frame
+        # (tests/golden/big_frame_decode.json, written by tests/golden/gen/make_goldens_r5.py in the build container - data, not the oracle)
+        stream_sha, pixel_sha = hashlib.sha256(stream.tobytes()).hexdigest(), hashlib.sha256(back.tobytes()).hexdigest()
+        parity = {"status": "no fixture for this frame"}
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "big_frame_decode.json")) as f:
+                for e in json.load(f)["entries"]:
+                    if (e["seed"], e["height"], e["width"], e["quality"]) == (1234, h, w, q):
+                        ok = e["sha256"] == stream_sha and e["decoded_sha256"] == pixel_sha and e["bytes"] == n.value
+                        if not ok:
+                            raise AssertionError("codec_resident: stream %s / pixels %s differ from the oracle's digests" % (stream_sha[:16], pixel_sha[:16]))
+                        parity = {"status": "ok", "against": "tests/golden/big_frame_decode.json (sha256 of the pinned oracle's stream and decoded pixels for this frame)",
+                                  "checked": "the stream tic_compress_dev wrote and the pixels tic_decompress_dev decoded from it in the timed calls"}
+        except OSError as ex:
+            parity = {"status": "fixture unreadable: %s" % ex}
         return {
+            "parity": parity,
             "workload": "the %dx%d frame of config 2 (seed 1234), quality=%d, image, stream and pixels resident in HBM" % (h, w, q),
             "compress_dev_us": round(t_enc * 1e6, 1), "compress_dev_mpix_s": round(h * w / t_enc / 1e6, 1),
             "pipelined_us": round(t_pipe * 1e6, 1), "pipelined_mpix_s": round(h * w / t_pipe / 1e6, 1),
             "pipelined_note": "tic_compress_dev_async: %d frames queued back to back, results collected afterwards (same stream bytes); per frame" % burst,
-            "stream_bytes": int(n.value), "stream_sha256": hashlib.sha256(stream.tobytes()).hexdigest(),
+            "stream_bytes": int(n.value), "stream_sha256": stream_sha, "decoded_sha256": pixel_sha,
             "decompress_dev_us": round(t_dec * 1e6, 1), "decompress_dev_mpix_s": round(h * w / t_dec / 1e6, 1),
             "decoder_path": int(L.tic_last_decode_path(ctx.handle)), "decoder_range_bits": rb.value, "decoder_runs": tr.value,
+            "decoder_header_guess": int(L.tic_last_decode_guess(ctx.handle)),
+            "decoder_note": "tic_decompress_dev launches on a guess of the stream's header (the header of the stream this context decoded last; 1 = the guess held, as for "
+                            "every call of this loop but the first) instead of reading 16 bytes from device memory first; a wrong guess costs a second decode",
             "round_trip_max_abs_error": int(err.max()), "round_trip_mean_abs_error": round(float(err.mean()), 3),
             "note": "host clock around the C-ABI call (launches + one wait included), median of 5 x 40 calls; parity of both directions is the test suite's business "
                     "(streams against the reference's, pixels against the reference's decoder) - the round-trip error here is the quantiser's",

@@ -163,7 +163,10 @@ open(os.path.join(sys.argv[2], "pid%d" % rank), "w").write(str(os.getpid()))
 if mode == "ok":
     sys.exit(0)
 if mode == "fail1" and rank == 1:
-    time.sleep(0.3)
+    t_end = time.time() + 20  # (every rank has come up - on a busy host an interpreter can take longer to start than this one to fail)
+    while time.time() < t_end and not all(os.path.exists(os.path.join(sys.argv[2], "pid%d" % r)) and os.path.getsize(os.path.join(sys.argv[2], "pid%d" % r)) for r in range(world)):
+        time.sleep(0.02)
+    time.sleep(0.1)
     sys.exit(3)
 time.sleep(600)   # "hang": everybody in mode hang, the survivors in mode fail1 / killed
 """
@@ -179,6 +182,8 @@ def _run_launcher(tmp_path, mode, world=3, timeout_s=30.0, killer=None):
     script = tmp_path / "child.py"
     script.write_text(_CHILD)
     out, err = io.StringIO(), io.StringIO()
+    for f in tmp_path.glob("pid*"):  # (an earlier launch's files)
+        f.unlink()
     if killer is not None:
         threading.Thread(target=killer, daemon=True).start()
     t0 = time.monotonic()
@@ -204,8 +209,6 @@ def test_launcher_relays_rank0_and_reports_failures(tmp_path):
 
     def killer():  # one rank dies mid-run (OOM killer, a GPU fault): SIGKILL to its exact pid
         p = tmp_path / "pid2"
-        for f in tmp_path.glob("pid*"):
-            f.unlink()
         while not p.exists() or not p.read_text():
             time.sleep(0.05)
         time.sleep(0.2)
@@ -213,7 +216,7 @@ def test_launcher_relays_rank0_and_reports_failures(tmp_path):
 
     rc, out, err, dt = _run_launcher(tmp_path, "hang", killer=killer)
     assert rc == 128 + signal.SIGKILL and dt < 10 and "rank 2 exited with -9" in err
-    rc, out, err, dt = _run_launcher(tmp_path, "hang", world=2, timeout_s=1.0)
+    rc, out, err, dt = _run_launcher(tmp_path, "hang", world=2, timeout_s=3.0)
     assert rc == 124 and dt < 10 and "still running" in err
     assert not [d for d in os.listdir("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp") if d.startswith("tic_rdv_") and
                 os.stat(os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", d)).st_uid == os.geteuid() and
