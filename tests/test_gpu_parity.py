@@ -1363,7 +1363,7 @@ def test_decompress_large_frame_device_against_host_decoder(ctx, monkeypatch):
 
     L = N.load()
     with open(os.path.join(os.path.dirname(__file__), "golden", "big_frame_decode.json")) as f:
-        want = {e["quality"]: e for e in json.load(f)["entries"]}
+        want = {e["quality"]: e for e in json.load(f)["entries"] if (e["seed"], e["height"], e["width"]) == (8192, 4096, 8192)}
     img = rand_frame(8192, 4096, 8192)
     for q in (50, 85):
         assert (want[q]["seed"], want[q]["height"], want[q]["width"]) == (8192, 4096, 8192)
