@@ -263,8 +263,8 @@ __device__ __forceinline__ long long wave_lookback(unsigned long long *desc, uin
 // the prefix of a long codeword (mode 2) - and what follows from the entry: the bits to advance, whether a block ended, the next mode.
 // Integer state and arithmetic: with the state in two booleans and the index in nested conditions the compiler kept the booleans as lane
 // masks in scalar registers, merged under the loop's exec mask at every step, and built three exec-mask regions out of the index - 75
-// instructions per step where this takes 50.  (The kernel's time did not move, 38.8 us: a walk is ~80 steps of ~200 ns, one wave per
-// SIMD, most of a step spent waiting for the table entry; profiles/r05_decoder.txt.)
+// instructions per step where this takes 50.  (The kernel's time did not move, 38.8 us: the walk is 16.7 us of it - a timing build that
+// walks twice - at one wave per SIMD; profiles/r05_decoder.txt.)
 // An entry of 0 (no codeword of at most 11 bits here): inside the AC symbols it is the prefix of a long codeword - no advance, mode 2;
 // with the DC category next or in the long table it is no codeword at all - skip a bit (a walk that is out of step, or a damaged stream).
 __device__ __forceinline__ void chain_step(const uint8_t *lutm, uint32_t pk, uint32_t &mode, uint32_t &adv, uint32_t &eob) {
