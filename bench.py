@@ -631,8 +631,37 @@ def codec_resident(args, ctx, L, N, q):
         ctx.check(L.tic_memcpy_d2h(ctx.handle, stream2.ctypes.data, d_out, n.value))
         assert np.array_equal(stream, stream2), "the asynchronous form wrote a different stream"
         t_dec = timed(lambda: ctx.check(L.tic_decompress_dev(ctx.handle, d_out, n.value, d_pix, w, img.size, None, None)))
+        back_sync = np.empty((h, w), np.uint8)
         rb, tr = C.c_int(), C.c_int()
         ctx.check(L.tic_last_decode_range(ctx.handle, C.byref(rb), C.byref(tr)))
+        guess_held = int(L.tic_last_decode_guess(ctx.handle))
+        # the same decoder with four tickets open (tic_decompress_dev_async): 64 frames, a frame is collected when the fourth behind it has been queued
+        dec_burst, dec_open = 64, 4
+        d_pix4 = []
+        for k in range(dec_open):
+            p = C.c_void_p()
+            ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(p)))
+            d_pix4.append(p)
+        try:
+            def dec_burst_fn():
+                tk = []
+                for k in range(dec_burst):
+                    if len(tk) == dec_open:
+                        ctx.check(L.tic_decompress_async_result(ctx.handle, tk.pop(0), 1, None, None))
+                    t = C.c_longlong()
+                    ctx.check(L.tic_decompress_dev_async(ctx.handle, d_out, n.value, d_pix4[k % dec_open], w, img.size, C.byref(t)))
+                    tk.append(t.value)
+                while tk:
+                    ctx.check(L.tic_decompress_async_result(ctx.handle, tk.pop(0), 1, None, None))
+            t_dec_pipe = timed(dec_burst_fn, reps=3) / dec_burst
+            for p in d_pix4:  # every destination holds the same pixels as the synchronous call's
+                b4 = np.empty((h, w), np.uint8)
+                ctx.check(L.tic_memcpy_d2h(ctx.handle, b4.ctypes.data, p, b4.size))
+                ctx.check(L.tic_memcpy_d2h(ctx.handle, back_sync.ctypes.data, d_pix, back_sync.size))
+                assert np.array_equal(b4, back_sync), "the asynchronous decode wrote different pixels"
+        finally:
+            for p in d_pix4:
+                L.tic_dev_free(ctx.handle, p)
         back = np.empty((h, w), np.uint8)
         ctx.check(L.tic_memcpy_d2h(ctx.handle, back.ctypes.data, d_pix, back.size))
         err = np.abs(back.astype(np.int16) - img.astype(np.int16))
@@ -660,7 +689,9 @@ def codec_resident(args, ctx, L, N, q):
             "stream_bytes": int(n.value), "stream_sha256": stream_sha, "decoded_sha256": pixel_sha,
             "decompress_dev_us": round(t_dec * 1e6, 1), "decompress_dev_mpix_s": round(h * w / t_dec / 1e6, 1),
             "decoder_path": int(L.tic_last_decode_path(ctx.handle)), "decoder_range_bits": rb.value, "decoder_runs": tr.value,
-            "decoder_header_guess": int(L.tic_last_decode_guess(ctx.handle)),
+            "decoder_header_guess": guess_held,
+            "decompress_pipelined_us": round(t_dec_pipe * 1e6, 1), "decompress_pipelined_mpix_s": round(h * w / t_dec_pipe / 1e6, 1),
+            "decompress_pipelined_note": "tic_decompress_dev_async: %d frames, %d tickets open at a time on streams of their own (same pixels); per frame" % (dec_burst, dec_open),
             "decoder_note": "tic_decompress_dev launches on a guess of the stream's header (the header of the stream this context decoded last; 1 = the guess held, as for "
                             "every call of this loop but the first) instead of reading 16 bytes from device memory first; a wrong guess costs a second decode",
             "round_trip_max_abs_error": int(err.max()), "round_trip_mean_abs_error": round(float(err.mean()), 3),

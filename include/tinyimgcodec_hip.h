@@ -251,6 +251,16 @@ int tic_last_decode_range(tic_ctx *ctx, int *range_bits, int *tries);
  * decoded again with its own header), 0 when no guess was made.  (No counterpart in the reference: decompress() codec.py:133-164 reads
  * the header from host memory.) */
 int tic_last_decode_guess(tic_ctx *ctx);
+/* tic_decompress_dev, asynchronously (the counterpart of tic_compress_dev_async for decompress() in a loop,
+ * /root/reference/tests/benchmark.py:19): a long stream is launched on the guess of its header on a stream of the ticket's own and the
+ * call returns; up to 4 tickets may be open per context and their frames overlap on the device.  tic_decompress_async_result waits
+ * (wait == 0: TIC_E_BUSY while in flight), checks what the kernels reported and, when the guess did not hold or the stream is anything
+ * but a whole well-formed one, decodes it again synchronously: a ticket's outcome is always tic_decompress_dev's for the same arguments.
+ * The destination must not be read before the result is collected; d_stream must stay valid until then.  Launches are ordered behind
+ * everything queued on the context's stream at the time of the call; tic_sync waits for them too. */
+int tic_decompress_dev_async(tic_ctx *ctx, const void *d_stream, size_t len, void *d_out, ptrdiff_t out_stride, size_t out_cap,
+                             long long *ticket);
+int tic_decompress_async_result(tic_ctx *ctx, long long ticket, int wait, int *h_out, int *w_out);
 
 /* ---- multi-GPU (the reference has no counterpart: it is single-process, codec.py:133-164 runs one image
  *      at a time).  One process per GPU; a batch shards by independent frames (frame i -> rank i / ceil(B/G)) with no

@@ -1520,6 +1520,62 @@ def test_decompress_dev_launches_on_a_guess_of_the_header(ctx, oracle, monkeypat
     ctx2.close()
 
 
+def test_decompress_dev_async_matches_the_synchronous_call(ctx, oracle):
+    """tic_decompress_dev_async / tic_decompress_async_result: frames launched on the guess of their header on streams of their own,
+    four tickets open at a time - every ticket's outcome (pixels, geometry, return code) is the synchronous call's: same geometry and
+    quality (the launch stands), another quality and a damaged stream (decoded again at collection), a short stream and a first call
+    without any guess (run synchronously at once); a fifth open ticket and a closed ticket are refused."""
+    L = N.load()
+    ctx2 = T.Context(0)
+    specs = [((2048, 2048), 50, 0), ((2048, 2048), 50, 0), ((2048, 2048), 50, 0), ((2048, 2048), 80, 0), ((2048, 2048), 50, 1), ((512, 512), 50, 0),
+             ((2048, 2048), 50, 0), ((2048, 2048), 50, 2), ((1504, 2000), 60, 0), ((2048, 2048), 50, 0)]
+    jobs = []
+    for k, ((h, w), q, damage) in enumerate(specs):
+        s = bytearray(T.compress(rand_frame(1300 + k, h, w), q, ctx=ctx))
+        if damage == 1:
+            s[len(s) // 2 + 11] ^= 0x10  # a flipped bit in the middle
+        elif damage == 2:
+            s = s[: len(s) * 6 // 10]     # cut short
+        s = np.frombuffer(bytes(s), np.uint8)
+        d_s, d_p = C.c_void_p(), C.c_void_p()
+        ctx2.check(L.tic_dev_alloc(ctx2.handle, s.size + 64, C.byref(d_s)))
+        ctx2.check(L.tic_dev_alloc(ctx2.handle, h * w, C.byref(d_p)))
+        ctx2.check(L.tic_memcpy_h2d(ctx2.handle, d_s, s.ctypes.data, s.size))
+        jobs.append((d_s, d_p, s, h, w, oracle.decompress(s.tobytes())))
+
+    def collect(k, ticket):
+        d_s, d_p, s, h, w, want = jobs[k]
+        hh, ww = C.c_int(), C.c_int()
+        rc = L.tic_decompress_async_result(ctx2.handle, ticket, 0, C.byref(hh), C.byref(ww))
+        if rc == N.TIC_E_BUSY:
+            rc = L.tic_decompress_async_result(ctx2.handle, ticket, 1, C.byref(hh), C.byref(ww))
+        assert rc == 0, (k, rc, L.tic_last_error(ctx2.handle))
+        assert (hh.value, ww.value) == (h, w), k
+        pix = np.empty((h, w), np.uint8)
+        ctx2.check(L.tic_memcpy_d2h(ctx2.handle, pix.ctypes.data, d_p, pix.size))
+        assert np.array_equal(pix, want), k
+        assert L.tic_decompress_async_result(ctx2.handle, ticket, 1, None, None) == N.TIC_E_ARG  # closed
+
+    open_tickets = []
+    for k, (d_s, d_p, s, h, w, want) in enumerate(jobs):
+        ctx2.check(L.tic_memset_dev(ctx2.handle, d_p, 0xEE, h * w))
+        t = C.c_longlong(-1)
+        ctx2.check(L.tic_decompress_dev_async(ctx2.handle, d_s, s.size, d_p, w, h * w, C.byref(t)))
+        open_tickets.append((k, t.value))
+        if len(open_tickets) == 4:
+            if k == 3:  # four tickets are open: a fifth is refused, and refusing it changes nothing
+                t5 = C.c_longlong(-1)
+                assert L.tic_decompress_dev_async(ctx2.handle, d_s, s.size, d_p, w, h * w, C.byref(t5)) == N.TIC_E_ARG
+            collect(*open_tickets.pop(0))
+    ctx2.check(L.tic_sync(ctx2.handle))  # (waits for the asynchronous decodes too)
+    while open_tickets:
+        collect(*open_tickets.pop(0))
+    assert L.tic_decompress_async_result(ctx2.handle, 10 ** 6, 1, None, None) == N.TIC_E_ARG
+    for d_s, d_p, *_ in jobs:
+        L.tic_dev_free(ctx2.handle, d_s); L.tic_dev_free(ctx2.handle, d_p)
+    ctx2.close()
+
+
 def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch):
     """The strip walk uses 32-bit pixel offsets; a frame of 4 GiB or more is cut into bands of whole block rows, one launch each
     (round 2 ran such frames on the exact kernel only).  TIC_BAND_BYTES lowers the limit so that a 3000 x 2112 frame is cut into

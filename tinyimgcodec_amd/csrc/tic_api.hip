@@ -30,6 +30,7 @@ using namespace tic;
 
 namespace {
 constexpr int kAsyncSlots = 64; // tickets of the asynchronous calls that may be open at once per context
+constexpr int kDecSlots = 4;    // ... of the asynchronous decodes (each holds a workspace: tens of MB for a 4096^2 stream)
 // Phase times of the batch pipeline (tic_last_batch_phases): a handful of steady_clock reads per chunk, summed per context.
 // 0 staging copies into pinned memory (pageable input) or registration of the caller's frames, 1 enqueueing (H2D, kernels, lengths),
 // 2 waiting for a chunk, 3 stream read-back, 4 hand-out into the caller's buffers, 5 waiting for a free slot.
@@ -122,6 +123,32 @@ struct tic_ctx {
     uint32_t dec_epoch = 0;                                     // calls of the device decoder on this workspace (its single-launch scans tell their words by it)
     DecStatus *h_dec_status = nullptr, *d_dec_status = nullptr; // host-mapped
     int last_decode_path = 0;                                  // 0 none, 1 device decoder, 2 host decoder (tic_last_decode_path)
+    // asynchronous device-resident decodes (tic_decompress_dev_async): ticket t lives in slot t % kDecSlots; every slot has its own HIP
+    // stream, workspace, look-back words and status words, so that the frames of a burst overlap (the measure kernel is one wave per
+    // SIMD waiting for table entries, the fused kernel issues float64 arithmetic: they share a CU well)
+    struct DecSlot {
+        long long ticket = -1;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        void *work = nullptr;
+        size_t work_bytes = 0;
+        unsigned long long *desc = nullptr;
+        size_t desc_words = 0;
+        uint32_t epoch = 0;
+        DecStatus *h_status = nullptr, *d_status = nullptr;
+        bool launched = false;   // false: the call ran synchronously (no guess to launch on): rc / h / w are its outcome
+        int rc = TIC_OK, h = 0, w = 0;
+        uint8_t head[16] = {0};  // the header the launch guessed
+        size_t n = 0;
+        const void *d_stream = nullptr; // the call, for the synchronous second try
+        size_t len = 0;
+        void *d_out = nullptr;
+        ptrdiff_t out_stride = 0;
+        size_t out_cap = 0;
+    };
+    DecSlot dec_slots[kDecSlots];
+    long long dec_async_next = 0;
+    hipEvent_t dec_order = nullptr; // a slot's stream starts behind everything queued on the context's stream so far
     uint8_t dec_head[16] = {0};                                  // header of the last stream tic_decompress_dev decoded on the device: the next call's guess
     bool dec_head_valid = false;
     int last_decode_guess = 0;                                  // tic_decompress_dev: 1 the last call's guess of the header held, -1 it did not (decoded again), 0 no guess
@@ -289,6 +316,15 @@ void tic_destroy(tic_ctx *ctx) {
     if (ctx->d_dec_desc) (void)hipFree(ctx->d_dec_desc);
     if (ctx->h_dec_tail) (void)hipHostFree(ctx->h_dec_tail);
     if (ctx->h_dec_status) (void)hipHostFree(ctx->h_dec_status);
+    for (auto &sl : ctx->dec_slots) {
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.work) (void)hipFree(sl.work);
+        if (sl.desc) (void)hipFree(sl.desc);
+        if (sl.h_status) (void)hipHostFree(sl.h_status);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
+    if (ctx->dec_order) (void)hipEventDestroy(ctx->dec_order);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -491,6 +527,8 @@ int tic_sync(tic_ctx *ctx) {
     if (!ctx) return TIC_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &sl : ctx->dec_slots) // (asynchronous decodes run on streams of their own)
+        if (sl.stream) HIPCHK(ctx, hipStreamSynchronize(sl.stream));
     return TIC_OK;
 }
 
@@ -1701,6 +1739,13 @@ static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int 
 // with *done = true when the image is complete in `out`; *done = false (and TIC_OK) when the device decoder met something unusual
 // or does not apply - the caller then decodes on the host, which reproduces the reference's behaviour on malformed streams (what
 // the device wrote to `out` until then is overwritten).
+// stream bits per lane of the device decoder: `mult` average blocks, at least `floor_words` 32-bit words, as an odd number of words up to 63
+static int decode_range_bits(size_t len, size_t n, size_t mult = 3, size_t floor_words = 17) {
+    size_t k = (mult * (len * 8) / n + 31) / 32;
+    k |= 1;
+    return (int)(k < floor_words ? floor_words : (k > 63 ? 63 : k)) * 32;
+}
+
 static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h, int w, int quality, int scaled_exp, uint8_t *out,
                             bool out_on_device, size_t out_stride, bool *done, bool src_on_device = false, const uint8_t *guessed_head = nullptr,
                             bool *guess_held = nullptr) {
@@ -1791,12 +1836,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
         unsigned a = 0, b = 0;
         if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 64 && b >= 9 && b <= 63) mult = a, floor_words = b | 1;
     }
-    auto odd_words = [floor_words](size_t bits) {
-        size_t k = (bits + 31) / 32;
-        k |= 1;
-        return (int)(k < floor_words ? floor_words : (k > 63 ? 63 : k)) * 32;
-    };
-    int range_bits = odd_words(mult * (len * 8) / n);
+    int range_bits = decode_range_bits(len, n, mult, floor_words);
     ctx->last_decode_tries = 0;
     if (const char *e = test_hook("TIC_DECODE_RANGE")) range_bits = atoi(e);
     if (!entropy_decode_gpu_range_ok(range_bits)) return set_err(ctx, TIC_E_ARG, "TIC_DECODE_RANGE=%d: not a range the device decoder takes", range_bits);
@@ -2051,6 +2091,130 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
         return idct_from_device(ctx, h, w, scaled ? 50 : quality, scaled ? quality : -1, (uint8_t *)d_out, true, (size_t)out_stride);
     }
     return set_err(ctx, TIC_E_ARG, "tic_decompress_dev: unreachable");
+}
+
+// tic_decompress_dev, asynchronously.  A long stream is LAUNCHED on the guess of its header (tic_decompress_dev above) on a stream of
+// the ticket's own and the call returns; tic_decompress_async_result waits for it and checks what the kernels reported - the header they
+// saw, nothing unusual on the chain, every block produced; if any of that fails (another header, a damaged or cut stream) the stream is
+// decoded again there, synchronously, by tic_decompress_dev itself, so the outcome of a ticket is always that of the synchronous call.
+// A call that cannot be launched on a guess (no stream decoded yet on this context, a short stream, a destination the kernels cannot
+// write directly or the guessed geometry does not fit) runs synchronously right away and its ticket only carries the outcome.
+int tic_decompress_dev_async(tic_ctx *ctx, const void *d_stream, size_t len, void *d_out, ptrdiff_t out_stride, size_t out_cap, long long *ticket) {
+    TIC_LOCK(ctx);
+    if (!ctx || !ticket) return TIC_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long long t = ctx->dec_async_next;
+    tic_ctx::DecSlot &sl = ctx->dec_slots[t % kDecSlots];
+    if (sl.ticket >= 0) return set_err(ctx, TIC_E_ARG, "%d asynchronous decodes are open: collect results (tic_decompress_async_result) first", kDecSlots);
+    sl.launched = false;
+    sl.d_stream = d_stream;
+    sl.len = len;
+    sl.d_out = d_out;
+    sl.out_stride = out_stride;
+    sl.out_cap = out_cap;
+    int h = 0, w = 0, quality = 0;
+    uint32_t flag = 0;
+    bool launch = ctx->dec_head_valid && d_stream && d_out && len * 8 >= 128 + (1u << 21) && len * 8 + 8192 < (1ull << 32) && ((uintptr_t)d_stream & 3u) == 0 &&
+                  out_stride % 8 == 0 && (uintptr_t)d_out % 8 == 0 && ctx->d_dec_luts && !test_hook("TIC_DECODE_NO_GUESS") && !test_hook("TIC_DECODE_HOST") &&
+                  !test_hook("TIC_DECODE_SERIAL") && parse_header(ctx->dec_head, 16, &h, &w, &quality, &flag) == TIC_OK;
+    const size_t n = launch ? num_blocks(h, w) : 0;
+    launch = launch && n >= 16384 && out_stride >= (ptrdiff_t)w && (size_t)(h - 1) * (size_t)out_stride + (size_t)w <= out_cap;
+    if (launch) {
+        if (!sl.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        if (!ctx->dec_order) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->dec_order, hipEventDisableTiming));
+        if (!sl.h_status) {
+            HIPCHK(ctx, hipHostMalloc((void **)&sl.h_status, 64, hipHostMallocMapped));
+            HIPCHK(ctx, hipHostGetDevicePointer((void **)&sl.d_status, sl.h_status, 0));
+        }
+        const size_t wb = entropy_decode_gpu_work_bytes(len, n);
+        if (wb > sl.work_bytes) { // (nothing of this slot is in flight: its ticket is closed)
+            if (sl.work) HIPCHK(ctx, hipFree(sl.work));
+            sl.work = nullptr;
+            sl.work_bytes = 0;
+            HIPCHK(ctx, hipMalloc(&sl.work, wb));
+            sl.work_bytes = wb;
+        }
+        size_t dw = entropy_decode_gpu_desc_words(len, n);
+        if (dw > sl.desc_words) {
+            dw = dw < 8192 ? 8192 : 2 * dw;
+            if (sl.desc) HIPCHK(ctx, hipFree(sl.desc));
+            sl.desc = nullptr;
+            sl.desc_words = 0;
+            HIPCHK(ctx, hipMalloc((void **)&sl.desc, dw * 8));
+            HIPCHK(ctx, hipMemset(sl.desc, 0, dw * 8));
+            sl.desc_words = dw;
+            sl.epoch = 0;
+        }
+        if (++sl.epoch >= (1u << 22)) {
+            HIPCHK(ctx, hipMemsetAsync(sl.desc, 0, sl.desc_words * 8, sl.stream));
+            sl.epoch = 1;
+        }
+        const bool scaled = (flag & (1u << 30)) != 0;
+        DecIdctArgs ia;
+        ia.out = (uint8_t *)d_out;
+        ia.h = h;
+        ia.w = w;
+        ia.stride = (long)out_stride;
+        ia.bw = (w + 7) / 8;
+        ia.aligned8 = 1;
+        ia.consts = ctx->d_consts + (scaled ? 50 : quality);
+        ia.scaled = scaled;
+        ia.pow2 = scaled ? ldexp(1.0, quality) : 1.0;
+        memset(sl.h_status, 0, sizeof(DecStatus));
+        // behind everything queued on the context's stream so far (the stream may just have been written there: tic_compress_dev_async)
+        HIPCHK(ctx, hipEventRecord(ctx->dec_order, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(sl.stream, ctx->dec_order, 0));
+        HIPCHK(ctx, entropy_decode_idct_gpu(d_stream, len, n, ctx->d_dec_luts, sl.work, sl.work_bytes, sl.desc, sl.desc_words, sl.epoch, ia, sl.d_status,
+                                            decode_range_bits(len, n), 0, sl.stream));
+        HIPCHK(ctx, hipEventRecord(sl.done, sl.stream));
+        memcpy(sl.head, ctx->dec_head, 16);
+        sl.n = n;
+        sl.h = h;
+        sl.w = w;
+        sl.launched = true;
+    } else {
+        sl.rc = tic_decompress_dev(ctx, d_stream, len, d_out, out_stride, out_cap, &sl.h, &sl.w);
+    }
+    sl.ticket = t;
+    ctx->dec_async_next = t + 1;
+    *ticket = t;
+    return TIC_OK;
+}
+
+// Outcome of an asynchronous decode: what tic_decompress_dev would have returned for the same arguments (and *h_out / *w_out, either
+// may be null).  wait == 0: TIC_E_BUSY while the frame is still in flight.  A ticket is closed by the call that returns anything else.
+int tic_decompress_async_result(tic_ctx *ctx, long long ticket, int wait, int *h_out, int *w_out) {
+    TIC_LOCK(ctx);
+    if (!ctx || ticket < 0) return TIC_E_ARG;
+    tic_ctx::DecSlot &sl = ctx->dec_slots[ticket % kDecSlots];
+    if (sl.ticket != ticket) return set_err(ctx, TIC_E_ARG, "decode ticket %lld is not open", ticket);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (sl.launched) {
+        if (!wait) {
+            const hipError_t q = hipEventQuery(sl.done);
+            if (q == hipErrorNotReady) return TIC_E_BUSY;
+            HIPCHK(ctx, q);
+        } else {
+            HIPCHK(ctx, hipEventSynchronize(sl.done));
+        }
+        DecStatus st;
+        memcpy(&st, sl.h_status, sizeof st); // (host-mapped: the slot's stream has drained)
+        if (memcmp(st.head, sl.head, 16) == 0 && st.giveup == 0 && st.m == sl.n) {
+            ctx->last_decode_path = 1;
+            ctx->last_decode_giveup = 0;
+            ctx->last_decode_guess = 1;
+            ctx->last_decode_tries = 1;
+            sl.rc = TIC_OK;
+        } else { // another header, or something unusual in the stream: the synchronous call settles it (and overwrites what this run wrote)
+            sl.rc = tic_decompress_dev(ctx, sl.d_stream, sl.len, sl.d_out, sl.out_stride, sl.out_cap, &sl.h, &sl.w);
+            if (ctx->last_decode_guess == 0) ctx->last_decode_guess = -1;
+        }
+    }
+    sl.ticket = -1;
+    if (h_out) *h_out = sl.h;
+    if (w_out) *w_out = sl.w;
+    return sl.rc;
 }
 
 // ---- self test hook (used by tests/ only; not part of the drop-in surface) --------------------------------
