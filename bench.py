@@ -632,6 +632,11 @@ def codec_resident(args, ctx, L, N, q):
         assert np.array_equal(stream, stream2), "the asynchronous form wrote a different stream"
         t_dec = timed(lambda: ctx.check(L.tic_decompress_dev(ctx.handle, d_out, n.value, d_pix, w, img.size, None, None)))
         back_sync = np.empty((h, w), np.uint8)
+        ctx.check(L.tic_set_decode_guess(ctx.handle, 0))  # the same call reading the 16-byte header from device memory first (no launch on a guess)
+        t_dec_read = timed(lambda: ctx.check(L.tic_decompress_dev(ctx.handle, d_out, n.value, d_pix, w, img.size, None, None)))
+        ctx.check(L.tic_set_decode_guess(ctx.handle, 1))
+        for _ in range(3):
+            ctx.check(L.tic_decompress_dev(ctx.handle, d_out, n.value, d_pix, w, img.size, None, None))
         rb, tr = C.c_int(), C.c_int()
         ctx.check(L.tic_last_decode_range(ctx.handle, C.byref(rb), C.byref(tr)))
         guess_held = int(L.tic_last_decode_guess(ctx.handle))
@@ -689,11 +694,12 @@ def codec_resident(args, ctx, L, N, q):
             "stream_bytes": int(n.value), "stream_sha256": stream_sha, "decoded_sha256": pixel_sha,
             "decompress_dev_us": round(t_dec * 1e6, 1), "decompress_dev_mpix_s": round(h * w / t_dec / 1e6, 1),
             "decoder_path": int(L.tic_last_decode_path(ctx.handle)), "decoder_range_bits": rb.value, "decoder_runs": tr.value,
-            "decoder_header_guess": guess_held,
+            "decoder_header_guess": guess_held, "decompress_dev_header_read_first_us": round(t_dec_read * 1e6, 1),
             "decompress_pipelined_us": round(t_dec_pipe * 1e6, 1), "decompress_pipelined_mpix_s": round(h * w / t_dec_pipe / 1e6, 1),
             "decompress_pipelined_note": "tic_decompress_dev_async: %d frames, %d tickets open at a time on streams of their own (same pixels); per frame" % (dec_burst, dec_open),
-            "decoder_note": "tic_decompress_dev launches on a guess of the stream's header (the header of the stream this context decoded last; 1 = the guess held, as for "
-                            "every call of this loop but the first) instead of reading 16 bytes from device memory first; a wrong guess costs a second decode",
+            "decoder_note": "tic_decompress_dev launches on a guess of the stream's header (the header of the stream this context decoded last, once two streams in a row "
+                            "came with the same one; 1 = the guess held, as for every call of this loop but the first two) instead of reading 16 bytes from device memory first; "
+                            "a wrong guess costs a second decode; decompress_dev_header_read_first_us is the same call with the guessing switched off (tic_set_decode_guess)",
             "round_trip_max_abs_error": int(err.max()), "round_trip_mean_abs_error": round(float(err.mean()), 3),
             "note": "host clock around the C-ABI call (launches + one wait included), median of 5 x 40 calls; parity of both directions is the test suite's business "
                     "(streams against the reference's, pixels against the reference's decoder) - the round-trip error here is the quantiser's",

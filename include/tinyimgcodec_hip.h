@@ -246,11 +246,15 @@ int tic_last_decode_giveup(tic_ctx *ctx);
  * Either pointer may be null.  (No counterpart in the reference: huffman.py:77-98 decodes bit by bit.) */
 int tic_last_decode_range(tic_ctx *ctx, int *range_bits, int *tries);
 /* tic_decompress_dev launches a long stream on a GUESS of its 16-byte header (the header of the stream this context decoded last: the
- * frames of a sequence, the images of a batch) instead of reading it from device memory first; the kernels echo the real header and a
- * wrong guess costs a second decode.  Returns 1 when the last tic_decompress_dev's guess held, -1 when it did not (the stream was
+ * frames of a sequence, the images of a batch; only after two equal headers in a row) instead of reading it from device memory first;
+ * the kernels echo the real header and a wrong guess costs a second decode.  Returns 1 when the last tic_decompress_dev's guess held, -1 when it did not (the stream was
  * decoded again with its own header), 0 when no guess was made.  (No counterpart in the reference: decompress() codec.py:133-164 reads
  * the header from host memory.) */
 int tic_last_decode_guess(tic_ctx *ctx);
+/* A guess is made only after two streams in a row came with the same header, so alternating geometries never pay for one; enable = 0
+ * turns the guessing off altogether for this context (every tic_decompress_dev reads the header first, tic_decompress_dev_async runs
+ * synchronously), 1 (the default) back on. */
+int tic_set_decode_guess(tic_ctx *ctx, int enable);
 /* tic_decompress_dev, asynchronously (the counterpart of tic_compress_dev_async for decompress() in a loop,
  * /root/reference/tests/benchmark.py:19): a long stream is launched on the guess of its header on a stream of the ticket's own and the
  * call returns; up to 4 tickets may be open per context and their frames overlap on the device.  tic_decompress_async_result waits

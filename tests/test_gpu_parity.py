@@ -1477,7 +1477,8 @@ def test_decompress_dev_launches_on_a_guess_of_the_header(ctx, oracle, monkeypat
     destination the guessed geometry does not fit, a short stream -> the stream is decoded with its own header; pixels equal the oracle's
     every time, the errors are the ones of a call that read the header first."""
     L = N.load()
-    specs = [((2048, 2048), 50, 1), ((2048, 2048), 50, 2), ((2048, 2048), 80, 3), ((1504, 2000), 50, 4), ((2048, 2048), 50, 5), ((512, 512), 50, 6), ((2048, 2048), 50, 7)]
+    specs = [((2048, 2048), 50, 1), ((2048, 2048), 50, 2), ((2048, 2048), 50, 8), ((2048, 2048), 80, 3), ((1504, 2000), 50, 4), ((2048, 2048), 50, 5), ((512, 512), 50, 6),
+             ((2048, 2048), 50, 7), ((2048, 2048), 50, 9)]
     streams = {}
     bufs = []
     for (h, w), q, seed in specs:
@@ -1488,7 +1489,10 @@ def test_decompress_dev_launches_on_a_guess_of_the_header(ctx, oracle, monkeypat
         ctx.check(L.tic_memcpy_h2d(ctx.handle, d_s, s.ctypes.data, s.size))
         bufs.append((d_s, d_p, s, h, w))
     ctx2 = T.Context(0)  # a fresh context: no stream decoded yet, no guess
-    want_guess = [0, 1, -1, -1, -1, 0, 1]  # first call: none; same header: held; quality / geometry changed: not held; 512^2: short stream, no guess (and the guess survives it)
+    # a guess is made after two equal headers in a row: calls 0 and 1 read the header, call 2 guesses and holds; then another quality (the guess
+    # fails, and the streak starts over), another geometry and back (no guess: no two equal headers in a row), a short stream (host decoder: no
+    # guess, nothing remembered), the same header again (second in a row: still read), and again (guessed, holds)
+    want_guess = [0, 0, 1, -1, 0, 0, 0, 0, 1]
     for k, (d_s, d_p, s, h, w) in enumerate(bufs):
         ctx2.check(L.tic_memset_dev(ctx2.handle, d_p, 0xEE, h * w))
         hh, ww = C.c_int(), C.c_int()
@@ -1502,14 +1506,24 @@ def test_decompress_dev_launches_on_a_guess_of_the_header(ctx, oracle, monkeypat
     d_s, d_p, s, h, w = bufs[0]
     assert L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w - 1, None, None) == N.TIC_E_SPACE
     assert L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w - 1, h * w, None, None) == N.TIC_E_ARG
-    # ... and a larger stream after a smaller guess: the guessed geometry fits the destination, the echo differs
-    d_s4, d_p4, s4, h4, w4 = bufs[3]
-    ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s4, s4.size, d_p4, w4, h4 * w4, None, None))
+    # ... and a larger stream after two smaller ones: the guessed geometry fits the destination, the echo differs
+    d_s4, d_p4, s4, h4, w4 = bufs[4]
+    for _ in range(2):
+        ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s4, s4.size, d_p4, w4, h4 * w4, None, None))
     ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w, None, None))
     assert L.tic_last_decode_guess(ctx2.handle) == -1
     pix = np.empty((h, w), np.uint8)
     ctx2.check(L.tic_memcpy_d2h(ctx2.handle, pix.ctypes.data, d_p, pix.size))
     assert np.array_equal(pix, oracle.decompress(s.tobytes()))
+    for _ in range(2):
+        ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w, None, None))
+    assert L.tic_last_decode_guess(ctx2.handle) == 1
+    ctx2.check(L.tic_set_decode_guess(ctx2.handle, 0))  # the switch: no guessing on this context
+    ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w, None, None))
+    assert L.tic_last_decode_guess(ctx2.handle) == 0
+    ctx2.check(L.tic_set_decode_guess(ctx2.handle, 1))
+    ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w, None, None))
+    assert L.tic_last_decode_guess(ctx2.handle) == 1
     if L.tic_build_has_test_hooks():
         monkeypatch.setenv("TIC_DECODE_NO_GUESS", "1")
         ctx2.check(L.tic_decompress_dev(ctx2.handle, d_s, s.size, d_p, w, h * w, None, None))
@@ -1527,8 +1541,10 @@ def test_decompress_dev_async_matches_the_synchronous_call(ctx, oracle):
     without any guess (run synchronously at once); a fifth open ticket and a closed ticket are refused."""
     L = N.load()
     ctx2 = T.Context(0)
-    specs = [((2048, 2048), 50, 0), ((2048, 2048), 50, 0), ((2048, 2048), 50, 0), ((2048, 2048), 80, 0), ((2048, 2048), 50, 1), ((512, 512), 50, 0),
-             ((2048, 2048), 50, 0), ((2048, 2048), 50, 2), ((1504, 2000), 60, 0), ((2048, 2048), 50, 0)]
+    A = ((2048, 2048), 50)
+    # (a launch on the guess needs two equal headers in a row before it: the first two frames, and the ones right behind a change, run synchronously)
+    specs = [A + (0,), A + (0,), A + (0,), A + (0,), ((2048, 2048), 80, 0), A + (0,), A + (0,), A + (0,), A + (1,), ((512, 512), 50, 0), A + (0,), A + (0,), A + (2,),
+             ((1504, 2000), 60, 0), A + (0,)]
     jobs = []
     for k, ((h, w), q, damage) in enumerate(specs):
         s = bytearray(T.compress(rand_frame(1300 + k, h, w), q, ctx=ctx))

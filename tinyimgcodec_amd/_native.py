@@ -131,6 +131,7 @@ SIGNATURES = {
     "tic_last_decode_giveup": (C.c_int, [_ctxp]),
     "tic_last_decode_range": (C.c_int, [_ctxp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tic_last_decode_guess": (C.c_int, [_ctxp]),
+    "tic_set_decode_guess": (C.c_int, [_ctxp, C.c_int]),
     "tic_decompress_dev_async": (C.c_int, [_ctxp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_ssize_t, C.c_size_t, C.POINTER(C.c_longlong)]),
     "tic_decompress_async_result": (C.c_int, [_ctxp, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tic_selftest_transpose": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -151,6 +151,8 @@ struct tic_ctx {
     hipEvent_t dec_order = nullptr; // a slot's stream starts behind everything queued on the context's stream so far
     uint8_t dec_head[16] = {0};                                  // header of the last stream tic_decompress_dev decoded on the device: the next call's guess
     bool dec_head_valid = false;
+    int dec_head_streak = 0;   // device decodes in a row (before the last one) whose header was dec_head: a guess is made from 1 on, i.e. after two equal headers
+    bool dec_guess_on = true;  // tic_set_decode_guess
     int last_decode_guess = 0;                                  // tic_decompress_dev: 1 the last call's guess of the header held, -1 it did not (decoded again), 0 no guess
     int last_decode_range = 0, last_decode_tries = 0;          // stream bits per lane of the device decoder's last run, and how many runs the last long stream took
     int last_decode_giveup = 0;                                // why the device decoder handed the last long stream to the host (DecStatus::giveup bits)
@@ -1970,6 +1972,13 @@ int tic_last_decode_guess(tic_ctx *ctx) {
     return ctx ? ctx->last_decode_guess : TIC_E_ARG;
 }
 
+int tic_set_decode_guess(tic_ctx *ctx, int enable) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    ctx->dec_guess_on = enable != 0;
+    return TIC_OK;
+}
+
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap) {
     TIC_LOCK(ctx);
     if (!ctx) return TIC_E_ARG;
@@ -2030,7 +2039,10 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
     // the guessed one, everything the run produced stands, without the read; when it is not (or the guess does not fit this call's
     // buffers), the header is read and the stream decoded again - what the first run wrote to d_out lies inside the bounds checked for
     // the guess and is overwritten.  (On an error return the contents of d_out are unspecified.)
-    const bool may_guess = ctx->dec_head_valid && len * 8 >= 128 + (1u << 21) && len * 8 < (1ull << 32) && !test_hook("TIC_DECODE_NO_GUESS");
+    // ... and only after two streams in a row came with the same header (dec_head_streak): alternating geometries never pay for a guess,
+    // a change behind a run of equal frames pays once.  tic_set_decode_guess(ctx, 0) turns the guessing off.
+    const bool may_guess = ctx->dec_guess_on && ctx->dec_head_valid && ctx->dec_head_streak >= 1 && len * 8 >= 128 + (1u << 21) && len * 8 < (1ull << 32) &&
+                           !test_hook("TIC_DECODE_NO_GUESS");
     for (int attempt = may_guess ? 0 : 1; attempt < 2; attempt++) {
         const bool guess = attempt == 0;
         uint8_t head[16] = {0};
@@ -2070,6 +2082,7 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
         }
         if (done) {
             ctx->last_decode_path = 1;
+            ctx->dec_head_streak = ctx->dec_head_valid && memcmp(ctx->dec_head, head, 16) == 0 ? (ctx->dec_head_streak < 1000 ? ctx->dec_head_streak + 1 : 1000) : 0;
             memcpy(ctx->dec_head, head, 16);
             ctx->dec_head_valid = true;
             return TIC_OK;
@@ -2114,7 +2127,7 @@ int tic_decompress_dev_async(tic_ctx *ctx, const void *d_stream, size_t len, voi
     sl.out_cap = out_cap;
     int h = 0, w = 0, quality = 0;
     uint32_t flag = 0;
-    bool launch = ctx->dec_head_valid && d_stream && d_out && len * 8 >= 128 + (1u << 21) && len * 8 + 8192 < (1ull << 32) && ((uintptr_t)d_stream & 3u) == 0 &&
+    bool launch = ctx->dec_guess_on && ctx->dec_head_valid && ctx->dec_head_streak >= 1 && d_stream && d_out && len * 8 >= 128 + (1u << 21) && len * 8 + 8192 < (1ull << 32) && ((uintptr_t)d_stream & 3u) == 0 &&
                   out_stride % 8 == 0 && (uintptr_t)d_out % 8 == 0 && ctx->d_dec_luts && !test_hook("TIC_DECODE_NO_GUESS") && !test_hook("TIC_DECODE_HOST") &&
                   !test_hook("TIC_DECODE_SERIAL") && parse_header(ctx->dec_head, 16, &h, &w, &quality, &flag) == TIC_OK;
     const size_t n = launch ? num_blocks(h, w) : 0;
@@ -2207,8 +2220,11 @@ int tic_decompress_async_result(tic_ctx *ctx, long long ticket, int wait, int *h
             ctx->last_decode_tries = 1;
             sl.rc = TIC_OK;
         } else { // another header, or something unusual in the stream: the synchronous call settles it (and overwrites what this run wrote)
+            const bool on = ctx->dec_guess_on;
+            ctx->dec_guess_on = false; // (the launch on the guess is what just failed: this time the header is read first)
             sl.rc = tic_decompress_dev(ctx, sl.d_stream, sl.len, sl.d_out, sl.out_stride, sl.out_cap, &sl.h, &sl.w);
-            if (ctx->last_decode_guess == 0) ctx->last_decode_guess = -1;
+            ctx->dec_guess_on = on;
+            ctx->last_decode_guess = -1;
         }
     }
     sl.ticket = -1;
