@@ -46,7 +46,6 @@
 
 #include "tic_entropy_dec_gpu.h"
 #include "tic_math.h"
-#include "tic_tables.h"
 
 namespace tic {
 namespace {
@@ -497,13 +496,7 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
 // (~100 cycles per symbol), which two waves per SIMD already overlap; what made the separate decode kernel slow were its 45
 // two-byte global stores per lane.
 constexpr int kDecodeWG = 256;
-constexpr bool dc_codes_fit_9_bits() { // kDcBits[l] = DC codewords of l + 1 bits
-    for (int l = 9; l < 16; l++)
-        if (kDcBits[l] != 0) return false;
-    return true;
-}
-static_assert(dc_codes_fit_9_bits() && kDecodeWG == 256, "the fused kernel's DC table holds the next 9 stream bits, two entries per thread");
-constexpr int kPairLutDw = 2048 + kLongCodes + 4; // DecLutsDev::ac2 + long32 (the DC symbol has a 1 KB table of its own, dc9)
+constexpr int kPairLutDw = 2048 + kLongCodes + 4; // DecLutsDev::ac2 + long32 (the DC symbol is looked up in memory, once per lane: no dc11 here)
 static_assert(offsetof(DecLutsDev, long32) == offsetof(DecLutsDev, ac2) + 8192 && offsetof(DecLutsDev, ac2) % 16 == 0 && (kPairLutDw * 4) % 16 == 0 &&
                   sizeof(DecLutsDev) >= offsetof(DecLutsDev, ac2) + kPairLutDw * 4,
               "the pair table and the long codewords are adjacent and copied in 16-byte pieces");
@@ -531,7 +524,6 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     __shared__ uint8_t zznat[64];
     __shared__ __attribute__((aligned(16))) double dq[64]; // the dequantisation constants, natural order (every lane reads the same entry: a broadcast)
     __shared__ long long scan_lds[16];
-    __shared__ uint16_t dc9[512]; // the DC table by the next 9 stream bits (no DC codeword is longer): every fourth entry of dc11
     uint32_t *lut = scratch;
     uint32_t *sbits = scratch + kLutDw;
     const unsigned long long total = (unsigned long long)*total_blocks;
@@ -541,11 +533,6 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     if (threadIdx.x < 64) {
         zznat[threadIdx.x] = a.consts->zznat[threadIdx.x];
         dq[threadIdx.x] = a.consts->div[threadIdx.x];
-    }
-    {
-        const uint16_t d0 = L->dc11[4u * threadIdx.x], d1 = L->dc11[4u * (threadIdx.x + kDecodeWG)];
-        dc9[threadIdx.x] = d0;
-        dc9[threadIdx.x + kDecodeWG] = d1;
     }
     { // the images start as zeros: the decoder writes the non-zero coefficients only
         uint4 *z = reinterpret_cast<uint4 *>(img);
@@ -584,7 +571,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
         wa = word_be(words, wi), wb = word_be(words, wi + 1u), wc = word_be(words, wi + 2u);
         const uint32_t wn = word_be(words, wi + 3u);
         const uint32_t pk = (uint32_t)(((((unsigned long long)wa) << 32) | wb) << (pos & 31u) >> 32);
-        const uint32_t e = dc9[pk >> 23];
+        const uint32_t e = L->dc11[pk >> 21]; // (one look-up per lane: from memory, no room in LDS for this table)
         if (!e) atomicOr(&st->giveup, 32);    // (measure or stitch walked this block: a DC codeword is there)
         dc_diff = (long long)value_of(pk, (int)(e >> 8), (int)(e & 15u));
         advance((e >> 8) + (e & 15u), wn);
