@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../tinyimgcodec_amd/csrc/tic_entropy.h"
@@ -223,6 +224,106 @@ int main() {
                 cases++;
             }
         }
+    }
+    // ---- the fused kernel's pair table (dec_pair_luts_fill): one look-up of the next 11 bits gives up to two AC symbols.  The kernel's
+    //      loop (tic_entropy_dec_gpu.hip, phase 1), restated here step for step, must emit the same (position, value) pairs, end on the same
+    //      bit and flag the same blocks as a loop that takes one symbol per look-up from dec_luts_fill's tables - from any bit of a real
+    //      stream or of random bits
+    {
+        std::vector<uint16_t> dc11(2048), ac11(2048), ac16(65536);
+        std::vector<uint32_t> ac2(2048), long32(196, 0u);
+        tic::dec_luts_fill(dc11.data(), ac11.data(), ac16.data());
+        tic::dec_pair_luts_fill(ac2.data(), long32.data());
+        auto value_of = [](uint32_t pk, int len, int size) {
+            if (size == 0) return 0;
+            const uint32_t x = (pk << len) >> (32 - size);
+            return (x >> (size - 1)) ? (int)x : (int)x - ((1 << size) - 1);
+        };
+        size_t pairs_seen = 0;
+        for (int kind = 0; kind < 3; kind++) {
+            const int h = 256, w = 512;
+            const size_t n = tic::num_blocks(h, w);
+            std::vector<uint8_t> bs(tic::compress_bound(h, w) + 64, 0);
+            size_t len = bs.size() - 64;
+            if (kind < 2) {
+                std::vector<int16_t> zz(n * 64);
+                for (size_t b = 0; b < n; b++)
+                    for (int k = 0; k < 64; k++) {
+                        const uint32_t r = rnd();
+                        int v = kind == 0 ? (r % 5 == 0 ? 0 : (int)(r % 2047) - 1023) : (r % 3 == 0 ? 0 : (int)(r % 15) - 7);
+                        zz[b * 64 + k] = (int16_t)v;
+                    }
+                if (tic::entropy_encode(zz.data(), h, w, 50, bs.data(), bs.size() - 64, &len) != 0) return fail("pair table: encode", h, w, kind);
+            } else {
+                for (size_t i = 16; i < len; i++) bs[i] = (uint8_t)rnd();
+            }
+            const size_t nbits = len * 8;
+            auto peek32 = [&](size_t pos) {
+                uint64_t v = 0;
+                for (int k = 0; k < 8; k++) v = (v << 8) | bs[(pos >> 3) + (size_t)k];
+                return (uint32_t)((v << (pos & 7)) >> 32);
+            };
+            struct Out { std::vector<int> at, val; size_t end; bool ok; };
+            for (int start = 0; start < 4000; start++) {
+                const size_t from = 128 + (size_t)(rnd() % (uint32_t)(nbits - 128 - 4096));
+                Out a, b;
+                { // one symbol per look-up
+                    size_t pos = from;
+                    int k = 1;
+                    a.ok = true;
+                    for (;;) {
+                        const uint32_t pk = peek32(pos);
+                        uint32_t e = ac11[pk >> 21];
+                        if (!e) e = ac16[pk >> 16];
+                        if (!e) { a.ok = false; break; }
+                        const int l = (int)(e >> 8), sz = (int)(e & 15);
+                        if ((e & 0xff) == 0) { pos += (size_t)l; break; }
+                        const int k_at = k + (int)((e >> 4) & 15);
+                        if (k_at > 63) { a.ok = false; break; }
+                        a.at.push_back(k_at);
+                        a.val.push_back(value_of(pk, l, sz));
+                        pos += (size_t)(l + sz);
+                        k = k_at + 1;
+                    }
+                    a.end = pos;
+                }
+                { // the kernel's loop
+                    size_t pos = from;
+                    int k = 1;
+                    bool live = true, in_long = false;
+                    b.ok = true;
+                    while (live) {
+                        const uint32_t pk = peek32(pos);
+                        const uint32_t li = (pk >> 16) - 0xff40u;
+                        const uint32_t e = in_long ? long32[li < 192u ? li : 192u] : ac2[pk >> 21];
+                        const bool none = e == 0u, esc = none && !in_long, nocode = none && in_long;
+                        const bool eob1 = !none && (e & 0xffu) == 0u;
+                        const int len1 = (int)((e >> 8) & 31u), size1 = (int)(e & 15u);
+                        const int k1 = k + (int)((e >> 4) & 15u);
+                        const bool bad1 = nocode || (!none && !eob1 && k1 > 63);
+                        if (!none && !eob1 && !bad1) { b.at.push_back(k1); b.val.push_back(value_of(pk, len1, size1)); }
+                        const bool has2 = ((e >> 13) & 1u) != 0u;
+                        const uint32_t e2 = e >> 14;
+                        const bool eob2 = has2 && (e2 & 0xffu) == 0u;
+                        const int len2 = (int)((e2 >> 8) & 31u), size2 = (int)(e2 & 15u);
+                        const int k2 = k1 + 1 + (int)((e2 >> 4) & 15u);
+                        const bool bad2 = has2 && !bad1 && !eob2 && k2 > 63;
+                        if (has2 && !eob2 && !bad1 && !bad2) { b.at.push_back(k2); b.val.push_back(value_of(pk << (len1 + size1), len2, size2)); pairs_seen++; }
+                        if (has2 && (eob1 || in_long)) return fail("pair table: a second symbol behind an EOB or a long codeword", (int)from, start, kind);
+                        pos += none ? 0u : (size_t)(e >> 27);
+                        k = none ? k : (has2 ? k2 + 1 : k1 + 1);
+                        in_long = esc;
+                        b.ok = b.ok && !bad1 && !bad2;
+                        live = !eob1 && !eob2 && !bad1 && !bad2;
+                    }
+                    b.end = pos;
+                }
+                if (a.ok != b.ok) return fail("pair table: one walk flags the block, the other does not", (int)from, start, kind);
+                if (a.at != b.at || a.val != b.val || (a.ok && a.end != b.end)) return fail("pair table: the walks differ", (int)from, start, kind);
+                cases++;
+            }
+        }
+        if (pairs_seen < 10000) return fail("pair table: hardly any look-up gave two symbols", (int)pairs_seen, 0, 0);
     }
     printf("host_selftest ok: %d cases\n", cases);
     return 0;
