@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t word_be(const Bits &s, uint32_t wi) {
 // are requested before the first is written; the loads are unconditional (the index is clamped, the value masked afterwards).
 template <int T>
 __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_word, uint32_t wcount, uint32_t sh, uint32_t nwords,
-                                            uint32_t last_mask) {
+                                            uint32_t last_mask, uint32_t tid /* 0 .. T-1: this thread among the T that stage this window */) {
     Bits s;
     s.lds = lds;
     s.glob = words;
@@ -101,7 +101,7 @@ __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__res
     s.last_mask = last_mask;
     constexpr int kBatch = 8;
     const uint32_t lastw = nwords - 1u; // (a stream has its 16-byte header: nwords >= 4)
-    for (uint32_t r0 = threadIdx.x; r0 < wcount; r0 += kBatch * T) {
+    for (uint32_t r0 = tid; r0 < wcount; r0 += kBatch * T) {
         uint32_t v[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
@@ -125,8 +125,8 @@ __device__ __forceinline__ Bits stage_words(uint32_t *lds, const uint32_t *__res
 }
 // the window of 64 consecutive ranges from bit first_bit (128 + 64 k range: a multiple of 32)
 template <int T>
-__device__ __forceinline__ Bits stage_bits(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_bit, uint32_t range, uint32_t nwords, uint32_t last_mask) {
-    return stage_words<T>(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, 31u /* no padding */, nwords, last_mask);
+__device__ __forceinline__ Bits stage_bits(uint32_t *lds, const uint32_t *__restrict__ words, uint32_t first_bit, uint32_t range, uint32_t nwords, uint32_t last_mask, uint32_t tid) {
+    return stage_words<T>(lds, words, first_bit >> 5, 64u * (range >> 5) + kOver, 31u /* no padding */, nwords, last_mask, tid);
 }
 // value bits behind a codeword of `len` bits (bitbuffer.py:55-65): x with its top bit clear stands for x - (2^size - 1)
 __device__ __forceinline__ int value_of(uint32_t pk, int len, int size) {
@@ -151,6 +151,22 @@ __device__ __forceinline__ void copy16_to_lds(void *lds, const void *__restrict_
     for (int k = 0; k < kPer; k++) {
         const int j = (int)threadIdx.x + k * T;
         if (j < n16) reinterpret_cast<uint4 *>(lds)[j] = v[k];
+    }
+}
+// the same with the workgroup's size known at run time only (the measure kernel: one to four waves)
+__device__ __forceinline__ void copy16_to_lds_rt(void *lds, const void *__restrict__ src, int n16) {
+    for (int j0 = (int)threadIdx.x; j0 < n16; j0 += 4 * (int)blockDim.x) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = j0 + k * (int)blockDim.x;
+            v[k] = reinterpret_cast<const uint4 *>(src)[j < n16 ? j : n16 - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = j0 + k * (int)blockDim.x;
+            if (j < n16) reinterpret_cast<uint4 *>(lds)[j] = v[k];
+        }
     }
 }
 static_assert(offsetof(DecLutsDev, dc11) % 16 == 0 && offsetof(DecLutsDev, ac11) % 16 == 0 && (offsetof(DecLutsDev, ac16) + 2 * kLongFirst) % 16 == 0 &&
@@ -204,8 +220,9 @@ __device__ __forceinline__ void scan_publish(unsigned long long *desc, uint32_t 
 // behind.  (Measured, profiles/r05_decoder.txt: the inclusive sums everywhere cost a 4096^2 stream 11 us - the workgroups of a launch's
 // first round arrive here together, nobody has an inclusive sum yet, and every window is a trip to memory of its own; eight windows
 // per trip: 19 us; without them a 16384^2 stream takes 1.15 ms instead of 0.95.)
-__device__ __forceinline__ long long wave_lookback(unsigned long long *desc, uint32_t half, uint32_t flat_grid, uint32_t epoch, long long own_total, DecStatus *st) {
-    const uint32_t lane = threadIdx.x & 63u, ep = epoch & 0xffffffu, nfront = blockIdx.x;
+__device__ __forceinline__ long long wave_lookback(unsigned long long *desc, uint32_t half, uint32_t flat_grid, uint32_t epoch, long long own_total, DecStatus *st,
+                                                   uint32_t tile /* this wave's (or workgroup's) index among the `ntiles` that publish sums */, uint32_t ntiles) {
+    const uint32_t lane = threadIdx.x & 63u, ep = epoch & 0xffffffu, nfront = tile;
     const unsigned long long *own = desc;
     // (an exit every wave reaches: a workgroup in front that never publishes - which the dispatch order rules out - ends the wait
     // after about a second, and the flag sends the whole stream to the host decoder)
@@ -221,7 +238,7 @@ __device__ __forceinline__ long long wave_lookback(unsigned long long *desc, uin
         return scan_sum_of(d);
     };
     long long sum = 0;
-    if (gridDim.x <= flat_grid) {
+    if (ntiles <= flat_grid) {
         for (uint32_t j0 = lane; j0 < nfront; j0 += 64u * 8u) {
             unsigned long long d[8];
 #pragma unroll
@@ -255,7 +272,7 @@ __device__ __forceinline__ long long wave_lookback(unsigned long long *desc, uin
         if (f < 64u) break;
         j_hi = j_hi > 64u ? j_hi - 64u : 0u;
     }
-    if (lane == 0u) __hip_atomic_store(&incl[blockIdx.x], scan_pack(epoch, sum + own_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0u) __hip_atomic_store(&incl[tile], scan_pack(epoch, sum + own_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return sum;
 }
 // One step of a chain walk: the look-up for the 32 stream bits `pk` in the chain tables (mdc | mac | mlong, adjacent in LDS) - the next
@@ -281,29 +298,36 @@ __device__ __forceinline__ void chain_step(const uint8_t *lutm, uint32_t pk, uin
 // block: the lanes of a wave then wait for each other at every block end - 630 symbol steps per wave where the longest lane has ~250
 // symbols.)  Here the position inside the block (is the DC category next?) is lane state and a block end is just another step.
 //
-// A workgroup is one wave.  Lanes 1..63 own 63 consecutive ranges; lane 0 SHADOWS the range in front of them - it walks it exactly as
+// A wave stands alone (a workgroup is one to four of them, sharing only the tables' trip from memory: 38.5 -> 36.0 us for a 4096^2 stream).
+// Lanes 1..63 own 63 consecutive ranges; lane 0 SHADOWS the range in front of them - it walks it exactly as
 // its owner (lane 63 of the workgroup before) does and writes nothing - so that every owner finds the exit of the range in front of
 // its own in the lane next to it: the stitch needs no second launch (its start, tables and window staged again, was a third of
 // it) and no workgroup waits for another.  1/63 more waves.
 constexpr uint32_t kOwned = 63; // ranges a workgroup owns
-__global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+__global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                                 uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
                                                                 uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
                                                                 unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
-                                                                DecStatus *__restrict__ st) {
+                                                                uint32_t ntiles, DecStatus *__restrict__ st) {
     __shared__ __attribute__((aligned(16))) uint8_t lutm[kChainLds];   // the chain tables: the measure walk
-    extern __shared__ uint32_t sbits[]; // stage_lds_words(range), the launch's dynamic LDS
-    const uint32_t lane = threadIdx.x;
-    if (blockIdx.x == 0u && lane < 4u) st->head[lane] = gwords[lane]; // (a stream has its 16-byte header: nwords >= 4)
-    const uint32_t t_first = blockIdx.x ? blockIdx.x * kOwned - 1u : 0u; // the window's first range
+    extern __shared__ uint32_t sbits_all[]; // stage_lds_words(range) per wave, the launch's dynamic LDS
+    // A workgroup is one to four WAVES that share nothing but the chain tables (6.4 KB from memory once per workgroup instead of once
+    // per wave) and the barrier behind the staging; `tile` is the wave's index among all waves of the launch - what rounds 4's
+    // one-wave workgroups called blockIdx.x.
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
+    uint32_t *sbits = sbits_all + wave * stage_lds_words(range);
+    if (tile == 0u && lane < 4u) st->head[lane] = gwords[lane]; // (a stream has its 16-byte header: nwords >= 4)
+    const uint32_t t_first = tile ? tile * kOwned - 1u : 0u; // the window's first range
     static_assert(offsetof(DecLutsDev, mac) == offsetof(DecLutsDev, mdc) + 2048 && offsetof(DecLutsDev, mlong) == offsetof(DecLutsDev, mac) + 4096 &&
                       offsetof(DecLutsDev, mdc) % 16 == 0,
                   "the chain tables are adjacent and copied in 16-byte pieces");
-    copy16_to_lds<64, kChainLds / 16>(lutm, L->mdc); // (stage_bits below ends with the barrier)
-    const Bits words = stage_bits<64>(sbits, gwords, 128u + t_first * range, range, nwords, last_mask);
+    copy16_to_lds_rt(lutm, L->mdc, kChainLds / 16); // (stage_bits below ends with the barrier)
+    const Bits words = stage_bits<64>(sbits, gwords, 128u + t_first * range, range, nwords, last_mask, lane);
+    if (tile >= ntiles) return; // (a wave behind the last range; behind the barrier)
     const bool shadow = lane == 0u;
-    const uint32_t t = blockIdx.x * kOwned + lane - 1u; // (lane 0 of workgroup 0: no such range)
-    const bool walks = (blockIdx.x != 0u || !shadow) && t < nranges;
+    const uint32_t t = tile * kOwned + lane - 1u; // (lane 0 of tile 0: no such range)
+    const bool walks = (tile != 0u || !shadow) && t < nranges;
     const bool mine = walks && !shadow;
     const uint32_t lo = 128u + (walks ? t : 0u) * range;
     const uint32_t hi = lo + range < fast_end ? lo + range : fast_end;
@@ -462,9 +486,9 @@ __global__ __launch_bounds__(64) void dec_measure_stitch_kernel(const uint32_t *
             if (lane >= (uint32_t)d) inc += o;
         }
         const long long tot = __shfl(inc, 63, 64);
-        if (lane == 63u) __hip_atomic_store(&desc[blockIdx.x], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, tot, st);
-        if (blockIdx.x == gridDim.x - 1u && lane == 63u) *grand_total = part + tot;
+        if (lane == 63u) __hip_atomic_store(&desc[tile], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, tot, st, tile, ntiles);
+        if (tile == ntiles - 1u && lane == 63u) *grand_total = part + tot;
         if (!mine) return;
         const unsigned long long first = (unsigned long long)(part + inc - (long long)nb);
         const uint32_t from_trace = n - a < nb ? n - a : nb, hand_n = nb - from_trace < cap ? nb - from_trace : cap; // (a <= n)
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     const unsigned long long last = b0 + kDecodeWG - 1 < m - 1 ? b0 + kDecodeWG - 1 : m - 1;
     const uint32_t w0 = bpos[b0] >> 5, w1 = bpos[last] >> 5;
     const uint32_t want = w1 >= w0 ? w1 - w0 + kOver : kOver;
-    const Bits words = stage_words<kDecodeWG>(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords, last_mask); // (ends with a barrier: tables, window, zeros, zznat)
+    const Bits words = stage_words<kDecodeWG>(sbits, gwords, w0, want < kBlkWin ? want : kBlkWin, 5u, nwords, last_mask, threadIdx.x); // (ends with a barrier: tables, window, zeros, zznat)
     // ---- phase 1: a lane per block, one SYMBOL per step (the values are needed here; the measure walk takes chains): the stream words under the read position sit
     // in registers (wa, wb) and the word behind them (wc) is fetched a step ahead, so that the table look-up is the only LDS access
     // on the lane's dependent chain; the coefficient's store (its address comes through the zig-zag table) is off that chain.
@@ -628,7 +652,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
         }
     }
     { // the sums of the workgroups in front, wave by wave (no barrier: a wave whose blocks were short goes on)
-        const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, dc_tile, st); // (every wave of the workgroup publishes the same inclusive sum: whichever is first)
+        const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, dc_tile, st, blockIdx.x, gridDim.x); // (every wave of the workgroup publishes the same inclusive sum: whichever is first)
         if (b < m) {
             const long long dc = part + dc_inc; // sum of the differences of blocks 0..b
             const int32_t dc32 = (int32_t)dc;   // (the host decoder's long long, narrowed where it is used)
@@ -761,13 +785,15 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     uint32_t *bpos = (uint32_t *)take(nblocks * 4);
     if ((size_t)(w - (char *)d_work) > work_bytes) return hipErrorInvalidValue;
     const uint32_t *words = (const uint32_t *)d_stream_words;
-    const dim3 bl(64);
     const uint32_t nwords = (uint32_t)((stream_bytes + 3) / 4);
     const uint32_t last_mask = (stream_bytes & 3) ? 0xffffffffu << (8u * (4u - (uint32_t)(stream_bytes & 3))) : 0xffffffffu; // (big-endian: the stream's bytes are the word's high bytes)
     // (*d_status is zeroed by the caller: it is host-mapped memory)
+    // waves per workgroup of the measure kernel: four while their windows fit 64 KB of LDS together with the tables, else two, else one
     const unsigned win_lds = stage_lds_words(range) * 4u;
-    hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3(measure_wgs), bl, win_lds, stream, words, nwords, last_mask, d_luts, fast_end, (uint32_t)nbits, range, nranges, starts,
-                       hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, (unsigned long long)nblocks, bpos, totals, d_status);
+    const unsigned wpw = (unsigned)kChainLds + 4u * win_lds <= 60000u ? 4u : ((unsigned)kChainLds + 2u * win_lds <= 60000u ? 2u : 1u);
+    hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3((measure_wgs + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, words, nwords, last_mask, d_luts, fast_end,
+                       (uint32_t)nbits, range, nranges, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, (unsigned long long)nblocks, bpos, totals,
+                       (uint32_t)measure_wgs, d_status);
     const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
     auto fused = [&](auto kern) {
         hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, desc_b, desc_half, (uint32_t)flat_grid, 2u * epoch + 1u,
