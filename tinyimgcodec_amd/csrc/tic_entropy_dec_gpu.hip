@@ -29,7 +29,7 @@
 //             (Rounds 2-3: a decode kernel that scattered the non-zero coefficients into a zeroed int16 [N][64] array - 45 two-byte
 //             stores per lane to 64 different lines each - then idct_kernel read the array back: 68 + 24 us and a 33.5 MB fill.  Round 4:
 //             four launches - measure + stitch, counts scan + positions, DC scan, decode + inverse with 8 lanes per block and the 8x8
-//             float64 matrix transposed through LDS: 111 us of kernels for a 4096^2 stream; now 85, profiles/r05_decoder.txt.)
+//             float64 matrix transposed through LDS: 111 us of kernels for a 4096^2 stream; now 83, profiles/r05_decoder.txt.)
 // The walks are one dependent chain of look-ups per lane: stream words and tables are staged in LDS (the codewords of 12-16 bits
 // included: as look-ups in memory they stalled a whole wave in every second step), and the chain is kept short - a range for the
 // measure walk, a block for the decode phase.  7 MB stream (4096^2 noise, q=50), rocprofv3: measure 282 -> 125 us, decode
@@ -509,16 +509,15 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
 }
 
 // ---- decode + inverse transform, fused --------------------------------------------------------------------------------------------
-// A workgroup per kDecodeWG consecutive blocks (one contiguous piece of the stream, staged in LDS: up to kBlkWin words, 500 bits
-// per block on average; what lies behind is read from memory).  Phase 1, a lane per BLOCK: lane b decodes the block at bpos[b] into
-// its LDS image - 64 int16 in NATURAL order (the zig-zag walk is undone by the store address), entry 0 = the integrated DC, saturated
-// as the host decoder saturates it.  Phase 2, 8 lanes per block, 8 blocks per wave and round: dequantise (coef x div, one rounding;
-// the scaled_dct branch's three), exact DCT-III down the columns, 8x8 float64 transpose through the wave's LDS buffer, exact DCT-III
-// along the rows, + 128, clip, truncating cast (codec.py:46-70, utils.py:40-45): idct_kernel's arithmetic, statement for statement.
-// LDS: tables 8.6 KB + window 16.9 KB + images 36 KB (144 B apart: the phase-2 reads of a wave's 8 blocks fall on 8 x 4 distinct
-// banks) + 4 x 2.2 KB of transpose buffers = 70 KB, two workgroups per CU.  The decode phase is a chain of LDS look-ups per lane
-// (~100 cycles per symbol), which two waves per SIMD already overlap; what made the separate decode kernel slow were its 45
-// two-byte global stores per lane.
+// A workgroup per kDecodeWG consecutive blocks (one contiguous piece of the stream, staged in LDS: up to kBlkWin words, 250 or 500 bits
+// per block on average; what lies behind is read from memory), a LANE PER BLOCK through both phases.  Phase 1: lane b decodes the block
+// at bpos[b] into its LDS image - 64 int16 in NATURAL order (the zig-zag walk is undone by the store address), entry 0 = the integrated
+// DC, saturated as the host decoder saturates it.  Phase 2: the same lane reads its image back, two columns at a time, dequantises (coef
+// x div, one rounding; the scaled_dct branch's three), runs the exact DCT-III down the columns and along the rows on 64 registers, + 128,
+// clip, truncating cast (codec.py:46-70, utils.py:40-45): idct_kernel's arithmetic with the passes' 1/4 folded into the conversion.
+// LDS: pair table 9 KB + window 8.7 (17.2) KB + images 33.8 KB (132 B apart) + constants = 52 (60) KB: three (two) workgroups per CU;
+// 138 VGPRs: three waves per SIMD.  (Rounds 2-4: phase 2 with 8 lanes per block and the 8x8 float64 matrix transposed through LDS, a
+// workgroup barrier between the phases; what made round 3's separate decode kernel slow were its 45 two-byte global stores per lane.)
 constexpr int kDecodeWG = 256;
 constexpr int kPairLutDw = 2048 + kLongCodes + 4; // DecLutsDev::ac2 + long32 (the DC symbol is looked up in memory, once per lane: no dc11 here)
 static_assert(offsetof(DecLutsDev, long32) == offsetof(DecLutsDev, ac2) + 8192 && offsetof(DecLutsDev, ac2) % 16 == 0 && (kPairLutDw * 4) % 16 == 0 &&
