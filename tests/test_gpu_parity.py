@@ -1380,6 +1380,54 @@ def test_decompress_large_frame_device_against_host_decoder(ctx, monkeypatch):
         assert sha(np.ascontiguousarray(host).tobytes()) == want[q]["decoded_sha256"], q
 
 
+def test_config5_frame_through_the_whole_codec_resident(ctx):
+    """BASELINE config 5's frame (16384 x 16384, seed 1234) at q = 50 through the whole codec with everything resident in HBM:
+    tic_compress_dev's stream (115 MB) and tic_decompress_dev's pixels against the pinned oracle's digests
+    (tests/golden/big_frame_decode.json).  The only test in which the device decoder's launches exceed 4,096 workgroups without a test
+    hook (16,384 and 27,000: the look-back through inclusive sums); the asynchronous decode of the same stream as well."""
+    import json
+
+    L = N.load()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "big_frame_decode.json")) as f:
+        want = [e for e in json.load(f)["entries"] if (e["seed"], e["height"], e["width"], e["quality"]) == (1234, 16384, 16384, 50)][0]
+    h = w = 16384
+    img = rand_frame(1234, h, w)
+    cap = L.tic_compress_bound(h, w)
+    d_img, d_str, d_pix = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_img)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, cap + 64, C.byref(d_str)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, img.size, C.byref(d_pix)))
+    try:
+        ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
+        del img
+        n = C.c_size_t()
+        ctx.check(L.tic_compress_dev(ctx.handle, d_img, h, w, w, 50, d_str, cap, C.byref(n)))
+        assert n.value == want["bytes"]
+        s = np.empty(n.value, np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, s.ctypes.data, d_str, n.value))
+        assert sha(s.tobytes()) == want["sha256"]
+        del s
+        pix = np.empty((h, w), np.uint8)
+        for mode in ("synchronous", "synchronous again (two equal headers in a row)", "on a guess of the header", "asynchronous"):
+            ctx.check(L.tic_memset_dev(ctx.handle, d_pix, 0xEE, h * w))
+            if mode == "asynchronous":
+                t = C.c_longlong(-1)
+                ctx.check(L.tic_decompress_dev_async(ctx.handle, d_str, n.value, d_pix, w, h * w, C.byref(t)))
+                hh, ww = C.c_int(), C.c_int()
+                ctx.check(L.tic_decompress_async_result(ctx.handle, t.value, 1, C.byref(hh), C.byref(ww)))
+                assert (hh.value, ww.value) == (h, w)
+            else:
+                ctx.check(L.tic_decompress_dev(ctx.handle, d_str, n.value, d_pix, w, h * w, None, None))
+            assert L.tic_last_decode_path(ctx.handle) == 1 and L.tic_last_decode_giveup(ctx.handle) == 0, mode
+            if mode in ("on a guess of the header", "asynchronous"):
+                assert L.tic_last_decode_guess(ctx.handle) == 1, mode
+            ctx.check(L.tic_memcpy_d2h(ctx.handle, pix.ctypes.data, d_pix, pix.size))
+            assert sha(pix.tobytes()) == want["decoded_sha256"], mode
+    finally:
+        for p_ in (d_img, d_str, d_pix):
+            L.tic_dev_free(ctx.handle, p_)
+
+
 def test_the_references_own_benchmark_set(ctx, monkeypatch):
     """Round 5: the reference's benchmark workload - data/1..49.gif x quality 90, 80, 50, 20, 10, 5 (/root/reference/tests/benchmark.py:12-23),
     streams and decoded pixels taken from the unmodified reference (tests/golden/gen/make_goldens_r5.py; benchmark_set.json / .npz).
