@@ -1380,16 +1380,17 @@ def test_decompress_large_frame_device_against_host_decoder(ctx, monkeypatch):
         assert sha(np.ascontiguousarray(host).tobytes()) == want[q]["decoded_sha256"], q
 
 
-def test_config5_frame_through_the_whole_codec_resident(ctx):
-    """BASELINE config 5's frame (16384 x 16384, seed 1234) at q = 50 through the whole codec with everything resident in HBM:
-    tic_compress_dev's stream (115 MB) and tic_decompress_dev's pixels against the pinned oracle's digests
+@pytest.mark.parametrize("q", [50, 10, 90])
+def test_config5_frame_through_the_whole_codec_resident(ctx, q):
+    """BASELINE config 5's frame (16384 x 16384, seed 1234) at q = 50, 10 and 90 through the whole codec with everything resident in HBM:
+    tic_compress_dev's stream (115 MB at q = 50) and tic_decompress_dev's pixels against the pinned oracle's digests
     (tests/golden/big_frame_decode.json).  The only test in which the device decoder's launches exceed 4,096 workgroups without a test
     hook (16,384 and 27,000: the look-back through inclusive sums); the asynchronous decode of the same stream as well."""
     import json
 
     L = N.load()
     with open(os.path.join(os.path.dirname(__file__), "golden", "big_frame_decode.json")) as f:
-        want = [e for e in json.load(f)["entries"] if (e["seed"], e["height"], e["width"], e["quality"]) == (1234, 16384, 16384, 50)][0]
+        want = [e for e in json.load(f)["entries"] if (e["seed"], e["height"], e["width"], e["quality"]) == (1234, 16384, 16384, q)][0]
     h = w = 16384
     img = rand_frame(1234, h, w)
     cap = L.tic_compress_bound(h, w)
@@ -1401,7 +1402,7 @@ def test_config5_frame_through_the_whole_codec_resident(ctx):
         ctx.check(L.tic_memcpy_h2d(ctx.handle, d_img, img.ctypes.data, img.size))
         del img
         n = C.c_size_t()
-        ctx.check(L.tic_compress_dev(ctx.handle, d_img, h, w, w, 50, d_str, cap, C.byref(n)))
+        ctx.check(L.tic_compress_dev(ctx.handle, d_img, h, w, w, q, d_str, cap, C.byref(n)))
         assert n.value == want["bytes"]
         s = np.empty(n.value, np.uint8)
         ctx.check(L.tic_memcpy_d2h(ctx.handle, s.ctypes.data, d_str, n.value))
