@@ -16,7 +16,7 @@ ap.add_argument("--pairs", type=int, default=12)
 ap.add_argument("--quality", type=int, default=50)
 ap.add_argument("settings", nargs="*", default=[""], help='knob settings to interleave, e.g. "TIC_SPLIT=16,13,10,7,4,2" ""')
 args = ap.parse_args()
-KNOBS = ("TIC_MAX_WGS", "TIC_SCHED", "TIC_CHUNK", "TIC_LDS_PAD", "TIC_SPLIT", "TIC_NOCAP")
+KNOBS = ("TIC_MAX_WGS", "TIC_SCHED", "TIC_CHUNK", "TIC_LDS_PAD", "TIC_SPLIT", "TIC_NOCAP", "TIC_ORDER")
 def apply(setting):
     for k in KNOBS: os.environ.pop(k, None)
     for kv in setting.split():
