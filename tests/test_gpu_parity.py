@@ -16,6 +16,13 @@ from tinyimgcodec_amd import _native as N
 pytestmark = pytest.mark.gpu
 
 
+def device_decoder_takes(nblocks, nbytes):
+    """The streams the device Huffman decoder takes (csrc/tic_api.hip device_decoder_takes): long ones (16,384 blocks, 2 Mbit), and short ones of at
+    least 1,024 blocks and 4 KB that hold 32 bits per block on average."""
+    bits = nbytes * 8
+    return (nblocks >= 16384 and bits >= 128 + (1 << 21)) or (nblocks >= 1024 and bits >= 128 + (1 << 15) and bits - 128 >= 32 * nblocks)
+
+
 def sha(b):
     return hashlib.sha256(bytes(b)).hexdigest()
 
@@ -1503,7 +1510,7 @@ def test_decompress_dev_resident_round_trip(ctx, oracle):
         hh, ww = C.c_int(), C.c_int()
         ctx.check(L.tic_decompress_dev(ctx.handle, d_str, n.value, d_pix, stride, h * stride, C.byref(hh), C.byref(ww)))
         assert (hh.value, ww.value) == (h, w)
-        long_enough = n.value * 8 >= 128 + (1 << 21) and L.tic_num_blocks(h, w) >= 16384
+        long_enough = device_decoder_takes(L.tic_num_blocks(h, w), n.value)
         assert L.tic_last_decode_path(ctx.handle) == (1 if long_enough else 2), (h, w)
         pix = np.empty((h, stride), np.uint8)
         ctx.check(L.tic_memcpy_d2h(ctx.handle, pix.ctypes.data, d_pix, pix.size))
@@ -1526,7 +1533,7 @@ def test_decompress_dev_launches_on_a_guess_of_the_header(ctx, oracle, monkeypat
     destination the guessed geometry does not fit, a short stream -> the stream is decoded with its own header; pixels equal the oracle's
     every time, the errors are the ones of a call that read the header first."""
     L = N.load()
-    specs = [((2048, 2048), 50, 1), ((2048, 2048), 50, 2), ((2048, 2048), 50, 8), ((2048, 2048), 80, 3), ((1504, 2000), 50, 4), ((2048, 2048), 50, 5), ((512, 512), 50, 6),
+    specs = [((2048, 2048), 50, 1), ((2048, 2048), 50, 2), ((2048, 2048), 50, 8), ((2048, 2048), 80, 3), ((1504, 2000), 50, 4), ((2048, 2048), 50, 5), ((200, 240), 50, 6),
              ((2048, 2048), 50, 7), ((2048, 2048), 50, 9)]
     streams = {}
     bufs = []
@@ -1539,7 +1546,7 @@ def test_decompress_dev_launches_on_a_guess_of_the_header(ctx, oracle, monkeypat
         bufs.append((d_s, d_p, s, h, w))
     ctx2 = T.Context(0)  # a fresh context: no stream decoded yet, no guess
     # a guess is made after two equal headers in a row: calls 0 and 1 read the header, call 2 guesses and holds; then another quality (the guess
-    # fails, and the streak starts over), another geometry and back (no guess: no two equal headers in a row), a short stream (host decoder: no
+    # fails, and the streak starts over), another geometry and back (no guess: no two equal headers in a row), a short stream (200 x 240: host decoder, no
     # guess, nothing remembered), the same header again (second in a row: still read), and again (guessed, holds)
     want_guess = [0, 0, 1, -1, 0, 0, 0, 0, 1]
     for k, (d_s, d_p, s, h, w) in enumerate(bufs):
@@ -1592,7 +1599,7 @@ def test_decompress_dev_async_matches_the_synchronous_call(ctx, oracle):
     ctx2 = T.Context(0)
     A = ((2048, 2048), 50)
     # (a launch on the guess needs two equal headers in a row before it: the first two frames, and the ones right behind a change, run synchronously)
-    specs = [A + (0,), A + (0,), A + (0,), A + (0,), ((2048, 2048), 80, 0), A + (0,), A + (0,), A + (0,), A + (1,), ((512, 512), 50, 0), A + (0,), A + (0,), A + (2,),
+    specs = [A + (0,), A + (0,), A + (0,), A + (0,), ((2048, 2048), 80, 0), A + (0,), A + (0,), A + (0,), A + (1,), ((200, 240), 50, 0), A + (0,), A + (0,), A + (2,),
              ((1504, 2000), 60, 0), A + (0,)]
     jobs = []
     for k, ((h, w), q, damage) in enumerate(specs):
@@ -1677,7 +1684,7 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
             want = oracle.decompress(s)
             monkeypatch.delenv("TIC_DECODE_HOST", raising=False)
             got = T.decompress(s, ctx=ctx)
-            long_enough = len(s) * 8 >= 128 + (1 << 21)  # (shorter streams decode serially on the host in well under a millisecond)
+            long_enough = device_decoder_takes(((img.shape[0] + 7) // 8) * ((img.shape[1] + 7) // 8), len(s))  # (shorter streams decode serially on the host)
             assert L.tic_last_decode_path(ctx.handle) == (1 if long_enough else 2), (name, q, len(s))
             if long_enough:
                 assert L.tic_last_decode_giveup(ctx.handle) == 0, (name, q)
@@ -1721,4 +1728,4 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
                         bad = bad[: len(s) // 3] + bytes(rng.integers(0, 256, 4096, dtype=np.uint8))
                     assert np.array_equal(T.decompress(bytes(bad), ctx=ctx), oracle.decompress(bytes(bad))), (name, q, k)
                     # (when the device decoder left the stream to the host it says why: a non-zero set of DecStatus::giveup bits)
-                    assert (L.tic_last_decode_path(ctx.handle) == 1) == (L.tic_last_decode_giveup(ctx.handle) == 0) or len(bad) * 8 < 128 + (1 << 21)
+                    assert (L.tic_last_decode_path(ctx.handle) == 1) == (L.tic_last_decode_giveup(ctx.handle) == 0) or not device_decoder_takes(((img.shape[0] + 7) // 8) * ((img.shape[1] + 7) // 8), len(bad))

@@ -1741,6 +1741,28 @@ static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int 
 // with *done = true when the image is complete in `out`; *done = false (and TIC_OK) when the device decoder met something unusual
 // or does not apply - the caller then decodes on the host, which reproduces the reference's behaviour on malformed streams (what
 // the device wrote to `out` until then is overwritten).
+// Streams the device decoder takes.  Long ones as in rounds 2-4 (16,384 blocks and 2 Mbit at least: the host PARALLEL decoder's own line).
+// Since round 5 also short ones - at least kDevDecodeMinBlocks blocks (a 256 x 256 frame) and kDevDecodeMinBits stream bits (4 KB): with
+// two launches instead of four the device decoder beats the host's serial decoder far below the old line, the reference's own benchmark
+// images (512 x 512, tests/benchmark.py) decompress() in 86 - 100 us instead of 132 - 387 - when the stream has kDevDecodeMinDensity bits
+// per block on average at least: sparser short streams (smooth, flat, blocky content) often hold a block longer than the 544-bit range
+// their average asks for, the first run gives up, and two runs cost more than the host decoder does on so few bits (tools/stress_decoder.py:
+// below 32 bits per block 160 of 342 valid streams took a second run, above it 3 of 458; profiles/r05_decoder.txt).
+// Hooks TIC_DECODE_MIN_BLOCKS / _BITS / _DENSITY move the lines for measurements.
+constexpr size_t kDevDecodeMinBlocks = 1024, kDevDecodeMinBits = 1u << 15, kDevDecodeMinDensity = 32;
+static bool device_decoder_takes(size_t n, size_t len) {
+    size_t min_blocks = kDevDecodeMinBlocks, min_bits = kDevDecodeMinBits, min_density = kDevDecodeMinDensity;
+    if (const char *e = test_hook("TIC_DECODE_MIN_BLOCKS")) min_blocks = (size_t)atol(e);
+    if (const char *e = test_hook("TIC_DECODE_MIN_BITS")) min_bits = (size_t)atol(e);
+    if (const char *e = test_hook("TIC_DECODE_MIN_DENSITY")) min_density = (size_t)atol(e);
+    if (min_bits < 8192) min_bits = 8192; // (entropy_decode_idct_gpu: a stream of at least 128 + 2 x 2,048 bits)
+    const size_t bits = len * 8;
+    if (bits + 8192 >= (1ull << 32) || bits < 128) return false;
+    const bool long_one = n >= 16384 && bits >= 128 + (1u << 21);
+    const bool short_one = n >= min_blocks && bits >= 128 + min_bits && bits - 128 >= min_density * n;
+    return long_one || short_one;
+}
+
 // stream bits per lane of the device decoder: `mult` average blocks, at least `floor_words` 32-bit words, as an odd number of words up to 63
 static int decode_range_bits(size_t len, size_t n, size_t mult = 3, size_t floor_words = 17) {
     size_t k = (mult * (len * 8) / n + 31) / 32;
@@ -1755,7 +1777,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     if (guess_held) *guess_held = false;
     const size_t n = num_blocks(h, w);
     // the host parallel decoder's own threshold: shorter streams are decoded serially in well under a millisecond
-    if (n < 16384 || len * 8 < 128 + (1u << 21) || len * 8 >= (1ull << 32) || test_hook("TIC_DECODE_SERIAL") || test_hook("TIC_DECODE_HOST")) return TIC_OK;
+    if (!device_decoder_takes(n, len) || test_hook("TIC_DECODE_SERIAL") || test_hook("TIC_DECODE_HOST")) return TIC_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_dec_luts) {
         DecLutsDev *l = new DecLutsDev();
@@ -2041,7 +2063,7 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
     // the guess and is overwritten.  (On an error return the contents of d_out are unspecified.)
     // ... and only after two streams in a row came with the same header (dec_head_streak): alternating geometries never pay for a guess,
     // a change behind a run of equal frames pays once.  tic_set_decode_guess(ctx, 0) turns the guessing off.
-    const bool may_guess = ctx->dec_guess_on && ctx->dec_head_valid && ctx->dec_head_streak >= 1 && len * 8 >= 128 + (1u << 21) && len * 8 < (1ull << 32) &&
+    const bool may_guess = ctx->dec_guess_on && ctx->dec_head_valid && ctx->dec_head_streak >= 1 && device_decoder_takes(kDevDecodeMinBlocks, len) &&
                            !test_hook("TIC_DECODE_NO_GUESS");
     for (int attempt = may_guess ? 0 : 1; attempt < 2; attempt++) {
         const bool guess = attempt == 0;
@@ -2127,11 +2149,11 @@ int tic_decompress_dev_async(tic_ctx *ctx, const void *d_stream, size_t len, voi
     sl.out_cap = out_cap;
     int h = 0, w = 0, quality = 0;
     uint32_t flag = 0;
-    bool launch = ctx->dec_guess_on && ctx->dec_head_valid && ctx->dec_head_streak >= 1 && d_stream && d_out && len * 8 >= 128 + (1u << 21) && len * 8 + 8192 < (1ull << 32) && ((uintptr_t)d_stream & 3u) == 0 &&
+    bool launch = ctx->dec_guess_on && ctx->dec_head_valid && ctx->dec_head_streak >= 1 && d_stream && d_out && ((uintptr_t)d_stream & 3u) == 0 &&
                   out_stride % 8 == 0 && (uintptr_t)d_out % 8 == 0 && ctx->d_dec_luts && !test_hook("TIC_DECODE_NO_GUESS") && !test_hook("TIC_DECODE_HOST") &&
                   !test_hook("TIC_DECODE_SERIAL") && parse_header(ctx->dec_head, 16, &h, &w, &quality, &flag) == TIC_OK;
     const size_t n = launch ? num_blocks(h, w) : 0;
-    launch = launch && n >= 16384 && out_stride >= (ptrdiff_t)w && (size_t)(h - 1) * (size_t)out_stride + (size_t)w <= out_cap;
+    launch = launch && device_decoder_takes(n, len) && out_stride >= (ptrdiff_t)w && (size_t)(h - 1) * (size_t)out_stride + (size_t)w <= out_cap;
     if (launch) {
         if (!sl.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));

@@ -11,6 +11,7 @@ L = N.load(); ctx = T.Context(0)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(4242)
 bad = dev = host_fallback = short = 0
+path_counts = {}  # valid streams by log2(bits per block): [streams, second runs, left to the host]
 second_runs = {0: 0, 1: 0, 2: 0}  # streams whose first choice of range did not hold, by kind of damage (0 = valid stream)
 rb, tr = C.c_int(), C.c_int()
 t0 = time.time()
@@ -35,6 +36,10 @@ for it in range(iters):
     a = T.decompress(s, ctx=ctx)
     path = L.tic_last_decode_path(ctx.handle)
     L.tic_last_decode_range(ctx.handle, C.byref(rb), C.byref(tr))
+    if dmg in (0, 3) and path_counts is not None:
+        bpb = len(s) * 8 / (((h + 7) // 8) * ((w + 7) // 8))
+        bk = min(int(np.log2(max(bpb, 1))), 9)
+        path_counts.setdefault(bk, [0, 0, 0]); path_counts[bk][0] += 1; path_counts[bk][1] += tr.value > 1; path_counts[bk][2] += path == 2
     if tr.value > 1:
         second_runs[dmg if dmg < 3 else 0] += 1
         print("second run: it", it, h, w, "q", q, "kind", kind, "damage", dmg, "bits per block %.0f" % (len(s) * 8 / (((h + 7) // 8) * ((w + 7) // 8))), "path", path, flush=True)
@@ -44,10 +49,14 @@ for it in range(iters):
     c = T.decompress(s, ctx=ctx)
     os.environ.pop("TIC_DECODE_SERIAL"); os.environ.pop("TIC_DECODE_HOST")
     dev += path == 1
-    if path == 2 and len(s) * 8 >= 128 + (1 << 21): host_fallback += 1
+    nblk = ((h + 7) // 8) * ((w + 7) // 8)
+    takes = (nblk >= 16384 and len(s) * 8 >= 128 + (1 << 21)) or (nblk >= 1024 and len(s) * 8 >= 128 + (1 << 15) and len(s) * 8 - 128 >= 32 * nblk)
+    if path == 2 and takes: host_fallback += 1
     elif path == 2: short += 1
     if not (np.array_equal(a, b) and np.array_equal(b, c)):
         bad += 1
         print("MISMATCH it", it, h, w, q, kind, dmg, "path", path, flush=True)
 print("%d streams (%d x %d .. ), device decoder on %d, given up to the host on %d long ones, %d too short; mismatches %d; second runs (longest range, or the 2,048-bit margin): %d on valid streams, %d on streams with a flipped bit, %d on cut streams; %.0f s" % (iters, 1024, 1100, dev, host_fallback, short, bad, second_runs[0], second_runs[1], second_runs[2], time.time() - t0))
+for bk in sorted(path_counts):
+    print("valid streams of %4d .. %4d bits per block: %3d, second runs %3d, left to the host decoder %3d" % (1 << bk, (2 << bk) - 1, *path_counts[bk]))
 sys.exit(1 if bad else 0)
