@@ -1648,6 +1648,25 @@ def test_decompress_dev_async_matches_the_synchronous_call(ctx, oracle):
     ctx2.close()
 
 
+def test_small_frames_leave_compress_through_host_mapped_memory(ctx, oracle, monkeypatch):
+    """tic_compress of a frame whose stream is at most 2 MB long lets the placing kernel write the stream into host-mapped memory and copies
+    it out with memcpy (no device-to-host DMA copy); larger frames, and every frame under TIC_NO_SMALL_PATH, go through the device stream
+    buffer: the same bytes either way, the reference's bytes, also right at the line and with a destination that is too small."""
+    L = N.load()
+    for (h, w), q in (((512, 512), 50), ((200, 333), 75), ((8, 8), 50), ((840, 768), 90), ((848, 768), 90), ((1080, 1920), 50)):  # (840 x 768: the last frame below the line, 848 x 768 the first above)
+        img = rand_frame(h * 3 + w, h, w)
+        want = oracle.compress(img, q)
+        monkeypatch.delenv("TIC_NO_SMALL_PATH", raising=False)
+        a = T.compress(img, q, ctx=ctx)
+        monkeypatch.setenv("TIC_NO_SMALL_PATH", "1")
+        b = T.compress(img, q, ctx=ctx)
+        monkeypatch.delenv("TIC_NO_SMALL_PATH")
+        assert a == want and b == want, (h, w, q, len(a), len(b), len(want))
+        out = np.zeros(len(want) - 1, np.uint8)
+        n = C.c_size_t()
+        assert L.tic_compress(ctx.handle, img.ctypes.data, h, w, w, q, out.ctypes.data, out.size, C.byref(n)) == N.TIC_E_SPACE
+
+
 def test_frames_beyond_the_32bit_walk_are_transformed_in_bands(ctx, monkeypatch):
     """The strip walk uses 32-bit pixel offsets; a frame of 4 GiB or more is cut into bands of whole block rows, one launch each
     (round 2 ran such frames on the exact kernel only).  TIC_BAND_BYTES lowers the limit so that a 3000 x 2112 frame is cut into
