@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--workload", choices=["auto", "config2", "config4"], default="auto",
                     help="auto: config 2 at N = 1 (the headline), config 4 at N > 1; config4 at N = 1 = the baseline of a config-4 scaling curve")
     ap.add_argument("--settle-ms", type=float, default=60.0, help="untimed back-to-back launches before the warm-up steps (clock settling)")
+    ap.add_argument("--per-launch", choices=["same", "separate", "off"], default="separate",
+                    help="per_launch_us {min, median, max} from events on the launches' own dispatch packets: in a pass of its own behind the timed one "
+                    "(default: a dispatch that carries events is followed by a 5 us gap, profiles/r06_driver_flags.txt), on the timed launches themselves, or not at all")
+    ap.add_argument("--no-preroll", dest="preroll", action="store_false", help="do not put the last 256 settling launches into the timed submission")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N > 1 without a launcher: watchdog over the N rank processes (s)")
     args = ap.parse_args()
 
@@ -313,18 +317,40 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
         return 256
 
     untimed = settle(args, ctx, L, burst)
-    if args.warmup > 0:
-        ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, h, w, pitch, q, d_out, variant, args.warmup, C.byref(ms)))
     barrier()
     t0 = time.perf_counter()
-    # exactly K launches, bracketed by HIP events on the launch stream; returns after the stream has drained
-    ctx.check(L.tic_dctq_dev_timed(ctx.handle, d_img, h, w, pitch, q, d_out, variant, args.steps, C.byref(ms)))
+    # W untimed warm-up launches, event, exactly K launches, event - ONE submission on the launch stream (tic_dctq_dev_timed_warm): the
+    # first event is stamped when the last warm-up launch retires with the timed launches queued behind it.  (Rounds 1-5 synchronised
+    # between warm-up and the first event: recorded on an idle stream it opened the interval with the first launch's submission latency,
+    # ~28 us on the driver's box = 1.4 us per step at K = 20, profiles/r06_driver_flags.txt.)  Returns after the stream has drained.
+    pre = 256 if args.preroll else 0
+    if args.per_launch == "same" and args.steps > 32768:
+        args.per_launch = "separate"
+    per = (C.c_float * (2 * args.steps))() if args.per_launch == "same" else None
+    ctx.check(L.tic_dctq_dev_timed_warm(ctx.handle, d_img, h, w, pitch, q, d_out, variant, pre + args.warmup, args.steps, C.byref(ms), per))
     barrier()
     wall_s = time.perf_counter() - t0
     ms_total_timed = ms.value
     kernel_ms = ms_total_timed / args.steps
     parity = coefficient_parity(ctx, L, d_out, h, w, q, nblk)  # the buffer the timed launches just wrote
-
+    per_launch = None
+    if args.per_launch != "off":
+        kp = args.steps if args.per_launch == "same" else min(args.steps, 1000)
+        if per is None:  # a pass of its own behind the timed one, never `value`
+            per = (C.c_float * (2 * kp))()
+            ctx.check(L.tic_dctq_dev_timed_warm(ctx.handle, d_img, h, w, pitch, q, d_out, variant, pre + args.warmup, kp, C.byref(ms), per))
+        dur = [float(per[2 * i]) * 1e3 for i in range(kp)]
+        end = [float(per[2 * i + 1]) * 1e3 for i in range(kp)]
+        gap = sorted(end[i] - end[i - 1] - dur[i] for i in range(1, kp)) or [0.0]
+        sd = sorted(dur)
+        per_launch = {"min": round(sd[0], 3), "median": round(sd[kp // 2], 3), "max": round(sd[-1], 3), "mean": round(sum(dur) / kp, 3),
+                      "gap_median": round(gap[len(gap) // 2], 3), "gap_max": round(gap[-1], 3),
+                      "first_start_to_last_end_per_launch": round(end[-1] / kp, 3), "launches": kp,
+                      "source": "start / stop events on each launch's own dispatch packet (hipExtLaunchKernelGGL): min / median / max / mean are the KERNEL's "
+                      "durations by the packet's time stamps - what rocprofv3's kernel trace reports; a dispatch that carries events is followed by a "
+                      "~5 us gap (gap_median), which is why this is " + ("the timed launches themselves" if args.per_launch == "same" else
+                      "a pass of its own behind the timed one (same untimed launches in front) and never `value`; ms_per_step - median = what the queue "
+                      "adds between two back-to-back launches of the timed pass")}
     cold = None
     if not args.no_cold:
         for _ in range(3):  # settle + warm-up of the rotating variant
@@ -372,14 +398,17 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
             "fallback_blocks_per_launch": fb.value,
             "parity": parity,
             "device": ctx.arch,
-            "timed_region": "the K launches between two HIP events recorded on the launch stream, inside the barrier + device-sync bracket: "
-            "`value`, `ms_per_step` and `roofline.achieved` are all this one interval (value x 3 B = roofline.achieved).  The host "
-            "clock around the same bracket is `wall_ms_per_step`; it adds the fixed cost of one submission ramp and one completion "
-            "wake-up, `wall_overhead_us_total`, which is per CALL, not per step (%d steps here)" % args.steps,
-            "wall_ms_per_step": round(wall_s * 1e3 / args.steps, 6),
-            "wall_overhead_us_total": round((wall_s * 1e3 - ms_total_timed) * 1e3, 1),
-            "wall_overhead_us_per_step": round((wall_s * 1e3 - ms_total_timed) * 1e3 / args.steps, 3),
-            "value_by_wall_clock": round(pixels * args.steps / wall_s / 1e6, 1),
+            "timed_region": "the last %d settling launches, the W warm-up launches, HIP event, the K timed launches, HIP event - one submission on the "
+            "launch stream, inside the barrier + device-sync bracket, so that the first event is stamped when the last warm-up launch retires "
+            "with the timed launches queued behind it: `value`, `ms_per_step` and `roofline.achieved` are all the interval between the two events "
+            "(value x 3 B = roofline.achieved).  The host clock around the bracket (`wall_ms_per_step`) holds the untimed launches too, plus one "
+            "submission ramp and one completion wake-up per CALL (`wall_overhead_us_total`)" % pre,
+            "per_launch_us": per_launch,
+            "launches_in_the_timed_submission": {"settling": pre, "warmup": args.warmup, "timed": args.steps},
+            "wall_ms_per_step": round(wall_s * 1e3 / (args.steps + args.warmup + pre), 6),
+            "wall_overhead_us_total": round((wall_s * 1e3 - kernel_ms * (args.steps + args.warmup + pre)) * 1e3, 1),
+            "value_by_wall_clock": round(pixels * (args.steps + args.warmup + pre) / wall_s / 1e6, 1),
+            "wall_note": "host clock over all launches of the bracket / their number; the overhead is the bracket minus that number x ms_per_step",
         },
         "roofline": {
             "bound": "hbm",

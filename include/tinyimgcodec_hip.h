@@ -130,6 +130,14 @@ int tic_dctq_dev_frames(tic_ctx *ctx, const void *d_images, int nframes, int h, 
  * (the stream the kernel is launched on).  *ms_total = elapsed milliseconds for all `iters` launches. */
 int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
                        void *d_coeffs_zz, int variant, int iters, float *ms_total);
+/* bench.py's form ("hipEvent time of the DCT+quant kernel only, >= 20 iterations after warm-up"): `warm`
+ * untimed launches, an event, `iters` timed launches, an event, all in ONE submission - the first event is stamped when the last
+ * warm-up launch retires with the timed launches already queued behind it (recorded on an idle stream it is stamped at once and the
+ * interval opens with the first launch's submission latency).  per_launch_ms: NULL, or room for 2 * iters floats - then every timed
+ * launch carries a start and a stop event on its own dispatch packet (no marker packets between the launches) and
+ * per_launch_ms[2i] = duration of launch i, per_launch_ms[2i+1] = start of the first timed launch .. end of launch i. */
+int tic_dctq_dev_timed_warm(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality,
+                            void *d_coeffs_zz, int variant, int warm, int iters, float *ms_total, float *per_launch_ms);
 /* The same for the batch form (nframes frames per launch). */
 int tic_dctq_dev_frames_timed(tic_ctx *ctx, const void *d_images, int nframes, int h, int w, ptrdiff_t row_stride,
                               ptrdiff_t frame_stride, int quality, void *d_coeffs_zz, ptrdiff_t coeff_frame_stride,

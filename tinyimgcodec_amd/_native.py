@@ -79,6 +79,11 @@ SIGNATURES = {
         C.c_int,
         [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
     ),
+    "tic_dctq_dev_timed_warm": (
+        C.c_int,
+        [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+         C.POINTER(C.c_float)],
+    ),
     "tic_dctq_dev_frames_timed": (
         C.c_int,
         [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int,

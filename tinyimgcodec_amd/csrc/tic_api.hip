@@ -85,6 +85,7 @@ struct tic_ctx {
     unsigned long long *d_fallback = nullptr;
     bool stats = false; // count guard-band fallbacks with a global atomic (diagnostic; serialises at ~12 ns per wave)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_steps; // tic_dctq_dev_timed_warm with per-launch times: one event behind every timed launch
     // scratch for the host-buffer entry points
     void *d_img = nullptr;
     size_t d_img_cap = 0;
@@ -307,6 +308,8 @@ void tic_destroy(tic_ctx *ctx) {
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto &e : ctx->ev_steps)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_img) (void)hipFree(ctx->d_img);
     if (ctx->d_coef) (void)hipFree(ctx->d_coef);
     if (ctx->d_consts) (void)hipFree(ctx->d_consts);
@@ -660,6 +663,55 @@ int tic_dctq_dev_timed(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return TIC_OK;
+}
+
+// The benchmark's form of the timed entry: `warm` untimed launches, an event, `iters` timed launches, an event - ONE submission,
+// nothing between the warm-up and the first event that the host waits for.  The first event is therefore stamped when the last
+// warm-up launch retires, with the timed launches already in the queue behind it; recorded on an IDLE stream (tic_dctq_dev_timed
+// after a synchronisation) it is stamped at once and the interval opens with whatever the host needs to get the first launch to
+// the device - 28 us on the driver's box in round 5, 1.4 us per step at K = 20 (profiles/r06_driver_flags.txt).
+// per_launch_ms: NULL, or room for 2 * iters floats.  Then every timed launch carries a start and a stop event on its OWN dispatch
+// packet (hipExtLaunchKernelGGL: the packet's time stamps, no marker packet between the launches - an event recorded behind every
+// launch costs 3 us per launch) and per_launch_ms[2 i] = duration of launch i, per_launch_ms[2 i + 1] = the time between the start
+// of the first timed launch and the end of launch i.
+int tic_dctq_dev_timed_warm(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_coeffs_zz,
+                            int variant, int warm, int iters, float *ms_total, float *per_launch_ms) {
+    TIC_LOCK(ctx);
+    int rc = check_geometry(ctx, h, w, row_stride, quality);
+    if (rc) return rc;
+    if (!ms_total || iters < 1 || warm < 0 || !d_image || !d_coeffs_zz) return set_err(ctx, TIC_E_ARG, "bad argument");
+    if (per_launch_ms && iters > 32768) return set_err(ctx, TIC_E_ARG, "per-launch times for at most 32768 launches");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, d_coeffs_zz);
+    const int v = dctq_kernel_id(variant);
+    if (v < 0) return set_err(ctx, TIC_E_ARG, "unknown kernel variant %d", variant);
+    if (per_launch_ms)
+        while ((int)ctx->ev_steps.size() < 2 * iters) {
+            hipEvent_t e = nullptr;
+            HIPCHK(ctx, hipEventCreate(&e));
+            ctx->ev_steps.push_back(e);
+        }
+    for (int i = 0; i < warm; i++) HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; i++) {
+        if (per_launch_ms)
+            HIPCHK(ctx, launch_dctq(a, v, ctx->stream, ctx->ev_steps[2 * i], ctx->ev_steps[2 * i + 1]));
+        else
+            HIPCHK(ctx, launch_dctq(a, v, ctx->stream));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    if (per_launch_ms)
+        for (int i = 0; i < iters; i++) {
+            // (a frame that does not take the strip kernel - padded strips only, bands - leaves its events unrecorded: reported as such)
+            if (hipEventElapsedTime(per_launch_ms + 2 * i, ctx->ev_steps[2 * i], ctx->ev_steps[2 * i + 1]) != hipSuccess ||
+                hipEventElapsedTime(per_launch_ms + 2 * i + 1, ctx->ev_steps[0], ctx->ev_steps[2 * i + 1]) != hipSuccess) {
+                (void)hipGetLastError();
+                return set_err(ctx, TIC_E_ARG, "per-launch times need a frame that takes the strip kernel in one launch");
+            }
+        }
     return TIC_OK;
 }
 

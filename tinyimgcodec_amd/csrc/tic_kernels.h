@@ -81,7 +81,9 @@ struct IdctArgs {
 
 // C-ABI kernel selector (TIC_KERNEL_AUTO / _EXACT / _HYBRID) -> launch_dctq's variant (1 exact, 2 strip kernel), -1 for anything else.
 int dctq_kernel_id(int abi_variant);
-hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream);
+// ev_start / ev_stop (both or neither): bound to the strip kernel's own dispatch packet (hipExtLaunchKernelGGL) - its start and end
+// time stamps, without a marker packet in the queue; ignored for the exact kernel and for banded frames
+hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_dctq_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_idct(const IdctArgs &a, hipStream_t stream);
 hipError_t launch_selftest_transpose(const void *in, void *out_dpp, void *out_ref, int nthreads, hipStream_t stream);

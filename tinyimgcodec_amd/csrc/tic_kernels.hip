@@ -17,6 +17,7 @@
 //           pixels, rational_slim); blocks with an irrational coefficient inside its band join a wave-local batch that is settled
 //           behind the loop in float64 (wave_redo_block / second_level_8), and only what that cannot decide takes the exact order.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1021,7 +1022,7 @@ int dctq_kernel_id(int abi_variant) { // (TIC_KERNEL_AUTO 0, TIC_KERNEL_EXACT 1,
 
 // variant 1: the exact kernel for every block; variant 2: the strip kernel on the rectangle of complete 64x8 strips with 8-byte
 // aligned rows, the exact kernel on what is left (right / bottom padding).
-hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
+hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a.ntiles <= 0) return hipSuccess;
     if (variant != 1 && variant != 2) return hipErrorInvalidValue;
     dim3 block(kWavesPerWG * 64);
@@ -1157,7 +1158,12 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream) {
             // pass order: columns first where the whole grid is resident at once (static shares: the tail decides), rows first for grids
             // of several rounds (dynamic dispatch: the average cost per strip decides); TIC_ORDER (test hook) forces one
             const bool cols = tune.order < 0 ? !multi_round : tune.order == 1;
-            if (cols)
+            if (ev_start && ev_stop) { // the dispatch packet's own time stamps (tic_dctq_dev_timed_warm's per-launch times)
+                if (cols)
+                    hipExtLaunchKernelGGL(dctq_strip_kernel<true>, grid, block, 0, stream, ev_start, ev_stop, 0, a);
+                else
+                    hipExtLaunchKernelGGL(dctq_strip_kernel<false>, grid, block, 0, stream, ev_start, ev_stop, 0, a);
+            } else if (cols)
                 hipLaunchKernelGGL(dctq_strip_kernel<true>, grid, block, 0, stream, a);
             else
                 hipLaunchKernelGGL(dctq_strip_kernel<false>, grid, block, 0, stream, a);

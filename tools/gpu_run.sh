@@ -12,7 +12,7 @@ run() { # name timeout cmd...
   echo "=== $name ($(date +%T))"
   timeout -k 10 "$t" "$@" > "gpurun_out/$name.txt" 2>&1
   local rc=$?
-  echo "=== $name exit $rc"; tail -n 25 "gpurun_out/$name.txt"
+  echo "=== $name exit $rc"; tail -n 25 "gpurun_out/$name.txt" | cut -c1-300
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name timed out: stopping"; exit 99; fi
   return 0
 }
@@ -56,6 +56,11 @@ for step in "$@"; do
                   run c5_rd_q$q 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/c5_rd_q$q -- python bench.py --height 16384 --width 16384 --quality $q --steps 3 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-config4 --no-cold
                   run c5_wr_q$q 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/c5_wr_q$q -- python bench.py --height 16384 --width 16384 --quality $q --steps 3 --warmup 1 --settle-ms 1 --no-cpu-baseline --no-config4 --no-cold
                 done ;;
+    driver_flags) T=${TIC_TAG:-a}
+                run df_tool_$T 300 python tools/driver_flags.py 5
+                for i in 1 2 3; do run df_short_${T}$i 200 python3 bench.py --gpus 1 --steps 20 --warmup 5; done
+                run df_long_$T 300 python3 bench.py --gpus 1 --steps 5000 --warmup 2000 --no-cpu-baseline ;;
+    driver_prof) rm -rf gpurun_out/df_prof; run df_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/df_prof -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-cold --no-config4 ;;
     sweep)      run sweep 600 python tools/sweep.py ;;
     prof)       rm -rf gpurun_out/prof; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --no-cpu-baseline --no-cold --no-config4 ;;
     prof_cold)  rm -rf gpurun_out/prof_cold; run prof_cold 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cold -- python bench.py --steps 50 --warmup 10 --settle-ms 1 --no-cpu-baseline --no-config4 ;;
