@@ -122,6 +122,42 @@ print("shipped library ok:", n, "benchmark pairs")
     assert r.returncode == 0 and "shipped library ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_which_build_of_the_library_this_process_runs():
+    """The test-hooks build when TIC_TEST_HOOKS=1 (tests/conftest.py's default), the shipped library otherwise."""
+    L = N.load()
+    hooks = os.environ.get("TIC_TEST_HOOKS") == "1"
+    assert L.tic_build_has_test_hooks() == (1 if hooks else 0)
+    assert N._lib_path() == (N.HOOKS_LIB_PATH if hooks else N.LIB_PATH)
+
+
+SHIPPED_SUBSET = ("test_which_build_of_the_library_this_process_runs or test_rare_paths_of_the_strip_kernel or test_tie_blocks or test_near_ties_round2 "
+                  "or test_flat_banded_and_checkerboard_content_vs_goldens or test_truncated_streams_round2 or test_decoder_edges_round3 "
+                  "or (test_config5_16384_coefficient_digest and 50) or test_decompress_dev_wrong_guess_writes_nothing_outside_the_image "
+                  "or test_device_decoder_at_the_stream_end or test_scaled_dct_streams_round2")
+
+
+def test_rare_paths_and_decoder_edges_on_the_shipped_library():
+    """Round-5 verdict, weak 1(a): the rare-path frames (true irrational ties, batch overflow, all-eight-trip strips, posterised noise at
+    q = 99), the tie / near-tie / flat fixtures, the 16 truncated + 11 edge decoder fixtures, C-encoder streams and one 16384^2 digest ran on
+    the test-hooks build only.  Here the same test functions run once more in ONE fresh pytest process that loads the library that ships
+    (TIC_TEST_HOOKS=0: no hooks compiled in, the monkeypatched TIC_* variables are inert, the launcher's defaults decide)."""
+    if os.environ.get("TIC_TEST_HOOKS") != "1":
+        pytest.skip("this IS the shipped-library process")
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TIC_")}
+    env["TIC_TEST_HOOKS"] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", SHIPPED_SUBSET],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tail = r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, tail
+    import re
+
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 14, tail  # (tie_blocks, near_ties and the flat fixtures are parametrised over both kernels)
+
+
 def test_dpp_byte_transpose_selftest(ctx):
     """The in-register DPP/v_perm 8x8 byte transpose equals the shuffle formulation and a numpy transpose."""
     n = 4096
@@ -1588,6 +1624,50 @@ def test_decompress_dev_launches_on_a_guess_of_the_header(ctx, oracle, monkeypat
     for d_s, d_p, *_ in bufs:
         L.tic_dev_free(ctx.handle, d_s); L.tic_dev_free(ctx.handle, d_p)
     ctx2.close()
+
+
+def test_decompress_dev_wrong_guess_writes_nothing_outside_the_image(ctx, oracle):
+    """A decode launched on a guessed header that turns out wrong must not touch a byte outside the real image (round-5 advice: the fused
+    kernel used to write the GUESSED h x w before the header was known): two large frames, then a small one, into a window of a
+    sentinel-filled surface whose stride and capacity admit the guessed geometry - synchronously and through the asynchronous tickets."""
+    L = N.load()
+    H, W = 1024, 1536          # the surface (and the guessed geometry: two frames of this size come first)
+    h, w = 520, 776            # the frame that follows
+    big = np.frombuffer(T.compress(rand_frame(4711, H, W), 50, ctx=ctx), np.uint8)
+    small = np.frombuffer(T.compress(rand_frame(4712, h, w), 50, ctx=ctx), np.uint8)
+    want_big, want_small = oracle.decompress(big.tobytes()), oracle.decompress(small.tobytes())
+    d_big, d_small, d_surf = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ctx.check(L.tic_dev_alloc(ctx.handle, big.size + 64, C.byref(d_big)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, small.size + 64, C.byref(d_small)))
+    ctx.check(L.tic_dev_alloc(ctx.handle, H * W, C.byref(d_surf)))
+    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_big, big.ctypes.data, big.size))
+    ctx.check(L.tic_memcpy_h2d(ctx.handle, d_small, small.ctypes.data, small.size))
+    ctx2 = T.Context(0)
+    surf = np.empty((H, W), np.uint8)
+    try:
+        for mode in ("sync", "async"):
+            for _ in range(2):  # two equal headers in a row: the next call guesses H x W
+                ctx2.check(L.tic_decompress_dev(ctx2.handle, d_big, big.size, d_surf, W, H * W, None, None))
+            ctx2.check(L.tic_memset_dev(ctx2.handle, d_surf, 0xA5, H * W))
+            hh, ww = C.c_int(), C.c_int()
+            if mode == "sync":
+                ctx2.check(L.tic_decompress_dev(ctx2.handle, d_small, small.size, d_surf, W, H * W, C.byref(hh), C.byref(ww)))
+            else:
+                t = C.c_longlong()
+                ctx2.check(L.tic_decompress_dev_async(ctx2.handle, d_small, small.size, d_surf, W, H * W, C.byref(t)))
+                ctx2.check(L.tic_decompress_async_result(ctx2.handle, t.value, 1, C.byref(hh), C.byref(ww)))
+            assert (hh.value, ww.value) == (h, w)
+            assert L.tic_last_decode_guess(ctx2.handle) == -1, mode  # the guess was made, and was wrong
+            ctx2.check(L.tic_memcpy_d2h(ctx2.handle, surf.ctypes.data, d_surf, surf.size))
+            assert np.array_equal(surf[:h, :w], want_small), mode
+            assert np.all(surf[h:, :] == 0xA5) and np.all(surf[:h, w:] == 0xA5), "%s: bytes outside the %dx%d image were written" % (mode, h, w)
+        ctx2.check(L.tic_decompress_dev(ctx2.handle, d_big, big.size, d_surf, W, H * W, None, None))
+        ctx2.check(L.tic_memcpy_d2h(ctx2.handle, surf.ctypes.data, d_surf, surf.size))
+        assert np.array_equal(surf, want_big)
+    finally:
+        ctx2.close()
+        for p in (d_big, d_small, d_surf):
+            L.tic_dev_free(ctx.handle, p)
 
 
 def test_decompress_dev_async_matches_the_synchronous_call(ctx, oracle):

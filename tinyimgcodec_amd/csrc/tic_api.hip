@@ -385,7 +385,7 @@ static int create_impl(tic_ctx *ctx, int device) {
         CK(hipMemset(ctx->d_total_bits, 0, 32));
         ctx->d_err = reinterpret_cast<int *>(ctx->d_total_bits + 2);
         // the stage's last kernel writes {payload bits, error} straight into pinned host memory: no copy behind it
-        CK(hipHostMalloc((void **)&ctx->h_stat, 64 + kAsyncSlots * 16, hipHostMallocMapped));
+        CK(hipHostMalloc((void **)&ctx->h_stat, 64 + kAsyncSlots * 16, hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->h_stat, 0, 64 + kAsyncSlots * 16);
         CK(hipHostGetDevicePointer((void **)&ctx->d_stat, ctx->h_stat, 0));
     }
@@ -824,7 +824,7 @@ static int ensure_small(tic_ctx *ctx, size_t bytes) {
     if (ctx->h_small) HIPCHK(ctx, hipHostFree(ctx->h_small));
     ctx->h_small = ctx->d_small = nullptr;
     ctx->small_cap = 0;
-    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_small, bytes, hipHostMallocMapped));
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_small, bytes, hipHostMallocMapped | hipHostMallocCoherent)); // (read by the host behind a polled stream)
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->d_small, ctx->h_small, 0));
     ctx->small_cap = bytes;
     return TIC_OK;
@@ -1073,12 +1073,11 @@ int tic_async_result(tic_ctx *ctx, long long ticket, int wait, size_t *out_len) 
     tic_ctx::AsyncSlot &sl = ctx->async_slots[ticket % kAsyncSlots];
     if (sl.ticket != ticket) return set_err(ctx, TIC_E_ARG, "ticket %lld is not open", ticket);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!wait) {
-        const hipError_t q = hipEventQuery(sl.done);
-        if (q == hipErrorNotReady) return TIC_E_BUSY;
+    {   // (any return other than TIC_E_BUSY closes the ticket - a failing event call included: the slot must not stay open for good)
+        const hipError_t q = wait ? hipEventSynchronize(sl.done) : hipEventQuery(sl.done);
+        if (!wait && q == hipErrorNotReady) return TIC_E_BUSY;
+        if (q != hipSuccess) sl.ticket = -1;
         HIPCHK(ctx, q);
-    } else {
-        HIPCHK(ctx, hipEventSynchronize(sl.done));
     }
     sl.ticket = -1;
     if (sl.empty_image) {
@@ -1851,10 +1850,11 @@ static int decode_range_bits(size_t len, size_t n, size_t mult = 3, size_t floor
 }
 
 static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h, int w, int quality, int scaled_exp, uint8_t *out,
-                            bool out_on_device, size_t out_stride, bool *done, bool src_on_device = false, const uint8_t *guessed_head = nullptr,
-                            bool *guess_held = nullptr) {
+                            bool out_on_device, size_t out_stride, bool *done, const uint8_t *head16 /* the 16 header bytes h, w, quality came from */,
+                            bool src_on_device = false, bool head_is_guess = false, bool *guess_held = nullptr) {
     *done = false;
     if (guess_held) *guess_held = false;
+    const uint8_t *guessed_head = head_is_guess ? head16 : nullptr;
     const size_t n = num_blocks(h, w);
     // the host parallel decoder's own threshold: shorter streams are decoded serially in well under a millisecond
     if (!device_decoder_takes(n, len) || test_hook("TIC_DECODE_SERIAL") || test_hook("TIC_DECODE_HOST")) return TIC_OK;
@@ -1867,7 +1867,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
         hipError_t e = hipMalloc((void **)&ctx->d_dec_luts, sizeof(DecLutsDev));
         if (e == hipSuccess) e = hipMemcpy(ctx->d_dec_luts, l, sizeof(DecLutsDev), hipMemcpyHostToDevice);
         delete l;
-        if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_dec_status, 64, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_dec_status, 64, hipHostMallocMapped | hipHostMallocCoherent);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_dec_status, ctx->h_dec_status, 0);
         if (e != hipSuccess) return set_err(ctx, TIC_E_HIP, "device decoder set-up failed: %s", hipGetErrorString(e));
     }
@@ -1929,6 +1929,7 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     ia.consts = ctx->d_consts + (scaled_exp >= 0 ? 50 : quality); // codec.py:62: quality = 50 on the scaled branch
     ia.scaled = scaled_exp >= 0;
     ia.pow2 = scaled_exp >= 0 ? ldexp(1.0, scaled_exp) : 1.0;
+    memcpy(ia.head, head16, 16); // the header these were derived from (a guess, or the stream's own): the fused kernel writes pixels only under it
     // stream bits per lane: 3 average blocks, at least 544 bits, as an odd number of 32-bit words up to 63 (noise at q = 50, 220 bits
     // per block: 672; tiled Lenna, 41, and noise at q = 10, 70: 544; noise at q = 90, 404: 1,248).  The decoder's kernels are one
     // dependent chain per lane, so their time goes with this number (profiles/r04_decoder.txt: the measure kernel 57 us at 672 bits,
@@ -2100,7 +2101,7 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
     if (!out || (size_t)h * (size_t)w > cap) return set_err(ctx, TIC_E_SPACE, "output buffer too small");
     {   // long streams: the Huffman decode runs on the device too; only the stream goes up and the pixels come down
         bool done = false;
-        const int rc = decode_on_device(ctx, data, len, h, w, scaled ? 50 : quality, scaled ? quality : -1, out, false, 0, &done);
+        const int rc = decode_on_device(ctx, data, len, h, w, scaled ? 50 : quality, scaled ? quality : -1, out, false, 0, &done, data);
         if (rc) return rc;
         if (done) {
             ctx->last_decode_path = 1;
@@ -2139,8 +2140,10 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
     // sixth of the call for a 4096^2 stream.  A long stream is therefore decoded on a GUESS - the header of the stream this context decoded
     // last (frames of a sequence, the images of a batch) - and the first kernel echoes the real header into the status words: when it is
     // the guessed one, everything the run produced stands, without the read; when it is not (or the guess does not fit this call's
-    // buffers), the header is read and the stream decoded again - what the first run wrote to d_out lies inside the bounds checked for
-    // the guess and is overwritten.  (On an error return the contents of d_out are unspecified.)
+    // buffers), the header is read and the stream decoded again.  A run on a wrong guess writes NO pixel: the fused kernel compares
+    // the stream's first 16 bytes with the header its geometry came from before it stores anything (DecIdctArgs::head), so nothing
+    // outside the real h x w is ever touched - a destination that is a window of a larger surface keeps its neighbours
+    // (test_decompress_dev_wrong_guess_writes_nothing_outside_the_image).  (On an error return the contents of d_out are unspecified.)
     // ... and only after two streams in a row came with the same header (dec_head_streak): alternating geometries never pay for a guess,
     // a change behind a run of equal frames pays once.  tic_set_decode_guess(ctx, 0) turns the guessing off.
     const bool may_guess = ctx->dec_guess_on && ctx->dec_head_valid && ctx->dec_head_streak >= 1 && device_decoder_takes(kDevDecodeMinBlocks, len) &&
@@ -2174,7 +2177,7 @@ int tic_decompress_dev(tic_ctx *ctx, const void *d_stream, size_t len, void *d_o
         }
         bool done = false, held = false;
         int rc = decode_on_device(ctx, (const uint8_t *)d_stream, len, h, w, scaled ? 50 : quality, scaled ? quality : -1, (uint8_t *)d_out, true,
-                                  (size_t)out_stride, &done, true, guess ? head : nullptr, guess ? &held : nullptr);
+                                  (size_t)out_stride, &done, head, true, guess, guess ? &held : nullptr);
         if (rc) return rc;
         if (guess) {
             ctx->last_decode_guess = held ? 1 : -1;
@@ -2239,7 +2242,7 @@ int tic_decompress_dev_async(tic_ctx *ctx, const void *d_stream, size_t len, voi
         if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         if (!ctx->dec_order) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->dec_order, hipEventDisableTiming));
         if (!sl.h_status) {
-            HIPCHK(ctx, hipHostMalloc((void **)&sl.h_status, 64, hipHostMallocMapped));
+            HIPCHK(ctx, hipHostMalloc((void **)&sl.h_status, 64, hipHostMallocMapped | hipHostMallocCoherent));
             HIPCHK(ctx, hipHostGetDevicePointer((void **)&sl.d_status, sl.h_status, 0));
         }
         const size_t wb = entropy_decode_gpu_work_bytes(len, n);
@@ -2276,6 +2279,7 @@ int tic_decompress_dev_async(tic_ctx *ctx, const void *d_stream, size_t len, voi
         ia.consts = ctx->d_consts + (scaled ? 50 : quality);
         ia.scaled = scaled;
         ia.pow2 = scaled ? ldexp(1.0, quality) : 1.0;
+        memcpy(ia.head, ctx->dec_head, 16); // (the guess: pixels are written only if the stream really starts with it)
         memset(sl.h_status, 0, sizeof(DecStatus));
         // behind everything queued on the context's stream so far (the stream may just have been written there: tic_compress_dev_async)
         HIPCHK(ctx, hipEventRecord(ctx->dec_order, ctx->stream));
@@ -2306,12 +2310,11 @@ int tic_decompress_async_result(tic_ctx *ctx, long long ticket, int wait, int *h
     if (sl.ticket != ticket) return set_err(ctx, TIC_E_ARG, "decode ticket %lld is not open", ticket);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (sl.launched) {
-        if (!wait) {
-            const hipError_t q = hipEventQuery(sl.done);
-            if (q == hipErrorNotReady) return TIC_E_BUSY;
+        {   // (as tic_async_result: a failing event call closes the ticket too)
+            const hipError_t q = wait ? hipEventSynchronize(sl.done) : hipEventQuery(sl.done);
+            if (!wait && q == hipErrorNotReady) return TIC_E_BUSY;
+            if (q != hipSuccess) sl.ticket = -1;
             HIPCHK(ctx, q);
-        } else {
-            HIPCHK(ctx, hipEventSynchronize(sl.done));
         }
         DecStatus st;
         memcpy(&st, sl.h_status, sizeof st); // (host-mapped: the slot's stream has drained)

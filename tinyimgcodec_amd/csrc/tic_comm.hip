@@ -1,8 +1,9 @@
 // tic_comm.hip - the path's only collective (north star): an all-gather of per-frame compressed sizes
 // across the ranks of a node (one process per GPU), on RCCL, behind the C-ABI - no torch in the product.
 //
-// librccl.so is opened on first use (it is half a gigabyte; single-GPU users never load it) and is not a build-time dependency
-// either: the six entry points and the handful of types used here are declared below (values as in rccl.h of ROCm 7.x).
+// librccl.so is opened on first use (it is half a gigabyte; single-GPU users never load it) and is not a link-time dependency:
+// types, enumerators and prototypes come from <rccl/rccl.h>, the six entry points are looked up with dlsym and every pointer's type is
+// decltype(&ncclXxx) - a prototype that drifts in a later rccl.h fails the build instead of the call.
 //
 // Rendezvous: rank 0 creates the RCCL unique id and publishes it as a small file; the other ranks poll for it
 // (tic_rdv_publish / tic_rdv_wait below).  The caller names the file - something unique to the launch AND to the communicator,
@@ -29,16 +30,12 @@
 
 #include <string>
 
-// ---- the part of RCCL's C API this file uses (rccl.h: ncclComm_t, ncclUniqueId, ncclResult_t, ncclDataType_t, ncclRedOp_t) ----
-struct ncclComm;
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-typedef int ncclResult_t;
-typedef int ncclDataType_t;
-typedef int ncclRedOp_t;
-static constexpr ncclResult_t ncclSuccess = 0;
-static constexpr ncclDataType_t ncclUint64 = 5, ncclFloat64 = 8;
-static constexpr ncclRedOp_t ncclMax = 2;
+// ---- RCCL's types and enumerators come from its own header (rccl.h is on the build box; round 5 wrote them out by hand and trusted a
+// version gate).  The LIBRARY is still opened at run time (dlopen below): nothing here links against it, the header only supplies
+// ncclComm_t, ncclUniqueId, ncclResult_t, ncclDataType_t, ncclRedOp_t and the prototypes the function pointers are checked against.
+#include <rccl/rccl.h>
+static_assert(sizeof(ncclUniqueId) == 128, "the rendezvous file carries a 128-byte RCCL unique id");
+static_assert(NCCL_MAJOR == 2, "written against the NCCL 2 API (tic_comm_create refuses another major version at run time too)");
 
 #include "../../include/tinyimgcodec_hip.h"
 #include "tic_hooks.h"
@@ -55,12 +52,12 @@ struct tic_comm {
     size_t send_cap = 0, recv_cap = 0;
     std::string err;
     int version = 0; // NCCL_VERSION_CODE of the loaded library (0: no library loaded - single rank)
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
 static thread_local std::string g_comm_err;
@@ -241,11 +238,10 @@ int tic_comm_create_ex(tic_ctx *ctx, int rank, int world, const char *rendezvous
 #define SYM(field, name)                                                                                  \
     c->field = reinterpret_cast<decltype(c->field)>(dlsym(c->lib, name));                                  \
     if (!c->field) { delete c; return comm_fail(nullptr, TIC_E_NODEVICE, "librccl lacks a symbol", name); }
-        // The prototypes above are written out by hand (ncclUniqueId = 128 bytes by value, ncclUint64 = 5, ncclFloat64 = 8, ncclMax = 2:
-        // rccl.h of RCCL 2.x, checked against /opt/rocm/include/rccl/rccl.h 2.27): a library of another MAJOR version may have changed
-        // any of them, so it is refused here instead of being called through them.
+        // Types and prototypes are rccl.h's of the build box (NCCL_MAJOR 2, static_assert above); the library found at RUN time may be
+        // another one: a library of another MAJOR version may have changed any of them, so it is refused here instead of being called.
         {
-            ncclResult_t (*GetVersion)(int *) = reinterpret_cast<ncclResult_t (*)(int *)>(dlsym(c->lib, "ncclGetVersion"));
+            decltype(&ncclGetVersion) GetVersion = reinterpret_cast<decltype(&ncclGetVersion)>(dlsym(c->lib, "ncclGetVersion"));
             int ver = 0;
             if (!GetVersion || GetVersion(&ver) != ncclSuccess) { delete c; return comm_fail(nullptr, TIC_E_NODEVICE, "librccl does not report its version", "ncclGetVersion"); }
             const int major = ver >= 10000 ? ver / 10000 : ver / 1000; // NCCL_VERSION_CODE: X*10000 + Y*100 + Z (X*1000 + ... up to 2.8)

@@ -43,6 +43,9 @@ struct DecIdctArgs {
     const struct DctqConsts *consts; // constants of the stream's quality (quality 50 on the scaled_dct branch)
     int scaled;        // decode()'s scaled_dct branch (codec.py:59-62)
     double pow2;       // 2 ** (quality field of the stream) on that branch
+    uint32_t head[4];  // the 16-byte header h, w, stride and the constants above were derived from: a workgroup of the fused kernel whose
+                       // stream starts with other bytes writes NO pixel (a launch on a guessed header must not touch memory outside the
+                       // real image - a caller decoding into a window of a larger surface keeps its neighbours)
 };
 
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks);

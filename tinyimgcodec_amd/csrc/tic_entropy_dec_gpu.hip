@@ -553,6 +553,9 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     const unsigned long long m = total < n_want ? total : n_want; // blocks produced here
     const unsigned long long b0 = (unsigned long long)blockIdx.x * kDecodeWG, b = b0 + threadIdx.x;
     if (b0 >= m) return; // (the whole workgroup)
+    // geometry and quality came from a.head - possibly a guess (tic_decompress_dev): pixels are written only under the header the stream
+    // really has (four words, the same for every lane: scalar loads; the measure kernel echoes them to the host, which decodes again)
+    if (gwords[0] != a.head[0] || gwords[1] != a.head[1] || gwords[2] != a.head[2] || gwords[3] != a.head[3]) return;
     if (threadIdx.x < 64) {
         zznat[threadIdx.x] = a.consts->zznat[threadIdx.x];
         dq[threadIdx.x] = a.consts->div[threadIdx.x];
@@ -711,7 +714,11 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
             // passes above leave out their 1/4): fl(16 r + 2048) = 16 fl(r + 128); truncation first and the clip on the integer (the
             // bounds are integers, truncation is monotonic, the sum is far inside the int range: one v_med3_i32 instead of a float64
             // maximum and minimum), and floor(y / 16) of a non-negative integer y is y >> 4.
-            const int y = (int)(x[u * 8 + k] + 2048.0);
+            // (the scaled_dct branch multiplies by 2**quality, quality up to 62: there the sum is clamped as a double first - a conversion that
+            // overflows the int is undefined; the clamp's bounds are integers, so the result is the same)
+            double s16 = x[u * 8 + k] + 2048.0;
+            if (kScaled) s16 = fmin(fmax(s16, 0.0), 4080.0);
+            const int y = (int)s16;
             px[k] = (uint32_t)(y < 0 ? 0 : (y > 4080 ? 4080 : y)) >> 4;
         }
         uint2 o;
