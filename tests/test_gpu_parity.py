@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 
 def device_decoder_takes(nblocks, nbytes):
     """The streams the device Huffman decoder takes (csrc/tic_api.hip device_decoder_takes): long ones (16,384 blocks, 2 Mbit), and short ones of at
-    least 1,024 blocks and 4 KB that hold 32 bits per block on average."""
+    least 1,024 blocks and 1 KB (round 6: whatever their density)."""
     bits = nbytes * 8
-    return (nblocks >= 16384 and bits >= 128 + (1 << 21)) or (nblocks >= 1024 and bits >= 128 + (1 << 15) and bits - 128 >= 32 * nblocks)
+    return (nblocks >= 16384 and bits >= 128 + (1 << 21)) or (nblocks >= 1024 and bits >= 128 + (1 << 13))
 
 
 def sha(b):
@@ -1808,8 +1808,8 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
                     assert L.tic_last_decode_path(ctx.handle) == 1, (name, q, rb)
                     assert L.tic_last_decode_range(ctx.handle, C.byref(rbits), C.byref(tries)) == 0
                     assert (rbits.value, tries.value) in ((int(rb), 1), (2016, 2)), (name, q, rb, rbits.value, tries.value)
-                    if q == 90 and rb == "288":  # blocks of 404 bits: this range cannot hold
-                        assert tries.value == 2, (name, q, rb)
+                    if q == 90 and rb == "288":  # blocks of 404 bits pass over whole ranges of 288 bits: rounds 2-5 needed the second run with the
+                        assert tries.value == 1, (name, q, rb)  # longest range here, round 6's stitch follows the chain from range to range
                 monkeypatch.delenv("TIC_DECODE_RANGE")
             monkeypatch.setenv("TIC_DECODE_HOST", "1")
             assert np.array_equal(T.decompress(s, ctx=ctx), want), (name, q, "host")

@@ -7,8 +7,10 @@ Same names, argument meaning and error behaviour as the reference so that it is 
     encode(image, quality=50) -> {"height","width","quality","dc","ac"}          codec.py:26-43
     decode(data) -> np.ndarray[uint8]                                            codec.py:46-70
 
-The transform stage (pad, level shift, DCT, quantise, zig-zag) runs in hand-written gfx950 kernels; the entropy
-stage runs in C on the host.  There is no Python or CPU fallback: without the HIP library and an MI355X these
+The transform stage (pad, level shift, DCT, quantise, zig-zag) and the entropy stage (DPCM, run lengths, Huffman codes, bit
+packing; the Huffman decode and the inverse transform of decompress()) run in hand-written gfx950 kernels; the library's host
+entropy coder (C++) serves encode()-style callers that hold coefficients on the host, and streams the device decoder hands back
+(damaged or very short ones).  There is no Python or CPU fallback for the device path: without the HIP library and an MI355X these
 functions raise tinyimgcodec_amd.NativeUnavailable.
 
 Documented differences from the reference (all outside its working domain):

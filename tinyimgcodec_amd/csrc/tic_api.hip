@@ -1821,14 +1821,14 @@ static int idctq_impl(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int 
 // or does not apply - the caller then decodes on the host, which reproduces the reference's behaviour on malformed streams (what
 // the device wrote to `out` until then is overwritten).
 // Streams the device decoder takes.  Long ones as in rounds 2-4 (16,384 blocks and 2 Mbit at least: the host PARALLEL decoder's own line).
-// Since round 5 also short ones - at least kDevDecodeMinBlocks blocks (a 256 x 256 frame) and kDevDecodeMinBits stream bits (4 KB): with
-// two launches instead of four the device decoder beats the host's serial decoder far below the old line, the reference's own benchmark
-// images (512 x 512, tests/benchmark.py) decompress() in 86 - 100 us instead of 132 - 387 - when the stream has kDevDecodeMinDensity bits
-// per block on average at least: sparser short streams (smooth, flat, blocky content) often hold a block longer than the 544-bit range
-// their average asks for, the first run gives up, and two runs cost more than the host decoder does on so few bits (tools/stress_decoder.py:
-// below 32 bits per block 160 of 342 valid streams took a second run, above it 3 of 458; profiles/r05_decoder.txt).
+// Since round 5 also short ones - at least kDevDecodeMinBlocks blocks (a 256 x 256 frame) and kDevDecodeMinBits stream bits: with two
+// launches instead of four the device decoder beats the host's serial decoder far below the old line, the reference's own benchmark
+// images (512 x 512, tests/benchmark.py) decompress() in 86 - 100 us instead of 132 - 387.  Round 5 kept streams below 32 bits per block
+// on the host (kDevDecodeMinDensity): sparse streams hold blocks longer than the 544-bit range their average asks for, the stitch gave
+// up and the second run cost more than the host decoder.  Round 6: the stitch follows the chain over such ranges (tic_entropy_dec_gpu.hip,
+// the fix-up loop), every density is taken, and the bit floor is 1 KB (the benchmark set's sparsest stream at q = 5 has 4,071 bytes).
 // Hooks TIC_DECODE_MIN_BLOCKS / _BITS / _DENSITY move the lines for measurements.
-constexpr size_t kDevDecodeMinBlocks = 1024, kDevDecodeMinBits = 1u << 15, kDevDecodeMinDensity = 32;
+constexpr size_t kDevDecodeMinBlocks = 1024, kDevDecodeMinBits = 1u << 13, kDevDecodeMinDensity = 0;
 static bool device_decoder_takes(size_t n, size_t len) {
     size_t min_blocks = kDevDecodeMinBlocks, min_bits = kDevDecodeMinBits, min_density = kDevDecodeMinDensity;
     if (const char *e = test_hook("TIC_DECODE_MIN_BLOCKS")) min_blocks = (size_t)atol(e);

@@ -48,6 +48,20 @@ struct DecIdctArgs {
                        // real image - a caller decoding into a window of a larger surface keeps its neighbours)
 };
 
+// One stream of a batch (entropy_decode_idct_gpu_batch): where its words, ranges, tiles, blocks and workgroups sit in the batch's arrays.
+// The stream starts at word `word0` of the batch's stream buffer (every stream 4-byte aligned there); the same margin-free run as
+// entropy_decode_idct_gpu with margin_bits = 0 (fast_end = stream_bits).
+struct DecFrame {
+    uint32_t word0, nwords, last_mask;  // the stream's words
+    uint32_t fast_end, stream_bits;
+    uint32_t nranges, range0;           // its ranges; index of its first range among the batch's (traces: range0 * cap entries in)
+    uint32_t tile0, ntiles;             // its waves in the measure kernel's grid
+    uint32_t blk0, nblocks;             // its blocks; index of its first block among the batch's (positions)
+    uint32_t wg0, nwgs;                 // its workgroups in the fused kernel's grid
+    uint32_t pad_;
+    DecIdctArgs idct;                   // where its pixels go, its geometry, constants and header
+};
+
 size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks);
 // d_stream_words: the whole stream (header included) in device memory, 4-byte aligned; the 4-byte word that holds its last byte is
 // read whole (the bytes behind the stream's end are masked off), nothing behind that word is touched.  range_bits: stream bits per lane, a value entropy_decode_gpu_range_ok() accepts - an odd
@@ -65,5 +79,18 @@ bool entropy_decode_gpu_range_ok(int range_bits);
 hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_bytes, size_t nblocks, const DecLutsDev *d_luts, void *d_work,
                                    size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, const DecIdctArgs &idct,
                                    DecStatus *d_status, int range_bits, int margin_bits, hipStream_t stream, int flat_grid = 4096);
+
+// The batch form: `nframes` whole streams in two launches.  d_frames / d_tile_frame / d_wg_frame: device copies of the descriptors, the frame of
+// every wave of the measure grid and of every workgroup of the fused grid; d_status: nframes entries, zeroed by the caller; the sums'
+// look-back words and the epoch as above; small_win: every stream has at most 240 bits per block on average.  A frame whose status comes back
+// with giveup != 0 or m != its block count is the caller's to decode again on its own.
+size_t entropy_decode_batch_work_bytes(size_t total_ranges_288, size_t total_blocks, size_t nframes);
+uint32_t entropy_decode_batch_tiles(uint32_t nranges);
+uint32_t entropy_decode_batch_wgs(size_t nblocks);
+uint32_t entropy_decode_batch_ranges(size_t stream_bytes, int range_bits);
+hipError_t entropy_decode_idct_gpu_batch(const void *d_words_all, const DecFrame *d_frames, const uint32_t *d_tile_frame, const uint32_t *d_wg_frame, uint32_t nframes,
+                                         uint32_t total_tiles, uint32_t total_wgs, uint32_t total_ranges, size_t total_blocks, bool small_win, const DecLutsDev *d_luts, void *d_work,
+                                         size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, DecStatus *d_status, int range_bits, hipStream_t stream,
+                                         int flat_grid = 4096);
 
 } // namespace tic

@@ -299,34 +299,40 @@ __device__ __forceinline__ void chain_step(const uint8_t *lutm, uint32_t pk, uin
 // symbols.)  Here the position inside the block (is the DC category next?) is lane state and a block end is just another step.
 //
 // A wave stands alone (a workgroup is one to four of them, sharing only the tables' trip from memory: 38.5 -> 36.0 us for a 4096^2 stream).
-// Lanes 1..63 own 63 consecutive ranges; lane 0 SHADOWS the range in front of them - it walks it exactly as
-// its owner (lane 63 of the workgroup before) does and writes nothing - so that every owner finds the exit of the range in front of
-// its own in the lane next to it: the stitch needs no second launch (its start, tables and window staged again, was a third of
-// it) and no workgroup waits for another.  1/63 more waves.
-constexpr uint32_t kOwned = 63; // ranges a workgroup owns
-__global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
-                                                                uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
-                                                                uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
-                                                                unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
-                                                                uint32_t ntiles, DecStatus *__restrict__ st) {
+// Lanes kShadow..63 own 60 consecutive ranges; lanes 0..kShadow-1 SHADOW the ranges in front of them - each walks its range exactly as
+// its owner (a lane of the workgroup before) does, and lanes 1.. also stitch it as the owner does, writing nothing but the trace (the
+// same words the owner writes) - so that every owner finds the exit of the range in front of its own in the lane next to it: the stitch
+// needs no second launch (its start, tables and window staged again, was a third of it) and no workgroup waits for another.
+// Round 6: FOUR shadows instead of one.  The true chain does not always enter a range where the walk of the range in front ended: a
+// block longer than a range passes over whole ranges (sparse streams - smooth, flat, blocky content at 8-15 bits per block - hold blocks
+// of 600 bits and more among thousands of 8: rounds 2-5 gave up on such a stream and decoded it again with the longest range, which is
+// why streams below 32 bits per block were kept on the host decoder).  Now a range the chain passes over, or walks through without
+// meeting its trace, hands its EXIT to the lane behind it and that lane stitches again from there (the fix-up loop below); a block is at
+// most 1,728 bits long, a range at least 544: four ranges in front of the first owned one are enough for the true entry to reach it.
+constexpr uint32_t kShadow = 4;            // ranges in front of its own that a wave shadows
+constexpr uint32_t kOwned = 64 - kShadow;  // ranges a wave owns
+__device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+                                                    uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
+                                                    uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
+                                                    unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
+                                                    uint32_t ntiles, DecStatus *__restrict__ st, const uint32_t tile /* this wave's index among the stream's `ntiles` waves */) {
     __shared__ __attribute__((aligned(16))) uint8_t lutm[kChainLds];   // the chain tables: the measure walk
     extern __shared__ uint32_t sbits_all[]; // stage_lds_words(range) per wave, the launch's dynamic LDS
     // A workgroup is one to four WAVES that share nothing but the chain tables (6.4 KB from memory once per workgroup instead of once
     // per wave) and the barrier behind the staging; `tile` is the wave's index among all waves of the launch - what rounds 4's
     // one-wave workgroups called blockIdx.x.
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + wave;
     uint32_t *sbits = sbits_all + wave * stage_lds_words(range);
     if (tile == 0u && lane < 4u) st->head[lane] = gwords[lane]; // (a stream has its 16-byte header: nwords >= 4)
-    const uint32_t t_first = tile ? tile * kOwned - 1u : 0u; // the window's first range
+    const uint32_t t_first = tile ? tile * kOwned - kShadow : 0u; // the window's first range
     static_assert(offsetof(DecLutsDev, mac) == offsetof(DecLutsDev, mdc) + 2048 && offsetof(DecLutsDev, mlong) == offsetof(DecLutsDev, mac) + 4096 &&
                       offsetof(DecLutsDev, mdc) % 16 == 0,
                   "the chain tables are adjacent and copied in 16-byte pieces");
     copy16_to_lds_rt(lutm, L->mdc, kChainLds / 16); // (stage_bits below ends with the barrier)
     const Bits words = stage_bits<64>(sbits, gwords, 128u + t_first * range, range, nwords, last_mask, lane);
     if (tile >= ntiles) return; // (a wave behind the last range; behind the barrier)
-    const bool shadow = lane == 0u;
-    const uint32_t t = tile * kOwned + lane - 1u; // (lane 0 of tile 0: no such range)
+    const bool shadow = lane < kShadow;
+    const uint32_t t = tile * kOwned + lane - kShadow; // (lanes 0..kShadow-1 of tile 0: no such range)
     const bool walks = (tile != 0u || !shadow) && t < nranges;
     const bool mine = walks && !shadow;
     const uint32_t lo = 128u + (walks ? t : 0u) * range;
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
     const uint32_t stop = hi + 1800u < stream_bits ? hi + 1800u : stream_bits; // (behind the stream's end there is nothing to walk: with margin_bits = 0 the last
                                                                                 // range's walk would go through 1,800 zero bits there, 600 steps with the whole launch waiting)
     const uint32_t cap = cap_of(range);
-    uint16_t *tr = starts + (size_t)(mine ? t : 0u) * cap;
+    uint16_t *tr = starts + (size_t)(walks ? t : 0u) * cap; // (a shadow writes the very words the range's owner writes: its own stitch reads them back)
     uint32_t pos = lo, bstart = lo, cnt = 0; // a block that STARTS in front of `hi` is measured to its end
     uint32_t mode = 0; // chain_step: the DC category comes next (a block starts here)
     bool live = walks && pos < hi;
@@ -380,45 +386,43 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
             wc = crossed ? wn : wc;
             wi = now;
         }
-        if (eob && mine && cnt < cap) tr[cnt] = (uint16_t)(bstart - lo);
+        if (eob && walks && cnt < cap) tr[cnt] = (uint16_t)(bstart - lo);
         cnt += eob;
         bstart = eob ? pos : bstart;
         live = (eob ? pos < hi : true) && pos < stop;
     }
     if (mine && cnt > cap) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
     // ---- stitch: does the true chain, entering where the walk of the range in front ended, meet this range's trace?
-    const uint32_t pos_in = (uint32_t)__shfl_up((int)pos, 1, 64); // (all 64 lanes are here: nobody has returned)
+    const uint32_t wend = pos; // where this range's own walk ended: the true chain's exit IF the chain met the trace inside the range
     const uint32_t n_rec = cnt;
     const uint32_t n = n_rec < cap ? n_rec : cap;
     // what the stitch finds out about this range: its blocks on the true chain (nb): `by_hand` of them measured below, from where the
-    // chain entered, the others the range's own trace from entry `a` on
-    uint32_t nb = 0, by_hand = 0, a = n;
-    auto stitch = [&]() {
+    // chain entered, the others the range's own trace from entry `a` on; and where the chain LEAVES the range (exit_pos)
+    uint32_t nb = 0, by_hand = 0, a = n, exit_pos = wend;
+    // the head of the trace, back from memory in one trip (this lane's own stores); entry 0 is the range's first bit
+    const uint32_t tr1 = tr[1], tr2 = tr[2]; // (entries behind n are never looked at; cap >= 3)
+    auto trace_at = [&](uint32_t k) { return k >= n ? 0xffffffffu : (k == 0u ? 0u : (k == 1u ? tr1 : (k == 2u ? tr2 : (uint32_t)tr[k]))); };
+    auto stitch = [&](uint32_t entry) {
+        nb = 0u, by_hand = 0u, a = n, exit_pos = entry;
         if (t == 0u) { // the first range starts on a true block start: its trace is the chain
             nb = n_rec;
             a = 0u;
+            exit_pos = wend;
             return;
         }
-        pos = pos_in; // hypothesis: where the true chain enters this range
+        pos = entry; // hypothesis: where the true chain enters this range
         if (pos >= fast_end) return; // the chain left the fast part of the stream in front of this range
-        // the head of the trace, back from memory in one trip (this lane's own stores); entry 0 is the range's first bit
-        const uint32_t tr1 = tr[1], tr2 = tr[2]; // (entries behind n are never looked at; cap >= 3)
-        auto trace_at = [&](uint32_t k) { return k >= n ? 0xffffffffu : (k == 0u ? 0u : (k == 1u ? tr1 : (k == 2u ? tr2 : (uint32_t)tr[k]))); };
         // the trace is sorted and the walk only moves forward: ONE pointer into the trace, advanced past the entries in front of the
         // walk (rounds 2-3 searched the trace from scratch at every block: eight dependent loads from memory where this takes one or two)
         uint32_t ap = 0;
         uint32_t ta = trace_at(0u);
         for (;;) {
-            if (pos >= hi) { // walked through the whole range without meeting its trace: the hypothesis for the next range fails
-                // (... unless there is no next range: the last one may be a few bits long, its own walk then has no time to fall in step,
-                // and nothing depends on where that walk ended - its blocks are the ones walked by hand here.  Rounds 2-3 gave up on
-                // such a stream and decoded it a second time with the longest range.)
-                if (t + 1u != nranges) atomicOr(&st->giveup, 4);
+            // the chain is past the range: it entered behind it (a block longer than the range passes over it: no block of the chain
+            // starts here) or it was walked by hand all the way through without meeting the trace - either way the chain's exit is `pos`,
+            // not the end of this range's own walk, and the lane behind stitches again from there (rounds 2-5 gave up here: bit 4)
+            if (pos >= hi || pos + 6u > stream_bits) { // (... or fewer bits than a block has are left: the chain has arrived at the stream's end, its padding)
                 nb = by_hand;
-                return;
-            }
-            if (pos + 6u > stream_bits) { // fewer bits than a block has: the chain has arrived at the stream's end (its padding)
-                nb = by_hand;
+                exit_pos = pos;
                 return;
             }
             // is `pos` a block start this range's trace recorded?
@@ -431,9 +435,10 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
                 // from here on the trace walked the true chain (whether its blocks are well-formed is checked where they are decoded)
                 nb = by_hand + (n_rec - ap);
                 a = ap;
+                exit_pos = wend;
                 return;
             }
-            if (by_hand < cap) hand[(size_t)t * cap + by_hand] = (uint16_t)want; // first bit of the by-hand block (pos >= lo: the walk enters behind the range before)
+            if (mine && by_hand < cap) hand[(size_t)t * cap + by_hand] = (uint16_t)want; // first bit of the by-hand block (pos >= lo: the walk enters behind the range before)
             // one block by hand: the same chain walk, from `pos` with the DC category next, to its EOB.  (Rounds 2-3 decoded the block
             // symbol by symbol with the one-symbol tables and checked it - a second set of tables in LDS, and three times the steps; whether
             // a block of the true chain is well-formed is checked where it is decoded, in the fused kernel, as for the trace's blocks.)
@@ -463,8 +468,9 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
                     // ... at the stream's end that is how the chain of a whole stream ends: in the padding bits behind its last block (fewer than
                     // 8 zeros, no block), and a cut stream's chain ends the same way in front of its open block - the host continues from it
                     // (whatever the ranges behind still add to the chain is caught where it is decoded: those blocks do not follow each other)
-                    if (pos + 2048u <= fast_end) atomicOr(&st->giveup, 16);
+                    if (mine && pos + 2048u <= fast_end) atomicOr(&st->giveup, 16);
                     nb = by_hand;
+                    exit_pos = fast_end; // (the chain ends here: the ranges behind hold none of its blocks)
                     return;
                 }
                 pos = p;
@@ -472,7 +478,27 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
             by_hand++;
         }
     };
-    if (mine) stitch();
+    // Every lane stitches on the hypothesis that the chain enters its range where the walk of the range in front ended; a lane whose
+    // neighbour reports another exit (the chain passed over that range, or went through it without meeting its trace) stitches again from
+    // that exit, and so on down the wave: as many rounds as ranges in a row are passed over (a 1,728-bit block: three of 544 bits).  Lane 0
+    // has no neighbour: its exit is taken to be its walk's end, the three shadows behind it put that right where it is not.
+    {
+        const bool can = walks && (t == 0u || lane != 0u);
+        uint32_t entry = (uint32_t)__shfl_up((int)wend, 1, 64); // (all 64 lanes are here: nobody has returned)
+        if (can) stitch(entry);
+        bool need = false;
+        for (int round = 0; round < 8; round++) {
+            const uint32_t pe = (uint32_t)__shfl_up((int)exit_pos, 1, 64);
+            need = can && t != 0u && pe != entry;
+            if (__ballot(need) == 0ull) break;
+            if (need) {
+                entry = pe;
+                stitch(entry);
+            }
+        }
+        if (need && mine) atomicOr(&st->giveup, 4); // (cannot happen within eight rounds: a block covers three ranges at most)
+    }
+    if (!mine) nb = 0u; // a shadow's blocks are counted by the range's owner
     // ---- index of every range's first true block, and with it the first bit of every block of the true chain - HERE, in the same launch
     // (rounds 2-4: a launch of its own, scan_counts_bpos_kernel, over arrays this kernel wrote): the wave sums its 63 counts, PUBLISHES the
     // sum (one 8-byte word that carries the launch's epoch, scan_pack below) and adds up the words of the workgroups in front of it - they were
@@ -508,6 +534,33 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
     }
 }
 
+// One stream per launch: a wave's tile is its index in the grid.
+__global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+                                                                uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
+                                                                uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
+                                                                unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
+                                                                uint32_t ntiles, DecStatus *__restrict__ st) {
+    measure_stitch_body(gwords, nwords, last_mask, L, fast_end, stream_bits, range, nranges, starts, hand, desc, desc_half, flat_grid, epoch, nblocks, bpos, grand_total, ntiles, st,
+                        blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+}
+// A BATCH of streams per launch (tic_decompress_batch: the reference's benchmark loop decodes 49 streams of 512 x 512 one after the other,
+// tests/benchmark.py:12-23 - two launches per stream are launch latency and little else).  Wave `g` of the grid works on stream
+// tile_frame[g], as that stream's wave g - tile0: its words, ranges, traces, sums, positions and status are the frame's own slices of the
+// batch's arrays (DecFrame), and nothing crosses a frame: the count of blocks in front of a range is taken over the frame's own waves.
+__global__ __launch_bounds__(256) void dec_measure_stitch_batch_kernel(const uint32_t *__restrict__ words_all, const DecFrame *__restrict__ frames, const uint32_t *__restrict__ tile_frame,
+                                                                      uint32_t total_tiles, const DecLutsDev *__restrict__ L, uint32_t range, uint16_t *__restrict__ starts_all,
+                                                                      uint16_t *__restrict__ hand_all, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid,
+                                                                      uint32_t epoch, uint32_t *__restrict__ bpos_all, long long *__restrict__ totals, DecStatus *__restrict__ status) {
+    const uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const bool beyond = g >= total_tiles; // (a wave behind the last stream's last range: it goes through the staging's barrier as that stream's wave `ntiles` and returns)
+    const uint32_t f = tile_frame[beyond ? total_tiles - 1u : g];
+    const DecFrame &F = frames[f];
+    const size_t cap = cap_of(range);
+    measure_stitch_body(words_all + F.word0, F.nwords, F.last_mask, L, F.fast_end, F.stream_bits, range, F.nranges, starts_all + (size_t)F.range0 * cap,
+                        hand_all + (size_t)F.range0 * cap, desc + F.tile0, desc_half, flat_grid, epoch, (unsigned long long)F.nblocks, bpos_all + F.blk0, totals + f, F.ntiles, status + f,
+                        beyond ? F.ntiles : g - F.tile0);
+}
+
 // ---- decode + inverse transform, fused --------------------------------------------------------------------------------------------
 // A workgroup per kDecodeWG consecutive blocks (one contiguous piece of the stream, staged in LDS: up to kBlkWin words, 250 or 500 bits
 // per block on average; what lies behind is read from memory), a LANE PER BLOCK through both phases.  Phase 1: lane b decodes the block
@@ -533,10 +586,10 @@ __constant__ int kAnnScalesDec[64] = { // ANNSCALES of the reference's scaled_dc
 // kWinWords: stream words of the workgroup's window: 2048 (+ kOver) hold 256 blocks of up to 256 bits on average - three workgroups
 // per CU - 4096 of up to 512 - two; what lies behind the window is read from memory
 template <uint32_t kWinWords, bool kScaled>
-__global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
-                                                                    const uint32_t *__restrict__ bpos, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
-                                                                    const long long *__restrict__ total_blocks, unsigned long long n_want, uint32_t stream_bits,
-                                                                    DecIdctArgs a, DecStatus *__restrict__ st) {
+__device__ __forceinline__ void decode_idct_body(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+                                                 const uint32_t *__restrict__ bpos, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
+                                                 const long long *__restrict__ total_blocks, unsigned long long n_want, uint32_t stream_bits,
+                                                 const DecIdctArgs &a, DecStatus *__restrict__ st, const uint32_t wg /* this workgroup among the stream's `nwgs` */, const uint32_t nwgs) {
     // tables + stream window
     constexpr uint32_t kBlkWin = kWinWords + kOver;
     constexpr uint32_t kBlkLds = kBlkWin + kBlkWin / 32 + 2;
@@ -551,7 +604,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     uint32_t *sbits = scratch + kLutDw;
     const unsigned long long total = (unsigned long long)*total_blocks;
     const unsigned long long m = total < n_want ? total : n_want; // blocks produced here
-    const unsigned long long b0 = (unsigned long long)blockIdx.x * kDecodeWG, b = b0 + threadIdx.x;
+    const unsigned long long b0 = (unsigned long long)wg * kDecodeWG, b = b0 + threadIdx.x;
     if (b0 >= m) return; // (the whole workgroup)
     // geometry and quality came from a.head - possibly a guess (tic_decompress_dev): pixels are written only under the header the stream
     // really has (four words, the same for every lane: scalar loads; the measure kernel echoes them to the host, which decodes again)
@@ -604,7 +657,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     }
     long long dc_tile;
     const long long dc_inc = wg_inclusive_scan(dc_diff, scan_lds, dc_tile);
-    scan_publish(desc, epoch, dc_tile);
+    if (threadIdx.x == 0) __hip_atomic_store(&desc[wg], scan_pack(epoch, dc_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (scan_publish, with the stream's own index)
     if (b < m) {
         bool ok = true;
         {
@@ -654,7 +707,7 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
         }
     }
     { // the sums of the workgroups in front, wave by wave (no barrier: a wave whose blocks were short goes on)
-        const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, dc_tile, st, blockIdx.x, gridDim.x); // (every wave of the workgroup publishes the same inclusive sum: whichever is first)
+        const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, dc_tile, st, wg, nwgs); // (every wave of the workgroup publishes the same inclusive sum: whichever is first)
         if (b < m) {
             const long long dc = part + dc_inc; // sum of the differences of blocks 0..b
             const int32_t dc32 = (int32_t)dc;   // (the host decoder's long long, narrowed where it is used)
@@ -739,6 +792,25 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
     }
 }
 
+template <uint32_t kWinWords, bool kScaled>
+__global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_decode_idct_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
+                                                                    const uint32_t *__restrict__ bpos, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
+                                                                    const long long *__restrict__ total_blocks, unsigned long long n_want, uint32_t stream_bits,
+                                                                    DecIdctArgs a, DecStatus *__restrict__ st) {
+    decode_idct_body<kWinWords, kScaled>(gwords, nwords, last_mask, L, bpos, desc, desc_half, flat_grid, epoch, total_blocks, n_want, stream_bits, a, st, blockIdx.x, gridDim.x);
+}
+// The batch form: workgroup g decodes 256 blocks of stream wg_frame[g] (a stream's blocks start a workgroup of their own: the DC sum
+// starts over with every frame, codec.py:53) and writes that frame's pixels through the frame's own DecIdctArgs.
+template <uint32_t kWinWords>
+__global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_decode_idct_batch_kernel(const uint32_t *__restrict__ words_all, const DecFrame *__restrict__ frames, const uint32_t *__restrict__ wg_frame,
+                                                                          const DecLutsDev *__restrict__ L, const uint32_t *__restrict__ bpos_all, unsigned long long *__restrict__ desc, uint32_t desc_half,
+                                                                          uint32_t flat_grid, uint32_t epoch, const long long *__restrict__ totals, DecStatus *__restrict__ status) {
+    const uint32_t f = wg_frame[blockIdx.x];
+    const DecFrame &F = frames[f];
+    decode_idct_body<kWinWords, false>(words_all + F.word0, F.nwords, F.last_mask, L, bpos_all + F.blk0, desc + F.wg0, desc_half, flat_grid, epoch, totals + f, (unsigned long long)F.nblocks,
+                                       F.stream_bits, F.idct, status + f, blockIdx.x - F.wg0, F.nwgs);
+}
+
 } // namespace
 
 bool entropy_decode_gpu_range_ok(int range_bits) {
@@ -808,6 +880,42 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const bool small_win = nbits / nblocks <= 240; // sparse enough for the small window: one workgroup more per CU
     if (idct.scaled) small_win ? fused(dec_decode_idct_kernel<2048, true>) : fused(dec_decode_idct_kernel<4096, true>);
     else small_win ? fused(dec_decode_idct_kernel<2048, false>) : fused(dec_decode_idct_kernel<4096, false>);
+    return hipGetLastError();
+}
+
+
+size_t entropy_decode_batch_work_bytes(size_t total_ranges_288, size_t total_blocks, size_t nframes) {
+    return total_ranges_288 * ((size_t)cap_of(kRangeMin) * 2 * 2) + total_blocks * 4 + nframes * 8 + 16384;
+}
+uint32_t entropy_decode_batch_tiles(uint32_t nranges) { return (nranges + kOwned - 1u) / kOwned; }
+uint32_t entropy_decode_batch_wgs(size_t nblocks) { return (uint32_t)((nblocks + kDecodeWG - 1) / kDecodeWG); }
+uint32_t entropy_decode_batch_ranges(size_t stream_bytes, int range_bits) { return (uint32_t)((stream_bytes * 8 - 128 + (size_t)range_bits - 1) / (size_t)range_bits); }
+
+hipError_t entropy_decode_idct_gpu_batch(const void *d_words_all, const DecFrame *d_frames, const uint32_t *d_tile_frame, const uint32_t *d_wg_frame, uint32_t nframes,
+                                         uint32_t total_tiles, uint32_t total_wgs, uint32_t total_ranges, size_t total_blocks, bool small_win, const DecLutsDev *d_luts, void *d_work,
+                                         size_t work_bytes, unsigned long long *d_desc, size_t desc_words, uint32_t epoch, DecStatus *d_status, int range_bits, hipStream_t stream,
+                                         int flat_grid) {
+    if (!entropy_decode_gpu_range_ok(range_bits) || nframes == 0 || total_tiles == 0 || total_wgs == 0) return hipErrorInvalidValue;
+    const uint32_t range = (uint32_t)range_bits, kCap = cap_of(range);
+    if (!d_desc || desc_words < 4 * (size_t)(total_tiles > total_wgs ? total_tiles : total_wgs) || epoch == 0 || epoch >= (1u << 22) || flat_grid < 0) return hipErrorInvalidValue;
+    const uint32_t desc_half = (uint32_t)(desc_words / 4);
+    unsigned long long *desc_r = d_desc, *desc_b = d_desc + 2 * (size_t)desc_half;
+    char *w = (char *)d_work;
+    auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) / 256 * 256; return (void *)p; };
+    long long *totals = (long long *)take((size_t)nframes * 8);
+    uint16_t *starts = (uint16_t *)take((size_t)total_ranges * kCap * 2), *hand = (uint16_t *)take((size_t)total_ranges * kCap * 2);
+    uint32_t *bpos = (uint32_t *)take(total_blocks * 4);
+    if ((size_t)(w - (char *)d_work) > work_bytes) return hipErrorInvalidValue;
+    const unsigned win_lds = stage_lds_words(range) * 4u;
+    const unsigned wpw = (unsigned)kChainLds + 4u * win_lds <= 60000u ? 4u : ((unsigned)kChainLds + 2u * win_lds <= 60000u ? 2u : 1u);
+    hipLaunchKernelGGL(dec_measure_stitch_batch_kernel, dim3((total_tiles + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, (const uint32_t *)d_words_all, d_frames, d_tile_frame,
+                       total_tiles, d_luts, range, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, bpos, totals, d_status);
+    if (small_win)
+        hipLaunchKernelGGL(dec_decode_idct_batch_kernel<2048>, dim3(total_wgs), dim3(kDecodeWG), 0, stream, (const uint32_t *)d_words_all, d_frames, d_wg_frame, d_luts, (const uint32_t *)bpos, desc_b,
+                           desc_half, (uint32_t)flat_grid, 2u * epoch + 1u, (const long long *)totals, d_status);
+    else
+        hipLaunchKernelGGL(dec_decode_idct_batch_kernel<4096>, dim3(total_wgs), dim3(kDecodeWG), 0, stream, (const uint32_t *)d_words_all, d_frames, d_wg_frame, d_luts, (const uint32_t *)bpos, desc_b,
+                           desc_half, (uint32_t)flat_grid, 2u * epoch + 1u, (const long long *)totals, d_status);
     return hipGetLastError();
 }
 

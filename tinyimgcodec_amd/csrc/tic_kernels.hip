@@ -489,13 +489,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         f32x4 m0, m1;
         f32x4 thr;
         u32x4 zzv;
-        // Constants: the workgroup copies the quality's 1600-byte block into LDS, 25 lanes of every wave one 16-byte piece
-        // each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
+        // Constants: the workgroup copies the quality's block (kStripBlkBytes = 2,624 bytes: tic_math.h) into LDS, 41 lanes of every wave
+        // one 16-byte piece each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
         // loads per wave in front of the first pixel load: four such loads more cost 0.67 us on a 4096^2 launch).
         // Every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_TAKE).
         u32x4 c_fill;
         {
-            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 25 pieces of 16 bytes per wave
+            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 41 pieces of 16 bytes per wave
             static_assert(kPpw * kWavesPerWG == kStripBlkPieces && kPpw <= 64, "constant block must split evenly over the waves");
             const uint32_t piece = lane < kPpw ? (uint32_t)(wave * kPpw + lane) : (uint32_t)kStripBlkPieces - 1u;
             const uint32_t fo = piece * 16u;

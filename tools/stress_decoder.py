@@ -43,6 +43,8 @@ for it in range(iters):
     if tr.value > 1:
         second_runs[dmg if dmg < 3 else 0] += 1
         print("second run: it", it, h, w, "q", q, "kind", kind, "damage", dmg, "bits per block %.0f" % (len(s) * 8 / (((h + 7) // 8) * ((w + 7) // 8))), "path", path, flush=True)
+        if dmg in (0, 3):  # a valid stream: why (the runs' give-up bits on stderr)
+            os.environ["TIC_DECODE_TRACE"] = "1"; sys.stdout.flush(); T.decompress(s, ctx=ctx); sys.stderr.flush(); os.environ.pop("TIC_DECODE_TRACE")
     os.environ["TIC_DECODE_HOST"] = "1"
     b = T.decompress(s, ctx=ctx)
     os.environ["TIC_DECODE_SERIAL"] = "1"
@@ -50,7 +52,7 @@ for it in range(iters):
     os.environ.pop("TIC_DECODE_SERIAL"); os.environ.pop("TIC_DECODE_HOST")
     dev += path == 1
     nblk = ((h + 7) // 8) * ((w + 7) // 8)
-    takes = (nblk >= 16384 and len(s) * 8 >= 128 + (1 << 21)) or (nblk >= 1024 and len(s) * 8 >= 128 + (1 << 15) and len(s) * 8 - 128 >= 32 * nblk)
+    takes = (nblk >= 16384 and len(s) * 8 >= 128 + (1 << 21)) or (nblk >= 1024 and len(s) * 8 >= 128 + (1 << 13))
     if path == 2 and takes: host_fallback += 1
     elif path == 2: short += 1
     if not (np.array_equal(a, b) and np.array_equal(b, c)):
