@@ -174,6 +174,7 @@ def main():
             out["config4"]["note"] = "the N = 1 baseline of every N > 1 line (scaling_baseline): same 256-frame shard, one GPU"
         if not args.no_config4:
             out["codec_resident"] = codec_resident(args, ctx, L, N, q)
+            out["bench_set"] = bench_set(args, ctx, L)
         if not args.no_cpu_baseline:
             img = rand_frame(1234, args.height, args.width)
             out["cpu_baseline"] = cpu_baseline(img, q, args.cpu_seconds, 1)
@@ -781,6 +782,84 @@ def codec_resident(args, ctx, L, N, q):
     finally:
         for p in (d_img, d_out, d_pix):
             L.tic_dev_free(ctx.handle, p)
+
+
+def bench_set(args, ctx, L):
+    """The reference's own benchmark workload (/root/reference/tests/benchmark.py:12-23: 49 images of 512 x 512, quality 90, 80, 50, 20, 10, 5; per image
+    compress() then decompress()) as TWO calls per quality, host memory to host memory: tic_compress_batch (49 images -> 49 streams) and
+    tic_decompress_batch (49 streams -> 49 images).  Pixels and the expected size / sha256 of every stream and decoded image are the
+    committed fixtures tests/golden/benchmark_set.{npz,json}, produced by the unmodified reference (tests/golden/gen/make_goldens_r5.py);
+    every stream and every image of the timed calls is checked against them.  Informational: never `value`."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    try:
+        man = json.load(open(os.path.join(gold, "benchmark_set.json")))["entries"]
+        px = np.load(os.path.join(gold, "benchmark_set.npz"))["pixels"]
+    except OSError as ex:
+        return {"status": "fixture unreadable: %s" % ex}
+    by = {(e["image"], e["quality"]): e for e in man}
+    n, h, w = px.shape
+    frames = [np.ascontiguousarray(px[i]) for i in range(n)]
+    cap = L.tic_compress_bound(h, w)
+    pool = np.empty((n, cap), dtype=np.uint8)
+    inp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+    outp = (C.c_void_p * n)(*[pool[i].ctypes.data for i in range(n)])
+    caps = (C.c_size_t * n)(*([cap] * n))
+    lens = (C.c_size_t * n)()
+    block = np.empty((n, h, w), dtype=np.uint8)
+    pix_p = (C.c_void_p * n)(*[block[i].ctypes.data for i in range(n)])
+    pix_c = (C.c_size_t * n)(*([h * w] * n))
+    rows, checked = {}, 0
+    tot_c = tot_d = 0.0
+    per_call = None
+    for q in (90, 80, 50, 20, 10, 5):
+        def comp():
+            ctx.check(L.tic_compress_batch(ctx.handle, inp, n, h, w, w, q, outp, caps, lens, 0))
+        comp()
+        tc = []
+        for _ in range(5):
+            t0 = time.perf_counter(); comp(); tc.append(time.perf_counter() - t0)
+        streams = [pool[i, : lens[i]].copy() for i in range(n)]
+        sp = (C.c_void_p * n)(*[s_.ctypes.data for s_ in streams])
+        sl = (C.c_size_t * n)(*[s_.size for s_ in streams])
+        def dec():
+            ctx.check(L.tic_decompress_batch(ctx.handle, sp, sl, n, pix_p, pix_c, None, None))
+        dec()
+        td = []
+        for _ in range(5):
+            block[:] = 0
+            t0 = time.perf_counter(); dec(); td.append(time.perf_counter() - t0)
+        nb, ns, nc, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        ctx.check(L.tic_last_decompress_batch(ctx.handle, C.byref(nb), C.byref(ns), C.byref(nc), C.byref(nd)))
+        for i in range(n):
+            e = by[(i + 1, q)]
+            if streams[i].size != e["bytes"] or hashlib.sha256(streams[i].tobytes()).hexdigest() != e["sha256"]:
+                raise AssertionError("bench_set: stream of image %d at q = %d differs from the reference's" % (i + 1, q))
+            if hashlib.sha256(block[i].tobytes()).hexdigest() != e["decoded_sha256"]:
+                raise AssertionError("bench_set: decoded image %d at q = %d differs from the reference's" % (i + 1, q))
+            checked += 1
+        c, d = sorted(tc)[2], sorted(td)[2]
+        tot_c += c; tot_d += d
+        rows["q%d" % q] = {"compress_batch_ms": round(c * 1e3, 3), "compress_images_per_s": round(n / c, 0), "decompress_batch_ms": round(d * 1e3, 3),
+                           "decompress_images_per_s": round(n / d, 0), "stream_kb_mean": round(float(sum(int(lens[i]) for i in range(n))) / n / 1024, 1),
+                           "decode": {"batch_frames": nb.value, "single_frames": ns.value, "chunks": nc.value, "copied_in_place": nd.value}}
+        if q == 50:  # the same 49 pairs one call per image, as the reference's loop is written (C-ABI: tic_compress / tic_decompress)
+            o1, n1 = np.empty(cap, np.uint8), C.c_size_t()
+            p1 = np.empty((h, w), np.uint8)
+            t0 = time.perf_counter()
+            for i in range(n):
+                ctx.check(L.tic_compress(ctx.handle, frames[i].ctypes.data, h, w, w, q, o1.ctypes.data, cap, C.byref(n1)))
+            t1 = time.perf_counter()
+            for i in range(n):
+                ctx.check(L.tic_decompress(ctx.handle, streams[i].ctypes.data, streams[i].size, p1.ctypes.data, p1.size))
+            t2 = time.perf_counter()
+            per_call = {"quality": 50, "compress_us": round((t1 - t0) / n * 1e6, 1), "decompress_us": round((t2 - t1) / n * 1e6, 1),
+                        "compress_images_per_s": round(n / (t1 - t0), 0), "decompress_images_per_s": round(n / (t2 - t1), 0)}
+    return {"workload": "%d images of %dx%d (the reference's data/1..49.gif as committed pixels) x quality 90, 80, 50, 20, 10, 5: tic_compress_batch then "
+                        "tic_decompress_batch, host memory to host memory, median of 5 calls each" % (n, h, w),
+            "compress_images_per_s": round(6 * n / tot_c, 0), "decompress_images_per_s": round(6 * n / tot_d, 0), "by_quality": rows, "per_call": per_call,
+            "parity": {"status": "ok", "pairs_checked": checked, "against": "tests/golden/benchmark_set.json (size + sha256 of the reference's stream and of its "
+                       "decoded image, per image and quality)", "checked": "the streams and images the timed calls produced"},
+            "reference": "the reference's compress() takes ~0.3 s and its decompress() ~0.14 s per 512 x 512 image on its authors' laptop (BASELINE.md section 1)"}
 
 
 def cpu_baseline(img, q, budget_s, threads):

@@ -235,6 +235,18 @@ int tic_idctq_scaled(tic_ctx *ctx, const int16_t *coeffs_zz, int h, int w, int e
  * encoder (header flag 1<<30 -> scaled_dct branch): host Huffman/RLE decode (huffman.py:36-38,66-98), GPU dequantise +
  * inverse DCT (utils.py:40-45,52) + clip + truncating uint8 cast.  out: uint8[h*w]. */
 int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, size_t cap);
+/* decompress() codec.py:167-189 of `n` streams in one call - the mirror of tic_compress_batch; what the loop of the reference's own
+ * benchmark does one stream at a time (tests/benchmark.py:12-23).  Frame i: exactly what tic_decompress(ctx, streams[i], lens[i], outs[i],
+ * caps[i]) gives; hs[i] / ws[i] (either array may be null) receive its geometry.  The streams of a chunk go up in one copy, are decoded by
+ * ONE launch of each of the device decoder's two kernels, and their pixels come down in one copy (straight into outs[] where the frames
+ * follow each other in memory).  Frames the batch kernels do not take - short or damaged streams, C-encoder streams - are decoded by
+ * tic_decompress itself behind the batch.  Headers are checked before any work (first bad frame's error, nothing decoded); a decode
+ * error is the first failing frame's, all other frames are complete. */
+int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size_t *lens, int n, uint8_t *const *outs, const size_t *caps,
+                         int *hs, int *ws);
+/* How the last tic_decompress_batch went (any pointer may be null): frames decoded by the batch kernels, frames that took the
+ * single-frame call, chunks, frames whose pixels were copied straight into the caller's memory. */
+int tic_last_decompress_batch(tic_ctx *ctx, int *batch_frames, int *single_frames, int *chunks, int *direct_frames);
 /* decompress() with stream and pixels both resident in device memory - the counterpart of tic_compress_dev (decompress()
  * codec.py:167-189 between two device buffers).  d_out receives h rows of w pixels, out_stride bytes apart (out_cap: bytes of
  * the buffer); *h / *w (may be null) receive the geometry of the header.  Long streams never leave the device; short ones and

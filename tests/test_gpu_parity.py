@@ -133,7 +133,7 @@ def test_which_build_of_the_library_this_process_runs():
 SHIPPED_SUBSET = ("test_which_build_of_the_library_this_process_runs or test_rare_paths_of_the_strip_kernel or test_tie_blocks or test_near_ties_round2 "
                   "or test_flat_banded_and_checkerboard_content_vs_goldens or test_truncated_streams_round2 or test_decoder_edges_round3 "
                   "or (test_config5_16384_coefficient_digest and 50) or test_decompress_dev_wrong_guess_writes_nothing_outside_the_image "
-                  "or test_device_decoder_at_the_stream_end or test_scaled_dct_streams_round2")
+                  "or test_device_decoder_at_the_stream_end or test_scaled_dct_streams_round2 or test_decompress_batch_mixed_streams")
 
 
 def test_rare_paths_and_decoder_edges_on_the_shipped_library():
@@ -1501,12 +1501,23 @@ def test_the_references_own_benchmark_set(ctx, monkeypatch):
                 streams = T.compress_batch(frames, q, threads=threads, ctx=ctx)
                 for i, s in enumerate(streams, 1):
                     assert len(s) == ents[i]["bytes"] and sha(s) == ents[i]["sha256"], (i, q, threads)
+            # the reference's loop as two calls per quality (round 6): 49 images -> 49 streams -> 49 images, one chunk, every frame on the batch kernels
+            images = T.decompress_batch(streams, ctx=ctx)
+            nb, ns, nc, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            ctx.check(L.tic_last_decompress_batch(ctx.handle, C.byref(nb), C.byref(ns), C.byref(nc), C.byref(nd)))
+            assert (nb.value, ns.value, nc.value, nd.value) == (49, 0, 1, 49), (q, nb.value, ns.value, nc.value, nd.value)
+            for i, im in enumerate(images, 1):
+                assert im.dtype == np.uint8 and im.shape == (512, 512) and sha(np.ascontiguousarray(im).tobytes()) == ents[i]["decoded_sha256"], (i, q, "decompress_batch")
+            rbits, tries = C.c_int(), C.c_int()
             for i in range(1, 50):
                 e, img = ents[i], px[i - 1]
                 s = T.compress(img, q, ctx=ctx)
                 assert len(s) == e["bytes"] and sha(s) == e["sha256"], (i, q)
                 out = T.decompress(s, ctx=ctx)
                 assert out.dtype == np.uint8 and sha(np.ascontiguousarray(out).tobytes()) == e["decoded_sha256"], (i, q)
+                # round 6: every stream of the set - down to 8 bits per block at q = 5 - on the device decoder, in ONE run
+                ctx.check(L.tic_last_decode_range(ctx.handle, C.byref(rbits), C.byref(tries)))
+                assert L.tic_last_decode_path(ctx.handle) == 1 and tries.value == 1, (i, q, L.tic_last_decode_path(ctx.handle), tries.value)
                 if i % 7 == 0:  # the serial host decoder and the resident pair on a spread of the images
                     monkeypatch.setenv("TIC_DECODE_SERIAL", "1")
                     assert sha(T.decompress(s, ctx=ctx).tobytes()) == e["decoded_sha256"], (i, q)
@@ -1524,6 +1535,58 @@ def test_the_references_own_benchmark_set(ctx, monkeypatch):
     finally:
         for d in (d_img, d_str, d_pix):
             L.tic_dev_free(ctx.handle, d)
+
+
+def test_decompress_batch_mixed_streams(ctx, oracle, golden):
+    """decompress_batch() == [decompress(s) for s in streams] on a batch of everything: unequal geometries and qualities, dense and sparse
+    content, ragged shapes (row pitch != width in the device buffer), an empty image, a stream too short for the device decoder, a
+    C-encoder stream (scaled_dct), a cut stream and one with a flipped bit (both end on the host decoder), a 2048^2 frame of noise at
+    q = 90 (the fused kernel's large window).  Through the C-ABI with scattered destinations too (the pinned route instead of the direct copy);
+    and the exceptions of decompress() for a stream shorter than its header and for one flagged as carrying a table."""
+    import struct
+
+    L = N.load()
+    rs = np.random.RandomState(5)
+    imgs = [(rand_frame(31, 512, 512), 50), (rand_frame(32, 520, 776), 80), (np.full((512, 640), 77, np.uint8), 50), (rand_frame(33, 1080, 1920), 20),
+            ((rand_frame(34, 600, 1000) // 64 * 64).astype(np.uint8), 10), (rand_frame(35, 203, 517), 90), (rand_frame(36, 64, 64), 50), (np.zeros((0, 8), np.uint8), 50),
+            (rand_frame(37, 2048, 2048), 90), (np.tile(golden("lenna")["img"], (2, 2)), 5), (rand_frame(38, 512, 512), 50)]
+    streams = [T.compress(im, q, ctx=ctx) for im, q in imgs]
+    sc = golden("scaled_streams")
+    streams.append(sc[str(sc["names"][0]) + "_bs"].tobytes())                      # a stream of the reference's C encoder
+    cut = streams[0][: len(streams[0]) * 2 // 3]
+    flip = bytearray(streams[3]); flip[len(flip) // 2] ^= 0x10
+    streams += [cut, bytes(flip)]
+    want = [oracle.decompress(s) for s in streams]
+    got = T.decompress_batch(streams, ctx=ctx)
+    assert len(got) == len(want)
+    for k, (g, w_) in enumerate(zip(got, want)):
+        assert g.dtype == np.uint8 and g.shape == w_.shape and np.array_equal(g, w_), k
+    nb, ns, nc, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ctx.check(L.tic_last_decompress_batch(ctx.handle, C.byref(nb), C.byref(ns), C.byref(nc), C.byref(nd)))
+    assert nb.value >= 8 and ns.value >= 3 and nb.value + ns.value == len(streams) - 1, (nb.value, ns.value)  # (the empty image takes neither)
+    # scattered destinations, as a C caller might hold them: same pixels through the pinned route
+    n = len(streams)
+    bufs = [np.frombuffer(s, np.uint8) for s in streams]
+    outs = [np.full(max(w_.size, 1) + 64, 0xCD, np.uint8) for w_ in want]
+    hs, ws = (C.c_int * n)(), (C.c_int * n)()
+    ctx.check(L.tic_decompress_batch(ctx.handle, (C.c_void_p * n)(*[b.ctypes.data for b in bufs]), (C.c_size_t * n)(*[b.size for b in bufs]), n,
+                                     (C.c_void_p * n)(*[o.ctypes.data for o in outs]), (C.c_size_t * n)(*[w_.size for w_ in want]), hs, ws))
+    for k, (o, w_) in enumerate(zip(outs, want)):
+        assert (hs[k], ws[k]) == w_.shape and np.array_equal(o[: w_.size].reshape(w_.shape), w_) and np.all(o[w_.size:] == 0xCD), k
+    ctx.check(L.tic_last_decompress_batch(ctx.handle, None, None, None, C.byref(nd)))
+    assert nd.value == 0
+    # a destination too small: the error of the first such frame, before anything is decoded
+    caps = (C.c_size_t * n)(*[w_.size for w_ in want])
+    caps[4] -= 1
+    assert L.tic_decompress_batch(ctx.handle, (C.c_void_p * n)(*[b.ctypes.data for b in bufs]), (C.c_size_t * n)(*[b.size for b in bufs]), n,
+                                  (C.c_void_p * n)(*[o.ctypes.data for o in outs]), caps, None, None) == N.TIC_E_SPACE
+    assert "frame 4" in L.tic_last_error(ctx.handle).decode()
+    with pytest.raises(struct.error):
+        T.decompress_batch([streams[0], streams[1][:10]], ctx=ctx)
+    tab = bytearray(streams[0]); tab[15] |= 0x80
+    with pytest.raises(ValueError):
+        T.decompress_batch([streams[0], bytes(tab)], ctx=ctx)
+    assert T.decompress_batch([], ctx=ctx) == []
 
 
 def test_decompress_dev_resident_round_trip(ctx, oracle):

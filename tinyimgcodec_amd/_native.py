@@ -131,6 +131,9 @@ SIGNATURES = {
     "tic_idctq": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "tic_idctq_scaled": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "tic_decompress": (C.c_int, [_ctxp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "tic_decompress_batch": (C.c_int, [_ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tic_last_decompress_batch": (C.c_int, [_ctxp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tic_decompress_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_ssize_t, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tic_last_decode_path": (C.c_int, [_ctxp]),
     "tic_last_decode_giveup": (C.c_int, [_ctxp]),

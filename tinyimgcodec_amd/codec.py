@@ -301,6 +301,37 @@ def decompress(data, ctx=None):
     return out
 
 
+def decompress_batch(streams, ctx=None):
+    """decompress() of many streams in one call -> list of uint8 arrays (stream order): the mirror of compress_batch, i.e. the loop of the
+    reference's benchmark (/root/reference/tests/benchmark.py:12-23: `decompress(data)` per image) as ONE call.  Every element is what
+    decompress() returns for that stream; the exceptions are decompress()'s (the first offending stream's, before anything is decoded).
+    The streams go up in one copy, two kernel launches decode all of them, the pixels come down in one copy (tic_decompress_batch)."""
+    ctx = _ctx(ctx)
+    bufs = [_as_bytes_view(d) for d in streams]
+    n = len(bufs)
+    if n == 0:
+        return []
+    hdrs = [parse_header(b) for b in bufs]  # struct.error for fewer than 16 bytes, as codec.py:118-119
+    for hd in hdrs:
+        if hd["flag"] & (1 << 31):
+            raise ValueError("stream carries an embedded Huffman table (little-endian flag bit 31): not supported")
+    # one block for all frames: equal geometries follow each other in memory, and the library copies the pixels of a chunk straight into it
+    sizes = [max(hd["height"], 0) * max(hd["width"], 0) for hd in hdrs]
+    block = np.zeros(sum(sizes), dtype=np.uint8)
+    outs, at = [], 0
+    for hd, sz in zip(hdrs, sizes):
+        outs.append(block[at:at + sz].reshape(max(hd["height"], 0), max(hd["width"], 0)) if sz else np.zeros((max(hd["height"], 0), max(hd["width"], 0)), np.uint8))
+        at += sz
+    L = N.load()
+    sp = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    sl = (C.c_size_t * n)(*[b.size for b in bufs])
+    op = (C.c_void_p * n)(*[o.ctypes.data if o.size else None for o in outs])
+    oc = (C.c_size_t * n)(*[o.size for o in outs])
+    with ctx.lock:
+        ctx.check(L.tic_decompress_batch(ctx.handle, sp, sl, n, op, oc, None, None))
+    return outs
+
+
 def decode(data, ctx=None):
     """decode() of the reference: dict with height, width, quality, scaled_dct, dc (DPCM'd), ac."""
     ctx = _ctx(ctx)

@@ -6,6 +6,7 @@
 
 #include <sched.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
@@ -49,6 +50,13 @@ struct BatchTrace {
 
 constexpr size_t kDecTailEnd = 512, kDecTailCoef = 64 * 1024; // device decoder: bytes of stream end prefetched, bytes of tail coefficients (pinned)
 constexpr int kChunk = 16;
+// ... of small frames more: a chunk of sixteen 512 x 512 frames is 4 MB - its copies and launches cost as much as its work (the reference's
+// benchmark set, 49 such frames, took four chunks: 20,000 frames/s); up to 64 frames while a chunk's pixels stay within 32 MB
+static inline int chunk_frames(int n, size_t img_bytes) {
+    size_t c = img_bytes ? (32u << 20) / img_bytes : (size_t)kChunk;
+    c = c < (size_t)kChunk ? (size_t)kChunk : (c > 64 ? 64 : c);
+    return n < (int)c ? n : (int)c;
+}
 struct Slot {
     uint8_t *pin_in = nullptr;
     int16_t *pin_out = nullptr;
@@ -163,6 +171,22 @@ struct tic_ctx {
     int last_decode_guess = 0;                                  // tic_decompress_dev: 1 the last call's guess of the header held, -1 it did not (decoded again), 0 no guess
     int last_decode_range = 0, last_decode_tries = 0;          // stream bits per lane of the device decoder's last run, and how many runs the last long stream took
     int last_decode_giveup = 0;                                // why the device decoder handed the last long stream to the host (DecStatus::giveup bits)
+    // batched decode (tic_decompress_batch): one pinned + one device buffer for a chunk's descriptors and streams, a device and a pinned
+    // buffer for its pixels, workspace, look-back words and per-frame status words - kept across calls
+    struct DecBatch {
+        uint8_t *h_in = nullptr, *d_in = nullptr;
+        size_t in_cap = 0;
+        uint8_t *d_pix = nullptr, *h_pix = nullptr;
+        size_t pix_cap = 0, hpix_cap = 0;
+        void *d_work = nullptr;
+        size_t work_bytes = 0;
+        unsigned long long *d_desc = nullptr;
+        size_t desc_words = 0;
+        uint32_t epoch = 0;
+        DecStatus *h_status = nullptr, *d_status = nullptr;
+        size_t status_cap = 0;
+    } dbat;
+    int last_dbatch_frames = 0, last_dbatch_fallback = 0, last_dbatch_chunks = 0, last_dbatch_direct = 0;
     // batch pipeline buffers, kept across calls (pinned allocations are expensive)
     std::vector<Slot> bslots;
     size_t bslot_img_bytes = 0, bslot_coef_bytes = 0;
@@ -336,6 +360,13 @@ void tic_destroy(tic_ctx *ctx) {
         if (sl.h_status) (void)hipHostFree(sl.h_status);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
+    if (ctx->dbat.h_in) (void)hipHostFree(ctx->dbat.h_in);
+    if (ctx->dbat.d_in) (void)hipFree(ctx->dbat.d_in);
+    if (ctx->dbat.d_pix) (void)hipFree(ctx->dbat.d_pix);
+    if (ctx->dbat.h_pix) (void)hipHostFree(ctx->dbat.h_pix);
+    if (ctx->dbat.d_work) (void)hipFree(ctx->dbat.d_work);
+    if (ctx->dbat.d_desc) (void)hipFree(ctx->dbat.d_desc);
+    if (ctx->dbat.h_status) (void)hipHostFree(ctx->dbat.h_status);
     if (ctx->dec_order) (void)hipEventDestroy(ctx->dec_order);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1339,7 +1370,7 @@ static int batch_impl(tic_ctx *ctx, const uint8_t *const *images, int n, int h, 
     const bool need_d2h = want_entropy || coeffs != nullptr;
     const size_t pitch = batch_pitch(w);
     const size_t img_bytes = pitch * (size_t)h, coef_bytes = nblk * 128;
-    const int chunk = n < kChunk ? n : kChunk;
+    const int chunk = chunk_frames(n, img_bytes);
     const int S = 3;
     int result = TIC_OK;
     rc = ensure_batch_slots(ctx, h, w, chunk);
@@ -1488,7 +1519,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t pitch = batch_pitch(w);
     const size_t img_bytes = pitch * (size_t)h, coef_bytes = nblk * 128, bound = align_up(compress_bound(h, w), 16);
-    const int chunk = n < kChunk ? n : kChunk;
+    const int chunk = chunk_frames(n, img_bytes);
     rc = ensure_batch_slots(ctx, h, w, chunk);
     if (rc) return rc;
     std::vector<Slot> &slots = ctx->bslots;
@@ -2121,6 +2152,284 @@ int tic_decompress(tic_ctx *ctx, const uint8_t *data, size_t len, uint8_t *out, 
     entropy_decode(data, len, h, w, ctx->h_zz);
     ctx->last_decode_path = 2;
     return idctq_impl(ctx, ctx->h_zz, h, w, scaled ? 50 : quality, scaled ? quality : -1, out, cap);
+}
+
+// decompress() of MANY streams at once (the mirror of tic_compress_batch; the reference's benchmark loop, tests/benchmark.py:12-23, decodes
+// 49 streams of 512 x 512 per quality one call after the other: 94-105 us each, launch and copy latency).  The streams of a chunk are packed
+// into one pinned buffer behind their descriptors and go up in ONE copy; ONE measure launch and ONE fused launch decode all of them (the
+// batch forms of the two kernels: every wave and workgroup looks up its frame, nothing crosses a frame - the DC sum starts over with every
+// frame, codec.py:53); the pixels of the chunk come down in ONE copy - straight into the caller's buffers where they follow each other in
+// memory (pinned for the call by one hipHostRegister), else through the context's pinned buffer and a few copy threads.
+// Frame i: what tic_decompress(ctx, streams[i], lens[i], outs[i], caps[i]) gives, geometry in hs[i] / ws[i] (either may be null).  A frame the
+// batch kernels do not take (a short or damaged stream, a C-encoder stream, anything the device decoder flags) is decoded by that very
+// call afterwards.  Errors: headers are checked before any work (the first bad frame's error, nothing decoded); an error while decoding is
+// the first failing frame's, the other frames are complete.
+int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size_t *lens, int n, uint8_t *const *outs, const size_t *caps, int *hs, int *ws) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    if (n < 0 || (n > 0 && (!streams || !lens || !outs || !caps))) return set_err(ctx, TIC_E_ARG, "bad batch arguments");
+    ctx->last_dbatch_frames = ctx->last_dbatch_fallback = ctx->last_dbatch_chunks = ctx->last_dbatch_direct = 0;
+    if (n == 0) return TIC_OK;
+    struct Fr { int h, w, q; size_t nblk; bool batch; };
+    std::vector<Fr> fr((size_t)n);
+    for (int i = 0; i < n; i++) { // the checks of tic_decompress, for every frame, before any work
+        int h, w, quality;
+        uint32_t flag;
+        if (!streams[i] || parse_header(streams[i], lens[i], &h, &w, &quality, &flag) != TIC_OK) return set_err(ctx, TIC_E_STREAM, "frame %d: stream shorter than the 16-byte header", i);
+        if (flag & (1u << 31)) return set_err(ctx, TIC_E_STREAM, "frame %d: streams with an embedded Huffman table are not supported", i);
+        const bool scaled = (flag & (1u << 30)) != 0;
+        if (h < 0 || w < 0) return set_err(ctx, TIC_E_STREAM, "frame %d: bad geometry in header", i);
+        if (scaled && (quality < 0 || quality > 62)) return set_err(ctx, TIC_E_QUALITY, "frame %d: scaled_dct exponent %d in header outside 0..62", i, quality);
+        if (!scaled && (quality < 1 || quality > 99)) return set_err(ctx, TIC_E_QUALITY, "frame %d: quality %d in header outside 1..99", i, quality);
+        const size_t nb = num_blocks(h, w);
+        if (nb && (!outs[i] || (size_t)h * (size_t)w > caps[i])) return set_err(ctx, TIC_E_SPACE, "frame %d: output buffer too small", i);
+        if (hs) hs[i] = h;
+        if (ws) ws[i] = w;
+        fr[(size_t)i] = {h, w, quality, nb, nb != 0 && !scaled && device_decoder_takes(nb, lens[i]) && !test_hook("TIC_DECODE_HOST") && !test_hook("TIC_DECODE_SERIAL")};
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_dec_luts) { // (as decode_on_device: the tables go up with the context's first device decode)
+        std::unique_ptr<DecLutsDev> l(new DecLutsDev());
+        dec_luts_fill(l->dc11, l->ac11, l->ac16);
+        dec_chain_luts_fill(l->mdc, l->mac, l->mlong);
+        dec_pair_luts_fill(l->ac2, l->long32);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_dec_luts, sizeof(DecLutsDev)));
+        HIPCHK(ctx, hipMemcpy(ctx->d_dec_luts, l.get(), sizeof(DecLutsDev), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_dec_status, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->d_dec_status, ctx->h_dec_status, 0));
+    }
+    tic_ctx::DecBatch &B = ctx->dbat;
+    auto grow_dev = [&](void **p, size_t *cap, size_t need) -> int {
+        if (need <= *cap) return TIC_OK;
+        if (*p) HIPCHK(ctx, hipFree(*p));
+        *p = nullptr, *cap = 0;
+        HIPCHK(ctx, hipMalloc(p, need + need / 4));
+        *cap = need + need / 4;
+        return TIC_OK;
+    };
+    auto grow_pin = [&](uint8_t **p, size_t *cap, size_t need) -> int {
+        if (need <= *cap) return TIC_OK;
+        if (*p) HIPCHK(ctx, hipHostFree(*p));
+        *p = nullptr, *cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void **)p, need + need / 4, hipHostMallocDefault));
+        *cap = need + need / 4;
+        return TIC_OK;
+    };
+    // chunks: frames in order, while the chunk's streams, pixels and frame count stay inside the limits (one 512 x 512 benchmark set - 49
+    // frames, 12.8 MB of pixels - is one chunk; sixteen 4096^2 frames are one)
+    constexpr size_t kMaxIn = 96u << 20, kMaxPix = 288u << 20;
+    constexpr int kMaxFrames = 1024;
+    int result = TIC_OK;
+    auto fail = [&](int rc) { if (result == TIC_OK) result = rc; };
+    std::vector<int> later; // frames for the single-frame call
+    for (int i = 0; i < n; i++)
+        if (!fr[(size_t)i].batch && fr[(size_t)i].nblk) later.push_back(i);
+    int i0 = 0;
+    while (i0 < n) {
+        // ---- the chunk's frames and the layout of its buffers
+        std::vector<int> ids;
+        size_t in_bytes = 0, pix_bytes = 0, ranges288 = 0, blocks = 0;
+        int range_bits = 0;
+        bool small_win = true;
+        int i1 = i0;
+        for (; i1 < n; i1++) {
+            const Fr &f = fr[(size_t)i1];
+            if (!f.batch) continue;
+            const size_t pitch = (size_t)(f.w % 8 == 0 ? f.w : (f.w + 7) / 8 * 8);
+            const size_t sb = align_up(lens[i1], 16) + 16, pb = align_up(pitch * (size_t)f.h, 256);
+            if (!ids.empty() && (in_bytes + sb > kMaxIn || pix_bytes + pb > kMaxPix || (int)ids.size() >= kMaxFrames)) break;
+            ids.push_back(i1);
+            in_bytes += sb, pix_bytes += pb, blocks += f.nblk, ranges288 += lens[i1] * 8 / 288 + 2;
+            const int rb = decode_range_bits(lens[i1], f.nblk);
+            range_bits = rb > range_bits ? rb : range_bits;
+            small_win = small_win && lens[i1] * 8 / f.nblk <= 240;
+        }
+        i0 = i1;
+        if (ids.empty()) break;
+        const uint32_t F = (uint32_t)ids.size();
+        std::vector<DecFrame> frames(F);
+        std::vector<size_t> pix_off(F), pitches(F);
+        uint32_t tiles = 0, wgs = 0, ranges = 0;
+        size_t blk = 0, words = 0, poff = 0;
+        for (uint32_t k = 0; k < F; k++) {
+            const int i = ids[k];
+            const Fr &f = fr[(size_t)i];
+            DecFrame &d = frames[k];
+            const size_t len = lens[i];
+            d.word0 = (uint32_t)words;
+            d.nwords = (uint32_t)((len + 3) / 4);
+            d.last_mask = (len & 3) ? 0xffffffffu << (8u * (4u - (uint32_t)(len & 3))) : 0xffffffffu;
+            d.stream_bits = d.fast_end = (uint32_t)(len * 8);
+            d.nranges = entropy_decode_batch_ranges(len, range_bits);
+            d.range0 = ranges;
+            d.tile0 = tiles;
+            d.ntiles = entropy_decode_batch_tiles(d.nranges);
+            d.blk0 = (uint32_t)blk;
+            d.nblocks = (uint32_t)f.nblk;
+            d.wg0 = wgs;
+            d.nwgs = entropy_decode_batch_wgs(f.nblk);
+            d.pad_ = 0;
+            pitches[k] = (size_t)(f.w % 8 == 0 ? f.w : (f.w + 7) / 8 * 8);
+            pix_off[k] = poff;
+            d.idct.out = nullptr; // (set below, when the pixel buffer exists)
+            d.idct.h = f.h, d.idct.w = f.w;
+            d.idct.stride = (long)pitches[k];
+            d.idct.bw = (f.w + 7) / 8;
+            d.idct.aligned8 = 1;
+            d.idct.consts = ctx->d_consts + f.q;
+            d.idct.scaled = 0;
+            d.idct.pow2 = 1.0;
+            memcpy(d.idct.head, streams[i], 16);
+            words += (align_up(len, 16) + 16) / 4;
+            ranges += d.nranges, tiles += d.ntiles, wgs += d.nwgs, blk += f.nblk;
+            poff += align_up(pitches[k] * (size_t)f.h, 256);
+        }
+        // one upload: descriptors, the frame of every measure wave, the frame of every fused workgroup, the streams
+        const size_t o_frames = 0, o_tiles = align_up(o_frames + F * sizeof(DecFrame), 256), o_wgs = align_up(o_tiles + (size_t)tiles * 4, 256),
+                     o_streams = align_up(o_wgs + (size_t)wgs * 4, 256), up_bytes = o_streams + words * 4;
+        if (up_bytes > B.in_cap) { // the pinned upload buffer and its device mirror grow together
+            if (B.h_in) HIPCHK(ctx, hipHostFree(B.h_in));
+            if (B.d_in) HIPCHK(ctx, hipFree(B.d_in));
+            B.h_in = B.d_in = nullptr, B.in_cap = 0;
+            const size_t cap = up_bytes + up_bytes / 4;
+            HIPCHK(ctx, hipHostMalloc((void **)&B.h_in, cap, hipHostMallocDefault));
+            HIPCHK(ctx, hipMalloc((void **)&B.d_in, cap));
+            B.in_cap = cap;
+        }
+        int rc = TIC_OK;
+        rc = grow_dev((void **)&B.d_pix, &B.pix_cap, poff);
+        if (rc) return rc;
+        rc = grow_dev(&B.d_work, &B.work_bytes, entropy_decode_batch_work_bytes(ranges288, blocks, F));
+        if (rc) return rc;
+        {
+            size_t dw = 4 * (size_t)((tiles > wgs ? tiles : wgs) + 2);
+            if (dw > B.desc_words) {
+                dw = dw < 8192 ? 8192 : 2 * dw;
+                if (B.d_desc) HIPCHK(ctx, hipFree(B.d_desc));
+                B.d_desc = nullptr, B.desc_words = 0;
+                HIPCHK(ctx, hipMalloc((void **)&B.d_desc, dw * 8));
+                HIPCHK(ctx, hipMemset(B.d_desc, 0, dw * 8));
+                B.desc_words = dw;
+                B.epoch = 0;
+            }
+            if (F > B.status_cap) {
+                if (B.h_status) HIPCHK(ctx, hipHostFree(B.h_status));
+                B.h_status = nullptr, B.status_cap = 0;
+                const size_t cap = F < 256 ? 256 : 2 * (size_t)F;
+                HIPCHK(ctx, hipHostMalloc((void **)&B.h_status, cap * sizeof(DecStatus), hipHostMallocMapped | hipHostMallocCoherent));
+                HIPCHK(ctx, hipHostGetDevicePointer((void **)&B.d_status, B.h_status, 0));
+                B.status_cap = cap;
+            }
+        }
+        for (uint32_t k = 0; k < F; k++) frames[k].idct.out = B.d_pix + pix_off[k];
+        memcpy(B.h_in + o_frames, frames.data(), F * sizeof(DecFrame));
+        {
+            uint32_t *tf = (uint32_t *)(B.h_in + o_tiles), *wf = (uint32_t *)(B.h_in + o_wgs);
+            for (uint32_t k = 0; k < F; k++) {
+                for (uint32_t t = 0; t < frames[k].ntiles; t++) tf[frames[k].tile0 + t] = k;
+                for (uint32_t g = 0; g < frames[k].nwgs; g++) wf[frames[k].wg0 + g] = k;
+            }
+            for (uint32_t k = 0; k < F; k++) { // (the bytes behind a stream's last word are never read: no need to clear them)
+                memcpy(B.h_in + o_streams + (size_t)frames[k].word0 * 4, streams[ids[k]], lens[ids[k]]);
+            }
+        }
+        memset(B.h_status, 0, F * sizeof(DecStatus));
+        if (++B.epoch >= (1u << 22)) {
+            HIPCHK(ctx, hipMemsetAsync(B.d_desc, 0, B.desc_words * 8, ctx->stream));
+            B.epoch = 1;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(B.d_in, B.h_in, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, entropy_decode_idct_gpu_batch(B.d_in + o_streams, (const DecFrame *)(B.d_in + o_frames), (const uint32_t *)(B.d_in + o_tiles), (const uint32_t *)(B.d_in + o_wgs), F, tiles,
+                                                  wgs, ranges, blk, small_win, ctx->d_dec_luts, B.d_work, B.work_bytes, B.d_desc, B.desc_words, B.epoch, B.d_status, range_bits,
+                                                  ctx->stream));
+        // ---- the pixels come down: one copy into the caller's memory where the frames are dense and follow each other there, else one copy
+        // into pinned memory and a few threads
+        bool dense = true;
+        for (uint32_t k = 0; k < F && dense; k++)
+            dense = pitches[k] == (size_t)fr[(size_t)ids[k]].w && (k == 0 || (outs[ids[k]] == outs[ids[k - 1]] + (pix_off[k] - pix_off[k - 1])));
+        bool direct = false;
+        if (dense && ctx->auto_register) {
+            const size_t total = pix_off[F - 1] + (size_t)fr[(size_t)ids[F - 1]].h * (size_t)fr[(size_t)ids[F - 1]].w;
+            bool pinned = host_pointer_is_pinned(outs[ids[0]]) && host_pointer_is_pinned(outs[ids[0]] + total - 1);
+            void *reg = nullptr;
+            if (!pinned && total >= (256u << 10)) {
+                const uintptr_t lo = (uintptr_t)outs[ids[0]] & ~(uintptr_t)4095, hi = ((uintptr_t)outs[ids[0]] + total + 4095) & ~(uintptr_t)4095;
+                if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+                    reg = (void *)lo;
+                    pinned = true;
+                } else
+                    (void)hipGetLastError();
+            }
+            if (pinned) {
+                hipError_t e = hipMemcpyAsync(outs[ids[0]], B.d_pix, total, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                direct = e == hipSuccess;
+                if (!direct) (void)hipGetLastError();
+            }
+            if (reg && hipHostUnregister(reg) != hipSuccess) (void)hipGetLastError();
+        }
+        if (!direct) {
+            rc = grow_pin(&B.h_pix, &B.hpix_cap, poff);
+            if (rc) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(B.h_pix, B.d_pix, poff, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        ctx->last_dbatch_chunks++;
+        ctx->last_dbatch_direct += direct ? (int)F : 0;
+        // ---- what the kernels report, frame by frame: the header they saw, nothing flagged, every block produced
+        std::vector<char> good(F);
+        for (uint32_t k = 0; k < F; k++) {
+            const DecStatus &st = B.h_status[k];
+            good[k] = memcmp(st.head, streams[ids[k]], 16) == 0 && st.giveup == 0 && st.m == (unsigned long long)frames[k].nblocks;
+            if (good[k]) ctx->last_dbatch_frames++;
+            else later.push_back(ids[k]);
+        }
+        if (!direct) {
+            auto hand_out = [&](int t, int T) {
+                if (T > 1) bind_pipeline_thread(ctx);
+                for (uint32_t k = (uint32_t)t; k < F; k += (uint32_t)T) {
+                    if (!good[k]) continue;
+                    const Fr &f = fr[(size_t)ids[k]];
+                    const uint8_t *src = B.h_pix + pix_off[k];
+                    if (pitches[k] == (size_t)f.w) memcpy(outs[ids[k]], src, (size_t)f.h * (size_t)f.w);
+                    else for (int y = 0; y < f.h; y++) memcpy(outs[ids[k]] + (size_t)y * (size_t)f.w, src + (size_t)y * pitches[k], (size_t)f.w);
+                }
+            };
+            const int T = poff < (2u << 20) || F < 2 ? 1 : (F < 8 ? (int)F : 8);
+            if (T == 1) hand_out(0, 1);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < T; t++) th.emplace_back(hand_out, t, T);
+                for (auto &x : th) x.join();
+            }
+        }
+    }
+    // frames the batch did not take, or did not finish: the single-frame call, with everything it knows (second run, host decoders)
+    std::sort(later.begin(), later.end());
+    for (int i : later) {
+        const int rc = tic_decompress(ctx, streams[i], lens[i], outs[i], caps[i]);
+        ctx->last_dbatch_fallback++;
+        if (rc != TIC_OK) {
+            if (result == TIC_OK) {
+                const std::string m = ctx->err;
+                set_err(ctx, rc, "frame %d: %s", i, m.c_str());
+            }
+            fail(rc);
+        }
+    }
+    return result;
+}
+
+// How the last tic_decompress_batch went: frames decoded by the batch kernels, frames that took the single-frame call (too short for the
+// device decoder, C-encoder streams, anything flagged), chunks, frames whose pixels were copied straight into the caller's memory.
+int tic_last_decompress_batch(tic_ctx *ctx, int *batch_frames, int *single_frames, int *chunks, int *direct_frames) {
+    TIC_LOCK(ctx);
+    if (!ctx) return TIC_E_ARG;
+    if (batch_frames) *batch_frames = ctx->last_dbatch_frames;
+    if (single_frames) *single_frames = ctx->last_dbatch_fallback;
+    if (chunks) *chunks = ctx->last_dbatch_chunks;
+    if (direct_frames) *direct_frames = ctx->last_dbatch_direct;
+    return TIC_OK;
 }
 
 // decompress() with stream and pixels both resident in HBM (the counterpart of tic_compress_dev): only the 16-byte header, the
