@@ -732,6 +732,73 @@ def test_compress_dev_async_matches_the_synchronous_call(ctx, manifest):
             L.tic_dev_free(ctx.handle, d)
 
 
+def test_compress_dev_async_two_lanes_in_one_context(ctx, oracle):
+    """Round 6: the tickets of ONE context alternate between two lanes (transform and packing on the lane's stream, placing on the
+    context's): 40 different frames at alternating qualities in one burst give the synchronous call's streams, ticket by ticket; a frame
+    with a coefficient that has no Huffman code reports TIC_E_RANGE through its own ticket and leaves its neighbours - one on each lane -
+    alone; a synchronous call between two bursts and a decode queued behind a ticket see the tickets' results."""
+    L = N.load()
+    h, w = 1024, 1024
+    frames = [rand_frame(7000 + k, h, w) if k % 5 else (rand_frame(7000 + k, h, w) // 32 * 32).astype(np.uint8) for k in range(40)]
+    quals = [(30, 50, 85, 12)[k % 4] for k in range(40)]
+    loud = np.where((np.indices((h, w))[1] % 8) < 4, 0, 255).astype(np.uint8)  # every block half black, half white: |AC| >= 1024 at q = 99
+    with pytest.raises(KeyError):
+        T.compress(loud, 99, ctx=ctx)
+    frames[17], quals[17] = loud, 99
+    cap = L.tic_compress_bound(h, w)
+    want = [None if k == 17 else oracle.compress(frames[k], quals[k]) for k in range(40)]
+    d_imgs, d_outs = [], []
+    try:
+        for f in frames:
+            a, b = C.c_void_p(), C.c_void_p()
+            ctx.check(L.tic_dev_alloc(ctx.handle, f.size, C.byref(a)))
+            ctx.check(L.tic_dev_alloc(ctx.handle, cap, C.byref(b)))
+            ctx.check(L.tic_memcpy_h2d(ctx.handle, a, np.ascontiguousarray(f).ctypes.data, f.size))
+            d_imgs.append(a)
+            d_outs.append(b)
+        n = C.c_size_t()
+        for burst in range(2):
+            for b in d_outs:
+                ctx.check(L.tic_memset_dev(ctx.handle, b, 0x11, cap))
+            ts = []
+            for k in range(40):
+                t = C.c_longlong()
+                ctx.check(L.tic_compress_dev_async(ctx.handle, d_imgs[k], h, w, w, quals[k], d_outs[k], cap, C.byref(t)))
+                ts.append(t.value)
+            order = range(40) if burst == 0 else reversed(range(40))  # results in any order
+            for k in order:
+                rc = L.tic_async_result(ctx.handle, ts[k], 1, C.byref(n))
+                if k == 17:
+                    assert rc == N.TIC_E_RANGE, rc
+                    continue
+                assert rc == N.TIC_OK and n.value == len(want[k]), (burst, k, rc, n.value)
+                got = np.empty(n.value, np.uint8)
+                ctx.check(L.tic_memcpy_d2h(ctx.handle, got.ctypes.data, d_outs[k], n.value))
+                assert got.tobytes() == want[k], (burst, k)
+            # a synchronous call between the bursts (the context's own scratch, the context's stream)
+            ctx.check(L.tic_compress_dev(ctx.handle, d_imgs[3], h, w, w, quals[3], d_outs[3], cap, C.byref(n)))
+            assert n.value == len(want[3])
+        # a decode queued right behind a ticket, before the ticket is collected: it sees the ticket's stream (the placing kernels run on the
+        # context's stream, the decoder starts behind everything queued there)
+        d_pix = C.c_void_p()
+        ctx.check(L.tic_dev_alloc(ctx.handle, h * w, C.byref(d_pix)))
+        d_imgs.append(d_pix)
+        for _ in range(3):  # (two equal headers in a row before the decoder launches on a guess)
+            ctx.check(L.tic_decompress_dev(ctx.handle, d_outs[3], len(want[3]), d_pix, w, h * w, None, None))
+        ctx.check(L.tic_memset_dev(ctx.handle, d_outs[3], 0, cap))
+        t, td = C.c_longlong(), C.c_longlong()
+        ctx.check(L.tic_compress_dev_async(ctx.handle, d_imgs[3], h, w, w, quals[3], d_outs[3], cap, C.byref(t)))
+        ctx.check(L.tic_decompress_dev_async(ctx.handle, d_outs[3], len(want[3]), d_pix, w, h * w, C.byref(td)))
+        ctx.check(L.tic_decompress_async_result(ctx.handle, td.value, 1, None, None))
+        ctx.check(L.tic_async_result(ctx.handle, t.value, 1, C.byref(n)))
+        pix = np.empty((h, w), np.uint8)
+        ctx.check(L.tic_memcpy_d2h(ctx.handle, pix.ctypes.data, d_pix, pix.size))
+        assert np.array_equal(pix, oracle.decompress(want[3]))
+    finally:
+        for d in d_imgs + d_outs:
+            L.tic_dev_free(ctx.handle, d)
+
+
 def test_compress_batch_over_several_contexts(ctx, manifest):
     """tic_compress_batch_multi / compress_batch(devices=[...]) (round 5): one process, a context and a host thread per listed device,
     contiguous shards, sizes in frame order - on a one-GPU box two contexts on device 0.  Streams equal the single-context batch

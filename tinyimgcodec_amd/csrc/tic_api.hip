@@ -110,6 +110,25 @@ struct tic_ctx {
     struct AsyncSlot { long long ticket = -1; size_t cap = 0; int early_rc = TIC_OK; hipEvent_t done = nullptr; bool empty_image = false; };
     AsyncSlot async_slots[kAsyncSlots];
     long long async_next = 0;
+    // ... their transform and packing kernels run on two LANES in turn (streams of their own, a coefficient buffer, an entropy workspace and
+    // a pair of error flags each), the placing kernels - the only writers of the callers' buffers - on the context's stream in ticket order:
+    // frame t + 1 is transformed and packed beside the packing and placing of frame t (tic_compress_dev_async)
+    struct AsyncLane {
+        hipStream_t stream = nullptr;
+        void *d_coef = nullptr;
+        size_t coef_cap = 0;
+        void *d_work = nullptr;
+        size_t work_bytes = 0;
+        int *d_err = nullptr; // [2], used in turn
+        int parity = 0;
+        hipEvent_t packed = nullptr, placed = nullptr; // the lane's last packing has run / the lane's last frame has been placed (on ctx->stream)
+        bool placed_valid = false;
+        unsigned long long order_seen = 0; // the burst (lane_epoch) whose starting point this lane's stream already waits for
+    };
+    AsyncLane lanes[2];
+    hipEvent_t lane_order = nullptr; // a burst's lanes start behind what the context's stream held when the burst began
+    int async_open = 0;              // tickets open
+    unsigned long long lane_epoch = 0;
     void *d_ent_work = nullptr;                 // workspace of the device entropy stage (tile sums, bit counts, staging slots)
     size_t ent_work_bytes = 0;
     int ent_parity = 0;
@@ -343,6 +362,16 @@ void tic_destroy(tic_ctx *ctx) {
     if (ctx->d_ent_work) (void)hipFree(ctx->d_ent_work);
     for (auto &sl : ctx->async_slots)
         if (sl.done) (void)hipEventDestroy(sl.done);
+    for (auto &ln : ctx->lanes) {
+        if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+        if (ln.d_coef) (void)hipFree(ln.d_coef);
+        if (ln.d_work) (void)hipFree(ln.d_work);
+        if (ln.d_err) (void)hipFree(ln.d_err);
+        if (ln.packed) (void)hipEventDestroy(ln.packed);
+        if (ln.placed) (void)hipEventDestroy(ln.placed);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
+    if (ctx->lane_order) (void)hipEventDestroy(ctx->lane_order);
     if (ctx->h_stat) (void)hipHostFree(ctx->h_stat);
     if (ctx->h_zz) (void)hipHostFree(ctx->h_zz);
     if (ctx->d_stream_buf) (void)hipFree(ctx->d_stream_buf);
@@ -1037,11 +1066,18 @@ int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t 
     return tic_entropy_encode_dev(ctx, ctx->d_coef, h, w, quality, d_out, cap, out_len);
 }
 
-// Asynchronous form of tic_compress_dev: the frame's launches (transform, pack, tile sums, place) are queued on the context's stream
-// and the call returns; a caller that compresses resident frames back to back pays the submission ramp and the completion wake-up
-// once per burst instead of once per frame.  The context's coefficient scratch and entropy workspace are reused from frame to
-// frame: the stream executes the frames in order.  The placing kernel leaves {payload bits, error} in the ticket's pair of the
-// host-mapped status block; tic_async_result reads it once the ticket's event has fired.
+// Asynchronous form of tic_compress_dev: the frame's launches (transform, pack, tile sums, place) are queued and the call returns; a
+// caller that compresses resident frames back to back pays the submission ramp and the completion wake-up once per burst instead of once
+// per frame.  Round 6: ONE context, TWO lanes.  Transform and packing of ticket t run on lane t & 1 - a stream, a coefficient buffer, an
+// entropy workspace and a pair of error flags of its own - and only the placing kernel, the stage's single writer of the caller's buffer and
+// of the ticket's status pair, is queued on the context's stream, behind the lane's packing and in ticket order.  The transform of frame
+// t + 1 (bound by HBM) and its packing thus run beside the packing (bound by vector issue) and placing of frame t: what round 5 reached
+// only from two contexts and two host threads (39 against 48 us per 4096^2 frame).  Ordering: a lane starts behind everything the context's
+// stream held when the burst's first ticket was issued (every synchronous entry point returns with that stream drained, so nothing else can
+// be in front of a later ticket); a lane's next frame waits for the placing of its previous one (it reuses the workspace that kernel
+// reads); whatever is queued on the context's stream afterwards runs behind the placing kernels, hence behind every kernel of the tickets.
+// The placing kernel leaves {payload bits, error} in the ticket's pair of the host-mapped status block; tic_async_result reads it once the
+// ticket's event has fired.  Until then the caller leaves the frame's input and output alone.
 int tic_compress_dev_async(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out, size_t cap,
                            long long *ticket) {
     TIC_LOCK(ctx);
@@ -1066,30 +1102,57 @@ int tic_compress_dev_async(tic_ctx *ctx, const void *d_image, int h, int w, ptrd
         HIPCHK(ctx, hipMemcpyAsync(d_out, hdr, 16, hipMemcpyHostToDevice, ctx->stream));
     } else {
         if (!d_image) return set_err(ctx, TIC_E_ARG, "null image pointer");
-        rc = ensure_scratch(ctx, 0, n * 128 + 16); // (grows only between bursts of one geometry: a reallocation waits for the stream)
-        if (rc) return rc;
-        const size_t wb = entropy_fused_work_bytes(n);
-        if (wb > ctx->ent_work_bytes) {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // frames in flight still use the old workspace
-            if (ctx->d_ent_work) HIPCHK(ctx, hipFree(ctx->d_ent_work));
-            ctx->d_ent_work = nullptr;
-            ctx->ent_work_bytes = 0;
-            HIPCHK(ctx, hipMalloc(&ctx->d_ent_work, wb));
-            ctx->ent_work_bytes = wb;
+        tic_ctx::AsyncLane &ln = ctx->lanes[t & 1];
+        if (!ln.stream) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ln.packed, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ln.placed, hipEventDisableTiming));
+            HIPCHK(ctx, hipMalloc((void **)&ln.d_err, 2 * sizeof(int)));
+            HIPCHK(ctx, hipMemset(ln.d_err, 0, 2 * sizeof(int)));
+        }
+        if (!ctx->lane_order) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_order, hipEventDisableTiming));
+        const size_t coef_bytes = n * 128 + 16, wb = entropy_fused_work_bytes(n);
+        if (coef_bytes > ln.coef_cap || wb > ln.work_bytes) { // (grows only between bursts of one geometry: frames in flight still use the old buffers)
+            HIPCHK(ctx, hipStreamSynchronize(ln.stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (coef_bytes > ln.coef_cap) {
+                if (ln.d_coef) HIPCHK(ctx, hipFree(ln.d_coef));
+                ln.d_coef = nullptr, ln.coef_cap = 0;
+                HIPCHK(ctx, hipMalloc(&ln.d_coef, coef_bytes));
+                ln.coef_cap = coef_bytes;
+            }
+            if (wb > ln.work_bytes) {
+                if (ln.d_work) HIPCHK(ctx, hipFree(ln.d_work));
+                ln.d_work = nullptr, ln.work_bytes = 0;
+                HIPCHK(ctx, hipMalloc(&ln.d_work, wb));
+                ln.work_bytes = wb;
+            }
         }
         hs[0] = 0;
         hs[1] = 0;
-        DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, ctx->d_coef);
-        HIPCHK(ctx, launch_dctq(a, dctq_kernel_id(TIC_KERNEL_HYBRID), ctx->stream));
+        if (ctx->async_open == 0) { // a burst begins: its lanes start behind whatever the context's stream holds now
+            HIPCHK(ctx, hipEventRecord(ctx->lane_order, ctx->stream));
+            ctx->lane_epoch++;
+        }
+        if (ln.order_seen != ctx->lane_epoch) {
+            HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->lane_order, 0));
+            ln.order_seen = ctx->lane_epoch;
+        }
+        if (ln.placed_valid) HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ln.placed, 0)); // the lane's previous frame has left its workspace
+        DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, ln.d_coef);
+        HIPCHK(ctx, launch_dctq(a, dctq_kernel_id(TIC_KERNEL_HYBRID), ln.stream));
         const size_t cap_words = ((cap - 16) / 16) * 4;
-        const int par = ctx->ent_parity;
-        ctx->ent_parity ^= 1;
+        const int par = ln.parity;
+        ln.parity ^= 1;
         // (the 8-lane packing kernel: it takes any block the format allows, so no second run can be needed)
-        HIPCHK(ctx, entropy_gpu_fused((const int16_t *)ctx->d_coef, n, 1, ctx->d_huff, ctx->d_ent_work, ctx->ent_work_bytes, d_out, 0, cap_words, h, w,
-                                      quality, nullptr, ds, ctx->d_err + par, ctx->d_err + (par ^ 1), kEntropyEightLanes, ctx->stream));
+        HIPCHK(ctx, entropy_gpu_fused((const int16_t *)ln.d_coef, n, 1, ctx->d_huff, ln.d_work, ln.work_bytes, d_out, 0, cap_words, h, w, quality, nullptr, ds,
+                                      ln.d_err + par, ln.d_err + (par ^ 1), kEntropyEightLanes, ln.stream, ctx->stream, ln.packed));
+        HIPCHK(ctx, hipEventRecord(ln.placed, ctx->stream));
+        ln.placed_valid = true;
     }
     HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
     sl.ticket = t;
+    ctx->async_open++;
     ctx->async_next = t + 1;
     *ticket = t;
     return TIC_OK;
@@ -1107,10 +1170,11 @@ int tic_async_result(tic_ctx *ctx, long long ticket, int wait, size_t *out_len) 
     {   // (any return other than TIC_E_BUSY closes the ticket - a failing event call included: the slot must not stay open for good)
         const hipError_t q = wait ? hipEventSynchronize(sl.done) : hipEventQuery(sl.done);
         if (!wait && q == hipErrorNotReady) return TIC_E_BUSY;
-        if (q != hipSuccess) sl.ticket = -1;
+        if (q != hipSuccess) { sl.ticket = -1; ctx->async_open--; }
         HIPCHK(ctx, q);
     }
     sl.ticket = -1;
+    ctx->async_open--;
     if (sl.empty_image) {
         *out_len = 16;
         return TIC_OK;

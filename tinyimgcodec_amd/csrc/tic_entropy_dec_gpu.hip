@@ -45,6 +45,7 @@
 #include <string.h>
 
 #include "tic_entropy_dec_gpu.h"
+#include "tic_hooks.h"
 #include "tic_math.h"
 
 namespace tic {
@@ -315,7 +316,7 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
                                                     uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
                                                     uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
                                                     unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
-                                                    uint32_t ntiles, DecStatus *__restrict__ st, const uint32_t tile /* this wave's index among the stream's `ntiles` waves */) {
+                                                    uint32_t ntiles, DecStatus *__restrict__ st, const uint32_t tile /* this wave's index among the stream's `ntiles` waves */, const uint32_t stitch_rounds) {
     __shared__ __attribute__((aligned(16))) uint8_t lutm[kChainLds];   // the chain tables: the measure walk
     extern __shared__ uint32_t sbits_all[]; // stage_lds_words(range) per wave, the launch's dynamic LDS
     // A workgroup is one to four WAVES that share nothing but the chain tables (6.4 KB from memory once per workgroup instead of once
@@ -487,7 +488,7 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
         uint32_t entry = (uint32_t)__shfl_up((int)wend, 1, 64); // (all 64 lanes are here: nobody has returned)
         if (can) stitch(entry);
         bool need = false;
-        for (int round = 0; round < 8; round++) {
+        for (uint32_t round = 0; round < stitch_rounds; round++) {
             const uint32_t pe = (uint32_t)__shfl_up((int)exit_pos, 1, 64);
             need = can && t != 0u && pe != entry;
             if (__ballot(need) == 0ull) break;
@@ -496,7 +497,7 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
                 stitch(entry);
             }
         }
-        if (need && mine) atomicOr(&st->giveup, 4); // (cannot happen within eight rounds: a block covers three ranges at most)
+        if (need && mine) atomicOr(&st->giveup, 4); // more ranges in a row than rounds without a synchronisation point (a block covers three at most: a walk that stays out of step - periodic content)
     }
     if (!mine) nb = 0u; // a shadow's blocks are counted by the range's owner
     // ---- index of every range's first true block, and with it the first bit of every block of the true chain - HERE, in the same launch
@@ -539,9 +540,9 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
                                                                 uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
                                                                 uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
                                                                 unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
-                                                                uint32_t ntiles, DecStatus *__restrict__ st) {
+                                                                uint32_t ntiles, DecStatus *__restrict__ st, uint32_t stitch_rounds) {
     measure_stitch_body(gwords, nwords, last_mask, L, fast_end, stream_bits, range, nranges, starts, hand, desc, desc_half, flat_grid, epoch, nblocks, bpos, grand_total, ntiles, st,
-                        blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+                        blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), stitch_rounds);
 }
 // A BATCH of streams per launch (tic_decompress_batch: the reference's benchmark loop decodes 49 streams of 512 x 512 one after the other,
 // tests/benchmark.py:12-23 - two launches per stream are launch latency and little else).  Wave `g` of the grid works on stream
@@ -550,7 +551,8 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
 __global__ __launch_bounds__(256) void dec_measure_stitch_batch_kernel(const uint32_t *__restrict__ words_all, const DecFrame *__restrict__ frames, const uint32_t *__restrict__ tile_frame,
                                                                       uint32_t total_tiles, const DecLutsDev *__restrict__ L, uint32_t range, uint16_t *__restrict__ starts_all,
                                                                       uint16_t *__restrict__ hand_all, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid,
-                                                                      uint32_t epoch, uint32_t *__restrict__ bpos_all, long long *__restrict__ totals, DecStatus *__restrict__ status) {
+                                                                      uint32_t epoch, uint32_t *__restrict__ bpos_all, long long *__restrict__ totals, DecStatus *__restrict__ status,
+                                                                      uint32_t stitch_rounds) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const bool beyond = g >= total_tiles; // (a wave behind the last stream's last range: it goes through the staging's barrier as that stream's wave `ntiles` and returns)
     const uint32_t f = tile_frame[beyond ? total_tiles - 1u : g];
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_batch_kernel(const uin
     const size_t cap = cap_of(range);
     measure_stitch_body(words_all + F.word0, F.nwords, F.last_mask, L, F.fast_end, F.stream_bits, range, F.nranges, starts_all + (size_t)F.range0 * cap,
                         hand_all + (size_t)F.range0 * cap, desc + F.tile0, desc_half, flat_grid, epoch, (unsigned long long)F.nblocks, bpos_all + F.blk0, totals + f, F.ntiles, status + f,
-                        beyond ? F.ntiles : g - F.tile0);
+                        beyond ? F.ntiles : g - F.tile0, stitch_rounds);
 }
 
 // ---- decode + inverse transform, fused --------------------------------------------------------------------------------------------
@@ -813,6 +815,15 @@ __global__ __launch_bounds__(kDecodeWG, kWinWords <= 2048u ? 3 : 2) void dec_dec
 
 } // namespace
 
+// rounds of the stitch's hand-over loop (a hook for measurements: TIC_DECODE_ROUNDS)
+static uint32_t stitch_rounds() {
+    if (const char *e = test_hook("TIC_DECODE_ROUNDS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) return (uint32_t)v;
+    }
+    return 8u;
+}
+
 bool entropy_decode_gpu_range_ok(int range_bits) {
     return range_bits >= kRangeMin && range_bits <= kRangeMax && range_bits % 64 == 32; // an odd number of 32-bit words
 }
@@ -871,7 +882,7 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const unsigned wpw = (unsigned)kChainLds + 4u * win_lds <= 60000u ? 4u : ((unsigned)kChainLds + 2u * win_lds <= 60000u ? 2u : 1u);
     hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3((measure_wgs + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, words, nwords, last_mask, d_luts, fast_end,
                        (uint32_t)nbits, range, nranges, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, (unsigned long long)nblocks, bpos, totals,
-                       (uint32_t)measure_wgs, d_status);
+                       (uint32_t)measure_wgs, d_status, stitch_rounds());
     const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
     auto fused = [&](auto kern) {
         hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, desc_b, desc_half, (uint32_t)flat_grid, 2u * epoch + 1u,
@@ -909,7 +920,7 @@ hipError_t entropy_decode_idct_gpu_batch(const void *d_words_all, const DecFrame
     const unsigned win_lds = stage_lds_words(range) * 4u;
     const unsigned wpw = (unsigned)kChainLds + 4u * win_lds <= 60000u ? 4u : ((unsigned)kChainLds + 2u * win_lds <= 60000u ? 2u : 1u);
     hipLaunchKernelGGL(dec_measure_stitch_batch_kernel, dim3((total_tiles + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, (const uint32_t *)d_words_all, d_frames, d_tile_frame,
-                       total_tiles, d_luts, range, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, bpos, totals, d_status);
+                       total_tiles, d_luts, range, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, bpos, totals, d_status, stitch_rounds());
     if (small_win)
         hipLaunchKernelGGL(dec_decode_idct_batch_kernel<2048>, dim3(total_wgs), dim3(kDecodeWG), 0, stream, (const uint32_t *)d_words_all, d_frames, d_wg_frame, d_luts, (const uint32_t *)bpos, desc_b,
                            desc_half, (uint32_t)flat_grid, 2u * epoch + 1u, (const long long *)totals, d_status);

@@ -31,6 +31,8 @@ size_t entropy_fused_work_bytes(size_t nblocks_total);
 hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int nframes, const HuffDev *d_tab, void *d_work,
                              size_t work_bytes, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w, int quality,
                              unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next, int mode,
-                             hipStream_t stream);
+                             hipStream_t stream, hipStream_t place_stream = nullptr, hipEvent_t pack_done = nullptr);
+// place_stream (with pack_done, an event of the caller's): the placing kernel - the stage's only writer of d_out, d_lens, d_status and
+// *d_err_next - is queued on place_stream behind the packing on `stream`; the packing of the NEXT frame may then run on `stream` beside it.
 
 } // namespace tic

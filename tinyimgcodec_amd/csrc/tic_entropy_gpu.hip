@@ -887,7 +887,7 @@ size_t entropy_fused_work_bytes(size_t nblocks_total) {
 hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int nframes, const HuffDev *d_tab, void *d_work,
                              size_t work_bytes, void *d_out, size_t out_frame_stride, size_t cap_words, int h, int w, int quality,
                              unsigned long long *d_lens, unsigned long long *d_status, int *d_err, int *d_err_next, int mode,
-                             hipStream_t stream) {
+                             hipStream_t stream, hipStream_t place_stream, hipEvent_t pack_done) {
     if (blocks_per_frame == 0 || nframes <= 0) return hipSuccess;
     const bool lane_form = mode == kEntropyLanePerBlock;
     const size_t part_blocks = lane_form ? (size_t)kPB : 8, grp = lane_form ? (size_t)kGroupL : (size_t)kGroup;
@@ -963,6 +963,11 @@ hipError_t entropy_gpu_fused(const int16_t *d_zz, size_t blocks_per_frame, int n
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     const size_t places_per_frame = (parts_per_frame + place - 1) / place;
+    if (place_stream != nullptr && place_stream != stream) { // the placing kernel on a stream of its own, behind the packing (and the tile sums)
+        if (!pack_done) return hipErrorInvalidValue;
+        if ((e = hipEventRecord(pack_done, stream)) != hipSuccess || (e = hipStreamWaitEvent(place_stream, pack_done, 0)) != hipSuccess) return e;
+        stream = place_stream;
+    }
 #define TIC_PLACE_ARGS                                                                                                                     \
     dim3((unsigned)(places_per_frame * (size_t)nframes)), dim3(256), 0, stream, stage, nbits, gsum, tile_sum, (unsigned long long)parts_per_frame, \
         (unsigned long long)groups_per_frame, (unsigned long long)places_per_frame, (unsigned long long)tiles_per_frame, (unsigned char *)d_out,   \

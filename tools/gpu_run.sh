@@ -63,6 +63,7 @@ for step in "$@"; do
     clock_profile) run clock_profile 120 python tools/clock_profile.py 500 300 ;;
     bench_set)  run bench_set 300 python tools/bench_set_timing.py ;;
     tests_dec)  run pytest_gpu_dec 900 python -m pytest tests -m gpu -x -q -k "decompress or decoder or benchmark_set or truncated or scaled or config5_frame or shipped" ;;
+    stress_rounds) export TIC_DECODE_ROUNDS=32; run stress_dec_r32 600 python tools/stress_decoder.py ${TIC_STRESS_DEC:-300}; unset TIC_DECODE_ROUNDS ;;
     driver_prof) rm -rf gpurun_out/df_prof; run df_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/df_prof -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-cold --no-config4 ;;
     sweep)      run sweep 600 python tools/sweep.py ;;
     prof)       rm -rf gpurun_out/prof; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --no-cpu-baseline --no-cold --no-config4 ;;
