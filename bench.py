@@ -344,6 +344,7 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
     if args.per_launch != "off":
         kp = args.steps if args.per_launch == "same" else min(args.steps, 1000)
         if per is None:  # a pass of its own behind the timed one, never `value`
+            settle(args, ctx, L, burst)  # (the parity check above left the device idle for ~100 ms: clocks settled again, as in front of the timed pass)
             per = (C.c_float * (2 * kp))()
             ctx.check(L.tic_dctq_dev_timed_warm(ctx.handle, d_img, h, w, pitch, q, d_out, variant, pre + args.warmup, kp, C.byref(ms), per))
         dur = [float(per[2 * i]) * 1e3 for i in range(kp)]
@@ -845,7 +846,8 @@ def bench_set(args, ctx, L):
         if q == 50:  # the same 49 pairs one call per image, as the reference's loop is written (C-ABI: tic_compress / tic_decompress)
             o1, n1 = np.empty(cap, np.uint8), C.c_size_t()
             p1 = np.empty((h, w), np.uint8)
-            for i in range(2):  # (the first call of a geometry allocates the context's small-frame buffers)
+            for i in range(n):  # one untimed pass: the first call of a geometry allocates the context's small-frame buffers, and the frames were
+                # pinned in place and released again by the batch call in front (their first upload as pageable memory afterwards costs 0.2 ms each)
                 ctx.check(L.tic_compress(ctx.handle, frames[i].ctypes.data, h, w, w, q, o1.ctypes.data, cap, C.byref(n1)))
                 ctx.check(L.tic_decompress(ctx.handle, streams[i].ctypes.data, streams[i].size, p1.ctypes.data, p1.size))
             t0 = time.perf_counter()

@@ -176,11 +176,14 @@ int tic_entropy_encode_dev(tic_ctx *ctx, const void *d_coeffs_zz, int h, int w, 
 /* compress() with image and stream both resident in HBM: transform kernels + device entropy stage. */
 int tic_compress_dev(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out,
                      size_t cap, size_t *out_len);
-/* The same, asynchronously: the frame's launches are queued on the context's stream and the call returns with a ticket; up to 64
- * tickets may be open per context.  For callers that compress resident frames back to back (compress() in a loop,
- * /root/reference/tests/benchmark.py:12-23): submission and completion are paid once per burst, not once per frame.  Frames
- * execute in call order.  tic_async_result delivers the frame's length or its error (same codes as tic_compress_dev) and closes
- * the ticket; with wait == 0 it returns TIC_E_BUSY while the frame is still in flight (tic_sync waits for everything queued). */
+/* The same, asynchronously: the frame's launches are queued and the call returns with a ticket; up to 64 tickets may be open per
+ * context.  For callers that compress resident frames back to back (compress() in a loop, /root/reference/tests/benchmark.py:12-23):
+ * submission and completion are paid once per burst, not once per frame, and the transform and packing of a frame run beside the
+ * packing and placing of the frame before it (two lanes inside the context).  The streams are WRITTEN in ticket order (the placing
+ * kernels run on the context's stream, so anything queued on the context afterwards sees them); until a ticket is collected its input
+ * must not be modified and its output not read.  tic_async_result delivers the frame's length or its error (same codes as
+ * tic_compress_dev) and closes the ticket; with wait == 0 it returns TIC_E_BUSY while the frame is still in flight (tic_sync waits for
+ * everything queued). */
 int tic_compress_dev_async(tic_ctx *ctx, const void *d_image, int h, int w, ptrdiff_t row_stride, int quality, void *d_out,
                            size_t cap, long long *ticket);
 int tic_async_result(tic_ctx *ctx, long long ticket, int wait, size_t *out_len);
@@ -267,7 +270,8 @@ int tic_last_decode_giveup(tic_ctx *ctx);
 int tic_last_decode_range(tic_ctx *ctx, int *range_bits, int *tries);
 /* tic_decompress_dev launches a long stream on a GUESS of its 16-byte header (the header of the stream this context decoded last: the
  * frames of a sequence, the images of a batch; only after two equal headers in a row) instead of reading it from device memory first;
- * the kernels echo the real header and a wrong guess costs a second decode.  Returns 1 when the last tic_decompress_dev's guess held, -1 when it did not (the stream was
+ * the kernels echo the real header and a wrong guess costs a second decode - and nothing else: a run on a wrong guess writes no pixel
+ * (the kernel that stores pixels compares the stream's first 16 bytes with the header its geometry came from), so no byte of d_out outside the real h x w is ever touched.  Returns 1 when the last tic_decompress_dev's guess held, -1 when it did not (the stream was
  * decoded again with its own header), 0 when no guess was made.  (No counterpart in the reference: decompress() codec.py:133-164 reads
  * the header from host memory.) */
 int tic_last_decode_guess(tic_ctx *ctx);

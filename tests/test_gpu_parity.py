@@ -1249,11 +1249,14 @@ def test_batch_takes_registered_frames_in_place(ctx, oracle):
     assert got == want
 
 
-def test_batch_pins_pageable_frames_in_place(ctx, oracle):
+def test_batch_pins_pageable_frames_in_place(ctx, oracle, monkeypatch):
     """Round 4: pageable frames of a batch are registered IN PLACE for the duration of the call when one range covers them (frames
     allocated one after the other), and staged through the pinned slots otherwise: same streams on every route, equal to the
     oracle's; nothing stays registered behind the call; tic_set_auto_register(0) restores the staging route."""
     L = N.load()
+    if not L.tic_build_has_test_hooks():
+        pytest.skip("needs chunks of 16 small frames (TIC_BATCH_CHUNK, a test hook): round 6 sends up to 64 frames of this size per chunk")
+    monkeypatch.setenv("TIC_BATCH_CHUNK", "16")
     n, h, w, q = 37, 520, 520, 50  # 270 KB per frame (above the 256 KB floor of the registered route), three chunks
     block = np.stack([rand_frame(5200 + i, h, w) for i in range(n)])
     want = [oracle.compress(block[i], q) for i in range(n)]

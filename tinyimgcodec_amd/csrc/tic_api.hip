@@ -55,6 +55,7 @@ constexpr int kChunk = 16;
 static inline int chunk_frames(int n, size_t img_bytes) {
     size_t c = img_bytes ? (32u << 20) / img_bytes : (size_t)kChunk;
     c = c < (size_t)kChunk ? (size_t)kChunk : (c > 64 ? 64 : c);
+    if (const char *e = test_hook("TIC_BATCH_CHUNK")) c = atoi(e) >= 1 && atoi(e) <= 64 ? (size_t)atoi(e) : c; // (tests: several chunks of small frames)
     return n < (int)c ? n : (int)c;
 }
 struct Slot {
@@ -117,12 +118,12 @@ struct tic_ctx {
         hipStream_t stream = nullptr;
         void *d_coef = nullptr;
         size_t coef_cap = 0;
-        void *d_work = nullptr;
-        size_t work_bytes = 0;
-        int *d_err = nullptr; // [2], used in turn
-        int parity = 0;
-        hipEvent_t packed = nullptr, placed = nullptr; // the lane's last packing has run / the lane's last frame has been placed (on ctx->stream)
-        bool placed_valid = false;
+        void *d_work[2] = {nullptr, nullptr}; // two entropy workspaces used in turn: the lane packs its next frame while the placing kernel
+        size_t work_bytes = 0;                // of the frame before still reads the other one
+        int *d_err = nullptr; // [4], used in turn (a placing kernel zeroes the flag of the lane's frame three ahead: no packing in flight uses it)
+        unsigned long long frames = 0;        // frames this lane has taken
+        hipEvent_t packed = nullptr, placed[2] = {nullptr, nullptr}; // the lane's last packing has run / the frame that used workspace k has been placed (on ctx->stream)
+        bool placed_valid[2] = {false, false};
         unsigned long long order_seen = 0; // the burst (lane_epoch) whose starting point this lane's stream already waits for
     };
     AsyncLane lanes[2];
@@ -365,10 +366,12 @@ void tic_destroy(tic_ctx *ctx) {
     for (auto &ln : ctx->lanes) {
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
         if (ln.d_coef) (void)hipFree(ln.d_coef);
-        if (ln.d_work) (void)hipFree(ln.d_work);
+        for (int k = 0; k < 2; k++) {
+            if (ln.d_work[k]) (void)hipFree(ln.d_work[k]);
+            if (ln.placed[k]) (void)hipEventDestroy(ln.placed[k]);
+        }
         if (ln.d_err) (void)hipFree(ln.d_err);
         if (ln.packed) (void)hipEventDestroy(ln.packed);
-        if (ln.placed) (void)hipEventDestroy(ln.placed);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (ctx->lane_order) (void)hipEventDestroy(ctx->lane_order);
@@ -1106,9 +1109,10 @@ int tic_compress_dev_async(tic_ctx *ctx, const void *d_image, int h, int w, ptrd
         if (!ln.stream) {
             HIPCHK(ctx, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
             HIPCHK(ctx, hipEventCreateWithFlags(&ln.packed, hipEventDisableTiming));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ln.placed, hipEventDisableTiming));
-            HIPCHK(ctx, hipMalloc((void **)&ln.d_err, 2 * sizeof(int)));
-            HIPCHK(ctx, hipMemset(ln.d_err, 0, 2 * sizeof(int)));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ln.placed[0], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ln.placed[1], hipEventDisableTiming));
+            HIPCHK(ctx, hipMalloc((void **)&ln.d_err, 4 * sizeof(int)));
+            HIPCHK(ctx, hipMemset(ln.d_err, 0, 4 * sizeof(int)));
         }
         if (!ctx->lane_order) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_order, hipEventDisableTiming));
         const size_t coef_bytes = n * 128 + 16, wb = entropy_fused_work_bytes(n);
@@ -1122,9 +1126,13 @@ int tic_compress_dev_async(tic_ctx *ctx, const void *d_image, int h, int w, ptrd
                 ln.coef_cap = coef_bytes;
             }
             if (wb > ln.work_bytes) {
-                if (ln.d_work) HIPCHK(ctx, hipFree(ln.d_work));
-                ln.d_work = nullptr, ln.work_bytes = 0;
-                HIPCHK(ctx, hipMalloc(&ln.d_work, wb));
+                for (int k = 0; k < 2; k++) {
+                    if (ln.d_work[k]) HIPCHK(ctx, hipFree(ln.d_work[k]));
+                    ln.d_work[k] = nullptr;
+                }
+                ln.work_bytes = 0;
+                HIPCHK(ctx, hipMalloc(&ln.d_work[0], wb));
+                HIPCHK(ctx, hipMalloc(&ln.d_work[1], wb));
                 ln.work_bytes = wb;
             }
         }
@@ -1138,17 +1146,17 @@ int tic_compress_dev_async(tic_ctx *ctx, const void *d_image, int h, int w, ptrd
             HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->lane_order, 0));
             ln.order_seen = ctx->lane_epoch;
         }
-        if (ln.placed_valid) HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ln.placed, 0)); // the lane's previous frame has left its workspace
+        const int wk = (int)(ln.frames & 1), ek = (int)(ln.frames & 3);
+        if (ln.placed_valid[wk]) HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ln.placed[wk], 0)); // the frame that used this workspace two lane-frames ago has been placed
         DctqArgs a = make_args(ctx, d_image, h, w, row_stride, quality, ln.d_coef);
         HIPCHK(ctx, launch_dctq(a, dctq_kernel_id(TIC_KERNEL_HYBRID), ln.stream));
         const size_t cap_words = ((cap - 16) / 16) * 4;
-        const int par = ln.parity;
-        ln.parity ^= 1;
         // (the 8-lane packing kernel: it takes any block the format allows, so no second run can be needed)
-        HIPCHK(ctx, entropy_gpu_fused((const int16_t *)ln.d_coef, n, 1, ctx->d_huff, ln.d_work, ln.work_bytes, d_out, 0, cap_words, h, w, quality, nullptr, ds,
-                                      ln.d_err + par, ln.d_err + (par ^ 1), kEntropyEightLanes, ln.stream, ctx->stream, ln.packed));
-        HIPCHK(ctx, hipEventRecord(ln.placed, ctx->stream));
-        ln.placed_valid = true;
+        HIPCHK(ctx, entropy_gpu_fused((const int16_t *)ln.d_coef, n, 1, ctx->d_huff, ln.d_work[wk], ln.work_bytes, d_out, 0, cap_words, h, w, quality, nullptr, ds,
+                                      ln.d_err + ek, ln.d_err + ((ek + 3) & 3), kEntropyEightLanes, ln.stream, ctx->stream, ln.packed));
+        HIPCHK(ctx, hipEventRecord(ln.placed[wk], ctx->stream));
+        ln.placed_valid[wk] = true;
+        ln.frames++;
     }
     HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
     sl.ticket = t;

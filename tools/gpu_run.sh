@@ -64,6 +64,9 @@ for step in "$@"; do
     bench_set)  run bench_set 300 python tools/bench_set_timing.py ;;
     tests_dec)  run pytest_gpu_dec 900 python -m pytest tests -m gpu -x -q -k "decompress or decoder or benchmark_set or truncated or scaled or config5_frame or shipped" ;;
     stress_rounds) export TIC_DECODE_ROUNDS=32; run stress_dec_r32 600 python tools/stress_decoder.py ${TIC_STRESS_DEC:-300}; unset TIC_DECODE_ROUNDS ;;
+    small_probe) run small_probe 120 python tools/small_compress_probe.py ;;
+    ab_r4)      run ab_r4 400 python tools/ab_libs.py tools/bin/lib_r4.so --rounds 7; run ab_r4_q90 300 python tools/ab_libs.py tools/bin/lib_r4.so --rounds 5 --quality 90 ;;
+    kernarg)    export HIP_FORCE_DEV_KERNARG=0; run kernarg0 120 python tools/driver_flags.py 3; export HIP_FORCE_DEV_KERNARG=1; run kernarg1 120 python tools/driver_flags.py 3; unset HIP_FORCE_DEV_KERNARG ;;
     driver_prof) rm -rf gpurun_out/df_prof; run df_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/df_prof -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-cold --no-config4 ;;
     sweep)      run sweep 600 python tools/sweep.py ;;
     prof)       rm -rf gpurun_out/prof; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --no-cpu-baseline --no-cold --no-config4 ;;
