@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--per-launch", choices=["same", "separate", "off"], default="separate",
                     help="per_launch_us {min, median, max} from events on the launches' own dispatch packets: in a pass of its own behind the timed one "
                     "(default: a dispatch that carries events is followed by a 5 us gap, profiles/r06_driver_flags.txt), on the timed launches themselves, or not at all")
-    ap.add_argument("--no-preroll", dest="preroll", action="store_false", help="do not put the last 256 settling launches into the timed submission")
+    ap.add_argument("--no-preroll", dest="preroll", action="store_false", help="do not put 32 more settling launches into the timed submission")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N > 1 without a launcher: watchdog over the N rank processes (s)")
     args = ap.parse_args()
 
@@ -330,7 +330,7 @@ def bench_config2(args, ctx, L, N, q, variant, barrier, ms):
     # first event is stamped when the last warm-up launch retires with the timed launches queued behind it.  (Rounds 1-5 synchronised
     # between warm-up and the first event: recorded on an idle stream it opened the interval with the first launch's submission latency,
     # ~28 us on the driver's box = 1.4 us per step at K = 20, profiles/r06_driver_flags.txt.)  Returns after the stream has drained.
-    pre = 256 if args.preroll else 0
+    pre = 32 if args.preroll else 0  # (256 measured no better and once worse - tools/driver_flags.py `preroll` rows, profiles/r06_driver_flags.txt: the host is 0.3 ms ahead with 32 already)
     if args.per_launch == "same" and args.steps > 32768:
         args.per_launch = "separate"
     per = (C.c_float * (2 * args.steps))() if args.per_launch == "same" else None

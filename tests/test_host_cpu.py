@@ -238,6 +238,22 @@ def test_guard_band_of_the_fast_path_is_a_bound(tmp_path):
 
 
 
+def test_division_of_the_tie_path_is_the_ieee_division(tmp_path):
+    """rational_quad / rational_slim of the strip kernel divide with tic_math.h div_rn since round 6 (five multiply-adds from the correctly
+    rounded reciprocal instead of the compiler's ~13-instruction division): the same function compiled for the host gives the compiler's
+    a / b bit for bit on every divisor of every quality (and 2,000 non-integral ones) times every tie point (k + 1/2) b with its neighbours
+    within 8 ulps, every multiple of 1/8 and random numerators - 8 x 10^8 quotients - and build_consts hands it RN(1 / b)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    exe = tmp_path / "div_selftest"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", str(exe), os.path.join(root, "tests", "native", "div_selftest.cpp")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith(": ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_strip_kernel_binary_keeps_its_landing_registers_private():
     """The production kernel's pixel loads land in v72..v79, registers the compiler may not allocate (amdgpu_num_vgpr(72)):
     a load in flight must never share a register with anything the compiler placed.  Checked on the SHIPPED binary by

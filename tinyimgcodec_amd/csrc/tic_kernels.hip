@@ -342,8 +342,8 @@ __device__ __forceinline__ int rational_quad(const uint32_t *ldsT, int b, int i,
     const double o = dpp_f64<TIC_DPP_QP_XOR2>(s2);              // the other half
     const double E = (k & 1) ? s2 - o : s2 + o;                 // k = 0: A + B, k = 1: A - B
     const double X = E * ((k & 1) ? (kTW3 * 0.5) : (kSq2h * 0.5));
-    const double div = cst_rat[2 * w + (k & 1)];
-    return (int)rint(X / div); // np.round(X / div): IEEE divide, half-even
+    const double div = cst_rat[2 * w + (k & 1)], rdiv = cst_rat[4 + 2 * w + (k & 1)];
+    return (int)rint(div_rn(X, div, rdiv)); // np.round(X / div): the correctly rounded quotient (tic_math.h div_rn: five multiply-adds), half-even
 }
 
 // Exact float64 sub-path of the four rational coefficients, 8 lanes per block, no LDS: rowLo/rowHi = pixel row i of the lane's
@@ -370,11 +370,7 @@ __device__ __forceinline__ int rational_slim(uint32_t rowLo, uint32_t rowHi, int
     const double E = (i & 1) ? A - B : A + B;                         // v = 0 | v = 4
     const double X = E * ((i & 1) ? (kTW3 * 0.5) : (kSq2h * 0.5));
     const double div = cst_rat[i & 3], rdiv = cst_rat[4 + (i & 3)];
-    const double t = X * rdiv;
-    double r = rint(t);
-    // the reciprocal product is within ~1e-12 of X/div: only a quotient that close to a tie needs the divide
-    if (fabs(fabs(t - r) - 0.5) < 1e-9) r = rint(X / div);
-    return (int)r;
+    return (int)rint(div_rn(X, div, rdiv)); // (round 5: the reciprocal product, and the compiler's division when a lane sat near a tie - in a tie strip one always does)
 }
 // A block redone by the whole wave in float64 straight from the definition (lane 8*u + c: t[u][c] = sum_r M[u][r] x[r][c], then
 // X[u][v = c] = sum_k M[v][k] t[u][k]; error ~1e-13, the reference's own is ~1e-12).  A rounding is decided when no .5 tie lies
@@ -660,7 +656,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
                 n_quad++;
                 if constexpr (kCols) {
                     const int rq = rational_quad(ldsT, b, i, cst_rat);
-                    if ((i & 2) == 0) *zz_ptr(i == 0 ? 0u : (i == 1 ? 28u : (i == 4 ? 20u : 78u))) = (int16_t)rq; // scan positions 0, 14, 10, 39
+                    // scan positions 0, 14, 10, 39 of lanes i = 0, 1, 4, 5: byte offsets 0, 28, 20, 78 = 28 (i & 1) + 20 (i >> 2) + 30 (i & 1)(i >> 2), by
+                    // arithmetic (as nested selects the compiler built three exec-mask regions out of them, inside the tie path)
+                    if ((i & 2) == 0) *zz_ptr(28u * (uint32_t)(i & 1) + 20u * (uint32_t)(i >> 2) + 30u * (uint32_t)((i & 1) & (i >> 2))) = (int16_t)rq;
                 } else { // rows first: no column sums at hand - from the pixels (load layout -> a row per lane of the block, through LDS)
                     uint32_t lo0, hi0;
                     raw_words(tag, lo0, hi0);

@@ -110,6 +110,29 @@ TIC_HD void idct8_exact(double &c0, double &c1, double &c2, double &c3, double &
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// a / b, correctly rounded (round to nearest even: the result of the IEEE division the reference's np.round(X / div) starts from,
+// utils.py:53), from y = RN(1 / b) in five multiply-adds.  The compiler's own float64 division is ~13 instructions on gfx950, four of
+// them at a quarter of the float64 rate (v_div_scale x 2, v_rcp_f64, v_div_fmas, v_div_fixup: they also cover subnormals, infinities
+// and exponent extremes, none of which occur here); rational_quad runs it once per tie strip, and tie strips are a sixth of the strips of a
+// noise frame and most strips of flat, banded or posterised content.
+// Why it is exact (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, section 4.7): q0 = RN(a y) is within 2 ulps of a / b;
+// r0 = a - q0 b is exactly representable (q0 is that close) and the fused multiply-add delivers it without rounding; q1 = RN(q0 + r0 y)
+// is a FAITHFUL rounding of a / b (error below one ulp); r1 = a - q1 b is again exact; and for a faithful q1 and y = RN(1 / b) - relative
+// error below 2^-53, which correct rounding of 1 / b guarantees - RN(q1 + r1 y) IS RN(a / b) (Markstein's theorem; a / b cannot lie on the
+// midpoint of two floating-point numbers, and the perturbation r1 y - r1 / b is too small to carry it across one).  Preconditions: b and
+// y normal, no overflow or underflow in a y and q b - here |a| <= 2^14 and 0.02 <= b <= 10^4.  y comes from the host's IEEE division
+// (build_consts), never from an iteration on the device.  tests/native/div_selftest.cpp checks the function against the compiler's division on
+// every divisor of every quality and 10^8 numerators, among them every tie point (k + 1/2) b and its neighbours within 8 ulps.
+// ---------------------------------------------------------------------------------------------------------
+TIC_HD double div_rn(double a, double b, double y /* RN(1 / b) */) {
+    const double q0 = a * y;
+    const double r0 = fma(-q0, b, a);
+    const double q1 = fma(r0, y, q0);
+    const double r1 = fma(-q1, b, a);
+    return fma(r1, y, q1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Fast path: Arai-Agui-Nakajima scaled 8-point DCT in float32 (5 multiplies, FMAs named explicitly).
 // Output k is the orthonormal DCT-II coefficient times aan[k]*sqrt(8), aan[0] = 1, aan[k] = sqrt(2)*cos(k*pi/16);
 // the scale is folded into the quantiser multiplier.  o0 and o4 are plain sums/differences of the inputs, hence

@@ -3,7 +3,7 @@
 three ways of bracketing the timed launches:
   idle   : warm-up call, synchronise, then event / K launches / event (tic_dctq_dev_timed: rounds 1-5's bench line)
   warm   : W launches, event, K launches, event in one submission (tic_dctq_dev_timed_warm)
-  preroll: the same with 256 more untimed launches in front of the W (the host is milliseconds ahead of the device at the first event)
+  preroll: the same with PRE (argv[2], default 32) more untimed launches in front of the W (the host is milliseconds ahead of the device at the first event)
   steps  : `warm` with a start and a stop event on every timed launch's own dispatch packet (hipExtLaunchKernelGGL): per-launch
            durations and gaps without marker packets in the queue
 Each measurement is preceded by 60 ms of settling bursts, as in bench.py.  python tools/driver_flags.py [rounds]"""
@@ -20,6 +20,7 @@ import tinyimgcodec_amd as T  # noqa: E402
 from tinyimgcodec_amd import _native as N  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+PRE = int(sys.argv[2]) if len(sys.argv) > 2 else 32  # untimed launches in front of the W of the `preroll` form
 L = N.load()
 ctx = T.Context(0)
 h = w = 4096
@@ -62,7 +63,7 @@ def steps(K, W):
 
 
 def preroll(K, W):
-    return warm(K, W + 256)
+    return warm(K, W + PRE)
 
 
 res = {}

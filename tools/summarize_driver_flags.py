@@ -44,15 +44,15 @@ if prof:
     out.append("")
     out.append("## the same command under rocprofv3 --kernel-trace (gpurun_out/df_prof): the 20 timed launches one by one")
     for a, b in zip(starts, starts[1:] + [len(ts)]):
-        if b - a == 281:
+        if b - a == 57:
             seg = ts[a:b]
             timed = seg[-20:]
-            out.append("submission of %d launches (256 settling + 5 warm-up + 20 timed); the 20 timed ones: duration us / gap to the launch in front us" % (b - a))
+            out.append("submission of %d launches (32 settling + 5 warm-up + 20 timed); the 20 timed ones: duration us / gap to the launch in front us" % (b - a))
             out.append("  " + "  ".join("%.2f/%.2f" % ((e - s) / 1e3, (s - seg[-21 + k][1]) / 1e3) for k, (s, e) in enumerate(timed)))
             out.append("  first timed start .. last timed end: %.2f us = %.3f us per launch; mean duration %.3f us" % ((timed[-1][1] - timed[0][0]) / 1e3, (timed[-1][1] - timed[0][0]) / 2e4,
                                                                                                                         sum(e - s for s, e in timed) / 2e4))
             break
     else:
-        out.append("(no submission of 281 launches found in the trace: %d strip-kernel launches, segments %s)" % (len(ts), [b - a for a, b in zip(starts, starts[1:] + [len(ts)])][:12]))
+        out.append("(no submission of 57 launches found in the trace: %d strip-kernel launches, segments %s)" % (len(ts), [b - a for a, b in zip(starts, starts[1:] + [len(ts)])][:12]))
 open(os.path.join(root, "profiles", "r06_driver_flags.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

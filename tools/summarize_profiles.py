@@ -42,9 +42,11 @@ if ks:
         if KERNEL in r["Name"]:
             out["kernel_stats"] = {"kernel": r["Name"], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
                                    "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
-# The K timed launches are the LAST K strip-kernel launches of the trace (bench.py --no-cold --no-config4: a statistics launch, the
-# settling bursts, W warm-up launches, then the K steps between the two HIP events): their average is the figure to hold against the
-# same run's bench line (roofline.kernel_us = ms_per_step), on the same box; rocprofv3's own AverageNs includes the settling launches.
+# The K timed launches: bench.py queues [settling launches of the submission, W warm-up launches, event, K timed launches, event] as ONE
+# submission (config.launches_in_the_timed_submission); in the trace that is the first run of exactly that many back-to-back launches (gaps
+# below 20 us) - the settling bursts in front of it are runs of 256, the per-launch pass behind it carries a 5 us gap behind every launch but
+# may have the same count: the first such run is the timed one.  The average of its last K launches is the figure to hold against the same
+# run's bench line (roofline.kernel_us = ms_per_step), on the same box; rocprofv3's own AverageNs includes every other launch of the run.
 kt = sorted(glob.glob(os.path.join(G, "prof", "*", "*kernel_trace.csv")), key=os.path.getmtime, reverse=True)
 bench_line = None
 for cand in ("prof.txt",):
@@ -55,16 +57,30 @@ for cand in ("prof.txt",):
                 bench_line = json.loads(ln)
 if kt and bench_line:
     K = int(bench_line["steps"])
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if KERNEL in r["Kernel_Name"]]
-    if len(d) >= K:
-        t = statistics.mean(d[-K:])
+    sub = bench_line["config"].get("launches_in_the_timed_submission", {"settling": 0, "warmup": int(bench_line["warmup"]), "timed": K})
+    want = int(sub["settling"]) + int(sub["warmup"]) + int(sub["timed"])
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kt[0])) if KERNEL in r["Kernel_Name"]))
+    runs, a = [], 0
+    for i in range(1, len(rows) + 1):
+        if i == len(rows) or rows[i][0] - rows[i - 1][1] > 20000:
+            runs.append((a, i))
+            a = i
+    seg = next(((x, y) for x, y in runs if y - x == want), None)
+    if seg is not None:
+        timed = rows[seg[1] - K:seg[1]]
+        d = [e - s_ for s_, e in timed]
+        t = statistics.mean(d)
+        span = (timed[-1][1] - timed[0][0]) / K
         out["timed_steps"] = {"steps": K, "average_ns": round(t, 1), "frac_of_8TBps": round(3.0 * 4096 * 4096 / t / 8000.0, 4),
+                              "first_start_to_last_end_per_launch_ns": round(span, 1), "min_ns": min(d), "max_ns": max(d),
                               "bench_line_kernel_us_hip_events": bench_line["roofline"]["kernel_us"], "bench_line_ms_per_step": bench_line["ms_per_step"],
                               "kernel_time_le_ms_per_step": bool(t / 1e6 <= bench_line["ms_per_step"] * 1.0005),
-                              "note": "the last K launches of the same rocprofv3 trace the bench line was printed under: kernel time (trace) <= ms_per_step (HIP events "
-                                      "around the K launches, which add the gaps between launches)"}
+                              "note": "the K timed launches of the same rocprofv3 trace the bench line was printed under (the last K of the first run of %d back-to-back "
+                                      "launches): kernel time (trace) <= ms_per_step (HIP events around the K launches, which add what the queue needs between two launches)" % want}
         with open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w") as f:
             json.dump(bench_line, f)
+    else:
+        out["timed_steps"] = {"error": "no run of %d back-to-back launches in the trace (runs: %s)" % (want, [y - x for x, y in runs][:20])}
 kc = sorted(glob.glob(os.path.join(G, "prof_cold", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if kc:
     shutil.copy(kc[0], os.path.join(P, f"{tag}_rocprofv3_kernel_stats_cold.csv"))
