@@ -395,10 +395,6 @@ def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden, monkeypatch):
         # many irrational trips per wave (narrow divisors): full batches, overflowing batches, ties in the same strips
         "noise at the top of the quality range": (rand_frame(12, 1024, 2048), (90, 97, 99)),
         "posterised noise (ties and trips in the same strips)": ((rand_frame(13, 1024, 2048) // 8 * 8 + 1).astype(np.uint8), (50, 90, 99)),
-        # round 6: the same rare paths under the ROTATED team schedule (4096 x 4096: the whole grid resident, a row's strips rotated against the
-        # row before) - whole strips redone in the exact order find their pixels through the rotated strip index
-        "irrational true tie in every block, 4096 x 4096 (rotated team schedule)": (np.tile(tt, (512, 512)), (50,)),
-        "posterised noise, 4096 x 4096 (rotated team schedule)": ((rand_frame(14, 4096, 4096) // 8 * 8 + 1).astype(np.uint8), (50, 99)),
     }
     monkeypatch.setenv("TIC_TUNE", "1")  # re-read the knobs at every launch
     for name, (img, quals) in frames.items():
@@ -417,8 +413,7 @@ def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden, monkeypatch):
 def test_strip_schedules_are_equivalent(ctx, monkeypatch):
     """Team / strided / chunked / round-interleaved walks (tuning knobs of launch_dctq) produce the same coefficients."""
     monkeypatch.setenv("TIC_TUNE", "1")  # re-read the knobs at every launch
-    frames = {"small grid": rand_frame(5, 1024, 1024), "large grid": rand_frame(6, 4096, 8192), "rotated team schedule (4096 x 4096)": rand_frame(4, 4096, 4096),
-              "rotated team schedule, tall (2048 wide, 8192 high)": rand_frame(3, 8192, 2048),
+    frames = {"small grid": rand_frame(5, 1024, 1024), "large grid": rand_frame(6, 4096, 8192),
               "team schedule, 65 strips per row": rand_frame(7, 2560, 4160),
               "team schedule falls back (more than 16 rows in round 0)": rand_frame(8, 6144, 6144),
               "ragged": rand_frame(9, 1999, 4171)}
@@ -427,12 +422,8 @@ def test_strip_schedules_are_equivalent(ctx, monkeypatch):
         ref = f.run(50, N.KERNEL_EXACT)
         for knobs in ({}, {"TIC_SPLIT": "0"}, {"TIC_SPLIT": "1,1,1,1,1"}, {"TIC_SCHED": "0"}, {"TIC_SCHED": "1", "TIC_CHUNK": "5"},
                       {"TIC_SCHED": "2"}, {"TIC_MAX_WGS": "512"}, {"TIC_ORDER": "0"}, {"TIC_ORDER": "1"}, {"TIC_ORDER": "0", "TIC_SCHED": "0"},
-                      {"TIC_ORDER": "1", "TIC_SCHED": "1", "TIC_CHUNK": "3"},
-                      # round 6: the team schedule's rotation (a row's strips rotated against the row before: DctqArgs::rot), off, by one, by odd and
-                      # large numbers of places, with other row weights and in the rows-first instantiation
-                      {"TIC_ROT": "0"}, {"TIC_ROT": "1"}, {"TIC_ROT": "77"}, {"TIC_ROT": "1023"}, {"TIC_ROT": "13", "TIC_SPLIT": "1,1,1,1,1,1"},
-                      {"TIC_ROT": "200", "TIC_ORDER": "0"}):
-            for k in ("TIC_SPLIT", "TIC_SCHED", "TIC_CHUNK", "TIC_MAX_WGS", "TIC_ORDER", "TIC_ROT"):
+                      {"TIC_ORDER": "1", "TIC_SCHED": "1", "TIC_CHUNK": "3"}):
+            for k in ("TIC_SPLIT", "TIC_SCHED", "TIC_CHUNK", "TIC_MAX_WGS", "TIC_ORDER"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in knobs.items():
                 monkeypatch.setenv(k, v)

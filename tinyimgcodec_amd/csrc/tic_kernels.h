@@ -51,14 +51,6 @@ struct DctqArgs {
     // rows of round r from byte r of split_lo (byte 8: split_hi).
     uint32_t magic_fast_tx, magic_tstep;
     unsigned long long split_lo, split_hi;
-    // team schedule, round 6: ROTATION.  Without it a wave's strips lie tstep strips apart - for a 4096-wide frame exactly 16 block rows
-    // apart at the SAME x: a wave walks down one 64-pixel column of the image, and what makes a strip expensive (ties in flat and
-    // posterised regions, trips in busy ones) is a property of the place - some waves met it in every strip, others never, and the launch
-    // ends with the unluckiest (posterised Lenna: 11.4 us against 9.4 us for a frame in which EVERY strip ties).  With rot > 0 the waves
-    // of row k take the row's tstep strips rotated by k * rot places: every wave's strips wander across the frame.  Only where the rows
-    // are whole rectangles (tstep a multiple of the strips per block row, the frame a whole number of rows): a step then adds tstep + rot
-    // strips, and when the position inside the row runs past tstep the cursor goes back one row's worth (band_in32 bytes, band_blk blocks).
-    uint32_t rot, band_in32, band_blk;
 };
 
 struct WideArgs {          // dctq_exact_wide_kernel: integer images outside 0..255

@@ -518,18 +518,12 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         // instructions per wave - four integer divisions - made the last of a CU's five workgroups issue its first load 3,000
         // cycles after the first, the 20 waves of a CU share one scalar unit; a table of per-wave start states read with s_load
         // was as slow: the scalar cache serves misses to distinct lines one by one.)
-        uint32_t tf, t_lim, bpos = 0; // (bpos: position inside the row, for the rotated team schedule)
+        uint32_t tf, t_lim;
         if (a.team_count > 0) { // 2-D grid: x = team, y = round
             const uint32_t r = blockIdx.y;
             const uint32_t row0 = (uint32_t)((r < 8u ? a.split_lo >> (8u * r) : a.split_hi) & 0xffull);
             const uint32_t row1 = (uint32_t)((r < 7u ? a.split_lo >> (8u * r + 8u) : a.split_hi) & 0xffull);
-            uint32_t slot = blockIdx.x * kWavesPerWG + (uint32_t)wave; // this wave's place among the row's tstep strips
-            if (a.rot) {                                               // ... rotated by rot places per row (DctqArgs::rot)
-                const uint32_t sft = slot + row0 * a.rot;
-                slot = sft - (a.magic_tstep ? __umulhi(sft, a.magic_tstep) : sft) * (uint32_t)a.tstep;
-            }
-            bpos = slot;
-            tf = row0 * (uint32_t)a.tstep + slot;
+            tf = (row0 * (uint32_t)a.team_count + blockIdx.x) * kWavesPerWG + (uint32_t)wave;
             t_lim = tf + (row1 - row0) * (uint32_t)a.tstep;
         } else if (a.round_wgs > 0) {
             const uint32_t rho = a.magic_tstep ? __umulhi(blockIdx.x, a.magic_tstep /* = magic of round_wgs in this schedule */) : blockIdx.x;
@@ -575,7 +569,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         asm volatile("global_load_dwordx2 v[" R "], %0, %1" : : "v"(ld_off), "s"(img_s + src_off) : TIC_RSV_CLOBBER); \
         n_issued++; txp += a.step_tx; in_off += a.in_step32; oblk += a.oblk_step;                            \
         if (__builtin_expect(txp >= a.fast_tx, 0)) { txp -= a.fast_tx; in_off += a.in_wrap32; oblk += a.oblk_wrap; } \
-        if (a.rot) { bpos += a.rot; if (bpos >= (uint32_t)a.tstep) { bpos -= (uint32_t)a.tstep; in_off -= a.band_in32; oblk -= a.band_blk; } } \
     } while (0)
     // waits until all but the N youngest vector-memory operations are done, then sends the strip's pixel rows from the landing pair
     // v[R] (which keeps the strip's bytes until the pair is loaded again, two strips later: the batch fetches the raw words from
@@ -817,11 +810,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
                             (uint16_t)zzn.z, (uint16_t)(zzn.z >> 16), (uint16_t)zzn.w, (uint16_t)(zzn.w >> 16)};
     for (unsigned long long todo = mask_exact; todo != 0ull; todo &= todo - 1ull) {
         const int k = __builtin_ctzll(todo);
-        long t = (long)t_first + (long)k * a.tstep; // strip index inside the fast rectangle
-        if (a.rot) { // the rotated team schedule: row (t_first / tstep + k), place (t_first % tstep + k * rot) mod tstep
-            const long row_first = t_first / a.tstep, place = ((long)t_first - row_first * a.tstep + (long)k * (long)a.rot) % a.tstep;
-            t = (row_first + k) * a.tstep + place;
-        }
+        const long t = (long)t_first + (long)k * a.tstep; // strip index inside the fast rectangle
         const int ty = (int)(t / a.fast_tx), tx = (int)(t - (long)ty * a.fast_tx);
         Strip s;
         s.by = ty;
@@ -996,7 +985,7 @@ static inline int grid_for(int ntiles) { return (ntiles + kWavesPerWG - 1) / kWa
 // the test-hook gate (tic_hooks.h, TIC_TEST_HOOKS=1: tests/test_gpu_parity.py::test_strip_schedules_are_equivalent drives every
 // schedule against the exact kernel) - read once, or at every launch when TIC_TUNE is set too.
 struct Tunables {
-    int max_wgs, sched, chunk, order, rot;
+    int max_wgs, sched, chunk, order;
     int split[8];
 };
 static Tunables read_tunables() {
@@ -1005,7 +994,6 @@ static Tunables read_tunables() {
     t.max_wgs = geti("TIC_MAX_WGS", 0);             // persistent grid size (0: resident workgroups of the chip)
     t.sched = geti("TIC_SCHED", 1);                 // grids larger than the chip: 0 strided, 1 chunked (default), 2 round-interleaved
     t.chunk = geti("TIC_CHUNK", kChunkStrips);      // strips per wave of schedules 1 and 2
-    t.rot = geti("TIC_ROT", 13);                    // team schedule: places by which a row's strips are rotated against the row before (0: off; DctqArgs::rot)
     t.order = geti("TIC_ORDER", -1);                // pass order of the strip kernel: -1 by grid (default), 0 rows first, 1 columns first
     // per-round row weights of the team schedule ("0" disables it): the six workgroups of a CU reach their first pixel
     // 1,400 ... 6,200 cycles after their own entry (profiles/r03_stamps_tail.txt), later rounds get fewer strip rows.  Round 5: the
@@ -1138,14 +1126,8 @@ hipError_t launch_dctq(DctqArgs a, int variant, hipStream_t stream, hipEvent_t e
             if (rows_total > 255) a.team_count = 0; // the kernel takes the row boundaries as bytes
             if (a.team_count == 0) a.tstep = a.nwaves;
         }
-        a.rot = a.band_in32 = a.band_blk = 0;
-        if (a.team_count > 0 && tune.rot > 0 && a.tstep % a.fast_tx == 0 && nfast % a.tstep == 0 && tune.rot < a.tstep && a.fast_tx > 1) {
-            a.rot = (uint32_t)tune.rot;
-            a.band_in32 = (uint32_t)((long)(a.tstep / a.fast_tx) * 8 * a.stride);
-            a.band_blk = (uint32_t)((long)(a.tstep / a.fast_tx) * a.bw);
-        }
-        a.step_ty = (a.tstep + (int)a.rot) / a.fast_tx; // (a step of the rotated schedule: tstep + rot strips)
-        a.step_tx = (a.tstep + (int)a.rot) % a.fast_tx;
+        a.step_ty = a.tstep / a.fast_tx;
+        a.step_tx = a.tstep % a.fast_tx;
         a.in_step32 = (uint32_t)((long)a.step_ty * 8 * a.stride + (long)a.step_tx * 64);
         a.in_wrap32 = (uint32_t)(8 * a.stride - (long)a.fast_tx * 64);
         a.oblk_step = (uint32_t)((long)a.step_ty * a.bw + (long)a.step_tx * 8);
