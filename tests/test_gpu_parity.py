@@ -395,6 +395,10 @@ def test_rare_paths_of_the_strip_kernel(ctx, oracle, golden, monkeypatch):
         # many irrational trips per wave (narrow divisors): full batches, overflowing batches, ties in the same strips
         "noise at the top of the quality range": (rand_frame(12, 1024, 2048), (90, 97, 99)),
         "posterised noise (ties and trips in the same strips)": ((rand_frame(13, 1024, 2048) // 8 * 8 + 1).astype(np.uint8), (50, 90, 99)),
+        # the same rare paths under the TEAM schedule (4096 x 4096: the whole grid resident at once, rows split between the rounds): whole strips
+        # redone in the exact order find their pixels through the team schedule's strip index
+        "irrational true tie in every block, 4096 x 4096 (team schedule)": (np.tile(tt, (512, 512)), (50,)),
+        "posterised noise, 4096 x 4096 (team schedule)": ((rand_frame(14, 4096, 4096) // 8 * 8 + 1).astype(np.uint8), (50, 99)),
     }
     monkeypatch.setenv("TIC_TUNE", "1")  # re-read the knobs at every launch
     for name, (img, quals) in frames.items():
