@@ -32,27 +32,30 @@ for tag in tags:
         keep = [l.rstrip() for l in open(tool) if re.match(r"^(idle|warm|preroll|steps)\s", l)]
         out.append("tools/driver_flags.py in one process (5 rounds, 60 ms of settling in front of every measurement):")
         out += ["  " + l for l in keep]
-prof = glob.glob(os.path.join(root, "gpurun_out", "df_prof", "*", "*_kernel_trace.csv"))
-if prof:
-    rows = [r for r in csv.DictReader(open(prof[0])) if "strip" in r["Kernel_Name"]]
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # the bench's launches in order: 1 statistics launch, settling bursts, then ONE submission of 256 + 5 + 20 launches (the timed pass), later the per-launch pass
-    ts = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-    gaps = [ts[i][0] - ts[i - 1][1] for i in range(1, len(ts))]
-    # the timed submission = the first run of exactly 281 back-to-back launches behind a gap of more than 20 us
-    starts = [0] + [i for i in range(1, len(ts)) if gaps[i - 1] > 20000]
+prof = sorted(glob.glob(os.path.join(root, "gpurun_out", "df_prof", "*", "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
+line = None
+pth = os.path.join(root, "gpurun_out", "df_prof.txt")
+if os.path.exists(pth):
+    for ln in open(pth).read().splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = json.loads(ln)
+if prof and line:
+    rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(prof[0])) if "strip" in r["Kernel_Name"])
+    sub = line["config"]["launches_in_the_timed_submission"]
+    want, first, K = sub["settling"] + sub["warmup"] + sub["timed"], int(line["config"]["untimed_launches"]), sub["timed"]
     out.append("")
-    out.append("## the same command under rocprofv3 --kernel-trace (gpurun_out/df_prof): the 20 timed launches one by one")
-    for a, b in zip(starts, starts[1:] + [len(ts)]):
-        if b - a == 57:
-            seg = ts[a:b]
-            timed = seg[-20:]
-            out.append("submission of %d launches (32 settling + 5 warm-up + 20 timed); the 20 timed ones: duration us / gap to the launch in front us" % (b - a))
-            out.append("  " + "  ".join("%.2f/%.2f" % ((e - s) / 1e3, (s - seg[-21 + k][1]) / 1e3) for k, (s, e) in enumerate(timed)))
-            out.append("  first timed start .. last timed end: %.2f us = %.3f us per launch; mean duration %.3f us" % ((timed[-1][1] - timed[0][0]) / 1e3, (timed[-1][1] - timed[0][0]) / 2e4,
-                                                                                                                        sum(e - s for s, e in timed) / 2e4))
-            break
+    out.append("## the same command under rocprofv3 --kernel-trace (tools/gpu_run.sh driver_prof): the timed launches one by one")
+    out.append("bench line of that run: ms_per_step %.3f us (HIP events), per_launch_us %s" % (line["ms_per_step"] * 1e3, {k: v for k, v in line["config"]["per_launch_us"].items() if k != "source"}))
+    if len(rows) >= first + want:
+        seg = rows[first:first + want]
+        timed = seg[-K:]
+        out.append("launches %d .. %d of the trace = the submission of %d settling + %d warm-up + %d timed launches; the %d timed ones, duration us / gap to the launch in front us:"
+                   % (first, first + want - 1, sub["settling"], sub["warmup"], K, K))
+        out.append("  " + "  ".join("%.2f/%.2f" % ((e - s) / 1e3, (s - seg[-K - 1 + k][1]) / 1e3) for k, (s, e) in enumerate(timed)))
+        out.append("  first timed start .. last timed end: %.2f us = %.3f us per launch; mean duration %.3f us; the %d untimed launches of the submission in front: mean %.3f us"
+                   % ((timed[-1][1] - timed[0][0]) / 1e3, (timed[-1][1] - timed[0][0]) / 1e3 / K, sum(e - s for s, e in timed) / 1e3 / K, want - K,
+                      sum(e - s for s, e in seg[:-K]) / 1e3 / max(want - K, 1)))
     else:
-        out.append("(no submission of 57 launches found in the trace: %d strip-kernel launches, segments %s)" % (len(ts), [b - a for a, b in zip(starts, starts[1:] + [len(ts)])][:12]))
+        out.append("(the trace holds %d launches, the submission would end at %d)" % (len(rows), first + want))
 open(os.path.join(root, "profiles", "r06_driver_flags.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

@@ -60,12 +60,10 @@ if kt and bench_line:
     sub = bench_line["config"].get("launches_in_the_timed_submission", {"settling": 0, "warmup": int(bench_line["warmup"]), "timed": K})
     want = int(sub["settling"]) + int(sub["warmup"]) + int(sub["timed"])
     rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kt[0])) if KERNEL in r["Kernel_Name"]))
-    runs, a = [], 0
-    for i in range(1, len(rows) + 1):
-        if i == len(rows) or rows[i][0] - rows[i - 1][1] > 20000:
-            runs.append((a, i))
-            a = i
-    seg = next(((x, y) for x, y in runs if y - x == want), None)
+    # (the launches in front of the submission are counted by the bench line itself: config.untimed_launches = the settling bursts + the
+    #  statistics launch; under the profiler a submission does not stay gap-free, so the launches are told by their place in the trace)
+    first = int(bench_line["config"]["untimed_launches"])
+    seg = (first, first + want) if len(rows) >= first + want else None
     if seg is not None:
         timed = rows[seg[1] - K:seg[1]]
         d = [e - s_ for s_, e in timed]
@@ -75,12 +73,12 @@ if kt and bench_line:
                               "first_start_to_last_end_per_launch_ns": round(span, 1), "min_ns": min(d), "max_ns": max(d),
                               "bench_line_kernel_us_hip_events": bench_line["roofline"]["kernel_us"], "bench_line_ms_per_step": bench_line["ms_per_step"],
                               "kernel_time_le_ms_per_step": bool(t / 1e6 <= bench_line["ms_per_step"] * 1.0005),
-                              "note": "the K timed launches of the same rocprofv3 trace the bench line was printed under (the last K of the first run of %d back-to-back "
-                                      "launches): kernel time (trace) <= ms_per_step (HIP events around the K launches, which add what the queue needs between two launches)" % want}
+                              "note": "the K timed launches of the same rocprofv3 trace the bench line was printed under (launches %d .. %d of the trace: the last K of the submission of %d"
+                                      " launches that follows the untimed ones): kernel time (trace) <= ms_per_step (HIP events around the K launches, which add what the queue needs between two launches)" % (seg[1] - K, seg[1] - 1, want)}
         with open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w") as f:
             json.dump(bench_line, f)
     else:
-        out["timed_steps"] = {"error": "no run of %d back-to-back launches in the trace (runs: %s)" % (want, [y - x for x, y in runs][:20])}
+        out["timed_steps"] = {"error": "the trace holds %d launches, the timed submission would end at launch %d" % (len(rows), first + want)}
 kc = sorted(glob.glob(os.path.join(G, "prof_cold", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if kc:
     shutil.copy(kc[0], os.path.join(P, f"{tag}_rocprofv3_kernel_stats_cold.csv"))
