@@ -44,16 +44,28 @@ for q in (10, 50, 90):
                 row.update(calls=int(r["Calls"]), average_ns=avg, min_ns=float(r["MinNs"]), max_ns=float(r["MaxNs"]),
                            achieved_GBps=round(ALG / avg, 1), frac_of_8TBps=round(ALG / avg / 8000.0, 4))
     kt = newest("c5_prof_q%d/*/*kernel_trace.csv" % q)
-    if kt:  # the K timed launches are the last K of the trace (bench.py: settling bursts, W warm-up launches, then K steps)
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt)) if KERNEL in r["Kernel_Name"]]
-        if len(d) >= 20:
-            row.update(timed_steps=20, timed_steps_average_ns=round(statistics.mean(d[-20:]), 1),
-                       timed_steps_frac_of_8TBps=round(ALG / statistics.mean(d[-20:]) / 8000.0, 4))
     txt = os.path.join(G, "c5_prof_q%d.txt" % q)
+    line = None
     if os.path.exists(txt):
-        m = re.search(r'"kernel_us": ([0-9.]+)', open(txt).read())
-        if m:
-            row["bench_line_kernel_us_hip_events"] = float(m.group(1))
+        for ln in open(txt).read().splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = json.loads(ln)
+    if kt and line:  # the K timed launches by their place in the trace: behind the line's untimed launches comes ONE submission of settling + W + K launches
+        tr = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kt)) if KERNEL in r["Kernel_Name"])
+        sub = line["config"]["launches_in_the_timed_submission"]
+        first, want, K = int(line["config"]["untimed_launches"]), sub["settling"] + sub["warmup"] + sub["timed"], sub["timed"]
+        if len(tr) >= first + want:
+            d = [e - s_ for s_, e in tr[first + want - K:first + want]]
+            row.update(timed_steps=K, timed_steps_average_ns=round(statistics.mean(d), 1), timed_steps_frac_of_8TBps=round(ALG / statistics.mean(d) / 8000.0, 4))
+    if line:
+        row["bench_line_kernel_us_hip_events"] = float(line["roofline"]["kernel_us"])
+    cold = os.path.join(G, "c5_cold_q%d.txt" % q)
+    if os.path.exists(cold):  # the run without the profiler: its warm and cold figures (three rotating pairs, 2.4 GB)
+        for ln in open(cold).read().splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                cl = json.loads(ln)
+                row.update(no_profiler_kernel_us=cl["roofline"]["kernel_us"], no_profiler_frac=cl["roofline"]["frac"], cold_kernel_us=cl["roofline"]["cold"]["kernel_us"],
+                           cold_frac=cl["roofline"]["frac_hbm_cold"], parity=cl["config"]["parity"]["status"])
     rd, wr = counter("c5_rd_q%d" % q, "FETCH_SIZE", KERNEL), counter("c5_wr_q%d" % q, "WRITE_SIZE", KERNEL)
     if rd and wr:
         rb, wb = rd * 1024 * fr, wr * 1024 * fw
@@ -65,14 +77,14 @@ out = {"round": tag, "workload": "BASELINE config 5: one 16384x16384 random uint
                   "then --pmc FETCH_SIZE and --pmc WRITE_SIZE in passes of their own)",
        "calibration": {"fetch_factor": round(fr, 4), "write_factor": round(fw, 4), "FETCH_SIZE_reported_KiB": cal_rd, "WRITE_SIZE_reported_KiB": cal_wr,
                        "kernel": "tools/microbench.hip shape_io 4096x4096 (same access shape, known bytes)"},
-       "reading": "average_ns is rocprofv3's average over ALL launches of the run (513 settling launches in bursts of 256, 3 warm-up, 20 timed): sustained "
-                  "back-to-back 800 MB launches run 6-8 % slower than the 20 timed launches behind the short pause that follows the settling bursts "
-                  "(timed_steps_average_ns, the last 20 launches of the same trace), which is the interval bench.py's HIP events bracket "
-                  "(bench_line_kernel_us_hip_events): the two agree to 0.3 %",
+       "reading": "average_ns is rocprofv3's average over ALL launches of the run (settling bursts of 256, the submission of 32 + 3 + 20 launches, the per-launch pass): "
+                  "sustained back-to-back 800 MB launches run slower than the 20 timed launches (timed_steps_average_ns: those launches by their place in the same trace), "
+                  "which is the interval bench.py's HIP events bracket (bench_line_kernel_us_hip_events, under the profiler; no_profiler_kernel_us without it); cold_* = three "
+                  "rotating frame / coefficient pairs, 2.4 GB: nothing survives in the 256 MiB Infinity Cache - the honest HBM figure",
        "parity": "tests/test_gpu_parity.py::test_config5_16384_coefficient_digest: sha256 of the coefficients at q = 10, 50, 90 equals the reference's (manifest.json)",
        "rows": rows}
 json.dump(out, open(os.path.join(P, "%s_config5.json" % tag), "w"), indent=1)
-keys = ["quality", "calls", "average_ns", "min_ns", "max_ns", "achieved_GBps", "frac_of_8TBps", "timed_steps_average_ns", "timed_steps_frac_of_8TBps", "bench_line_kernel_us_hip_events", "hbm_read_bytes",
+keys = ["quality", "calls", "average_ns", "min_ns", "max_ns", "achieved_GBps", "frac_of_8TBps", "timed_steps_average_ns", "timed_steps_frac_of_8TBps", "bench_line_kernel_us_hip_events", "no_profiler_kernel_us", "no_profiler_frac", "cold_kernel_us", "cold_frac", "parity", "hbm_read_bytes",
         "hbm_write_bytes", "hbm_bytes_per_launch", "traffic_over_algorithmic"]
 with open(os.path.join(P, "%s_config5.csv" % tag), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=keys, extrasaction="ignore")
