@@ -151,14 +151,8 @@ __device__ __forceinline__ void transpose8x8_dwords(uint32_t *lds, int b, int i,
 
 // Exact path for the lane's block: float64, pocketfft order, true IEEE division, round-half-even.
 // colLo/colHi: the lane's pixel column (8 bytes).  Out: q[v] = quantised coefficient (u = i, v) as int.
-// kFast (the strip kernel's passes behind its loop): the eight quotients through div_rn (tic_math.h: five multiply-adds each, the same
-// correctly rounded result) with divisors and reciprocals from the workgroup's LDS constants, instead of eight IEEE divisions (~13
-// instructions each) on divisors fetched from memory - a block with a TRUE tie of an irrational coefficient (one block in 4,096 of posterised
-// natural content, every block of the tie fixtures) keeps a whole wave here at the launch's tail.  The exact kernel - the tests' reference -
-// keeps the compiler's division.
-template <bool kFast = false>
 __device__ __forceinline__ void exact_block(uint32_t colLo, uint32_t colHi, uint32_t *lds, int b, int i,
-                                         const DctqConsts *__restrict__ C, int q[8], const double *lds_div = nullptr, const double *lds_rdiv = nullptr) {
+                                         const DctqConsts *__restrict__ C, int q[8]) {
     double c[8];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -177,17 +171,11 @@ __device__ __forceinline__ void exact_block(uint32_t colLo, uint32_t colHi, uint
 #pragma unroll
     for (int k = 0; k < 8; k++) c[k] = __hiloint2double((int)wh[k], (int)w[k]);
     dct8_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); // axis -1: along frequency row u = i
-    if constexpr (kFast) {
-        const double *dv = lds_div + i * 8, *rv = lds_rdiv + i * 8;
+    const double *div = C->div + i * 8;
 #pragma unroll
-        for (int v = 0; v < 8; v++) q[v] = (int)rint(div_rn(c[v], dv[v], rv[v])); // np.round(X / div), the quotient correctly rounded
-    } else {
-        const double *div = C->div + i * 8;
-#pragma unroll
-        for (int v = 0; v < 8; v++) {
-            q[v] = (int)rint(c[v] / div[v]); // np.round(X / div): IEEE divide, half-even
-            __builtin_amdgcn_sched_barrier(0); // one division at a time: keeps the register footprint of the 8 expansions small
-        }
+    for (int v = 0; v < 8; v++) {
+        q[v] = (int)rint(c[v] / div[v]); // np.round(X / div): IEEE divide, half-even
+        __builtin_amdgcn_sched_barrier(0); // one division at a time: keeps the register footprint of the 8 expansions small
     }
 }
 
@@ -497,13 +485,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         f32x4 m0, m1;
         f32x4 thr;
         u32x4 zzv;
-        // Constants: the workgroup copies the quality's block (kStripBlkBytes = 3,136 bytes: tic_math.h) into LDS, 49 lanes of every wave
+        // Constants: the workgroup copies the quality's block (kStripBlkBytes = 2,624 bytes: tic_math.h) into LDS, 41 lanes of every wave
         // one 16-byte piece each (the first version let every lane load its own multipliers, thresholds and offsets - 8, then 12 wave-wide
         // loads per wave in front of the first pixel load: four such loads more cost 0.67 us on a 4096^2 launch).
         // Every VMEM instruction from here to the end of the loop is issued by hand and counted (see TIC_TAKE).
         u32x4 c_fill;
         {
-            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 49 pieces of 16 bytes per wave
+            constexpr int kPpw = kStripBlkPieces / kWavesPerWG; // 41 pieces of 16 bytes per wave
             static_assert(kPpw * kWavesPerWG == kStripBlkPieces && kPpw <= 64, "constant block must split evenly over the waves");
             const uint32_t piece = lane < kPpw ? (uint32_t)(wave * kPpw + lane) : (uint32_t)kStripBlkPieces - 1u;
             const uint32_t fo = piece * 16u;
@@ -798,7 +786,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
             const uint4 zo = *reinterpret_cast<const uint4 *>(cst_zz + i * 8); // byte offsets in the image of (u = i, v = 0..7)
             const uint32_t zw[4] = {zo.x, zo.y, zo.z, zo.w};
             int qx[8];
-            exact_block<true>(lo, hi, ldsT, b, i, C, qx, reinterpret_cast<const double *>(cst_blk + kBlkDiv), reinterpret_cast<const double *>(cst_blk + kBlkRdiv));
+            exact_block(lo, hi, ldsT, b, i, C, qx);
             if (have && ((m_exact >> e) & 1u)) {
 #pragma unroll
                 for (int v = 0; v < 8; v++) img16[((zw[v >> 1] >> (16 * (v & 1))) & 0xffffu) >> 1] = (int16_t)qx[v];
@@ -836,8 +824,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 6) __attribute__((amdgpu_num_vgpr
         // the second level for the whole strip; the exact order only if it leaves something undecided (a tie of a rational
         // coefficient included: this path has no column sums at hand)
         const uint32_t und = second_level_8(lo, hi, ldsT, b, i, reinterpret_cast<const double *>(cst_blk + kBlkMul64), q);
-        if (__ballot(und != 0u) != 0ull)
-            exact_block<true>(lo, hi, ldsT, b, i, C, q, reinterpret_cast<const double *>(cst_blk + kBlkDiv), reinterpret_cast<const double *>(cst_blk + kBlkRdiv));
+        if (__ballot(und != 0u) != 0ull) exact_block(lo, hi, ldsT, b, i, C, q);
         store_zigzag(reinterpret_cast<uint32_t *>(ldsZ), b, i, zz, q, a.out, s);
     }
 }

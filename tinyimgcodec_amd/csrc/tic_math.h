@@ -215,15 +215,14 @@ struct DctqConsts {
     uint16_t zzofs[64];  // index u*8+v: byte offset of natural coefficient (u,v) in the block's zig-zag int16[64]
     uint8_t zznat[64];   // natural index u*8+v of scan position k (= kZigzag)
     // Everything the strip kernel needs, packed as the image its workgroups copy into LDS with one 16-byte load per lane
-    // (196 lanes): [0,256) mulN, [256,384) thrR, [384,512) zzofs, [512,576) div, then 1/div, of the rational coefficients (0,0) (0,4) (4,0) (4,4),
-    // [576,1088) cosm, [1088,1600) rdiv, [1600,2112) mul64, [2112,2368) mulT, [2368,2496) thrG, [2496,2624) zzofsT, [2624,3136) div (round 6: the
-    // exact-order pass behind the loop divides with div_rn and takes both tables from LDS instead of eight divisors per lane from memory).
-    alignas(16) unsigned char strip_blk[3136];
+    // (164 lanes): [0,256) mulN, [256,384) thrR, [384,512) zzofs, [512,576) div, then 1/div, of the rational coefficients (0,0) (0,4) (4,0) (4,4),
+    // [576,1088) cosm, [1088,1600) rdiv, [1600,2112) mul64, [2112,2368) mulT, [2368,2496) thrG, [2496,2624) zzofsT.
+    alignas(16) unsigned char strip_blk[2624];
 };
-constexpr int kStripBlkBytes = 3136;
+constexpr int kStripBlkBytes = 2624;
 constexpr int kStripBlkPieces = kStripBlkBytes / 16;
 constexpr int kBlkMul = 0, kBlkThr = 256, kBlkZz = 384, kBlkRat = 512, kBlkCos = 576, kBlkRdiv = 1088, kBlkMul64 = 1600; // offsets inside strip_blk
-constexpr int kBlkMulT = 2112, kBlkThrT = 2368, kBlkZzT = 2496, kBlkDiv = 2624;
+constexpr int kBlkMulT = 2112, kBlkThrT = 2368, kBlkZzT = 2496;
 
 // Accept threshold of the fast path as a float: the kernel accepts a rounding when fl32(|t - rint(t)|) <= thr.  The distance
 // is a float32 result in [0, 0.5]: above 0.25 it is rounded by at most 2^-26, i.e. by less than the gap between thr and the next
@@ -304,7 +303,6 @@ inline bool build_consts(double quality, DctqConsts *c) {
         memcpy(p + kBlkMulT, c->mulT, 256);
         memcpy(p + kBlkThrT, c->thrG, 128);
         memcpy(p + kBlkZzT, c->zzofsT, 128);
-        memcpy(p + kBlkDiv, c->div, 512);
     }
     return true;
 }
