@@ -1661,7 +1661,9 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
                 if (T > 1) bind_pipeline_thread(ctx);
                 for (int k = t; k < cnt; k += T) memcpy(outs[first + k], src + (size_t)k * row, (size_t)lens[k]);
             };
-            const int T = cnt < 4 ? 1 : 4;
+            size_t total = 0;
+            for (int k = 0; k < cnt; k++) total += (size_t)lens[k];
+            const int T = cnt < 4 || total < (4u << 20) ? 1 : 4; // (starting and joining four threads costs 0.15-0.2 ms: more than copying 4 MB)
             if (T == 1) {
                 hand_out(0, 1);
             } else {
@@ -1696,7 +1698,13 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         (void)auto_register_frames(ctx, images, 0, n, img_bytes);
         BT_STOP(0);
     }
-    std::thread reader([&]() {
+    // A batch of ONE chunk (the reference's benchmark set: 49 frames of 512 x 512) runs on the calling thread: enqueue, wait, read back, hand out.
+    // Starting the two pipeline threads costs more than the chunk's work when the host is busy - their first wake-up came 3-10 ms late in
+    // one call in three on a shared box (tools/batch_small_probe.py: chunk_wait 0.008 ms, the reader found the chunk long finished).
+    const bool inline_path = n <= chunk;
+    std::thread reader, hander;
+    if (!inline_path) {
+    reader = std::thread([&]() {
         bind_pipeline_thread(ctx);
         (void)hipSetDevice(ctx->device);
         for (;;) {
@@ -1725,7 +1733,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         }
         cv_hand.notify_one();
     });
-    std::thread hander([&]() {
+    hander = std::thread([&]() {
         bind_pipeline_thread(ctx);
         for (;;) {
             int k;
@@ -1746,6 +1754,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
             cv_free.notify_all();
         }
     });
+    }
     int c = 0;
     for (int first = 0; first < n && result == TIC_OK; first += chunk, c++) {
         const int cnt = n - first < chunk ? n - first : chunk;
@@ -1790,6 +1799,13 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
             s.count = 0;
             break;
         }
+        if (inline_path) {
+            int r = read_back(s, ctx->rstream);
+            if (r == TIC_OK) r = hand_out_chunk(s);
+            s.count = 0;
+            if (r != TIC_OK) result = r;
+            continue;
+        }
         {
             std::lock_guard<std::mutex> l(mu);
             busy[si] = 1;
@@ -1802,13 +1818,17 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         stop_read = true;
     }
     cv_read.notify_one();
-    reader.join(); // (each drains its queue first)
-    hander.join();
+    BT_START();
+    if (reader.joinable()) reader.join(); // (each drains its queue first)
+    if (hander.joinable()) hander.join();
     if (result == TIC_OK) result = fin_result;
     (void)hipStreamSynchronize(ctx->bstream[0]);
     (void)hipStreamSynchronize(ctx->bstream[1]);
     (void)hipStreamSynchronize(ctx->rstream);
+    BT_STOP(6); // (tic_last_batch_phases [6]: the caller's wait for the pipeline's threads and streams, [7]: releasing the frames pinned for the call)
+    BT_START();
     auto_unregister_all(ctx);
+    BT_STOP(7);
     for (auto &sl : slots) sl.count = 0;
     return result;
 }
@@ -2241,6 +2261,7 @@ int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size
     if (!ctx) return TIC_E_ARG;
     if (n < 0 || (n > 0 && (!streams || !lens || !outs || !caps))) return set_err(ctx, TIC_E_ARG, "bad batch arguments");
     ctx->last_dbatch_frames = ctx->last_dbatch_fallback = ctx->last_dbatch_chunks = ctx->last_dbatch_direct = 0;
+    ctx->bt = BatchTrace(); // (tic_last_batch_phases: [0] packing the upload buffer, [1] enqueue, [2] wait + download, [4] hand-out, [5] single-frame calls)
     if (n == 0) return TIC_OK;
     struct Fr { int h, w, q; size_t nblk; bool batch; };
     std::vector<Fr> fr((size_t)n);
@@ -2393,6 +2414,7 @@ int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size
                 B.status_cap = cap;
             }
         }
+        BT_START();
         for (uint32_t k = 0; k < F; k++) frames[k].idct.out = B.d_pix + pix_off[k];
         memcpy(B.h_in + o_frames, frames.data(), F * sizeof(DecFrame));
         {
@@ -2406,6 +2428,8 @@ int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size
             }
         }
         memset(B.h_status, 0, F * sizeof(DecStatus));
+        BT_STOP(0);
+        BT_START();
         if (++B.epoch >= (1u << 22)) {
             HIPCHK(ctx, hipMemsetAsync(B.d_desc, 0, B.desc_words * 8, ctx->stream));
             B.epoch = 1;
@@ -2414,6 +2438,8 @@ int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size
         HIPCHK(ctx, entropy_decode_idct_gpu_batch(B.d_in + o_streams, (const DecFrame *)(B.d_in + o_frames), (const uint32_t *)(B.d_in + o_tiles), (const uint32_t *)(B.d_in + o_wgs), F, tiles,
                                                   wgs, ranges, blk, small_win, ctx->d_dec_luts, B.d_work, B.work_bytes, B.d_desc, B.desc_words, B.epoch, B.d_status, range_bits,
                                                   ctx->stream));
+        BT_STOP(1);
+        BT_START();
         // ---- the pixels come down: one copy into the caller's memory where the frames are dense and follow each other there, else one copy
         // into pinned memory and a few threads
         bool dense = true;
@@ -2446,6 +2472,7 @@ int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size
             HIPCHK(ctx, hipMemcpyAsync(B.h_pix, B.d_pix, poff, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
+        BT_STOP(2);
         ctx->last_dbatch_chunks++;
         ctx->last_dbatch_direct += direct ? (int)F : 0;
         // ---- what the kernels report, frame by frame: the header they saw, nothing flagged, every block produced
@@ -2456,6 +2483,7 @@ int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size
             if (good[k]) ctx->last_dbatch_frames++;
             else later.push_back(ids[k]);
         }
+        BT_START();
         if (!direct) {
             auto hand_out = [&](int t, int T) {
                 if (T > 1) bind_pipeline_thread(ctx);
@@ -2475,6 +2503,7 @@ int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size
                 for (auto &x : th) x.join();
             }
         }
+        BT_STOP(4);
     }
     // frames the batch did not take, or did not finish: the single-frame call, with everything it knows (second run, host decoders)
     std::sort(later.begin(), later.end());
