@@ -199,6 +199,11 @@ int tic_compress(tic_ctx *ctx, const uint8_t *image, int h, int w, ptrdiff_t row
  * out_lens[i] receives each size. */
 int tic_compress_batch(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
                        int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int threads);
+/* A batch of one chunk (up to 64 small frames) whose outs[] are the rows of one block of memory (equal distances, 8-byte aligned: a pool of
+ * n x cap bytes) has its streams stored straight into that block by the read-back kernel (the block is pinned for the call; off with
+ * tic_set_auto_register(ctx, 0)); bytes of outs[i] behind out_lens[i], up to the chunk's longest stream, are then NOT preserved.
+ * *streams = how many streams of the last tic_compress_batch went that way. */
+int tic_last_batch_zero_copy(tic_ctx *ctx, int *streams);
 
 /* The same batch spread over nctx contexts - one per GPU of the node - by ONE process: a host thread per context, contiguous
  * shards of ceil(n / nctx) frames in frame order, no exchange between the shards; out_lens in frame order.  What a caller that

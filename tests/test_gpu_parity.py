@@ -1571,10 +1571,13 @@ def test_the_references_own_benchmark_set(ctx, monkeypatch):
         for q, ents in sorted(by_q.items()):
             assert sorted(ents) == list(range(1, 50))
             frames = [px[i - 1] for i in range(1, 50)]
-            for threads in (0, 4):  # device entropy stage / host coder
+            for threads in (4, 0):  # host coder / device entropy stage
                 streams = T.compress_batch(frames, q, threads=threads, ctx=ctx)
                 for i, s in enumerate(streams, 1):
                     assert len(s) == ents[i]["bytes"] and sha(s) == ents[i]["sha256"], (i, q, threads)
+            zc = C.c_int(-1)  # round 6: one chunk, the mirror's pool of n x cap bytes: the read-back kernel stored all 49 streams straight into it
+            ctx.check(L.tic_last_batch_zero_copy(ctx.handle, C.byref(zc)))
+            assert zc.value == 49, (q, zc.value)
             # the reference's loop as two calls per quality (round 6): 49 images -> 49 streams -> 49 images, one chunk, every frame on the batch kernels
             images = T.decompress_batch(streams, ctx=ctx)
             nb, ns, nc, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int()

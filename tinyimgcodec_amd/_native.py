@@ -66,6 +66,7 @@ SIGNATURES = {
     "tic_set_auto_register": (C.c_int, [_ctxp, C.c_int]),
     "tic_last_batch_auto_registered": (C.c_int, [_ctxp, C.POINTER(C.c_int)]),
     "tic_last_batch_phases": (C.c_int, [_ctxp, C.POINTER(C.c_double)]),
+    "tic_last_batch_zero_copy": (C.c_int, [_ctxp, C.POINTER(C.c_int)]),
     "tic_memcpy_h2d": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tic_memcpy_d2h": (C.c_int, [_ctxp, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tic_memset_dev": (C.c_int, [_ctxp, C.c_void_p, C.c_int, C.c_size_t]),

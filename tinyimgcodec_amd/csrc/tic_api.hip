@@ -219,6 +219,7 @@ struct tic_ctx {
     // how the last batch call took its input: frames copied to the device from where the caller holds them (pinned or registered
     // memory) / frames staged through the pipeline's pinned slots (pageable memory)
     int last_batch_direct_frames = 0, last_batch_staged_frames = 0;
+    int last_batch_zero_copy = 0; // streams of the last batch the read-back kernel stored straight into the caller's buffers
     mutable BatchTrace bt; // phase times of the last batch call
     // Pageable frames of a batch call are pinned in place for the duration of the call where that is one cheap registration
     // (auto_register_frames) instead of being copied into the pinned slots by CPU threads
@@ -565,6 +566,12 @@ int tic_last_batch_auto_registered(tic_ctx *ctx, int *frames) {
     TIC_LOCK(ctx);
     if (!ctx || !frames) return TIC_E_ARG;
     *frames = ctx->last_batch_autoreg_frames;
+    return TIC_OK;
+}
+int tic_last_batch_zero_copy(tic_ctx *ctx, int *streams) {
+    TIC_LOCK(ctx);
+    if (!ctx || !streams) return TIC_E_ARG;
+    *streams = ctx->last_batch_zero_copy;
     return TIC_OK;
 }
 int tic_last_batch_phases(tic_ctx *ctx, double *ms8) {
@@ -1574,6 +1581,16 @@ __global__ __launch_bounds__(256) void readback_rows_kernel(const uint4 *__restr
         __builtin_nontemporal_store(reinterpret_cast<const u32x4v *>(s)[i], reinterpret_cast<u32x4v *>(d) + i);
 }
 
+// ... and straight into the CALLER's buffers when those are rows of one block of memory (a pool of n x cap bytes: what compress_batch() of the
+// Python mirror and bench.py hold), pinned for the call: 8-byte pieces, because a row pitch of tic_compress_bound() bytes is a multiple of 8, not 16.
+__global__ __launch_bounds__(256) void readback_rows8_kernel(const uint2 *__restrict__ src, size_t src_pitch8, uint2 *__restrict__ dst, size_t dst_pitch8, size_t row8) {
+    const uint2 *s = src + (size_t)blockIdx.y * src_pitch8;
+    uint2 *d = dst + (size_t)blockIdx.y * dst_pitch8;
+    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < row8; i += (size_t)gridDim.x * 256u)
+        __builtin_nontemporal_store(reinterpret_cast<const u32x2v *>(s)[i], reinterpret_cast<u32x2v *>(d) + i);
+}
+
 static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n, int h, int w, ptrdiff_t row_stride,
                               int quality, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
     int rc = check_stream_geometry(ctx, h, w, row_stride, quality);
@@ -1597,6 +1614,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     std::vector<Slot> &slots = ctx->bslots;
     const int S = (int)slots.size();
     int result = TIC_OK;
+    const bool inline_path = n <= chunk; // a batch of ONE chunk runs on the calling thread (below)
     // finishing a chunk, part 1: wait for its lengths, then read its streams back into pinned memory
     auto read_back = [&](Slot &s, hipStream_t st) -> int {
         if (s.count == 0) return TIC_OK;
@@ -1620,6 +1638,45 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
         // ONE strided copy brings the head of every frame's stream buffer - as many bytes as the longest stream has - into
         // the slot's pinned buffer (16 separate copies of ~0.9 MB cost ~45 us each, 2.5 x their transfer time); frames of one
         // batch compress to similar sizes, so little more than the streams themselves crosses PCIe.
+        // Zero copy (round 6; a batch of one chunk only - it runs on the calling thread, which owns the call's registrations): the caller's
+        // buffers are rows of ONE block of memory (equal distances, 8-byte aligned: a pool of n x cap bytes) -> the block is pinned for the
+        // call and the shader stores every stream where the caller wants it; the copy out of the pipeline's pinned buffer (0.12-0.28 ms for the
+        // 49 streams of the reference's benchmark set: a third of the call) does not happen.  The rows are written up to the chunk's longest
+        // stream rounded to 8 bytes (all within the frames' capacities, checked): bytes behind a stream's end are not preserved.
+        if (inline_path && ctx->auto_register && s.count >= 2 && maxlen >= 16) {
+            const uint8_t *base = outs[s.first];
+            const size_t P = (size_t)(outs[s.first + 1] - outs[s.first]), row8 = (maxlen + 7) / 8;
+            bool ok = outs[s.first + 1] > outs[s.first] && P % 8 == 0 && (uintptr_t)base % 8 == 0 && P >= row8 * 8;
+            for (int k = 0; k < s.count && ok; k++) ok = outs[s.first + k] == base + (size_t)k * P && caps[s.first + k] >= row8 * 8;
+            const size_t span = ok ? (size_t)(s.count - 1) * P + row8 * 8 : 0;
+            void *reg = nullptr;
+            if (ok && !(host_pointer_is_pinned(base) && host_pointer_is_pinned(base + span - 1))) {
+                const uintptr_t lo = (uintptr_t)base & ~(uintptr_t)4095, hi = ((uintptr_t)base + span + 4095) & ~(uintptr_t)4095;
+                if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+                    reg = (void *)lo;
+                    ctx->autoregs.push_back(reg); // (released with the call's other registrations, behind its last synchronisation)
+                } else {
+                    (void)hipGetLastError();
+                    ok = false;
+                }
+            }
+            void *d_dst = nullptr;
+            if (ok && hipHostGetDevicePointer(&d_dst, (void *)base, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                ok = false;
+            }
+            if (ok) {
+                BT_START();
+                hipLaunchKernelGGL(readback_rows8_kernel, dim3(64, (unsigned)s.count), dim3(256), 0, st, (const uint2 *)s.d_streams, bound / 8, (uint2 *)d_dst, P / 8, row8);
+                hipError_t e = hipGetLastError();
+                if (e == hipSuccess) e = hipEventRecord(s.rb_done, st);
+                BT_STOP(3);
+                if (e != hipSuccess) return set_err(ctx, TIC_E_HIP, "stream read-back failed: %s", hipGetErrorString(e));
+                s.rb_row = 0; // (nothing to hand out)
+                ctx->last_batch_zero_copy += s.count;
+                return TIC_OK;
+            }
+        }
         const size_t pin_cap = coef_bytes * (size_t)chunk; // size of pin_out (ensure_batch_slots)
         const size_t row = align_up(maxlen, 256);
         const bool packed = row * (size_t)s.count <= pin_cap;
@@ -1692,6 +1749,7 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     bool stop_read = false, stop_hand = false;
     int fin_result = TIC_OK;
     ctx->last_batch_direct_frames = ctx->last_batch_staged_frames = ctx->last_batch_autoreg_frames = 0;
+    ctx->last_batch_zero_copy = 0;
     ctx->bt = BatchTrace();
     if ((size_t)row_stride == pitch && pitch == (size_t)w) { // the whole batch as one range, if it is one
         BT_START();
@@ -1701,7 +1759,6 @@ static int compress_batch_gpu(tic_ctx *ctx, const uint8_t *const *images, int n,
     // A batch of ONE chunk (the reference's benchmark set: 49 frames of 512 x 512) runs on the calling thread: enqueue, wait, read back, hand out.
     // Starting the two pipeline threads costs more than the chunk's work when the host is busy - their first wake-up came 3-10 ms late in
     // one call in three on a shared box (tools/batch_small_probe.py: chunk_wait 0.008 ms, the reader found the chunk long finished).
-    const bool inline_path = n <= chunk;
     std::thread reader, hander;
     if (!inline_path) {
     reader = std::thread([&]() {

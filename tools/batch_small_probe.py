@@ -20,8 +20,9 @@ for q in (90, 50, 5):
         ctx.check(L.tic_compress_batch(ctx.handle, inp, n, h, w, w, q, outp, caps, lens, 0))
         dt = time.perf_counter() - t0
         ctx.check(L.tic_last_batch_phases(ctx.handle, tr))
+        zc = C.c_int(); ctx.check(L.tic_last_batch_zero_copy(ctx.handle, C.byref(zc)))
         if rep >= 3:
-            print("q=%d compress_batch %.3f ms: stage/register %.3f enqueue %.3f chunk_wait %.3f read_back %.3f hand_out %.3f slot_wait %.3f join+sync %.3f unregister %.3f" % (q, dt * 1e3, tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6], tr[7]), flush=True)
+            print("q=%d compress_batch %.3f ms: stage/register %.3f enqueue %.3f chunk_wait %.3f read_back %.3f hand_out %.3f slot_wait %.3f join+sync %.3f unregister %.3f zero-copy streams %d" % (q, dt * 1e3, tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6], tr[7], zc.value), flush=True)
     streams = [pool[i, : lens[i]].copy() for i in range(n)]
     block = np.empty((n, h, w), np.uint8)
     sp = (C.c_void_p * n)(*[s.ctypes.data for s in streams]); sl = (C.c_size_t * n)(*[s.size for s in streams])
