@@ -2024,6 +2024,10 @@ static bool device_decoder_takes(size_t n, size_t len) {
 
 // stream bits per lane of the device decoder: `mult` average blocks, at least `floor_words` 32-bit words, as an odd number of words up to 63
 static int decode_range_bits(size_t len, size_t n, size_t mult = 3, size_t floor_words = 17) {
+    // (nearly flat content - below 7 stream bits per block: DC code + end-of-block and little else - is periodic bit patterns in which a walk can stay
+    //  out of step for tens of ranges: ranges twice as long there.  tools/stress_decoder.py 600: second runs on valid streams of 4-7 bits per block 1 in
+    //  24 instead of 4; everywhere else the longer range only costs - the benchmark loop's decompress() +10-17 us, profiles/r06_decoder.txt)
+    if (floor_words == 17 && len * 8 < 7 * n) floor_words = 33;
     size_t k = (mult * (len * 8) / n + 31) / 32;
     k |= 1;
     return (int)(k < floor_words ? floor_words : (k > 63 ? 63 : k)) * 32;
