@@ -1931,7 +1931,7 @@ def test_decompress_long_streams_on_the_device_decoder(ctx, oracle, golden, monk
                 assert L.tic_last_decode_range(ctx.handle, C.byref(rbits), C.byref(tries)) == 0
                 avg = (len(s) * 8) / (((img.shape[0] + 7) // 8) * ((img.shape[1] + 7) // 8))
                 floor = 1056 if avg < 7 else 544  # (round 6: nearly flat content gets ranges twice as long)
-                    assert tries.value == 1 and rbits.value % 64 == 32 and max(floor, 3 * avg - 32) <= rbits.value <= max(floor, 3 * avg + 64), \
+                assert tries.value == 1 and rbits.value % 64 == 32 and max(floor, 3 * avg - 32) <= rbits.value <= max(floor, 3 * avg + 64), \
                     (name, q, rbits.value, tries.value, avg)  # the first choice of range held: no second run
             assert np.array_equal(got, want), (name, q)
             # the sums inside the two kernels (block counts, DC differences): launches above TIC_DECODE_FLAT_GRID workgroups look back through
