@@ -888,6 +888,7 @@ int tic_last_fallback_blocks(tic_ctx *ctx, unsigned long long *count) {
     return rc;
 }
 
+constexpr size_t kDecHostPixBytes = 1u << 20; // tic_decompress: images of at most this many bytes leave through tic_ctx::h_small as well
 constexpr size_t kSmallHostBytes = 2u << 20; // tic_compress: frames whose stream bound is at most this go through tic_ctx::h_small
 static int ensure_small(tic_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->small_cap) return TIC_OK;
@@ -2103,11 +2104,20 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     // where the pixels go: a device destination whose rows are 8-byte aligned takes them straight from the kernels (row stores are
     // cropped to w); anything else gets them from the context's image buffer with one strided copy at the end
     const bool direct = out_on_device && out_stride % 8 == 0 && (uintptr_t)out % 8 == 0;
+    // a small image on its way to host memory: the kernels store its rows (8-byte aligned, back to back) into the context's host-mapped
+    // buffer, and one memcpy behind the wait that reads the status takes them to the caller - no copy command, no second wait
+    // (a 512 x 512 image: 30 us between the last kernel and the end of the read-back, profiles/r05_decoder.txt)
+    const size_t pitch8 = align_up((size_t)w, 8);
+    const bool host_pix = !out_on_device && pitch8 * (size_t)h <= kDecHostPixBytes && !test_hook("TIC_DECODE_NO_HOSTPIX");
+    if (host_pix) {
+        rc = ensure_small(ctx, kSmallHostBytes);
+        if (rc) return rc;
+    }
     DecIdctArgs ia;
-    ia.out = direct ? out : (uint8_t *)ctx->d_img;
+    ia.out = direct ? out : host_pix ? ctx->d_small : (uint8_t *)ctx->d_img;
     ia.h = h;
     ia.w = w;
-    ia.stride = direct ? (long)out_stride : (long)pitch;
+    ia.stride = direct ? (long)out_stride : host_pix ? (long)pitch8 : (long)pitch;
     ia.bw = (w + 7) / 8;
     ia.aligned8 = 1;
     ia.consts = ctx->d_consts + (scaled_exp >= 0 ? 50 : quality); // codec.py:62: quality = 50 on the scaled branch
@@ -2208,9 +2218,12 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
         a.scaled = ia.scaled;
         a.pow2 = ia.pow2;
         HIPCHK(ctx, launch_idct(a, ctx->stream));
-        if (direct || !big.empty()) HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (the caller's pixels are complete when this returns)
+        if (direct || host_pix || !big.empty()) HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (the caller's pixels are complete when this returns)
     }
-    if (!direct) {
+    if (host_pix) { // (the stream has drained: the kernels' stores have arrived)
+        if (pitch8 == (size_t)w) memcpy(out, ctx->h_small, (size_t)h * (size_t)w);
+        else for (int y = 0; y < h; y++) memcpy(out + (size_t)y * (size_t)w, ctx->h_small + (size_t)y * pitch8, (size_t)w);
+    } else if (!direct) {
         HIPCHK(ctx, hipMemcpy2DAsync(out, out_on_device ? out_stride : (size_t)w, ctx->d_img, pitch, (size_t)w, (size_t)h,
                                      out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
