@@ -2024,11 +2024,15 @@ static bool device_decoder_takes(size_t n, size_t len) {
 }
 
 // stream bits per lane of the device decoder: `mult` average blocks, at least `floor_words` 32-bit words, as an odd number of words up to 63
-static int decode_range_bits(size_t len, size_t n, size_t mult = 3, size_t floor_words = 17) {
+// Round 6's rule: TWO average blocks, at least 288 bits (rounds 3-5: three, at least 544 - then a range in which the walk did not fall in step with the
+// chain ended the run; now it hands its exit on, and ranges below 544 bits get eight shadows in front of a wave's own).  tools/range_rule_sweep.py,
+// profiles/r06_decoder.txt (7): a 512^2 stream at q = 50 / 10 76 / 71 us instead of 88 / 85, 4096^2 noise at q = 90 / 10 121 / 70 instead of 129 / 76;
+// second runs in 600 stress streams 4 instead of 2 (all below 32 bits per block).
+static int decode_range_bits(size_t len, size_t n, size_t mult = 2, size_t floor_words = 9) {
     // (nearly flat content - below 7 stream bits per block: DC code + end-of-block and little else - is periodic bit patterns in which a walk can stay
     //  out of step for tens of ranges: ranges twice as long there.  tools/stress_decoder.py 600: second runs on valid streams of 4-7 bits per block 1 in
     //  24 instead of 4; everywhere else the longer range only costs - the benchmark loop's decompress() +10-17 us, profiles/r06_decoder.txt)
-    if (floor_words == 17 && len * 8 < 7 * n) floor_words = 33;
+    if (floor_words == 9 && len * 8 < 7 * n) floor_words = 33;
     size_t k = (mult * (len * 8) / n + 31) / 32;
     k |= 1;
     return (int)(k < floor_words ? floor_words : (k > 63 ? 63 : k)) * 32;
@@ -2124,13 +2128,12 @@ static int decode_on_device(tic_ctx *ctx, const uint8_t *data, size_t len, int h
     ia.scaled = scaled_exp >= 0;
     ia.pow2 = scaled_exp >= 0 ? ldexp(1.0, scaled_exp) : 1.0;
     memcpy(ia.head, head16, 16); // the header these were derived from (a guess, or the stream's own): the fused kernel writes pixels only under it
-    // stream bits per lane: 3 average blocks, at least 544 bits, as an odd number of 32-bit words up to 63 (noise at q = 50, 220 bits
-    // per block: 672; tiled Lenna, 41, and noise at q = 10, 70: 544; noise at q = 90, 404: 1,248).  The decoder's kernels are one
+    // stream bits per lane (decode_range_bits): 2 average blocks, at least 288 bits, as an odd number of 32-bit words up to 63 (noise at q = 50,
+    // 220 bits per block: 480; tiled Lenna, 41, and noise at q = 10, 70: 288; noise at q = 90, 404: 864).  The decoder's kernels are one
     // dependent chain per lane, so their time goes with this number (profiles/r04_decoder.txt: the measure kernel 57 us at 672 bits,
-    // 76 at 1,024).  A range in which the range's own walk does not fall in step with the true chain - a block longer than the range,
-    // or, below ~400 bits, a walk that stays out of step for all of it (noise at q = 10 at 288 bits: one range in 20,000) - makes the
-    // stitch give up with bit 4: one more try with the longest range, then the host decoder takes over
-    size_t mult = 3, floor_words = 17;
+    // 76 at 1,024).  A run in which more ranges in a row than the stitch has rounds stay without a synchronisation point (periodic content),
+    // or whose blocks do not follow each other where they are decoded, gives up: one more try with the longest range, then the host decoder
+    size_t mult = 2, floor_words = 9;
     if (const char *e = test_hook("TIC_DECODE_RULE")) { // "<average blocks per range>,<least words per range>": measurements of the rule itself
         unsigned a = 0, b = 0;
         if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 64 && b >= 9 && b <= 63) mult = a, floor_words = b | 1;
@@ -2430,7 +2433,7 @@ int tic_decompress_batch(tic_ctx *ctx, const uint8_t *const *streams, const size
             d.nranges = entropy_decode_batch_ranges(len, range_bits);
             d.range0 = ranges;
             d.tile0 = tiles;
-            d.ntiles = entropy_decode_batch_tiles(d.nranges);
+            d.ntiles = entropy_decode_batch_tiles(d.nranges, range_bits);
             d.blk0 = (uint32_t)blk;
             d.nblocks = (uint32_t)f.nblk;
             d.wg0 = wgs;

@@ -85,7 +85,7 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
 // look-back words and the epoch as above; small_win: every stream has at most 240 bits per block on average.  A frame whose status comes back
 // with giveup != 0 or m != its block count is the caller's to decode again on its own.
 size_t entropy_decode_batch_work_bytes(size_t total_ranges_288, size_t total_blocks, size_t nframes);
-uint32_t entropy_decode_batch_tiles(uint32_t nranges);
+uint32_t entropy_decode_batch_tiles(uint32_t nranges, int range_bits);
 uint32_t entropy_decode_batch_wgs(size_t nblocks);
 uint32_t entropy_decode_batch_ranges(size_t stream_bytes, int range_bits);
 hipError_t entropy_decode_idct_gpu_batch(const void *d_words_all, const DecFrame *d_frames, const uint32_t *d_tile_frame, const uint32_t *d_wg_frame, uint32_t nframes,

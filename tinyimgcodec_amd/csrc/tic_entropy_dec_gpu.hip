@@ -310,19 +310,22 @@ __device__ __forceinline__ void chain_step(const uint8_t *lutm, uint32_t pk, uin
 // why streams below 32 bits per block were kept on the host decoder).  Now a range the chain passes over, or walks through without
 // meeting its trace, hands its EXIT to the lane behind it and that lane stitches again from there (the fix-up loop below); a block is at
 // most 1,728 bits long, a range at least 544: four ranges in front of the first owned one are enough for the true entry to reach it.
-constexpr uint32_t kShadow = 4;            // ranges in front of its own that a wave shadows
-constexpr uint32_t kOwned = 64 - kShadow;  // ranges a wave owns
+// (later in round 6: the count is the launch's - `shadows`, dec_shadows() - so that ranges below 544 bits get EIGHT: the same 2,300 bits in front of the
+//  first owned range for the true entry to arrive through)
+constexpr uint32_t kShadowMax = 16;        // ranges in front of its own that a wave shadows: at most (sizes the look-back words)
 __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                     uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
                                                     uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
                                                     unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
-                                                    uint32_t ntiles, DecStatus *__restrict__ st, const uint32_t tile /* this wave's index among the stream's `ntiles` waves */, const uint32_t stitch_rounds) {
+                                                    uint32_t ntiles, DecStatus *__restrict__ st, const uint32_t tile /* this wave's index among the stream's `ntiles` waves */, const uint32_t stitch_rounds,
+                                                    const uint32_t kShadow /* ranges in front of its own that the wave shadows */) {
     __shared__ __attribute__((aligned(16))) uint8_t lutm[kChainLds];   // the chain tables: the measure walk
     extern __shared__ uint32_t sbits_all[]; // stage_lds_words(range) per wave, the launch's dynamic LDS
     // A workgroup is one to four WAVES that share nothing but the chain tables (6.4 KB from memory once per workgroup instead of once
     // per wave) and the barrier behind the staging; `tile` is the wave's index among all waves of the launch - what rounds 4's
     // one-wave workgroups called blockIdx.x.
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t kOwned = 64u - kShadow; // ranges a wave owns
     uint32_t *sbits = sbits_all + wave * stage_lds_words(range);
     if (tile == 0u && lane < 4u) st->head[lane] = gwords[lane]; // (a stream has its 16-byte header: nwords >= 4)
     const uint32_t t_first = tile ? tile * kOwned - kShadow : 0u; // the window's first range
@@ -540,9 +543,9 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t 
                                                                 uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
                                                                 uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
                                                                 unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
-                                                                uint32_t ntiles, DecStatus *__restrict__ st, uint32_t stitch_rounds) {
+                                                                uint32_t ntiles, DecStatus *__restrict__ st, uint32_t stitch_rounds, uint32_t shadows) {
     measure_stitch_body(gwords, nwords, last_mask, L, fast_end, stream_bits, range, nranges, starts, hand, desc, desc_half, flat_grid, epoch, nblocks, bpos, grand_total, ntiles, st,
-                        blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), stitch_rounds);
+                        blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), stitch_rounds, shadows);
 }
 // A BATCH of streams per launch (tic_decompress_batch: the reference's benchmark loop decodes 49 streams of 512 x 512 one after the other,
 // tests/benchmark.py:12-23 - two launches per stream are launch latency and little else).  Wave `g` of the grid works on stream
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_batch_kernel(const uin
                                                                       uint32_t total_tiles, const DecLutsDev *__restrict__ L, uint32_t range, uint16_t *__restrict__ starts_all,
                                                                       uint16_t *__restrict__ hand_all, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid,
                                                                       uint32_t epoch, uint32_t *__restrict__ bpos_all, long long *__restrict__ totals, DecStatus *__restrict__ status,
-                                                                      uint32_t stitch_rounds) {
+                                                                      uint32_t stitch_rounds, uint32_t shadows) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const bool beyond = g >= total_tiles; // (a wave behind the last stream's last range: it goes through the staging's barrier as that stream's wave `ntiles` and returns)
     const uint32_t f = tile_frame[beyond ? total_tiles - 1u : g];
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_batch_kernel(const uin
     const size_t cap = cap_of(range);
     measure_stitch_body(words_all + F.word0, F.nwords, F.last_mask, L, F.fast_end, F.stream_bits, range, F.nranges, starts_all + (size_t)F.range0 * cap,
                         hand_all + (size_t)F.range0 * cap, desc + F.tile0, desc_half, flat_grid, epoch, (unsigned long long)F.nblocks, bpos_all + F.blk0, totals + f, F.ntiles, status + f,
-                        beyond ? F.ntiles : g - F.tile0, stitch_rounds);
+                        beyond ? F.ntiles : g - F.tile0, stitch_rounds, shadows);
 }
 
 // ---- decode + inverse transform, fused --------------------------------------------------------------------------------------------
@@ -824,6 +827,16 @@ static uint32_t stitch_rounds() {
     return 8u;
 }
 
+// ranges in front of its own that a wave of the measure kernel shadows: the true entry into the wave's first own range has to arrive through them - a
+// block of the chain is up to 1,728 bits long and a walk needs a few blocks to fall in step (hook for measurements: TIC_DECODE_SHADOWS)
+static uint32_t dec_shadows(int range_bits) {
+    if (const char *e = test_hook("TIC_DECODE_SHADOWS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= (int)kShadowMax) return (uint32_t)v;
+    }
+    return range_bits < 544 ? 8u : 4u;
+}
+
 bool entropy_decode_gpu_range_ok(int range_bits) {
     return range_bits >= kRangeMin && range_bits <= kRangeMax && range_bits % 64 == 32; // an odd number of 32-bit words
 }
@@ -836,7 +849,7 @@ size_t entropy_decode_gpu_work_bytes(size_t stream_bytes, size_t nblocks) {
 
 size_t entropy_decode_gpu_desc_words(size_t stream_bytes, size_t nblocks) { // look-back words of the two sums (own and inclusive sums: a quarter of the array each)
     const size_t nranges = stream_bytes * 8 / kRangeMin + 2;
-    const size_t tr = nranges / kOwned + 2, tb = nblocks / kDecodeWG + 2; // (workgroups of the measure kernel and of the fused kernel)
+    const size_t tr = nranges / (64 - kShadowMax) + 2, tb = nblocks / kDecodeWG + 2; // (workgroups of the measure kernel and of the fused kernel)
     return 4 * (tr > tb ? tr : tb);
 }
 
@@ -858,7 +871,8 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     // words read as zeros, raises giveup bit 256 (a cut stream: the caller comes back with the margin).
     const uint32_t fast_end = (uint32_t)(nbits - (size_t)margin_bits);
     const uint32_t nranges = (uint32_t)((fast_end - 128 + kRange - 1) / kRange);
-    const unsigned measure_wgs = (nranges + kOwned - 1u) / kOwned;
+    const uint32_t shadows = dec_shadows(range_bits), owned = 64u - shadows;
+    const unsigned measure_wgs = (nranges + owned - 1u) / owned;
     const size_t ntiles_r = measure_wgs, ntiles_b = (nblocks + kDecodeWG - 1) / kDecodeWG; // (the workgroups of the two kernels are the tiles of the two sums)
     // The look-back words of the two sums live in an array of their own that holds nothing else, ever: a word there either is zero
     // (since allocation) or carries the epoch of the launch that wrote it, and the caller never reuses an epoch on it.  (Inside the
@@ -882,7 +896,7 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     const unsigned wpw = (unsigned)kChainLds + 4u * win_lds <= 60000u ? 4u : ((unsigned)kChainLds + 2u * win_lds <= 60000u ? 2u : 1u);
     hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3((measure_wgs + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, words, nwords, last_mask, d_luts, fast_end,
                        (uint32_t)nbits, range, nranges, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, (unsigned long long)nblocks, bpos, totals,
-                       (uint32_t)measure_wgs, d_status, stitch_rounds());
+                       (uint32_t)measure_wgs, d_status, stitch_rounds(), shadows);
     const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
     auto fused = [&](auto kern) {
         hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, desc_b, desc_half, (uint32_t)flat_grid, 2u * epoch + 1u,
@@ -898,7 +912,7 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
 size_t entropy_decode_batch_work_bytes(size_t total_ranges_288, size_t total_blocks, size_t nframes) {
     return total_ranges_288 * ((size_t)cap_of(kRangeMin) * 2 * 2) + total_blocks * 4 + nframes * 8 + 16384;
 }
-uint32_t entropy_decode_batch_tiles(uint32_t nranges) { return (nranges + kOwned - 1u) / kOwned; }
+uint32_t entropy_decode_batch_tiles(uint32_t nranges, int range_bits) { const uint32_t owned = 64u - dec_shadows(range_bits); return (nranges + owned - 1u) / owned; }
 uint32_t entropy_decode_batch_wgs(size_t nblocks) { return (uint32_t)((nblocks + kDecodeWG - 1) / kDecodeWG); }
 uint32_t entropy_decode_batch_ranges(size_t stream_bytes, int range_bits) { return (uint32_t)((stream_bytes * 8 - 128 + (size_t)range_bits - 1) / (size_t)range_bits); }
 
@@ -920,7 +934,7 @@ hipError_t entropy_decode_idct_gpu_batch(const void *d_words_all, const DecFrame
     const unsigned win_lds = stage_lds_words(range) * 4u;
     const unsigned wpw = (unsigned)kChainLds + 4u * win_lds <= 60000u ? 4u : ((unsigned)kChainLds + 2u * win_lds <= 60000u ? 2u : 1u);
     hipLaunchKernelGGL(dec_measure_stitch_batch_kernel, dim3((total_tiles + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, (const uint32_t *)d_words_all, d_frames, d_tile_frame,
-                       total_tiles, d_luts, range, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, bpos, totals, d_status, stitch_rounds());
+                       total_tiles, d_luts, range, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, bpos, totals, d_status, stitch_rounds(), dec_shadows(range_bits));
     if (small_win)
         hipLaunchKernelGGL(dec_decode_idct_batch_kernel<2048>, dim3(total_wgs), dim3(kDecodeWG), 0, stream, (const uint32_t *)d_words_all, d_frames, d_wg_frame, d_luts, (const uint32_t *)bpos, desc_b,
                            desc_half, (uint32_t)flat_grid, 2u * epoch + 1u, (const long long *)totals, d_status);
