@@ -269,7 +269,7 @@ int tic_last_decode_path(tic_ctx *ctx);
  * first range, 4 a range without a synchronisation point, 8 / 16 / 32 an incident on the true chain, 2 trace overflow, 64 no block
  * produced). */
 int tic_last_decode_giveup(tic_ctx *ctx);
-/* ... and the stream bits per lane the device decoder's last run worked with (3 average blocks, 544 ... 2,016), and how many runs the
+/* ... and the stream bits per lane the device decoder's last run worked with (2 average blocks, 288 ... 2,016; 1,056 at least for nearly flat streams), and how many runs the
  * last long stream took: 2 = the first choice met a range without a synchronisation point and the longest range was tried.
  * Either pointer may be null.  (No counterpart in the reference: huffman.py:77-98 decodes bit by bit.) */
 int tic_last_decode_range(tic_ctx *ctx, int *range_bits, int *tries);
