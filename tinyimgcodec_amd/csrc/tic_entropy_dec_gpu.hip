@@ -295,6 +295,18 @@ __device__ __forceinline__ void chain_step(const uint8_t *lutm, uint32_t pk, uin
     adv = none ? (mode != 1u ? 1u : 0u) : e >> 1;
     mode = none ? ((0x18u >> (2u * mode)) & 3u) /* 0 -> 0, 1 -> 2, 2 -> 1 */ : (eob ^ 1u);
 }
+// Diagnostic build only (make -C tools bin/libvar_700.so VARSRC=tic_entropy_dec_gpu.hip; tools/dec_stamps.py): the 100 MHz clock at the phase boundaries of the two
+// kernels, taken by lane 0 of the first and of the last wave / workgroup of a launch - where a kernel that is one chain of trips to memory spends its time
+#if defined(TIC_EXP) && TIC_EXP == 700
+__device__ unsigned long long g_dec_stamps[4][16];
+#define DEC_STAMP(row_first, is_first, is_last, k)                                                                               \
+    do {                                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                               \
+        if ((threadIdx.x & 63u) == 0u && ((is_first) || (is_last))) g_dec_stamps[(row_first) + ((is_first) ? 0 : 1)][k] = wall_clock64(); \
+    } while (0)
+#else
+#define DEC_STAMP(row_first, is_first, is_last, k) do {} while (0)
+#endif
 // Measure and stitch, one kernel.  The lanes of a wave walk side by side, a look-up per step.  (Round 3's first version looped per
 // block: the lanes of a wave then wait for each other at every block end - 630 symbol steps per wave where the longest lane has ~250
 // symbols.)  Here the position inside the block (is the DC category next?) is lane state and a block end is just another step.
@@ -327,6 +339,8 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t kOwned = 64u - kShadow; // ranges a wave owns
     uint32_t *sbits = sbits_all + wave * stage_lds_words(range);
+#define MS_STAMP(k) DEC_STAMP(0, tile == 0u, tile + 1u == ntiles, k)
+    MS_STAMP(0);
     if (tile == 0u && lane < 4u) st->head[lane] = gwords[lane]; // (a stream has its 16-byte header: nwords >= 4)
     const uint32_t t_first = tile ? tile * kOwned - kShadow : 0u; // the window's first range
     static_assert(offsetof(DecLutsDev, mac) == offsetof(DecLutsDev, mdc) + 2048 && offsetof(DecLutsDev, mlong) == offsetof(DecLutsDev, mac) + 4096 &&
@@ -335,6 +349,7 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
     copy16_to_lds_rt(lutm, L->mdc, kChainLds / 16); // (stage_bits below ends with the barrier)
     const Bits words = stage_bits<64>(sbits, gwords, 128u + t_first * range, range, nwords, last_mask, lane);
     if (tile >= ntiles) return; // (a wave behind the last range; behind the barrier)
+    MS_STAMP(1);
     const bool shadow = lane < kShadow;
     const uint32_t t = tile * kOwned + lane - kShadow; // (lanes 0..kShadow-1 of tile 0: no such range)
     const bool walks = (tile != 0u || !shadow) && t < nranges;
@@ -396,6 +411,7 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
         live = (eob ? pos < hi : true) && pos < stop;
     }
     if (mine && cnt > cap) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
+    MS_STAMP(2);
     // ---- stitch: does the true chain, entering where the walk of the range in front ended, meet this range's trace?
     const uint32_t wend = pos; // where this range's own walk ended: the true chain's exit IF the chain met the trace inside the range
     const uint32_t n_rec = cnt;
@@ -489,7 +505,9 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
     {
         const bool can = walks && (t == 0u || lane != 0u);
         uint32_t entry = (uint32_t)__shfl_up((int)wend, 1, 64); // (all 64 lanes are here: nobody has returned)
+        MS_STAMP(3);
         if (can) stitch(entry);
+        MS_STAMP(4);
         bool need = false;
         for (uint32_t round = 0; round < stitch_rounds; round++) {
             const uint32_t pe = (uint32_t)__shfl_up((int)exit_pos, 1, 64);
@@ -502,6 +520,7 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
         }
         if (need && mine) atomicOr(&st->giveup, 4); // more ranges in a row than rounds without a synchronisation point (a block covers three at most: a walk that stays out of step - periodic content)
     }
+    MS_STAMP(5);
     if (!mine) nb = 0u; // a shadow's blocks are counted by the range's owner
     // ---- index of every range's first true block, and with it the first bit of every block of the true chain - HERE, in the same launch
     // (rounds 2-4: a launch of its own, scan_counts_bpos_kernel, over arrays this kernel wrote): the wave sums its 63 counts, PUBLISHES the
@@ -519,6 +538,7 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
         if (lane == 63u) __hip_atomic_store(&desc[tile], scan_pack(epoch, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, tot, st, tile, ntiles);
         if (tile == ntiles - 1u && lane == 63u) *grand_total = part + tot;
+        MS_STAMP(6);
         if (!mine) return;
         const unsigned long long first = (unsigned long long)(part + inc - (long long)nb);
         const uint32_t from_trace = n - a < nb ? n - a : nb, hand_n = nb - from_trace < cap ? nb - from_trace : cap; // (a <= n)
@@ -535,7 +555,9 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
         };
         emit(hand + (size_t)t * cap, hand_n, first);
         emit(tr + a, from_trace, first + (nb - from_trace));
+        MS_STAMP(7);
     }
+#undef MS_STAMP
 }
 
 // One stream per launch: a wave's tile is its index in the grid.
@@ -607,6 +629,8 @@ __device__ __forceinline__ void decode_idct_body(const uint32_t *__restrict__ gw
     __shared__ long long scan_lds[16];
     uint32_t *lut = scratch;
     uint32_t *sbits = scratch + kLutDw;
+#define FD_STAMP(k) DEC_STAMP(2, wg == 0u && threadIdx.x == 0, wg + 1u == nwgs && threadIdx.x == 0, k)
+    FD_STAMP(0);
     const unsigned long long total = (unsigned long long)*total_blocks;
     const unsigned long long m = total < n_want ? total : n_want; // blocks produced here
     const unsigned long long b0 = (unsigned long long)wg * kDecodeWG, b = b0 + threadIdx.x;
@@ -638,6 +662,7 @@ __device__ __forceinline__ void decode_idct_body(const uint32_t *__restrict__ gw
     // as well): the lane decodes its block's DC symbol first, the workgroup sums its 256 differences and PUBLISHES the sum (scan_publish),
     // then the lanes decode their AC symbols - and only behind them every wave adds up the sums of the workgroups in front (published
     // long since: nobody spins), because the integrated DC is needed for one store at the block's end and nothing else.
+    FD_STAMP(1);
     int16_t *c = reinterpret_cast<int16_t *>(img + (size_t)threadIdx.x * kImgStrideB);
     uint32_t pos = my_pos;
     uint32_t wi = pos >> 5;
@@ -660,6 +685,7 @@ __device__ __forceinline__ void decode_idct_body(const uint32_t *__restrict__ gw
         dc_diff = (long long)value_of(pk, (int)(e >> 8), (int)(e & 15u));
         advance((e >> 8) + (e & 15u), wn);
     }
+    FD_STAMP(2);
     long long dc_tile;
     const long long dc_inc = wg_inclusive_scan(dc_diff, scan_lds, dc_tile);
     if (threadIdx.x == 0) __hip_atomic_store(&desc[wg], scan_pack(epoch, dc_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (scan_publish, with the stream's own index)
@@ -711,6 +737,7 @@ __device__ __forceinline__ void decode_idct_body(const uint32_t *__restrict__ gw
             st->m = m;
         }
     }
+    FD_STAMP(3);
     { // the sums of the workgroups in front, wave by wave (no barrier: a wave whose blocks were short goes on)
         const long long part = wave_lookback(desc, desc_half, flat_grid, epoch, dc_tile, st, wg, nwgs); // (every wave of the workgroup publishes the same inclusive sum: whichever is first)
         if (b < m) {
@@ -724,6 +751,7 @@ __device__ __forceinline__ void decode_idct_body(const uint32_t *__restrict__ gw
     // the phases (a wave whose blocks were short goes on while the others still decode), nothing but the lane's own image read back.
     // (Rounds 2-4: 8 lanes per block, 8 blocks per wave and round, the 8x8 float64 matrix transposed through LDS between the passes:
     // the same arithmetic, plus two LDS round trips and a workgroup barrier per round; profiles/r05_decoder.txt.)
+    FD_STAMP(4);
     if (b >= m) return;
     asm volatile("" ::: "memory"); // (the image's two-byte stores above are read back as 16-byte pieces)
     double x[64]; // x[u * 8 + v]: natural order
@@ -756,6 +784,7 @@ __device__ __forceinline__ void decode_idct_body(const uint32_t *__restrict__ gw
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    FD_STAMP(5);
     const uint32_t blk = (uint32_t)b; // (bit positions are 32-bit: fewer than 2^32 / 6 blocks)
     const uint32_t by = blk / (uint32_t)a.bw, bx = blk - by * (uint32_t)a.bw;
     const int x0 = (int)bx * 8;
@@ -795,6 +824,8 @@ __device__ __forceinline__ void decode_idct_body(const uint32_t *__restrict__ gw
         p += a.stride;
         __builtin_amdgcn_sched_barrier(0);
     }
+    FD_STAMP(6);
+#undef FD_STAMP
 }
 
 template <uint32_t kWinWords, bool kScaled>
@@ -945,3 +976,9 @@ hipError_t entropy_decode_idct_gpu_batch(const void *d_words_all, const DecFrame
 }
 
 } // namespace tic
+
+#if defined(TIC_EXP) && TIC_EXP == 700
+extern "C" int tic_debug_dec_stamps(unsigned long long *out /* [4][16]: measure first / last wave, fused first / last workgroup */) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tic::g_dec_stamps), sizeof(tic::g_dec_stamps));
+}
+#endif
