@@ -312,7 +312,7 @@ __device__ unsigned long long g_dec_stamps[4][16];
 // symbols.)  Here the position inside the block (is the DC category next?) is lane state and a block end is just another step.
 //
 // A wave stands alone (a workgroup is one to four of them, sharing only the tables' trip from memory: 38.5 -> 36.0 us for a 4096^2 stream).
-// Lanes kShadow..63 own 60 consecutive ranges; lanes 0..kShadow-1 SHADOW the ranges in front of them - each walks its range exactly as
+// Lanes kShadow..63 own 64 - kShadow consecutive ranges; lanes 0..kShadow-1 SHADOW the ranges in front of them - each walks its range exactly as
 // its owner (a lane of the workgroup before) does, and lanes 1.. also stitch it as the owner does, writing nothing but the trace (the
 // same words the owner writes) - so that every owner finds the exit of the range in front of its own in the lane next to it: the stitch
 // needs no second launch (its start, tables and window staged again, was a third of it) and no workgroup waits for another.
