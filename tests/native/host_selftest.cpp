@@ -209,11 +209,11 @@ int main() {
                         const uint32_t pk = peek32(pos);
                         const uint32_t li = (pk >> 16) - 0xff40u;
                         const uint32_t e = in_long ? mlong[li < 192u ? li : 192u] : (at_dc ? mdc[pk >> 21] : mac[pk >> 20]);
-                        const bool none = e == 0, esc = none && !in_long && !at_dc, eob = (e & 1u) != 0;
-                        pos += esc ? 0u : (none ? 1u : e >> 1);
+                        const bool eob = (e & 1u) != 0; // entry = (bits << 3) | (next table << 1) | EOB, also where no codeword is (tic_entropy.cpp chain_entry)
+                        pos += e >> 3;
                         if (eob) ends2.push_back(pos);
-                        at_dc = none ? at_dc : eob;
-                        in_long = esc;
+                        at_dc = ((e >> 1) & 3u) == 0u;
+                        in_long = ((e >> 1) & 3u) == 2u;
                     }
                 }
                 // the chain walk may overshoot the 3,000-bit horizon by one chain: compare the common prefix, which must be nearly all

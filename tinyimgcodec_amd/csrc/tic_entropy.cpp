@@ -646,6 +646,12 @@ void dec_luts_fill(uint16_t *dc11, uint16_t *ac11, uint16_t *ac16) {
 // (a symbol's length is its codeword's plus its size: the value bits themselves are not needed), stopping behind an EOB (the DC table
 // comes next) and in front of anything that is not a codeword.  Symbol by symbol this is exactly the sequence of steps the
 // one-symbol walk makes, so both walks stand on the same bits at every block end.
+// An entry is everything the walk's next step needs: (bits consumed << 3) | (table of the next step << 1) | (the chain ended with EOB) - table 0: the DC
+// category comes next (behind an EOB), 1: AC symbols, 2: the long AC codewords.  A window without a codeword is an entry like any other: with the DC category
+// next, skip a bit and stay (a walk out of step, or a damaged stream); inside the AC symbols it is the prefix of a long codeword - consume nothing, go to
+// table 2; in table 2 skip a bit and go back to the AC symbols.  (Until late in round 6 the entry was (bits << 1) | EOB, 0 for no codeword, and the walk
+// derived the rest: eight instructions of a step of 49.)
+static inline uint8_t chain_entry(int bits, int next_table, bool eob) { return (uint8_t)((bits << 3) | (next_table << 1) | (eob ? 1 : 0)); }
 static void build_chain(const uint16_t *first_lut16, bool first_is_dc, const uint16_t *ac_lut16, int W, uint8_t *out) {
     for (unsigned w = 0; w < (1u << W); w++) {
         int pos = 0, total = 0;
@@ -666,17 +672,17 @@ static void build_chain(const uint16_t *first_lut16, bool first_is_dc, const uin
                 break;
             }
         }
-        out[w] = (uint8_t)(total ? (total << 1) | (eob ? 1 : 0) : 0); // total <= 22
+        out[w] = total ? chain_entry(total, eob ? 0 : 1, eob) : (first_is_dc ? chain_entry(1, 0, false) : chain_entry(0, 2, false)); // total <= 22
     }
 }
 void dec_chain_luts_fill(uint8_t *mdc, uint8_t *mac, uint8_t *mlong) {
     const EncTables &T = tables();
     build_chain(T.dcd.lut, true, T.acd.lut, 11, mdc);
     build_chain(T.acd.lut, false, T.acd.lut, 12, mac);
-    memset(mlong, 0, 256);
+    memset(mlong, chain_entry(1, 1, false), 256); // (also the slot of an index out of range, behind the 192 codewords)
     for (int i = 0; i < 0x10000 - 0xff40; i++) {
         const uint16_t e = T.acd.lut[0xff40 + i];
-        mlong[i] = (uint8_t)(e ? ((e >> 8) + (e & 15)) << 1 : 0); // (never EOB: its codeword has 4 bits)
+        if (e) mlong[i] = chain_entry((e >> 8) + (e & 15), 1, false); // (at most 16 + 11 bits; never EOB: its codeword has 4 bits)
     }
 }
 

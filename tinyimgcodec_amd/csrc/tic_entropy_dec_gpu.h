@@ -12,8 +12,8 @@ struct DecLutsDev {
     uint16_t dc11[2048];
     uint16_t ac11[2048];
     uint16_t ac16[65536];
-    // the measure walk's tables: one look-up consumes a CHAIN of symbols (it needs block ends, not values): entry = (bits consumed << 1)
-    // | (the chain ended with EOB), 0 = no codeword of at most 11 bits here.  mdc: the next 11 stream bits with the DC category next;
+    // the measure walk's tables: one look-up consumes a CHAIN of symbols (it needs block ends, not values): entry = (bits consumed << 3)
+    // | (table of the next step: 0 mdc, 1 mac, 2 mlong) << 1 | (the chain ended with EOB); a window without a codeword has an entry too (tic_entropy.cpp chain_entry).  mdc: the next 11 stream bits with the DC category next;
     // mac: the next 12 bits inside the AC symbols; mlong: the AC codewords of 12..16 bits (index: the next 16 bits - 0xff40), one symbol.
     uint8_t mdc[2048];
     uint8_t mac[4096];

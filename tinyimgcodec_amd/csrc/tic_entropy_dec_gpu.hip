@@ -283,17 +283,16 @@ __device__ __forceinline__ long long wave_lookback(unsigned long long *desc, uin
 // masks in scalar registers, merged under the loop's exec mask at every step, and built three exec-mask regions out of the index - 75
 // instructions per step where this takes 50.  (The kernel's time did not move, 38.8 us: the walk is 16.7 us of it - a timing build that
 // walks twice - at one wave per SIMD; profiles/r05_decoder.txt.)
-// An entry of 0 (no codeword of at most 11 bits here): inside the AC symbols it is the prefix of a long codeword - no advance, mode 2;
-// with the DC category next or in the long table it is no codeword at all - skip a bit (a walk that is out of step, or a damaged stream).
+// A window without a codeword (of at most 11 bits) has an entry like any other: inside the AC symbols it is the prefix of a long codeword - no advance,
+// mode 2; with the DC category next or in the long table it is no codeword at all - skip a bit (a walk that is out of step, or a damaged stream).
 __device__ __forceinline__ void chain_step(const uint8_t *lutm, uint32_t pk, uint32_t &mode, uint32_t &adv, uint32_t &eob) {
     const uint32_t shift = mode == 2u ? 16u : 21u - mode;
     const uint32_t base = mode == 2u ? 6144u - (uint32_t)kLongFirst : mode << 11; // (wraps: a long codeword's 16 bits are >= 0xff40)
     const uint32_t idx = base + (pk >> shift);
     const uint32_t e = lutm[idx < 6144u + (uint32_t)kLongCodes ? idx : 6144u + (uint32_t)kLongCodes]; // (never out of range by the walk's own rules; the slot behind the tables holds a zero)
-    const bool none = e == 0u;
-    eob = e & 1u; // (bits of a chain of symbols << 1) | the chain ends with EOB
-    adv = none ? (mode != 1u ? 1u : 0u) : e >> 1;
-    mode = none ? ((0x18u >> (2u * mode)) & 3u) /* 0 -> 0, 1 -> 2, 2 -> 1 */ : (eob ^ 1u);
+    eob = e & 1u;         // (bits to advance << 3) | (the next step's table << 1) | the chain ends with EOB: tic_entropy.cpp chain_entry - a window
+    adv = e >> 3;         // without a codeword has an entry too (skip a bit; or, inside the AC symbols, the prefix of a long codeword: advance nothing,
+    mode = (e >> 1) & 3u; // table 2 next), so the step derives nothing
 }
 // Diagnostic build only (make -C tools bin/libvar_700.so VARSRC=tic_entropy_dec_gpu.hip; tools/dec_stamps.py): the 100 MHz clock at the phase boundaries of the two
 // kernels, taken by lane 0 of the first and of the last wave / workgroup of a launch - where a kernel that is one chain of trips to memory spends its time
@@ -324,7 +323,9 @@ __device__ unsigned long long g_dec_stamps[4][16];
 // most 1,728 bits long, a range at least 544: four ranges in front of the first owned one are enough for the true entry to reach it.
 // (later in round 6: the count is the launch's - `shadows`, dec_shadows() - so that ranges below 544 bits get EIGHT: the same 2,300 bits in front of the
 //  first owned range for the true entry to arrive through)
+constexpr uint32_t kEveryStepTiles = 128; // launches of at most this many waves store a trace word at every step of the walk (below)
 constexpr uint32_t kShadowMax = 16;        // ranges in front of its own that a wave shadows: at most (sizes the look-back words)
+template <bool kStoreEveryStep>
 __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                     uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
                                                     uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
@@ -405,10 +406,14 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
             wc = crossed ? wn : wc;
             wi = now;
         }
-        if (eob && walks && cnt < cap) tr[cnt] = (uint16_t)(bstart - lo);
+        // A store at every step - into the trace's last place, which no range fills (a block has at least 6 bits: at most cap - 2 block starts), when no
+        // block ends - is six instructions less than the branch around a store per block: a 512^2 stream's launch 22 us instead of 24.  A 4096^2 stream's
+        // takes 64 instead of 33 that way - five million two-byte stores - so only launches of up to kEveryStepTiles waves do it (profiles/r06_decoder.txt (11)).
+        if (kStoreEveryStep) tr[eob && cnt < cap ? cnt : cap - 1u] = (uint16_t)(bstart - lo);
+        else if (eob && cnt < cap) tr[cnt] = (uint16_t)(bstart - lo); // (a lane is in this loop only if it walks)
         cnt += eob;
         bstart = eob ? pos : bstart;
-        live = (eob ? pos < hi : true) && pos < stop;
+        live = pos < (eob ? hi : stop); // a block that STARTS in front of `hi` is walked to its end (hi <= stop)
     }
     if (mine && cnt > cap) atomicOr(&st->giveup, 2); // (cannot happen: a block has at least 6 bits)
     MS_STAMP(2);
@@ -561,18 +566,20 @@ __device__ __forceinline__ void measure_stitch_body(const uint32_t *__restrict__
 }
 
 // One stream per launch: a wave's tile is its index in the grid.
+template <bool kStoreEveryStep>
 __global__ __launch_bounds__(256) void dec_measure_stitch_kernel(const uint32_t *__restrict__ gwords, uint32_t nwords, uint32_t last_mask, const DecLutsDev *__restrict__ L,
                                                                 uint32_t fast_end, uint32_t stream_bits, uint32_t range, uint32_t nranges, uint16_t *__restrict__ starts,
                                                                 uint16_t *__restrict__ hand, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid, uint32_t epoch,
                                                                 unsigned long long nblocks, uint32_t *__restrict__ bpos, long long *__restrict__ grand_total,
                                                                 uint32_t ntiles, DecStatus *__restrict__ st, uint32_t stitch_rounds, uint32_t shadows) {
-    measure_stitch_body(gwords, nwords, last_mask, L, fast_end, stream_bits, range, nranges, starts, hand, desc, desc_half, flat_grid, epoch, nblocks, bpos, grand_total, ntiles, st,
+    measure_stitch_body<kStoreEveryStep>(gwords, nwords, last_mask, L, fast_end, stream_bits, range, nranges, starts, hand, desc, desc_half, flat_grid, epoch, nblocks, bpos, grand_total, ntiles, st,
                         blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), stitch_rounds, shadows);
 }
 // A BATCH of streams per launch (tic_decompress_batch: the reference's benchmark loop decodes 49 streams of 512 x 512 one after the other,
 // tests/benchmark.py:12-23 - two launches per stream are launch latency and little else).  Wave `g` of the grid works on stream
 // tile_frame[g], as that stream's wave g - tile0: its words, ranges, traces, sums, positions and status are the frame's own slices of the
 // batch's arrays (DecFrame), and nothing crosses a frame: the count of blocks in front of a range is taken over the frame's own waves.
+template <bool kStoreEveryStep>
 __global__ __launch_bounds__(256) void dec_measure_stitch_batch_kernel(const uint32_t *__restrict__ words_all, const DecFrame *__restrict__ frames, const uint32_t *__restrict__ tile_frame,
                                                                       uint32_t total_tiles, const DecLutsDev *__restrict__ L, uint32_t range, uint16_t *__restrict__ starts_all,
                                                                       uint16_t *__restrict__ hand_all, unsigned long long *__restrict__ desc, uint32_t desc_half, uint32_t flat_grid,
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(256) void dec_measure_stitch_batch_kernel(const uin
     const uint32_t f = tile_frame[beyond ? total_tiles - 1u : g];
     const DecFrame &F = frames[f];
     const size_t cap = cap_of(range);
-    measure_stitch_body(words_all + F.word0, F.nwords, F.last_mask, L, F.fast_end, F.stream_bits, range, F.nranges, starts_all + (size_t)F.range0 * cap,
+    measure_stitch_body<kStoreEveryStep>(words_all + F.word0, F.nwords, F.last_mask, L, F.fast_end, F.stream_bits, range, F.nranges, starts_all + (size_t)F.range0 * cap,
                         hand_all + (size_t)F.range0 * cap, desc + F.tile0, desc_half, flat_grid, epoch, (unsigned long long)F.nblocks, bpos_all + F.blk0, totals + f, F.ntiles, status + f,
                         beyond ? F.ntiles : g - F.tile0, stitch_rounds, shadows);
 }
@@ -925,9 +932,12 @@ hipError_t entropy_decode_idct_gpu(const void *d_stream_words, size_t stream_byt
     // waves per workgroup of the measure kernel: four while their windows fit 64 KB of LDS together with the tables, else two, else one
     const unsigned win_lds = stage_lds_words(range) * 4u;
     const unsigned wpw = (unsigned)kChainLds + 4u * win_lds <= 60000u ? 4u : ((unsigned)kChainLds + 2u * win_lds <= 60000u ? 2u : 1u);
-    hipLaunchKernelGGL(dec_measure_stitch_kernel, dim3((measure_wgs + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, words, nwords, last_mask, d_luts, fast_end,
-                       (uint32_t)nbits, range, nranges, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, (unsigned long long)nblocks, bpos, totals,
-                       (uint32_t)measure_wgs, d_status, stitch_rounds(), shadows);
+    auto measure = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((measure_wgs + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, words, nwords, last_mask, d_luts, fast_end, (uint32_t)nbits, range,
+                           nranges, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, (unsigned long long)nblocks, bpos, totals, (uint32_t)measure_wgs, d_status,
+                           stitch_rounds(), shadows);
+    };
+    measure_wgs <= kEveryStepTiles ? measure(dec_measure_stitch_kernel<true>) : measure(dec_measure_stitch_kernel<false>);
     const dim3 dgrid((unsigned)((nblocks + kDecodeWG - 1) / kDecodeWG));
     auto fused = [&](auto kern) {
         hipLaunchKernelGGL(kern, dgrid, dim3(kDecodeWG), 0, stream, words, nwords, last_mask, d_luts, (const uint32_t *)bpos, desc_b, desc_half, (uint32_t)flat_grid, 2u * epoch + 1u,
@@ -964,8 +974,11 @@ hipError_t entropy_decode_idct_gpu_batch(const void *d_words_all, const DecFrame
     if ((size_t)(w - (char *)d_work) > work_bytes) return hipErrorInvalidValue;
     const unsigned win_lds = stage_lds_words(range) * 4u;
     const unsigned wpw = (unsigned)kChainLds + 4u * win_lds <= 60000u ? 4u : ((unsigned)kChainLds + 2u * win_lds <= 60000u ? 2u : 1u);
-    hipLaunchKernelGGL(dec_measure_stitch_batch_kernel, dim3((total_tiles + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, (const uint32_t *)d_words_all, d_frames, d_tile_frame,
-                       total_tiles, d_luts, range, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, bpos, totals, d_status, stitch_rounds(), dec_shadows(range_bits));
+    auto measure = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((total_tiles + wpw - 1u) / wpw), dim3(64u * wpw), wpw * win_lds, stream, (const uint32_t *)d_words_all, d_frames, d_tile_frame, total_tiles, d_luts,
+                           range, starts, hand, desc_r, desc_half, (uint32_t)flat_grid, 2u * epoch, bpos, totals, d_status, stitch_rounds(), dec_shadows(range_bits));
+    };
+    total_tiles <= kEveryStepTiles ? measure(dec_measure_stitch_batch_kernel<true>) : measure(dec_measure_stitch_batch_kernel<false>);
     if (small_win)
         hipLaunchKernelGGL(dec_decode_idct_batch_kernel<2048>, dim3(total_wgs), dim3(kDecodeWG), 0, stream, (const uint32_t *)d_words_all, d_frames, d_wg_frame, d_luts, (const uint32_t *)bpos, desc_b,
                            desc_half, (uint32_t)flat_grid, 2u * epoch + 1u, (const long long *)totals, d_status);
