@@ -7,10 +7,14 @@
 //   TIC_ENT_DIRECT_GROUPS   device entropy stage: group count above which stream offsets are summed in two levels
 //   TIC_DECODE_SERIAL       Huffman decoder: always the host's serial decoder
 //   TIC_DECODE_RANGE        device Huffman decoder: stream bits per lane (an odd number of 32-bit words, 288 ... 2016) instead of the choice by block length
-//   TIC_DECODE_RULE         device Huffman decoder: "<average blocks per range>,<least words per range>" instead of 3,17 (measurements of the rule)
+//   TIC_DECODE_RULE         device Huffman decoder: "<average blocks per range>,<least words per range>" instead of 2,9 (measurements of the rule)
+//   TIC_DECODE_SHADOWS      device Huffman decoder: ranges in front of its own that a wave of the measure kernel shadows (1 ... 16; default 4, 8 below 544 bits per range)
+//   TIC_DECODE_ROUNDS       device Huffman decoder: hand-over rounds of the stitch (default 8)
+//   TIC_DECODE_NO_HOSTPIX   tic_decompress of small images through the device image buffer and a DMA copy, as large ones (not through host-mapped memory)
+//   TIC_BATCH_CHUNK         tic_compress_batch: frames per chunk instead of the choice by frame size
 //   TIC_DECODE_NO_GUESS     tic_decompress_dev always reads the header first (no launch on a guess of it)
 //   TIC_NO_SMALL_PATH       tic_compress of small frames through the device stream buffer and a DMA copy, as large ones (not through host-mapped memory)
-//   TIC_DECODE_MIN_BLOCKS, TIC_DECODE_MIN_BITS, TIC_DECODE_MIN_DENSITY   the shortest stream the device Huffman decoder takes (defaults 1024 blocks, 32768 bits, 32 bits per block)
+//   TIC_DECODE_MIN_BLOCKS, TIC_DECODE_MIN_BITS, TIC_DECODE_MIN_DENSITY   the shortest stream the device Huffman decoder takes (defaults 1024 blocks, 8192 bits, any density)
 //   TIC_DECODE_FLAT_GRID    device Huffman decoder: launches of up to this many workgroups sum all words in front (default 4096; 0: inclusive sums always)
 //   TIC_DECODE_MARGIN       device Huffman decoder: first run with the 2,048-bit margin and the host's tail (rounds 2-3's only mode; now the second run's)
 //   TIC_DECODE_TRACE        device Huffman decoder: one line per run on stderr (range, margin, give-up bits, blocks produced)
